@@ -1,0 +1,70 @@
+"""CPU restatement of the HSC and BCE objectives (test infrastructure; see oracle/__init__.py).
+
+Follows reference `src/eoe/training/hsc.py:12-21` (HSCTrainer.compute_anomaly_score / .loss) and
+`src/eoe/training/bce.py:15-20` (BCETrainer.compute_anomaly_score / .loss).  torch-CPU fp32; autograd gives
+the gradients, and the closed forms below (`*_grad`) are what the HIP backward kernels implement.
+"""
+import torch
+
+
+def hsc_dists(features: torch.Tensor) -> torch.Tensor:
+    # hsc.py:13,18  dists = sqrt(norm(f, p=2, dim=1)**2 + 1) - 1   (pseudo-Huber distance to the origin)
+    nrm = torch.sqrt((features * features).sum(dim=1))
+    return torch.sqrt(nrm * nrm + 1) - 1
+
+
+def hsc_score(features: torch.Tensor) -> torch.Tensor:
+    # hsc.py:12-15  scores = 1 - exp(-dists)
+    return 1 - torch.exp(-hsc_dists(features))
+
+
+def hsc_losses(features: torch.Tensor, labels: torch.Tensor, nominal_label: int = 0) -> torch.Tensor:
+    # hsc.py:18-20  per-sample loss: dists for nominal samples, -log(scores + 1e-9) otherwise
+    d = hsc_dists(features)
+    s = 1 - torch.exp(-d)
+    return torch.where(labels == nominal_label, d, -torch.log(s + 1e-9))
+
+
+def hsc_loss(features: torch.Tensor, labels: torch.Tensor, nominal_label: int = 0) -> torch.Tensor:
+    # hsc.py:21  losses.mean()
+    return hsc_losses(features, labels, nominal_label).mean()
+
+
+def hsc_loss_grad(features: torch.Tensor, labels: torch.Tensor, nominal_label: int = 0,
+                  inv_count: float = None) -> torch.Tensor:
+    """closed-form d(mean loss)/d(features): f * coef_i, coef_i = dl/dd * 1/sqrt(|f|^2+1) / N
+    (SURVEY.md section 8a row A6)."""
+    n = features.shape[0]
+    inv = (1.0 / n) if inv_count is None else inv_count
+    ss = (features * features).sum(dim=1)
+    root = torch.sqrt(ss + 1)
+    d = root - 1
+    e = torch.exp(-d)
+    dl_dd = torch.where(labels == nominal_label, torch.ones_like(d), -e / (1 - e + 1e-9))
+    return features * (dl_dd / root * inv)[:, None]
+
+
+def bce_score(features: torch.Tensor, nominal_label: int = 0) -> torch.Tensor:
+    # bce.py:15-17  sigmoid(features).squeeze(); 1 - score if nominal_label != 0
+    s = torch.sigmoid(features).squeeze()
+    return s if nominal_label == 0 else (1 - s)
+
+
+def bce_losses(features: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    # numerically stable form of -[y log sig(x) + (1-y) log(1-sig(x))], what
+    # torch.nn.functional.binary_cross_entropy_with_logits computes (bce.py:20)
+    x = features.reshape(features.shape[0], -1).squeeze(1) if features.dim() > 1 else features
+    y = labels.to(x.dtype)
+    return torch.clamp(x, min=0) - x * y + torch.log1p(torch.exp(-torch.abs(x)))
+
+
+def bce_loss(features: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    # bce.py:19-20  mean reduction
+    return bce_losses(features, labels).mean()
+
+
+def bce_loss_grad(features: torch.Tensor, labels: torch.Tensor, inv_count: float = None) -> torch.Tensor:
+    n = features.shape[0]
+    inv = (1.0 / n) if inv_count is None else inv_count
+    x = features.reshape(n)
+    return ((torch.sigmoid(x) - labels.to(x.dtype)) * inv).reshape(features.shape)

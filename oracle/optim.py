@@ -1,0 +1,46 @@
+"""CPU restatement of the optimiser and LR schedule of the hot path (test infrastructure).
+
+Follows reference `src/eoe/training/ad_trainer.py:383-384` -- `torch.optim.Adam(params, lr, weight_decay=wdk,
+amsgrad=False)` (betas (0.9, 0.999), eps 1e-8, L2-in-gradient weight decay, bias-corrected) and
+`MultiStepLR(opt, milestones, 0.1)` stepped once per epoch (`ad_trainer.py:468`).  Third-party arithmetic:
+torch >= 2.3.1 (`src/requirements.txt:7`), single-tensor Adam update order.
+"""
+import math
+from typing import List, Optional
+import torch
+
+
+class AdamState:
+    def __init__(self, params: List[torch.Tensor]):
+        self.step = [0 for _ in params]
+        self.m = [torch.zeros_like(p) for p in params]
+        self.v = [torch.zeros_like(p) for p in params]
+
+
+def adam_step(params: List[torch.Tensor], grads: List[Optional[torch.Tensor]], state: AdamState,
+              lr: float, weight_decay: float = 0.0, beta1: float = 0.9, beta2: float = 0.999,
+              eps: float = 1e-8) -> None:
+    """in-place Adam update; params whose grad is None are skipped and their step does not advance
+    (SURVEY.md section 7 'Adam details')."""
+    with torch.no_grad():
+        for i, (p, g) in enumerate(zip(params, grads)):
+            if g is None:
+                continue
+            state.step[i] += 1
+            t = state.step[i]
+            if weight_decay != 0:
+                g = g + weight_decay * p
+            m, v = state.m[i], state.v[i]
+            m.add_((g - m) * (1 - beta1))                    # exp_avg.lerp_(grad, 1 - beta1)
+            v.mul_(beta2).add_(g * g * (1 - beta2))          # exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+            bc1 = 1 - beta1 ** t
+            bc2 = 1 - beta2 ** t
+            step_size = lr / bc1
+            denom = v.sqrt() / math.sqrt(bc2) + eps
+            p.add_(m / denom * (-step_size))
+
+
+def multistep_lr(base_lr: float, milestones: List[int], epoch: int, gamma: float = 0.1) -> float:
+    """learning rate in effect during `epoch` (0-based) when sched.step() is called at each epoch end."""
+    k = sum(1 for m in milestones if epoch >= m)
+    return base_lr * (gamma ** k)

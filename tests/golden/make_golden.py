@@ -1,0 +1,226 @@
+#!/usr/bin/env python
+"""Generates the golden fixtures under tests/golden/ by running the REFERENCE's own modules.
+
+Run in the build container only (needs /root/reference; never on the GPU box):
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+What is reference code here: `eoe.models.cnn.CNN32`, `eoe.models.custom_base.CustomNet`, and
+`clip/model.py`'s `VisualTransformer` / `ResidualAttentionBlock` (imported from /root/reference/src), driven by
+the stock third-party calls the reference's trainer makes (`torch.optim.Adam`, `MultiStepLR`,
+`binary_cross_entropy_with_logits`, `torch.norm`, `sklearn.metrics.roc_curve/auc/average_precision_score`;
+`src/eoe/training/ad_trainer.py:8,383-384,453-454,517-521`, `hsc.py:13-21`, `bce.py:16-20`).
+`eoe.training.*` and `eoe.datasets.*` cannot be imported here (ordinary ModuleNotFoundError: torchvision,
+kornia, cv2, tensorboard -- SURVEY.md section 8c), so the trainer loop / objectives are driven through those
+stock calls in this script.  Weights and inputs come from oracle.fill (a pure function of name/shape), so the
+fixtures hold only small outputs.  Only data is written; no reference source is copied.
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/src")
+sys.dont_write_bytecode = True
+
+from oracle import fill, models as omodels, trainer as otrainer  # noqa: E402  (only for the fill rule / batches)
+
+from eoe.models.cnn import CNN32 as RefCNN32                       # noqa: E402
+from eoe.models.custom_base import CustomNet as RefCustomNet       # noqa: E402
+
+_spec = importlib.util.spec_from_file_location(
+    "ref_clip_model", "/root/reference/src/eoe/models/clip_official/clip/model.py")
+ref_clip = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(ref_clip)
+
+torch.set_num_threads(8)
+torch.manual_seed(0)
+
+
+def hsc_loss_ref(f, y):
+    d = torch.sqrt(torch.norm(f, p=2, dim=1) ** 2 + 1) - 1
+    s = 1 - torch.exp(-d)
+    return torch.where(y == 0, d, -torch.log(s + 1e-9)).mean()
+
+
+def hsc_score_ref(f):
+    d = torch.sqrt(torch.norm(f, p=2, dim=1) ** 2 + 1) - 1
+    return 1 - torch.exp(-d)
+
+
+def bce_loss_ref(f, y):
+    return F.binary_cross_entropy_with_logits(f.squeeze(), y.float())
+
+
+def bce_score_ref(f):
+    return torch.sigmoid(f).squeeze()
+
+
+LOSS = {"hsc": (hsc_loss_ref, hsc_score_ref), "bce": (bce_loss_ref, bce_score_ref)}
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def grad_summary(model):
+    """per-tensor gradient norm, sum and first 16 values (full tensors would be too large to commit)"""
+    out = {}
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        g = p.grad.detach().double()
+        out[f"gnorm/{n}"] = g.norm().item()
+        out[f"gsum/{n}"] = g.sum().item()
+        out[f"ghead/{n}"] = p.grad.detach().flatten()[:16].numpy().copy()
+    return out
+
+
+def run_trajectory(model, batches, objective, lr, wd, freeze=False):
+    """the reference inner loop (ad_trainer.py:428-436) with the stock Adam"""
+    loss_fn, score_fn = LOSS[objective]
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=wd, amsgrad=False)
+    if freeze:
+        model.freeze_parts()
+    losses, scores, first = [], [], None
+    for imgs, lbls in batches:
+        opt.zero_grad()
+        feats = model(imgs)
+        loss = loss_fn(feats, lbls)
+        loss.backward()
+        if first is None:
+            first = grad_summary(model)
+            first["features0"] = feats.detach().numpy().copy()
+            for n, b in model.named_buffers():      # BN running stats after the first forward
+                first[f"buf0/{n}"] = b.numpy().copy()
+        opt.step()
+        opt.zero_grad()
+        losses.append(loss.item())
+        scores.append(score_fn(feats.detach()).numpy().copy())
+    return np.array(losses, np.float64), np.stack(scores), first
+
+
+# ----------------------------------------------------------------------------------------------- G1 objectives
+def g1():
+    f = torch.from_numpy(fill.fill("g1/features", (16, 256), std=0.08))
+    y = torch.from_numpy(fill.fill_int("g1/labels", (16,), 0, 2))
+    out = {}
+    for name in ("hsc", "bce"):
+        ff = (f if name == "hsc" else f[:, :1] * 20).clone().requires_grad_(True)
+        loss = LOSS[name][0](ff, y)
+        loss.backward()
+        out[f"{name}_loss"] = loss.item()
+        out[f"{name}_scores"] = LOSS[name][1](ff.detach()).numpy()
+        out[f"{name}_grad"] = ff.grad.numpy()
+    # known answers
+    z = torch.zeros(2, 256)
+    out["hsc_zero_nominal"] = hsc_loss_ref(z, torch.zeros(2, dtype=torch.long)).item()
+    out["hsc_zero_oe"] = hsc_loss_ref(z, torch.ones(2, dtype=torch.long)).item()
+    r3 = torch.zeros(1, 256)
+    r3[0, :3] = 1.0
+    out["hsc_sqrt3_score"] = hsc_score_ref(r3).numpy()
+    save("g1_objectives", **out)
+
+
+# ----------------------------------------------------------------------------------------------- G2 CNN32
+def g2():
+    for clf, obj in ((False, "hsc"), (True, "bce")):
+        m = RefCNN32(bias=True, clf=clf)
+        omodels.deterministic_init(m, tag="cnn32")
+        batches = [otrainer.synthetic_batch(f"g2/b{i}", 8, 8, 32) for i in range(5)]
+        losses, scores, first = run_trajectory(m, batches, obj, lr=1e-3, wd=0.0)
+        save(f"g2_cnn32_{obj}", losses=losses, scores=scores, **first)
+
+
+# ----------------------------------------------------------------------------------------------- G3 ViT
+class RefClipNet(RefCustomNet):
+    def __init__(self, layers, clf=False, freeze=False):
+        super().__init__(512, prediction_head=True, clf=clf, freeze=freeze)
+        self.feature_model = ref_clip.VisualTransformer(224, 32, 768, layers, 12, 512)
+
+
+def g3():
+    for layers, n_half, steps, obj, freeze in ((2, 2, 3, "hsc", False), (2, 2, 3, "bce", False),
+                                               (2, 2, 3, "hsc", True), (12, 1, 2, "hsc", False)):
+        m = RefClipNet(layers, clf=(obj == "bce"), freeze=freeze)
+        omodels.deterministic_init(m, tag="vit", layers=layers)
+        batches = [otrainer.synthetic_batch(f"g3/b{i}", n_half, n_half, 224) for i in range(steps)]
+        # lr / wd of the CLIP runner defaults (train_clip_imagenet.py:13-17)
+        losses, scores, first = run_trajectory(m, batches, obj, lr=1e-4, wd=1e-3, freeze=freeze)
+        tag = f"g3_vit_l{layers}_{obj}" + ("_frozen" if freeze else "")
+        with torch.no_grad():
+            m.eval()
+            enc = m.feature_model(batches[0][0]).numpy()       # encoder output after the K steps
+        save(tag, losses=losses, scores=scores, enc_after=enc, **first)
+
+
+# ----------------------------------------------------------------------------------------------- G4 block
+def g4():
+    blk = ref_clip.ResidualAttentionBlock(768, 12)
+    omodels.deterministic_init(blk, tag="blk", layers=12)
+    x = torch.from_numpy(fill.fill("g4/x", (50, 2, 768), std=1.0)).requires_grad_(True)   # LND (model.py:227)
+    y = blk(x)
+    w = torch.from_numpy(fill.fill("g4/dy", (50, 2, 768), std=1.0))
+    (y * w).sum().backward()
+    save("g4_block", y=y.detach().numpy(), dx=x.grad.numpy(), **grad_summary(blk))
+
+
+# ----------------------------------------------------------------------------------------------- G7 metrics
+def g7():
+    from sklearn.metrics import roc_curve, auc, average_precision_score
+    out = {}
+    for i, (n, ties) in enumerate(((64, False), (200, True), (1000, True), (10, False))):
+        s = fill.fill(f"g7/s{i}", (n,), std=1.0)
+        if ties:
+            s = np.round(s * 4) / 4
+        y = fill.fill_int(f"g7/y{i}", (n,), 0, 2)
+        y[0], y[1] = 0, 1
+        fpr, tpr, _ = roc_curve(y, s)
+        out[f"auc{i}"] = auc(fpr, tpr)
+        out[f"ap{i}"] = average_precision_score(y, s)
+        out[f"n{i}"] = n
+        out[f"ties{i}"] = int(ties)
+    save("g7_metrics", **out)
+
+
+# ----------------------------------------------------------------------------------------------- G8 Adam / LR
+def g8():
+    out = {}
+    for wd in (0.0, 1e-3):
+        ps = [torch.nn.Parameter(torch.from_numpy(fill.fill(f"g8/p{i}", s, std=0.5)))
+              for i, s in enumerate(((7, 5), (33,), (4, 3, 2)))]
+        opt = torch.optim.Adam(ps, lr=1e-2, weight_decay=wd, amsgrad=False)
+        for t in range(5):
+            opt.zero_grad()
+            for i, p in enumerate(ps):
+                if i == 1 and t in (1, 2):
+                    p.grad = None                      # a param without grad is skipped, its step does not advance
+                else:
+                    p.grad = torch.from_numpy(fill.fill(f"g8/g{i}/t{t}", tuple(p.shape), std=0.1))
+            opt.step()
+        for i, p in enumerate(ps):
+            out[f"wd{wd}/p{i}"] = p.detach().numpy().copy()
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=1e-3)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, [3, 5, 6], 0.1)
+    lrs = []
+    for ep in range(9):
+        lrs.append(sched.get_last_lr()[0])
+        opt.step()
+        sched.step()
+    out["multistep_lrs"] = np.array(lrs)
+    save("g8_adam", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g7", "g8"]
+    for w in which:
+        globals()[w]()
