@@ -1,0 +1,13 @@
+"""eoe_amd -- MI355X-native (gfx950) implementation of the outlier-exposure AD training hot path of
+liznerski/eoe: the ADTrainer inner loop (mixed normal+OE batch -> encoder -> anomaly score -> HSC / BCE loss ->
+backward -> Adam) as hand-written HIP kernels behind a C ABI (include/eoe_hip.h, libeoe_hip.so), surfaced through
+torch.autograd.Function bindings so the reference's nn.Module / trainer-hook / optimizer API stays unchanged.
+
+There is no CPU fallback: importing this package loads (or builds) the HIP library and fails loudly otherwise.
+"""
+from . import _lib                      # noqa: F401  (loads libeoe_hip.so; raises if unavailable)
+from .ops import set_compute_dtype, compute_dtype, hsc_loss, hsc_score, bce_loss, bce_score, linear  # noqa: F401
+from .optim import FusedAdam            # noqa: F401
+
+__all__ = ["set_compute_dtype", "compute_dtype", "hsc_loss", "hsc_score", "bce_loss", "bce_score", "linear",
+           "FusedAdam"]

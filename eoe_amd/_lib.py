@@ -1,0 +1,118 @@
+"""ctypes binding of libeoe_hip.so (the C ABI in include/eoe_hip.h).  There is NO fallback: if the library is
+missing and cannot be built, importing this module raises."""
+import ctypes as C
+import os
+import re
+
+from . import _build
+
+ABI_VERSION = 1
+EOE_F16, EOE_BF16 = 1, 2
+EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_GELU_BWD = 0, 1, 2, 3
+ADAM_CHUNK, ADAM_GROUPS = 8192, 4
+
+_vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", _vp), ("B", _vp), ("C", _vp), ("bias", _vp), ("aux", _vp), ("aux_out", _vp),
+                ("M", _i32), ("N", _i32), ("K", _i32),
+                ("lda", _i32), ("ldb", _i32), ("ldc", _i32), ("ldaux", _i32),
+                ("dtype", _i32), ("epilogue", _i32), ("out_f32", _i32), ("accumulate", _i32), ("alpha", _f32)]
+
+
+class AdamChunk(C.Structure):
+    _fields_ = [("p_off", _i64), ("g_off", _i64), ("m_off", _i64), ("v_off", _i64), ("n", _i32), ("group", _i32)]
+
+
+class AdamScalars(C.Structure):
+    _fields_ = [("step_size", _f32 * ADAM_GROUPS), ("bc2_sqrt", _f32 * ADAM_GROUPS)]
+
+
+class VitBlockFwdArgs(C.Structure):
+    _fields_ = [("n", _i32), ("L", _i32), ("D", _i32), ("heads", _i32), ("dtype", _i32), ("eps", _f32),
+                ("ln1_g", _vp), ("ln1_b", _vp), ("ln2_g", _vp), ("ln2_b", _vp),
+                ("b_in", _vp), ("b_out", _vp), ("b_fc", _vp), ("b_proj", _vp),
+                ("w_in", _vp), ("w_out", _vp), ("w_fc", _vp), ("w_proj", _vp),
+                ("w_in_t", _vp), ("w_out_t", _vp), ("w_fc_t", _vp), ("w_proj_t", _vp),
+                ("x_in", _vp), ("x_mid", _vp), ("x_out", _vp),
+                ("xn1", _vp), ("qkv", _vp), ("att", _vp), ("xn2", _vp), ("hpre", _vp), ("hact", _vp),
+                ("stats1", _vp), ("stats2", _vp)]
+
+
+class VitBlockBwdArgs(C.Structure):
+    _fields_ = [("f", VitBlockFwdArgs), ("dx_out", _vp), ("dx_in", _vp),
+                ("g_ln1_g", _vp), ("g_ln1_b", _vp), ("g_ln2_g", _vp), ("g_ln2_b", _vp),
+                ("g_b_in", _vp), ("g_b_out", _vp), ("g_b_fc", _vp), ("g_b_proj", _vp),
+                ("g_w_in", _vp), ("g_w_out", _vp), ("g_w_fc", _vp), ("g_w_proj", _vp),
+                ("accumulate", _i32),
+                ("d16_a", _vp), ("d16_b", _vp), ("dh", _vp), ("dqkv", _vp), ("dx_mid", _vp)]
+
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); must match include/eoe_hip.h
+SIGNATURES = {
+    "eoe_abi_version": [],
+    "eoe_last_error": [],
+    "eoe_gemm_nt": [C.POINTER(GemmArgs), _vp],
+    "eoe_gemm_tn": [C.POINTER(GemmArgs), _vp],
+    "eoe_cast_transpose": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
+    "eoe_patchify": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "eoe_embed_lnpre_fwd": [_vp] * 8 + [C.c_int, C.c_int, C.c_int, _f32, _vp],
+    "eoe_embed_lnpre_bwd": [_vp] * 9 + [C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "eoe_layernorm_fwd": [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, C.c_int, C.c_int, _vp],
+    "eoe_layernorm_bwd": [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int,
+                          C.c_int, _vp],
+    "eoe_colsum": [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "eoe_cast": [_vp, _vp, _sz, C.c_int, _vp],
+    "eoe_attn_fwd": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "eoe_attn_bwd": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "eoe_hsc_fwd": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _vp],
+    "eoe_hsc_bwd": [_vp, _vp, _i64, _vp, _vp, _vp, C.c_int, C.c_int, _f32, C.c_int, _vp],
+    "eoe_hsc_score": [_vp, _vp, C.c_int, C.c_int, _vp],
+    "eoe_bce_fwd": [_vp, _vp, _i64, _vp, _vp, _vp, C.c_int, _f32, _vp],
+    "eoe_bce_bwd": [_vp, _vp, _vp, _vp, C.c_int, _f32, _vp],
+    "eoe_adam_multi": [_vp, _vp, _vp, _vp, _vp, C.c_int, C.POINTER(AdamScalars), _f32, _f32, _f32, _f32, _vp, C.c_int,
+                       _vp],
+    "eoe_vit_block_fwd": [C.POINTER(VitBlockFwdArgs), _vp],
+    "eoe_vit_block_bwd": [C.POINTER(VitBlockBwdArgs), _vp],
+}
+_RESTYPES = {"eoe_last_error": C.c_char_p}
+
+
+def header_symbols():
+    """names of every function declared in include/eoe_hip.h (used by the CPU test of the export list)"""
+    hdr = os.path.join(os.path.dirname(_build.HERE), "include", "eoe_hip.h")
+    txt = open(hdr).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(eoe_[a-z0-9_]+)\s*\(", txt)))
+
+
+def _load():
+    if _build.needs_build():
+        if _build.hipcc_path() is None and not os.path.exists(_build.LIB):
+            raise ImportError("eoe_amd: libeoe_hip.so is missing and hipcc is not available to build it; "
+                              "there is no CPU fallback")
+        if _build.hipcc_path() is not None:
+            _build.build(verbose=False)
+    lib = C.CDLL(_build.LIB)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)            # AttributeError here = the library does not export the ABI
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    v = lib.eoe_abi_version()
+    if v != ABI_VERSION:
+        raise ImportError(f"eoe_amd: libeoe_hip.so has ABI version {v}, expected {ABI_VERSION}")
+    return lib
+
+
+lib = _load()
+
+
+class EoeError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib.eoe_last_error()
+        raise EoeError(f"{what}: error {rc}: {msg.decode() if msg else ''}")

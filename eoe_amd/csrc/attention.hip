@@ -1,0 +1,385 @@
+// Multi-head self-attention for short sequences (L <= 64 tokens, head dim 64; ViT-B/32: L = 50, 12 heads),
+// one wavefront per (image, head), everything in registers + one small LDS image per operand that needs a
+// transposed (k-strided) read.  v_mfma_f32_16x16x32_{f16,bf16}; scores are computed TRANSPOSED
+// (S^T = K Q^T: key on the accumulator row = register index, query on the lane), so
+//   * the softmax row reduction is 16 in-lane values + two cross-lane steps (xor 16, xor 32),
+//   * the probabilities are already the B operand of the next product (O^T = V^T P^T sums over the key =
+//     accumulator-row index: no lane movement, no LDS) -- with the k order inside a 32-key step permuted to
+//     (j<4: key 32s+4g+j, j>=4: key 32s+16+4g+j-4), which the other operand reproduces by choosing which 4-row
+//     blocks its ds_read_b64_tr_b16 transposed reads fetch.
+// Backward recomputes the probabilities (L*L is tiny) in both orientations: lane = query for dQ, and
+// lane = key (operands swapped) for dV and dK, so that every product sums over an accumulator-row index.
+#include "common.h"
+
+namespace {
+
+constexpr int ROWB = 160;            // LDS row pitch in bytes (64 x 16-bit + pad): conflict-free transposed reads
+constexpr int TILEB = 64 * ROWB;     // one 64 x 64 operand image
+
+template <typename T> using V8 = typename T16<T>::v8;
+
+template <typename T>
+__device__ __forceinline__ V8<T> zero8() {
+    i16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    return __builtin_bit_cast(V8<T>, z);
+}
+
+// stage rows [0, L) of a 64-wide head slice into an LDS image, zero rows [L, 64)
+template <typename T>
+__device__ __forceinline__ void stage_tile(char* lds, const T* src, int ld, int L, int lane) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + (lane >> 3), ch = lane & 7;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row < L) v = *(const u32x4*)(src + (size_t)row * ld + ch * 8);
+        *(u32x4*)(lds + row * ROWB + ch * 16) = v;
+    }
+}
+
+// row-major fragment (operand element j <-> column 8*(lane>>4)+j of k-step ks) straight from global memory
+template <typename T>
+__device__ __forceinline__ V8<T> gfrag(const T* src, int ld, int L, int t, int ks, int lane) {
+    const int row = t * 16 + (lane & 15);
+    if (row >= L) return zero8<T>();
+    return __builtin_bit_cast(V8<T>, *(const u32x4*)(src + (size_t)row * ld + (ks * 4 + (lane >> 4)) * 8));
+}
+// the same fragment from an LDS image
+template <typename T>
+__device__ __forceinline__ V8<T> lfrag(const char* lds, int t, int ks, int lane) {
+    const int row = t * 16 + (lane & 15);
+    return __builtin_bit_cast(V8<T>, *(const u32x4*)(lds + row * ROWB + (ks * 4 + (lane >> 4)) * 16));
+}
+// transposed fragment: lane <-> column 16*tc + (lane&15); element j <-> row perm(s, lane>>4, j) (see header)
+template <typename T>
+__device__ __forceinline__ V8<T> tfrag(const char* lds, int tc, int s, int lane) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const char* a = lds + (32 * s + 4 * g + q) * ROWB + (16 * tc + 4 * p) * 2;
+    i16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4v*)(a));
+    i16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4v*)(a + 16 * ROWB));
+    i16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return __builtin_bit_cast(V8<T>, r);
+}
+// two accumulator tiles (rows 32s+0..15 and 32s+16..31 of a transposed product) as the next B operand
+template <typename T>
+__device__ __forceinline__ V8<T> acc_as_operand(const f32x4& lo, const f32x4& hi) {
+    V8<T> r;
+    r[0] = (T)lo[0]; r[1] = (T)lo[1]; r[2] = (T)lo[2]; r[3] = (T)lo[3];
+    r[4] = (T)hi[0]; r[5] = (T)hi[1]; r[6] = (T)hi[2]; r[7] = (T)hi[3];
+    return r;
+}
+
+__device__ __forceinline__ float group_max(float v) {   // over the 4 lanes sharing lane&15
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+// transposed scores -> normalised probabilities in place; returns per-tq (max, sum) through mx/sm
+template <typename T>
+__device__ __forceinline__ void softmax_T(f32x4 (&s)[4][4], int L, float scale, int lane, float (&mx)[4],
+                                          float (&sm)[4]) {
+    const int lg = lane >> 4;
+#pragma unroll
+    for (int tq = 0; tq < 4; ++tq) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * tk + 4 * lg + r;
+                const float v = (key < L) ? s[tk][tq][r] * scale : -INFINITY;
+                s[tk][tq][r] = v;
+                m = fmaxf(m, v);
+            }
+        m = group_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(s[tk][tq][r] - m);
+                s[tk][tq][r] = e;
+                sum += e;
+            }
+        sum = group_sum(sum);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[tk][tq][r] *= inv;
+        mx[tq] = m;
+        sm[tq] = sum;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <typename T>
+__global__ __launch_bounds__(64) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L,
+                                                      int heads, float scale) {
+    __shared__ __attribute__((aligned(16))) char vs[TILEB];
+    const int lane = threadIdx.x;
+    const int img = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int D = heads * 64, ld = 3 * D;
+    const T* qp = qkv + (size_t)img * L * ld + h * 64;
+    const T* kp = qp + D;
+    const T* vp = qp + 2 * D;
+
+    stage_tile<T>(vs, vp, ld, L, lane);
+
+    f32x4 s[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        V8<T> kf[4], qf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            kf[t] = gfrag<T>(kp, ld, L, t, ks, lane);
+            qf[t] = gfrag<T>(qp, ld, L, t, ks, lane);
+        }
+#pragma unroll
+        for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+            for (int tq = 0; tq < 4; ++tq) s[tk][tq] = T16<T>::mfma16(kf[tk], qf[tq], s[tk][tq]);
+    }
+    float mx[4], sm[4];
+    softmax_T<T>(s, L, scale, lane, mx, sm);
+
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const int lr = lane & 15, lg = lane >> 4;
+#pragma unroll
+    for (int td = 0; td < 4; ++td) {
+        f32x4 o[4];
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq) o[tq] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const V8<T> vf = tfrag<T>(vs, td, st, lane);
+#pragma unroll
+            for (int tq = 0; tq < 4; ++tq)
+                o[tq] = T16<T>::mfma16(vf, acc_as_operand<T>(s[2 * st][tq], s[2 * st + 1][tq]), o[tq]);
+        }
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq) {
+            const int query = 16 * tq + lr;
+            if (query < L)
+                *(u32x2*)(out + ((size_t)img * L + query) * D + h * 64 + 16 * td + 4 * lg) =
+                    pack4<T>(o[tq][0], o[tq][1], o[tq][2], o[tq][3]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+template <typename T>
+__global__ __launch_bounds__(64) void attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+                                                      T* __restrict__ dqkv, int L, int heads, float scale) {
+    __shared__ __attribute__((aligned(16))) char smem[3 * TILEB + 2 * 64 * 4];
+    char* qs = smem;
+    char* ks_ = smem + TILEB;
+    char* dos = smem + 2 * TILEB;
+    float* lse_s = (float*)(smem + 3 * TILEB);
+    float* dlt_s = lse_s + 64;
+
+    const int lane = threadIdx.x, lr = lane & 15, lg = lane >> 4;
+    const int img = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int D = heads * 64, ld = 3 * D;
+    const T* qp = qkv + (size_t)img * L * ld + h * 64;
+    const T* kp = qp + D;
+    const T* vp = qp + 2 * D;
+    const T* dop = dout + (size_t)img * L * D + h * 64;
+    T* dqp = dqkv + (size_t)img * L * ld + h * 64;
+
+    stage_tile<T>(qs, qp, ld, L, lane);
+    stage_tile<T>(ks_, kp, ld, L, lane);
+    stage_tile<T>(dos, dop, D, L, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- phase A: lane = query.  S^T = K Q^T, dP^T = V dO^T
+    {
+        f32x4 s[4][4], dp[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                dp[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            V8<T> kf[4], qf[4], vf[4], df[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                kf[t] = lfrag<T>(ks_, t, ks, lane);
+                qf[t] = lfrag<T>(qs, t, ks, lane);
+                vf[t] = gfrag<T>(vp, ld, L, t, ks, lane);
+                df[t] = lfrag<T>(dos, t, ks, lane);
+            }
+#pragma unroll
+            for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+                for (int tq = 0; tq < 4; ++tq) {
+                    s[tk][tq] = T16<T>::mfma16(kf[tk], qf[tq], s[tk][tq]);
+                    dp[tk][tq] = T16<T>::mfma16(vf[tk], df[tq], dp[tk][tq]);
+                }
+        }
+        float mx[4], sm[4];
+        softmax_T<T>(s, L, scale, lane, mx, sm);
+        // delta[q] = sum_key P dP ;  dS^T = P^T (dP^T - delta) * scale   (written over dp)
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq) {
+            float dl = 0.f;
+#pragma unroll
+            for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dl += s[tk][tq][r] * dp[tk][tq][r];
+            dl = group_sum(dl);
+#pragma unroll
+            for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dp[tk][tq][r] = s[tk][tq][r] * (dp[tk][tq][r] - dl) * scale;
+            if (lg == 0) {
+                lse_s[16 * tq + lr] = mx[tq] + __logf(sm[tq]);
+                dlt_s[16 * tq + lr] = dl;
+            }
+        }
+        // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]
+#pragma unroll
+        for (int td = 0; td < 4; ++td) {
+            f32x4 o[4];
+#pragma unroll
+            for (int tq = 0; tq < 4; ++tq) o[tq] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const V8<T> kt = tfrag<T>(ks_, td, st, lane);
+#pragma unroll
+                for (int tq = 0; tq < 4; ++tq)
+                    o[tq] = T16<T>::mfma16(kt, acc_as_operand<T>(dp[2 * st][tq], dp[2 * st + 1][tq]), o[tq]);
+            }
+#pragma unroll
+            for (int tq = 0; tq < 4; ++tq) {
+                const int query = 16 * tq + lr;
+                if (query < L)
+                    *(u32x2*)(dqp + (size_t)query * ld + 16 * td + 4 * lg) = pack4<T>(o[tq][0], o[tq][1], o[tq][2], o[tq][3]);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- phase B: lane = key (operands swapped).  S = Q K^T, dP = dO V^T; rows (registers) = queries
+    {
+        f32x4 s[4][4], dp[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                dp[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            V8<T> kf[4], qf[4], vf[4], df[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                kf[t] = lfrag<T>(ks_, t, ks, lane);
+                qf[t] = lfrag<T>(qs, t, ks, lane);
+                vf[t] = gfrag<T>(vp, ld, L, t, ks, lane);
+                df[t] = lfrag<T>(dos, t, ks, lane);
+            }
+#pragma unroll
+            for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+                for (int tk = 0; tk < 4; ++tk) {
+                    s[tq][tk] = T16<T>::mfma16(qf[tq], kf[tk], s[tq][tk]);
+                    dp[tq][tk] = T16<T>::mfma16(df[tq], vf[tk], dp[tq][tk]);
+                }
+        }
+        // P = exp(S*scale - lse[q]);  dS = P (dP - delta[q]) * scale
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq) {
+            const f32x4 lse = *(const f32x4*)(lse_s + 16 * tq + 4 * lg);
+            const f32x4 dl = *(const f32x4*)(dlt_s + 16 * tq + 4 * lg);
+#pragma unroll
+            for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __expf(s[tq][tk][r] * scale - lse[r]);
+                    s[tq][tk][r] = p;
+                    dp[tq][tk][r] = p * (dp[tq][tk][r] - dl[r]) * scale;
+                }
+        }
+        // dV^T[d][key] = sum_q dO^T[d][q] P[q][key] ;  dK^T[d][key] = sum_q Q^T[d][q] dS[q][key]
+#pragma unroll
+        for (int td = 0; td < 4; ++td) {
+            f32x4 ov[4], ok[4];
+#pragma unroll
+            for (int tk = 0; tk < 4; ++tk) {
+                ov[tk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                ok[tk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const V8<T> dot = tfrag<T>(dos, td, st, lane);
+                const V8<T> qt = tfrag<T>(qs, td, st, lane);
+#pragma unroll
+                for (int tk = 0; tk < 4; ++tk) {
+                    ov[tk] = T16<T>::mfma16(dot, acc_as_operand<T>(s[2 * st][tk], s[2 * st + 1][tk]), ov[tk]);
+                    ok[tk] = T16<T>::mfma16(qt, acc_as_operand<T>(dp[2 * st][tk], dp[2 * st + 1][tk]), ok[tk]);
+                }
+            }
+#pragma unroll
+            for (int tk = 0; tk < 4; ++tk) {
+                const int key = 16 * tk + lr;
+                if (key < L) {
+                    *(u32x2*)(dqp + (size_t)key * ld + 2 * D + 16 * td + 4 * lg) = pack4<T>(ov[tk][0], ov[tk][1], ov[tk][2], ov[tk][3]);
+                    *(u32x2*)(dqp + (size_t)key * ld + D + 16 * td + 4 * lg) = pack4<T>(ok[tk][0], ok[tk][1], ok[tk][2], ok[tk][3]);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int eoe_attn_fwd(const void* qkv, void* out, int n, int L, int heads, int dtype, void* stream) {
+    EOE_CHECK_ARG(qkv && out && n > 0 && heads > 0, "attn_fwd: bad args");
+    EOE_CHECK_ARG(L >= 1 && L <= 64, "attn: sequence length %d not in [1, 64]", L);
+    const float scale = 0.125f;   // 1/sqrt(64)
+    if (dtype == EOE_F16)
+        hipLaunchKernelGGL((attn_fwd_kernel<f16_t>), dim3(n * heads), dim3(64), 0, (hipStream_t)stream,
+                           (const f16_t*)qkv, (f16_t*)out, L, heads, scale);
+    else if (dtype == EOE_BF16)
+        hipLaunchKernelGGL((attn_fwd_kernel<bf16_t>), dim3(n * heads), dim3(64), 0, (hipStream_t)stream,
+                           (const bf16_t*)qkv, (bf16_t*)out, L, heads, scale);
+    else
+        return eoe_set_error(EOE_ERR_ARG, "attn_fwd: bad dtype %d", dtype);
+    EOE_CHECK_LAUNCH("attn_fwd");
+    return 0;
+}
+
+extern "C" int eoe_attn_bwd(const void* qkv, const void* dout, void* dqkv, int n, int L, int heads, int dtype,
+                            void* stream) {
+    EOE_CHECK_ARG(qkv && dout && dqkv && n > 0 && heads > 0, "attn_bwd: bad args");
+    EOE_CHECK_ARG(L >= 1 && L <= 64, "attn: sequence length %d not in [1, 64]", L);
+    const float scale = 0.125f;
+    if (dtype == EOE_F16)
+        hipLaunchKernelGGL((attn_bwd_kernel<f16_t>), dim3(n * heads), dim3(64), 0, (hipStream_t)stream,
+                           (const f16_t*)qkv, (const f16_t*)dout, (f16_t*)dqkv, L, heads, scale);
+    else if (dtype == EOE_BF16)
+        hipLaunchKernelGGL((attn_bwd_kernel<bf16_t>), dim3(n * heads), dim3(64), 0, (hipStream_t)stream,
+                           (const bf16_t*)qkv, (const bf16_t*)dout, (bf16_t*)dqkv, L, heads, scale);
+    else
+        return eoe_set_error(EOE_ERR_ARG, "attn_bwd: bad dtype %d", dtype);
+    EOE_CHECK_LAUNCH("attn_bwd");
+    return 0;
+}

@@ -1,0 +1,127 @@
+// Shared device/host helpers for the eoe_amd HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/eoe_hip.h"
+
+// ---------------------------------------------------------------------------------------------------
+// error convention: 0 = ok, non-zero = error, message via eoe_last_error()
+// ---------------------------------------------------------------------------------------------------
+extern thread_local char g_eoe_err[512];
+int eoe_set_error(int code, const char* fmt, ...);
+
+#define EOE_CHECK_ARG(cond, ...)                         \
+    do {                                                 \
+        if (!(cond)) return eoe_set_error(EOE_ERR_ARG, __VA_ARGS__); \
+    } while (0)
+
+#define EOE_CHECK_LAUNCH(name)                                                            \
+    do {                                                                                  \
+        hipError_t e__ = hipGetLastError();                                               \
+        if (e__ != hipSuccess)                                                            \
+            return eoe_set_error(EOE_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+#define EOE_TRY(expr)              \
+    do {                           \
+        int rc__ = (expr);         \
+        if (rc__ != 0) return rc__; \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------
+// 16-bit element types: one code path templated on the storage/MFMA type
+// ---------------------------------------------------------------------------------------------------
+typedef _Float16 f16_t;
+typedef __bf16 bf16_t;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+typedef short i16x8 __attribute__((ext_vector_type(8)));
+typedef short i16x4v __attribute__((__vector_size__(4 * sizeof(short))));   // type of the tr16 builtin
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+template <typename T> struct T16;
+template <> struct T16<f16_t> {
+    typedef f16x8 v8;
+    typedef f16x4 v4;
+    static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct T16<bf16_t> {
+    typedef bf16x8 v8;
+    typedef bf16x4 v4;
+    static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+
+template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }   // RNE (v_cvt_*)
+
+// pack 4 floats into 4 x 16-bit (8 bytes)
+template <typename T> __device__ __forceinline__ u32x2 pack4(float a, float b, float c, float d) {
+    typename T16<T>::v4 v;
+    v[0] = (T)a; v[1] = (T)b; v[2] = (T)c; v[3] = (T)d;
+    return __builtin_bit_cast(u32x2, v);
+}
+template <typename T> __device__ __forceinline__ void unpack4(u32x2 u, float* o) {
+    typename T16<T>::v4 v = __builtin_bit_cast(typename T16<T>::v4, u);
+    o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3];
+}
+template <typename T> __device__ __forceinline__ void unpack8(u32x4 u, float* o) {
+    typename T16<T>::v8 v = __builtin_bit_cast(typename T16<T>::v8, u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+}
+template <typename T> __device__ __forceinline__ u32x4 pack8(const float* o) {
+    typename T16<T>::v8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (T)o[i];
+    return __builtin_bit_cast(u32x4, v);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wavefront (64 lanes) reductions
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// buffer resource (raw, bounds-checked: an out-of-range offset reads 0)
+typedef __attribute__((address_space(3))) void lds_void_t;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+#define EOE_OOB 0x80000000u
+
+__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float quick_gelu_grad_f(float x) {
+    float s = 1.0f / (1.0f + __expf(-1.702f * x));
+    return s * (1.0f + 1.702f * x * (1.0f - s));
+}
+
+// bijective XCD-aware remap of a 1-D block id (blocks b and b+8 share an XCD): every XCD gets a contiguous
+// chunk of the logical tile order, so neighbouring tiles hit the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+    int q = nblocks >> 3, r = nblocks & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,677 @@
+// HBM-bound kernels of the hot path: casts/transposes of the master weights, patch extraction + normalise,
+// token assembly + ln_pre, LayerNorm forward/backward, column sums (bias gradients), objectives, fused Adam.
+// One wavefront (64 lanes) per row for the row-wise ops, float4 / 8-byte vector accesses, shuffle reductions.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ cast/transpose
+template <typename T>
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, size_t n) {
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+    for (; i + 3 < n; i += stride) {
+        f32x4 v = *(const f32x4*)(src + i);
+        *(u32x2*)(dst + i) = pack4<T>(v[0], v[1], v[2], v[3]);
+    }
+    // tail (n % 4) handled by the first threads of block 0
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        size_t j = (n & ~(size_t)3) + threadIdx.x;
+        dst[j] = (T)src[j];
+    }
+}
+
+// 64x64 tile transpose through LDS: reads fp32 rows coalesced, writes the straight 16-bit copy and the
+// transposed 16-bit copy, both coalesced.
+template <typename T>
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, T* __restrict__ dst, T* __restrict__ dst_t,
+                                      int rows, int cols) {
+    __shared__ float tile[64][65];
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 256 threads: 4 rows per pass
+    for (int r = ty; r < 64; r += 4) {
+        const int gr = r0 + r, gc = c0 + tx;
+        float v = 0.f;
+        if (gr < rows && gc < cols) {
+            v = src[(size_t)gr * cols + gc];
+            if (dst) dst[(size_t)gr * cols + gc] = (T)v;
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    if (dst_t) {
+        for (int c = ty; c < 64; c += 4) {
+            const int gc = c0 + c, gr = r0 + tx;
+            if (gc < cols && gr < rows) dst_t[(size_t)gc * rows + gr] = (T)tile[tx][c];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ patchify
+// one block per (image, patch-row py): reads 3 * p rows of res floats (coalesced), writes g patches.
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                const float* __restrict__ stdv, T* __restrict__ out, int res, int p) {
+    const int g = res / p;
+    const int n = blockIdx.x / g, py = blockIdx.x % g;
+    const int per_c = p * res;                        // floats per channel in this patch row
+    const int total = 3 * per_c;
+    const int kdim = 3 * p * p;
+    for (int i = threadIdx.x * 4; i < total; i += blockDim.x * 4) {
+        const int c = i / per_c, rem = i % per_c;
+        const int ky = rem / res, xx = rem % res;     // xx multiple of 4, p multiple of 4
+        const int px = xx / p, kx = xx % p;
+        f32x4 v = *(const f32x4*)(x + (((size_t)n * 3 + c) * res + (py * p + ky)) * res + xx);
+        if (mean) {
+            const float m = mean[c], s = 1.0f / stdv[c];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (v[r] - m) * s;
+        }
+        T* o = out + ((size_t)(n * g + py) * g + px) * kdim + c * p * p + ky * p + kx;
+        *(u32x2*)o = pack4<T>(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ LayerNorm
+// one wavefront per row; D <= 64 * 4 * LN_MAXV
+constexpr int LN_MAXV = 4;   // float4 per lane -> D <= 1024
+
+struct RowStats { float mean, rstd; };
+
+template <int NV>
+__device__ __forceinline__ RowStats row_stats(const f32x4 (&v)[NV], int D, int lane, float eps) {
+    constexpr int nv = NV;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = v[i][r] - mean;
+                q += d * d;
+            }
+        }
+    const float var = wave_sum(q) / D;
+    return {mean, 1.0f / sqrtf(var + eps)};
+}
+
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, void* __restrict__ y, float* __restrict__ stats,
+                                     int rows, int D, float eps, int out_f32) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    constexpr int nv = NV;    // float4 groups per lane (D = 256 * NV)
+    f32x4 v[NV];
+    const float* xr = x + (size_t)row * ldx;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (i < nv) v[i] = *(const f32x4*)(xr + i * 256 + lane * 4);
+    const RowStats st = row_stats<NV>(v, D, lane, eps);
+    if (stats && lane == 0) {
+        stats[row * 2] = st.mean;
+        stats[row * 2 + 1] = st.rstd;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (i < nv) {
+            const int c = i * 256 + lane * 4;
+            const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (v[i][r] - st.mean) * st.rstd * g[r] + b[r];
+            if (out_f32)
+                *(f32x4*)((float*)y + (size_t)row * D + c) = (f32x4){o[0], o[1], o[2], o[3]};
+            else
+                *(u32x2*)((T*)y + (size_t)row * D + c) = pack4<T>(o[0], o[1], o[2], o[3]);
+        }
+}
+
+// backward: rows are strided over the grid; each wave accumulates dgamma/dbeta partials in registers,
+// the block combines its 4 waves through LDS and issues one fp32 atomic per column.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restrict__ dy, int dy_f32, const float* __restrict__ x, int ldx,
+                                     const float* __restrict__ stats, const float* __restrict__ gamma,
+                                     const float* __restrict__ dres, float* __restrict__ dx_out, int ld_out,
+                                     T* __restrict__ dx16, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                     int rows, int D) {
+    __shared__ float red[2][4][1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int nv = NV;
+    f32x4 ag[NV], ab[NV], gm[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        ag[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        ab[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (i < nv) gm[i] = *(const f32x4*)(gamma + i * 256 + lane * 4);
+    }
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+        f32x4 g[NV], xh[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (i < nv) {
+                const int c = i * 256 + lane * 4;
+                f32x4 d;
+                if (dy_f32) {
+                    d = *(const f32x4*)((const float*)dy + (size_t)row * D + c);
+                } else {
+                    float t[4];
+                    unpack4<T>(*(const u32x2*)((const T*)dy + (size_t)row * D + c), t);
+                    d = (f32x4){t[0], t[1], t[2], t[3]};
+                }
+                const f32x4 xv = *(const f32x4*)(x + (size_t)row * ldx + c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    xh[i][r] = (xv[r] - mean) * rstd;
+                    ab[i][r] += d[r];
+                    ag[i][r] += d[r] * xh[i][r];
+                    g[i][r] = d[r] * gm[i][r];
+                    s1 += g[i][r];
+                    s2 += g[i][r] * xh[i][r];
+                }
+            }
+        s1 = wave_sum(s1) / D;
+        s2 = wave_sum(s2) / D;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (i < nv) {
+                const int c = i * 256 + lane * 4;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = rstd * (g[i][r] - s1 - xh[i][r] * s2);
+                if (dres) {
+                    const f32x4 rv = *(const f32x4*)(dres + (size_t)row * ld_out + c);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] += rv[r];
+                }
+                *(f32x4*)(dx_out + (size_t)row * ld_out + c) = (f32x4){o[0], o[1], o[2], o[3]};
+                if (dx16) *(u32x2*)(dx16 + (size_t)row * D + c) = pack4<T>(o[0], o[1], o[2], o[3]);
+            }
+    }
+    if (!dgamma) return;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (i < nv) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                red[0][wave][i * 256 + lane * 4 + r] = ag[i][r];
+                red[1][wave][i * 256 + lane * 4 + r] = ab[i][r];
+            }
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        const float sg = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+        const float sb = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+        atomicAdd(dgamma + c, sg);
+        atomicAdd(dbeta + c, sb);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ embed + ln_pre
+// one wavefront per token row: x0 = (l == 0 ? cls : tok[n*(L-1) + l-1]) + pos[l];  y = LN(x0)
+template <int NV>
+__global__ __launch_bounds__(256) void embed_lnpre_fwd_kernel(const float* __restrict__ tok, const float* __restrict__ cls,
+                                       const float* __restrict__ pos, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, float* __restrict__ x0,
+                                       float* __restrict__ y, float* __restrict__ stats, int n, int L, int D,
+                                       float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n * L) return;
+    const int img = row / L, l = row % L;
+    constexpr int nv = NV;
+    const float* src = (l == 0) ? cls : tok + ((size_t)img * (L - 1) + (l - 1)) * D;
+    f32x4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (i < nv) {
+            const int c = i * 256 + lane * 4;
+            v[i] = *(const f32x4*)(src + c) + *(const f32x4*)(pos + (size_t)l * D + c);
+            *(f32x4*)(x0 + (size_t)row * D + c) = v[i];
+        }
+    const RowStats st = row_stats<NV>(v, D, lane, eps);
+    if (lane == 0) {
+        stats[row * 2] = st.mean;
+        stats[row * 2 + 1] = st.rstd;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (i < nv) {
+            const int c = i * 256 + lane * 4;
+            const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (v[i][r] - st.mean) * st.rstd * g[r] + b[r];
+            *(f32x4*)(y + (size_t)row * D + c) = o;
+        }
+}
+
+// backward: one block per token position l (grid = L), waves stride over the images; dpos[l] and (l == 0)
+// dcls are complete sums over the batch -> plain stores/adds without atomics; dgamma/dbeta via atomics.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void embed_lnpre_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x0,
+                                       const float* __restrict__ stats, const float* __restrict__ gamma,
+                                       T* __restrict__ dtok, float* __restrict__ dcls, float* __restrict__ dpos,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int n, int L, int D) {
+    __shared__ float red[3][4][1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l = blockIdx.x;
+    constexpr int nv = NV;
+    f32x4 ag[NV], ab[NV], ap[NV], gm[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        ag[i] = ab[i] = ap[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (i < nv) gm[i] = *(const f32x4*)(gamma + i * 256 + lane * 4);
+    }
+    for (int img = wave; img < n; img += 4) {
+        const size_t row = (size_t)img * L + l;
+        const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+        f32x4 g[NV], xh[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (i < nv) {
+                const int c = i * 256 + lane * 4;
+                const f32x4 d = *(const f32x4*)(dy + row * D + c);
+                const f32x4 xv = *(const f32x4*)(x0 + row * D + c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    xh[i][r] = (xv[r] - mean) * rstd;
+                    ab[i][r] += d[r];
+                    ag[i][r] += d[r] * xh[i][r];
+                    g[i][r] = d[r] * gm[i][r];
+                    s1 += g[i][r];
+                    s2 += g[i][r] * xh[i][r];
+                }
+            }
+        s1 = wave_sum(s1) / D;
+        s2 = wave_sum(s2) / D;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (i < nv) {
+                const int c = i * 256 + lane * 4;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    o[r] = rstd * (g[i][r] - s1 - xh[i][r] * s2);
+                    ap[i][r] += o[r];
+                }
+                if (l > 0)
+                    *(u32x2*)(dtok + ((size_t)img * (L - 1) + (l - 1)) * D + c) = pack4<T>(o[0], o[1], o[2], o[3]);
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (i < nv) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                red[0][wave][i * 256 + lane * 4 + r] = ag[i][r];
+                red[1][wave][i * 256 + lane * 4 + r] = ab[i][r];
+                red[2][wave][i * 256 + lane * 4 + r] = ap[i][r];
+            }
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        const float sg = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+        const float sb = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+        const float sp = red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c];
+        atomicAdd(dgamma + c, sg);
+        atomicAdd(dbeta + c, sb);
+        dpos[(size_t)l * D + c] += sp;
+        if (l == 0) dcls[c] += sp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ column sums
+// block = 256 threads = 64 column-groups(4 cols = 8 B) x 4 row lanes; grid.x over column groups of 256 cols,
+// grid.y strides rows; combine through LDS then one atomic per column per block.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int ldx, float* __restrict__ out, int rows, int cols) {
+    __shared__ float red[4][256];
+    const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 256 + cg * 4;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < cols) {
+        for (int r = blockIdx.y * 4 + rl; r < rows; r += gridDim.y * 4) {
+            float t[4];
+            unpack4<T>(*(const u32x2*)(x + (size_t)r * ldx + c), t);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] += t[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[rl][cg * 4 + k] = a[k];
+    __syncthreads();
+    const int cc = blockIdx.x * 256 + threadIdx.x;
+    if (cc < cols) atomicAdd(out + cc, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------ objectives
+// HSC rows: one wavefront per sample
+__global__ __launch_bounds__(256) void hsc_rows_kernel(const float* __restrict__ f, const int64_t* __restrict__ labels, int64_t nominal,
+                                float* __restrict__ scores, float* __restrict__ dists, float* __restrict__ losses,
+                                int n, int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    float ss = 0.f;
+    for (int c = lane; c < d; c += 64) {
+        const float v = f[(size_t)row * d + c];
+        ss += v * v;
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) {
+        const float nrm = sqrtf(ss);                     // hsc.py:13  norm(f)**2 + 1
+        const float dist = sqrtf(nrm * nrm + 1.0f) - 1.0f;
+        const float sc = 1.0f - expf(-dist);
+        if (scores) scores[row] = sc;
+        if (dists) dists[row] = dist;
+        if (losses) losses[row] = (labels[row] == nominal) ? dist : -logf(sc + 1e-9f);
+    }
+}
+
+// deterministic fixed-order sum of n floats by one block -> out[0] = scale * sum
+__global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict__ v, float* __restrict__ out, int n, float scale) {
+    __shared__ float red[16];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) a += v[i];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+        out[0] = s * scale;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void hsc_bwd_kernel(const float* __restrict__ f, const int64_t* __restrict__ labels, int64_t nominal,
+                               const float* __restrict__ gscale, float* __restrict__ df, T* __restrict__ df16, int n,
+                               int d, float inv_count) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    float ss = 0.f;
+    for (int c = lane; c < d; c += 64) {
+        const float v = f[(size_t)row * d + c];
+        ss += v * v;
+    }
+    ss = wave_sum(ss);
+    const float root = sqrtf(ss + 1.0f);
+    const float dist = root - 1.0f;
+    const float e = expf(-dist);
+    const float dl_dd = (labels[row] == nominal) ? 1.0f : -e / (1.0f - e + 1e-9f);
+    const float coef = dl_dd / root * inv_count * (gscale ? gscale[0] : 1.0f);
+    for (int c = lane; c < d; c += 64) {
+        const float g = f[(size_t)row * d + c] * coef;
+        if (df) df[(size_t)row * d + c] = g;
+        if (df16) df16[(size_t)row * d + c] = (T)g;
+    }
+}
+
+__global__ __launch_bounds__(256) void bce_rows_kernel(const float* __restrict__ x, const int64_t* __restrict__ labels, int64_t nominal,
+                                float* __restrict__ scores, float* __restrict__ losses, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i], y = (float)labels[i];
+    const float s = 1.0f / (1.0f + expf(-v));
+    if (scores) scores[i] = (nominal == 0) ? s : 1.0f - s;
+    if (losses) losses[i] = fmaxf(v, 0.f) - v * y + log1pf(expf(-fabsf(v)));
+}
+
+__global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ labels,
+                               const float* __restrict__ gscale, float* __restrict__ dx, int n, float inv_count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float s = 1.0f / (1.0f + expf(-x[i]));
+    dx[i] = (s - (float)labels[i]) * inv_count * (gscale ? gscale[0] : 1.0f);
+}
+
+// ------------------------------------------------------------------------------------------ Adam
+// one block per chunk of <= EOE_ADAM_CHUNK elements; float4 accesses (chunk offsets are multiples of 4 for
+// 16-B aligned parameter starts; scalar path otherwise).
+template <typename T>
+__global__ __launch_bounds__(256) void adam_multi_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                  float* __restrict__ v, const eoe_adam_chunk* __restrict__ chunks,
+                                  eoe_adam_scalars sc, float beta1, float beta2, float eps, float wd,
+                                  T* __restrict__ shadow) {
+    const eoe_adam_chunk ck = chunks[blockIdx.x];
+    const float step_size = sc.step_size[ck.group & (EOE_ADAM_GROUPS - 1)];
+    const float bc2_sqrt = sc.bc2_sqrt[ck.group & (EOE_ADAM_GROUPS - 1)];
+    float* pp = p + ck.p_off;
+    const float* gg = g + ck.g_off;
+    float* mm = m + ck.m_off;
+    float* vv = v + ck.v_off;
+    T* sh = shadow ? shadow + ck.p_off : nullptr;
+    const bool aligned = (((ck.p_off | ck.g_off | ck.m_off | ck.v_off) & 3) == 0);
+    auto upd = [&](float pv, float gv, float& mv, float& vvv) -> float {
+        if (wd != 0.f) gv = gv + wd * pv;
+        mv = mv + (gv - mv) * (1.0f - beta1);
+        vvv = vvv * beta2 + (1.0f - beta2) * gv * gv;
+        const float denom = sqrtf(vvv) / bc2_sqrt + eps;
+        return pv - step_size * (mv / denom);
+    };
+    if (aligned) {
+        const int n4 = ck.n >> 2;
+        for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+            f32x4 pv = *(f32x4*)(pp + i * 4), gv = *(const f32x4*)(gg + i * 4);
+            f32x4 mv = *(f32x4*)(mm + i * 4), vx = *(f32x4*)(vv + i * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = mv[r], b = vx[r];
+                pv[r] = upd(pv[r], gv[r], a, b);
+                mv[r] = a;
+                vx[r] = b;
+            }
+            *(f32x4*)(pp + i * 4) = pv;
+            *(f32x4*)(mm + i * 4) = mv;
+            *(f32x4*)(vv + i * 4) = vx;
+            if (sh) *(u32x2*)(sh + i * 4) = pack4<T>(pv[0], pv[1], pv[2], pv[3]);
+        }
+        for (int i = (n4 << 2) + threadIdx.x; i < ck.n; i += blockDim.x) {
+            float a = mm[i], b = vv[i];
+            const float np = upd(pp[i], gg[i], a, b);
+            pp[i] = np; mm[i] = a; vv[i] = b;
+            if (sh) sh[i] = (T)np;
+        }
+    } else {
+        for (int i = threadIdx.x; i < ck.n; i += blockDim.x) {
+            float a = mm[i], b = vv[i];
+            const float np = upd(pp[i], gg[i], a, b);
+            pp[i] = np; mm[i] = a; vv[i] = b;
+            if (sh) sh[i] = (T)np;
+        }
+    }
+}
+
+}  // namespace
+
+#define DISPATCH_NV(D, ...)                                      \
+    do {                                                         \
+        switch ((D) / 256) {                                     \
+            case 1: { constexpr int NV = 1; __VA_ARGS__; } break; \
+            case 2: { constexpr int NV = 2; __VA_ARGS__; } break; \
+            case 3: { constexpr int NV = 3; __VA_ARGS__; } break; \
+            default: { constexpr int NV = 4; __VA_ARGS__; } break; \
+        }                                                        \
+    } while (0)
+
+#define DISPATCH_T(dtype, ...)                                  \
+    do {                                                        \
+        if ((dtype) == EOE_F16) { typedef f16_t T; __VA_ARGS__; } \
+        else if ((dtype) == EOE_BF16) { typedef bf16_t T; __VA_ARGS__; } \
+        else return eoe_set_error(EOE_ERR_ARG, "bad dtype %d", (int)(dtype)); \
+    } while (0)
+
+extern "C" int eoe_cast(const float* src, void* dst, size_t n, int dtype, void* stream) {
+    EOE_CHECK_ARG(src && dst, "cast: null pointer");
+    if (n == 0) return 0;
+    int grid = (int)((n / 4 + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((cast_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (T*)dst, n));
+    EOE_CHECK_LAUNCH("cast");
+    return 0;
+}
+
+extern "C" int eoe_cast_transpose(const float* src, void* dst, void* dst_t, int rows, int cols, int dtype,
+                                  void* stream) {
+    EOE_CHECK_ARG(src && (dst || dst_t) && rows > 0 && cols > 0, "cast_transpose: bad args");
+    dim3 grid(cdiv(cols, 64), cdiv(rows, 64));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((cast_transpose_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, src,
+                                         (T*)dst, (T*)dst_t, rows, cols));
+    EOE_CHECK_LAUNCH("cast_transpose");
+    return 0;
+}
+
+extern "C" int eoe_patchify(const float* x, const float* mean, const float* stdv, void* out, int n, int res,
+                            int patch, int dtype, void* stream) {
+    EOE_CHECK_ARG(x && out && n > 0, "patchify: bad args");
+    EOE_CHECK_ARG(res % patch == 0 && patch % 4 == 0, "patchify: res %% patch != 0 or patch %% 4 != 0");
+    EOE_CHECK_ARG((mean == nullptr) == (stdv == nullptr), "patchify: mean/std must both be given or both NULL");
+    const int g = res / patch;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((patchify_kernel<T>), dim3(n * g), dim3(256), 0, (hipStream_t)stream, x, mean,
+                                         stdv, (T*)out, res, patch));
+    EOE_CHECK_LAUNCH("patchify");
+    return 0;
+}
+
+extern "C" int eoe_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, void* y,
+                                 float* stats, int rows, int D, float eps, int dtype, int out_f32, void* stream) {
+    EOE_CHECK_ARG(x && gamma && beta && y && rows > 0, "layernorm_fwd: bad args");
+    EOE_CHECK_ARG(D % 256 == 0 && D <= 1024 && ldx % 4 == 0, "layernorm: D must be a multiple of 256, <= 1024");
+    DISPATCH_T(dtype, DISPATCH_NV(D, hipLaunchKernelGGL((layernorm_fwd_kernel<T, NV>), dim3(cdiv(rows, 4)), dim3(256), 0,
+                                         (hipStream_t)stream, x, ldx, gamma, beta, y, stats, rows, D, eps, out_f32)));
+    EOE_CHECK_LAUNCH("layernorm_fwd");
+    return 0;
+}
+
+extern "C" int eoe_layernorm_bwd(const void* dy, int dy_f32, const float* x, int ldx, const float* stats,
+                                 const float* gamma, const float* dres, float* dx_out, int ld_out, void* dx16,
+                                 float* dgamma, float* dbeta, int rows, int D, int dtype, void* stream) {
+    EOE_CHECK_ARG(dy && x && stats && gamma && dx_out && rows > 0, "layernorm_bwd: bad args");
+    EOE_CHECK_ARG(D % 256 == 0 && D <= 1024 && ldx % 4 == 0 && ld_out % 4 == 0, "layernorm: D must be a multiple of 256, <= 1024");
+    EOE_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma/dbeta must both be given or both NULL");
+    int grid = cdiv(rows, 4);
+    if (grid > 512) grid = 512;
+    DISPATCH_T(dtype, DISPATCH_NV(D, hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy,
+                                         dy_f32, x, ldx, stats, gamma, dres, dx_out, ld_out, (T*)dx16, dgamma, dbeta,
+                                         rows, D)));
+    EOE_CHECK_LAUNCH("layernorm_bwd");
+    return 0;
+}
+
+extern "C" int eoe_embed_lnpre_fwd(const float* tok, const float* cls, const float* pos, const float* gamma,
+                                   const float* beta, float* x0, float* y, float* stats, int n, int L, int D,
+                                   float eps, void* stream) {
+    EOE_CHECK_ARG(tok && cls && pos && gamma && beta && x0 && y && stats && n > 0 && L > 1, "embed_lnpre_fwd: bad args");
+    EOE_CHECK_ARG(D % 256 == 0 && D <= 1024, "embed_lnpre: D must be a multiple of 256, <= 1024");
+    DISPATCH_NV(D, hipLaunchKernelGGL((embed_lnpre_fwd_kernel<NV>), dim3(cdiv(n * L, 4)), dim3(256), 0, (hipStream_t)stream, tok, cls, pos,
+                       gamma, beta, x0, y, stats, n, L, D, eps));
+    EOE_CHECK_LAUNCH("embed_lnpre_fwd");
+    return 0;
+}
+
+extern "C" int eoe_embed_lnpre_bwd(const float* dy, const float* x0, const float* stats, const float* gamma,
+                                   void* dtok, float* dcls, float* dpos, float* dgamma, float* dbeta, int n, int L,
+                                   int D, int dtype, void* stream) {
+    EOE_CHECK_ARG(dy && x0 && stats && gamma && dtok && dcls && dpos && dgamma && dbeta && n > 0 && L > 1,
+                  "embed_lnpre_bwd: bad args");
+    EOE_CHECK_ARG(D % 256 == 0 && D <= 1024, "embed_lnpre: D must be a multiple of 256, <= 1024");
+    DISPATCH_T(dtype, DISPATCH_NV(D, hipLaunchKernelGGL((embed_lnpre_bwd_kernel<T, NV>), dim3(L), dim3(256), 0, (hipStream_t)stream, dy, x0,
+                                         stats, gamma, (T*)dtok, dcls, dpos, dgamma, dbeta, n, L, D)));
+    EOE_CHECK_LAUNCH("embed_lnpre_bwd");
+    return 0;
+}
+
+extern "C" int eoe_colsum(const void* x, int ldx, float* out, int rows, int cols, int dtype, int accumulate,
+                          void* stream) {
+    EOE_CHECK_ARG(x && out && rows > 0 && cols > 0, "colsum: bad args");
+    EOE_CHECK_ARG(cols % 4 == 0 && ldx % 4 == 0, "colsum: cols and ldx must be multiples of 4");
+    if (!accumulate) {
+        if (hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), (hipStream_t)stream) != hipSuccess)
+            return eoe_set_error(EOE_ERR_LAUNCH, "colsum: memset failed");
+    }
+    int gy = cdiv(rows, 4 * 16);
+    if (gy > 128) gy = 128;
+    if (gy < 1) gy = 1;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), dim3(cdiv(cols, 256), gy), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)x, ldx, out, rows, cols));
+    EOE_CHECK_LAUNCH("colsum");
+    return 0;
+}
+
+extern "C" int eoe_hsc_fwd(const float* f, const int64_t* labels, int64_t nominal_label, float* loss, float* scores,
+                           float* dists, float* losses, int n, int d, float inv_count, void* stream) {
+    EOE_CHECK_ARG(f && labels && n > 0 && d > 0, "hsc_fwd: bad args");
+    EOE_CHECK_ARG(!loss || losses, "hsc_fwd: the loss needs the per-sample `losses` buffer");
+    hipLaunchKernelGGL(hsc_rows_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, f, labels, nominal_label,
+                       scores, dists, losses, n, d);
+    EOE_CHECK_LAUNCH("hsc_rows");
+    if (loss) {
+        hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, losses, loss, n, inv_count);
+        EOE_CHECK_LAUNCH("hsc_sum");
+    }
+    return 0;
+}
+
+extern "C" int eoe_hsc_score(const float* f, float* scores, int n, int d, void* stream) {
+    EOE_CHECK_ARG(f && scores && n > 0 && d > 0, "hsc_score: bad args");
+    hipLaunchKernelGGL(hsc_rows_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, f, (const int64_t*)nullptr,
+                       (int64_t)0, scores, (float*)nullptr, (float*)nullptr, n, d);
+    EOE_CHECK_LAUNCH("hsc_score");
+    return 0;
+}
+
+extern "C" int eoe_hsc_bwd(const float* f, const int64_t* labels, int64_t nominal_label, const float* gscale,
+                           float* df, void* df16, int n, int d, float inv_count, int dtype, void* stream) {
+    EOE_CHECK_ARG(f && labels && (df || df16) && n > 0 && d > 0, "hsc_bwd: bad args");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((hsc_bwd_kernel<T>), dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, f,
+                                         labels, nominal_label, gscale, df, (T*)df16, n, d, inv_count));
+    EOE_CHECK_LAUNCH("hsc_bwd");
+    return 0;
+}
+
+extern "C" int eoe_bce_fwd(const float* x, const int64_t* labels, int64_t nominal_label, float* loss, float* scores,
+                           float* losses, int n, float inv_count, void* stream) {
+    EOE_CHECK_ARG(x && labels && n > 0, "bce_fwd: bad args");
+    EOE_CHECK_ARG(!loss || losses, "bce_fwd: the loss needs the per-sample `losses` buffer");
+    hipLaunchKernelGGL(bce_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, labels, nominal_label,
+                       scores, losses, n);
+    EOE_CHECK_LAUNCH("bce_rows");
+    if (loss) {
+        hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, losses, loss, n, inv_count);
+        EOE_CHECK_LAUNCH("bce_sum");
+    }
+    return 0;
+}
+
+extern "C" int eoe_bce_bwd(const float* x, const int64_t* labels, const float* gscale, float* dx, int n,
+                           float inv_count, void* stream) {
+    EOE_CHECK_ARG(x && labels && dx && n > 0, "bce_bwd: bad args");
+    hipLaunchKernelGGL(bce_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, labels, gscale, dx, n,
+                       inv_count);
+    EOE_CHECK_LAUNCH("bce_bwd");
+    return 0;
+}
+
+extern "C" int eoe_adam_multi(float* p, const float* g, float* m, float* v, const eoe_adam_chunk* chunks,
+                              int n_chunks, const eoe_adam_scalars* scalars, float beta1, float beta2, float eps,
+                              float weight_decay, void* shadow16, int dtype, void* stream) {
+    EOE_CHECK_ARG(p && g && m && v && chunks && scalars && n_chunks > 0, "adam_multi: bad args");
+    if (!shadow16) dtype = EOE_BF16;
+    const eoe_adam_scalars sc = *scalars;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((adam_multi_kernel<T>), dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, p, g,
+                                         m, v, chunks, sc, beta1, beta2, eps, weight_decay, (T*)shadow16));
+    EOE_CHECK_LAUNCH("adam_multi");
+    return 0;
+}

@@ -1,0 +1,410 @@
+// MFMA GEMMs for gfx950: 128x128x64 tiles, 4 wavefronts (2x2, 64x64 each), v_mfma_f32_16x16x32_{f16,bf16},
+// operands staged global -> LDS with bounds-checked LDS-DMA (buffer_load ... lds, 16 B per lane; an
+// out-of-range lane reads 0, which is the zero padding of ragged M / N / T tails), two LDS stages.
+//
+//   NT:  C[M,N] = A[M,K] . B[N,K]^T   both operands K-contiguous; LDS image [128 rows][64 k] with the 16-B chunk
+//        index XOR-swizzled by (row>>1)&7 (applied on the SOURCE address, LDS-DMA writes linearly), fragments
+//        by ds_read_b128, conflict-free.
+//   TN:  C[M,N] = A[T,M]^T . B[T,N]   reduction over rows (wgrad); LDS image [64 t][128 cols] with the 32-B
+//        granule XOR-swizzled by (t&3)|((t>>3)&1)<<2, fragments by ds_read_b64_tr_b16 (hardware transpose).
+//
+// The MFMA is issued with the weight-side fragment as the A operand so that each lane ends up holding 4
+// consecutive output COLUMNS of one output row (D: col = lane&15 -> m, row = 4*(lane>>4)+r -> n): epilogue
+// loads/stores are 8-B (16-bit) or 16-B (fp32) vectors along the contiguous dimension.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * 64 * 2;          // one operand tile, 16 KiB
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;       // A + B
+constexpr int SMEM_BYTES = 2 * STAGE_BYTES;       // two stages, 64 KiB -> 2 workgroups per CU
+
+struct GemmP {
+    const void* A; const void* B; void* C; const float* bias; const void* aux; void* aux_out;
+    int M, N, K, lda, ldb, ldc, ldaux, out_f32, accumulate;
+    float alpha;
+    unsigned bytesA, bytesB;
+};
+
+template <typename T, int EPI>
+__device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[4][4], int m_base, int n_base, int lane) {
+    const int lr = lane & 15, lg = lane >> 4;
+    const bool vec_ok = ((p.ldc & 3) == 0) && ((p.N & 3) == 0);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = m_base + mi * 16 + lr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n_base + ni * 16 + lg * 4;
+            if (n >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r] * p.alpha;
+            const int nvalid = (p.N - n) < 4 ? (p.N - n) : 4;
+            if (p.bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (r < nvalid) v[r] += p.bias[n + r];
+            }
+            const size_t off = (size_t)m * p.ldc + n;
+            if (EPI == EOE_EPI_GELU) {
+                // pre-activation (16-bit, saved for backward) and activation
+                T* pre = (T*)p.aux_out;
+                T* act = (T*)p.C;
+                if (vec_ok) {
+                    // the saved pre-activation is what backward differentiates: activate its ROUNDED value
+                    u32x2 pk = pack4<T>(v[0], v[1], v[2], v[3]);
+                    float pr[4];
+                    unpack4<T>(pk, pr);
+                    *(u32x2*)(pre + off) = pk;
+                    *(u32x2*)(act + off) = pack4<T>(quick_gelu_f(pr[0]), quick_gelu_f(pr[1]),
+                                                    quick_gelu_f(pr[2]), quick_gelu_f(pr[3]));
+                } else {
+                    for (int r = 0; r < nvalid; ++r) {
+                        T q = (T)v[r];
+                        pre[off + r] = q;
+                        act[off + r] = (T)quick_gelu_f((float)q);
+                    }
+                }
+                continue;
+            }
+            if (EPI == EOE_EPI_RESIDUAL) {
+                const float* res = (const float*)p.aux + (size_t)m * p.ldaux + n;
+                if (vec_ok && (p.ldaux & 3) == 0) {
+                    f32x4 rv = *(const f32x4*)res;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                } else {
+                    for (int r = 0; r < nvalid; ++r) v[r] += res[r];
+                }
+            }
+            if (EPI == EOE_EPI_GELU_BWD) {
+                const T* pre = (const T*)p.aux + (size_t)m * p.ldaux + n;
+                if (vec_ok && (p.ldaux & 3) == 0) {
+                    float pr[4];
+                    unpack4<T>(*(const u32x2*)pre, pr);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= quick_gelu_grad_f(pr[r]);
+                } else {
+                    for (int r = 0; r < nvalid; ++r) v[r] *= quick_gelu_grad_f((float)pre[r]);
+                }
+            }
+            if (p.out_f32) {
+                float* c = (float*)p.C + off;
+                if (vec_ok) {
+                    f32x4 o = {v[0], v[1], v[2], v[3]};
+                    if (p.accumulate) {
+                        f32x4 old = *(f32x4*)c;
+                        o += old;
+                    }
+                    *(f32x4*)c = o;
+                } else {
+                    for (int r = 0; r < nvalid; ++r) c[r] = p.accumulate ? c[r] + v[r] : v[r];
+                }
+            } else {
+                T* c = (T*)p.C + off;
+                if (vec_ok) {
+                    *(u32x2*)c = pack4<T>(v[0], v[1], v[2], v[3]);
+                } else {
+                    for (int r = 0; r < nvalid; ++r) c[r] = (T)v[r];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ NT
+template <typename T, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+
+    __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.bytesA);
+    __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.bytesB);
+
+    // staging: wave-load wl (0..15) covers tile rows 8*wl .. 8*wl+7, 128 B each; lane -> (row, 16-B slot)
+    unsigned offA[4], offB[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int wl = wave * 4 + j;
+        const int row = wl * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);            // logical chunk fetched into this slot
+        const int ga = m0 + row, gb = n0 + row;
+        offA[j] = (ga < p.M) ? (unsigned)(((size_t)ga * p.lda + c * 8) * 2) : EOE_OOB;
+        offB[j] = (gb < p.N) ? (unsigned)(((size_t)gb * p.ldb + c * 8) * 2) : EOE_OOB;
+    }
+    auto stage = [&](int buf, int k0) {
+        char* sa = smem + buf * STAGE_BYTES;
+        char* sb = sa + TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int wl = wave * 4 + j;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(sa + wl * 1024), 16,
+                                                     offA[j] + (unsigned)k0 * 2u, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(sb + wl * 1024), 16,
+                                                     offB[j] + (unsigned)k0 * 2u, 0, 0, 0);
+        }
+    };
+
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int sw = (lr >> 1) & 7;
+    // per-lane fragment byte offsets inside a tile for k-step 0 / 1
+    const int fragA = (wm0 + lr) * 128, fragB = (wn0 + lr) * 128;
+    const int ch0 = ((0 + lg) ^ sw) * 16, ch1 = ((4 + lg) ^ sw) * 16;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) stage(buf ^ 1, (kt + 1) * BK);
+        const char* sa = smem + buf * STAGE_BYTES;
+        const char* sb = sa + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ch = ks ? ch1 : ch0;
+            typename T16<T>::v8 xa[4], wb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xa[i] = *(const typename T16<T>::v8*)(sa + fragA + i * 16 * 128 + ch);
+                wb[i] = *(const typename T16<T>::v8*)(sb + fragB + i * 16 * 128 + ch);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = T16<T>::mfma16(wb[ni], xa[mi], acc[mi][ni]);
+        }
+        __syncthreads();
+    }
+    epilogue<T, EPI>(p, acc, m0 + wm0, n0 + wn0, lane);
+}
+
+// ------------------------------------------------------------------------------------------------ TN
+template <typename T>
+__device__ __forceinline__ typename T16<T>::v8 tr_frag(const char* base, int off_lo) {
+    // two transposed 4-row reads (rows +0..3 and +4..7 of this lane group's 8-row k block)
+    i16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4v*)(base + off_lo));
+    i16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4v*)(base + off_lo + 4 * 256));
+    i16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return __builtin_bit_cast(typename T16<T>::v8, r);
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p, int t_per_split) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles = tiles_n * ((p.M + BM - 1) / BM);
+    const int split = blockIdx.x / tiles;                 // split-T index (atomic accumulation when > 1 splits)
+    const int tile = xcd_remap(blockIdx.x % tiles, tiles);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int t_begin = split * t_per_split;
+    const int t_end = min(p.K, t_begin + t_per_split);
+
+    __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.bytesA);
+    __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.bytesB);
+
+    // staging: wave-load wl (0..15) covers tile rows (t) 4*wl .. 4*wl+3, 256 B each; lane -> (row, 16-B slot)
+    int srow[4];
+    unsigned colA[4], colB[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int wl = wave * 4 + j;
+        const int row = wl * 4 + (lane >> 4);
+        const int s = lane & 15;
+        const int f = (row & 3) | (((row >> 3) & 1) << 2);
+        const int c16 = ((((s >> 1) ^ f) << 1) | (s & 1));       // logical 16-B chunk (8 columns) fetched
+        srow[j] = row;
+        const int ca = m0 + c16 * 8, cb = n0 + c16 * 8;
+        colA[j] = (ca < p.M) ? (unsigned)(ca * 2) : EOE_OOB;
+        colB[j] = (cb < p.N) ? (unsigned)(cb * 2) : EOE_OOB;
+    }
+    auto stage = [&](int buf, int t0) {
+        char* sa = smem + buf * STAGE_BYTES;
+        char* sb = sa + TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int wl = wave * 4 + j;
+            const int t = t0 + srow[j];
+            const bool ok = t < t_end;
+            const unsigned oa = (ok && colA[j] != EOE_OOB) ? (unsigned)((size_t)t * p.lda * 2) + colA[j] : EOE_OOB;
+            const unsigned ob = (ok && colB[j] != EOE_OOB) ? (unsigned)((size_t)t * p.ldb * 2) + colB[j] : EOE_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(sa + wl * 1024), 16, oa, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(sb + wl * 1024), 16, ob, 0, 0, 0);
+        }
+    };
+
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int lr = lane & 15, lg = lane >> 4;
+    // transposed read: lane 4q+p of a 16-lane group addresses row q of the group's 4-row block, columns 4p..4p+3
+    const int q = lr >> 2, pp = lr & 3;
+    // k-step ks, read half h: row = 32*ks + 8*lg + 4*h + q ;  f(row) = q | ((lg&1)<<2)  (independent of ks, h)
+    const int f = q | ((lg & 1) << 2);
+    const int row_off = (8 * lg + q) * 256;
+    int colbyteA[4], colbyteB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        colbyteA[i] = ((((wm0 >> 4) + i) ^ f) << 5) + pp * 8;
+        colbyteB[i] = ((((wn0 >> 4) + i) ^ f) << 5) + pp * 8;
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (t_end - t_begin + BK - 1) / BK;
+    if (nk > 0) {
+        stage(0, t_begin);
+        __syncthreads();
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) stage(buf ^ 1, t_begin + (kt + 1) * BK);
+        const char* sa = smem + buf * STAGE_BYTES;
+        const char* sb = sa + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            typename T16<T>::v8 xa[4], wb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xa[i] = tr_frag<T>(sa, ks * 32 * 256 + row_off + colbyteA[i]);
+                wb[i] = tr_frag<T>(sb, ks * 32 * 256 + row_off + colbyteB[i]);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = T16<T>::mfma16(wb[ni], xa[mi], acc[mi][ni]);
+        }
+        __syncthreads();
+    }
+    if (gridDim.x > (unsigned)tiles) {
+        // split-T: fp32 atomic accumulation into C (caller zeroed C or accumulates into it)
+        const int lr2 = lane & 15, lg2 = lane >> 4;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int m = m0 + wm0 + mi * 16 + lr2;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = n0 + wn0 + ni * 16 + lg2 * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < p.N) atomicAdd((float*)p.C + (size_t)m * p.ldc + n + r, acc[mi][ni][r] * p.alpha);
+            }
+        }
+    } else {
+        epilogue<T, EPI>(p, acc, m0 + wm0, n0 + wn0, lane);
+    }
+}
+
+template <typename T>
+int launch_nt(const GemmP& p, int epi, hipStream_t s) {
+    const int grid = cdiv(p.M, BM) * cdiv(p.N, BN);
+#define EOE_NT_CASE(E)                                                                      \
+    case E:                                                                                 \
+        hipFuncSetAttribute((const void*)gemm_nt_kernel<T, E>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES); \
+        hipLaunchKernelGGL((gemm_nt_kernel<T, E>), dim3(grid), dim3(256), SMEM_BYTES, s, p); \
+        break;
+    switch (epi) {
+        EOE_NT_CASE(EOE_EPI_NONE)
+        EOE_NT_CASE(EOE_EPI_GELU)
+        EOE_NT_CASE(EOE_EPI_RESIDUAL)
+        EOE_NT_CASE(EOE_EPI_GELU_BWD)
+        default: return eoe_set_error(EOE_ERR_ARG, "gemm_nt: unknown epilogue %d", epi);
+    }
+#undef EOE_NT_CASE
+    EOE_CHECK_LAUNCH("gemm_nt");
+    return 0;
+}
+
+template <typename T>
+int launch_tn(const GemmP& p, int splits, hipStream_t s) {
+    const int tiles = cdiv(p.M, BM) * cdiv(p.N, BN);
+    int t_per = cdiv(cdiv(p.K, splits), BK) * BK;
+    if (t_per < BK) t_per = BK;
+    splits = cdiv(p.K, t_per);
+    if (splits < 1) splits = 1;
+    hipFuncSetAttribute((const void*)gemm_tn_kernel<T, EOE_EPI_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    hipLaunchKernelGGL((gemm_tn_kernel<T, EOE_EPI_NONE>), dim3(tiles * splits), dim3(256), SMEM_BYTES, s, p, t_per);
+    EOE_CHECK_LAUNCH("gemm_tn");
+    return 0;
+}
+
+int fill_params(const eoe_gemm_args* a, GemmP& p, bool tn) {
+    EOE_CHECK_ARG(a != nullptr, "gemm: null args");
+    EOE_CHECK_ARG(a->A && a->B && a->C, "gemm: null operand");
+    EOE_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "gemm: bad shape %d %d %d", a->M, a->N, a->K);
+    EOE_CHECK_ARG(a->dtype == EOE_F16 || a->dtype == EOE_BF16, "gemm: bad dtype %d", a->dtype);
+    EOE_CHECK_ARG((a->lda % 8) == 0 && (a->ldb % 8) == 0, "gemm: lda/ldb must be multiples of 8 (16-B rows)");
+    EOE_CHECK_ARG((((uintptr_t)a->A | (uintptr_t)a->B) & 15) == 0, "gemm: A/B must be 16-B aligned");
+    EOE_CHECK_ARG(!a->accumulate || a->out_f32, "gemm: accumulate needs an fp32 C");
+    p.A = a->A; p.B = a->B; p.C = a->C; p.bias = a->bias; p.aux = a->aux; p.aux_out = a->aux_out;
+    p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ldaux = a->ldaux;
+    p.out_f32 = a->out_f32; p.accumulate = a->accumulate; p.alpha = a->alpha;
+    size_t ba, bb;
+    if (!tn) {
+        EOE_CHECK_ARG((a->K % BK) == 0, "gemm_nt: K=%d must be a multiple of %d", a->K, BK);
+        EOE_CHECK_ARG(a->lda >= a->K && a->ldb >= a->K, "gemm_nt: leading dims smaller than K");
+        ba = ((size_t)(a->M - 1) * a->lda + a->K) * 2;
+        bb = ((size_t)(a->N - 1) * a->ldb + a->K) * 2;
+    } else {
+        EOE_CHECK_ARG((a->M % 8) == 0 && (a->N % 8) == 0, "gemm_tn: M, N must be multiples of 8");
+        EOE_CHECK_ARG(a->lda >= a->M && a->ldb >= a->N, "gemm_tn: leading dims smaller than M/N");
+        ba = ((size_t)(a->K - 1) * a->lda + a->M) * 2;
+        bb = ((size_t)(a->K - 1) * a->ldb + a->N) * 2;
+    }
+    EOE_CHECK_ARG(ba < 0x7fffffffull && bb < 0x7fffffffull, "gemm: operand larger than 2 GiB");
+    p.bytesA = (unsigned)ba; p.bytesB = (unsigned)bb;
+    if (a->epilogue == EOE_EPI_GELU) EOE_CHECK_ARG(a->aux_out && !a->out_f32, "gemm: GELU epilogue needs aux_out, 16-bit C");
+    if (a->epilogue == EOE_EPI_RESIDUAL) EOE_CHECK_ARG(a->aux && a->out_f32, "gemm: RESIDUAL epilogue needs aux, fp32 C");
+    if (a->epilogue == EOE_EPI_GELU_BWD) EOE_CHECK_ARG(a->aux, "gemm: GELU_BWD epilogue needs aux");
+    return 0;
+}
+
+}  // namespace
+
+// heuristic split of the wgrad reduction so that small outputs still fill the chip (fp32 atomics combine)
+int eoe_gemm_tn_splits(int M, int N, int T) {
+    const int tiles = cdiv(M, BM) * cdiv(N, BN);
+    int s = 1;
+    while (tiles * s < 384 && s < 16 && T / (s * 2) >= 512) s *= 2;
+    return s;
+}
+
+extern "C" int eoe_gemm_nt(const eoe_gemm_args* a, void* stream) {
+    GemmP p;
+    EOE_TRY(fill_params(a, p, false));
+    return a->dtype == EOE_F16 ? launch_nt<f16_t>(p, a->epilogue, (hipStream_t)stream)
+                               : launch_nt<bf16_t>(p, a->epilogue, (hipStream_t)stream);
+}
+
+extern "C" int eoe_gemm_tn(const eoe_gemm_args* a, void* stream) {
+    GemmP p;
+    EOE_TRY(fill_params(a, p, true));
+    EOE_CHECK_ARG(a->epilogue == EOE_EPI_NONE && a->out_f32, "gemm_tn: only plain fp32 output is supported");
+    int splits = eoe_gemm_tn_splits(a->M, a->N, a->K);
+    if (splits > 1 && !a->accumulate) {
+        // atomically combined partial sums need a zeroed destination
+        EOE_CHECK_ARG(a->ldc == a->N, "gemm_tn: split reduction needs a dense C");
+        if (hipMemsetAsync(a->C, 0, (size_t)a->M * a->N * sizeof(float), (hipStream_t)stream) != hipSuccess)
+            return eoe_set_error(EOE_ERR_LAUNCH, "gemm_tn: memset failed");
+    }
+    if (splits > 1 && a->bias) return eoe_set_error(EOE_ERR_ARG, "gemm_tn: bias with split reduction");
+    return a->dtype == EOE_F16 ? launch_tn<f16_t>(p, splits, (hipStream_t)stream)
+                               : launch_tn<bf16_t>(p, splits, (hipStream_t)stream);
+}

@@ -1,0 +1,112 @@
+// Fused launch chains for one ViT residual block (clip/model.py:167-188 and its backward): the host side only
+// enqueues kernels on the caller's stream; there is no host synchronisation and no allocation in here.
+#include <hip/hip_runtime.h>
+#include "../../include/eoe_hip.h"
+
+int eoe_set_error(int code, const char* fmt, ...);
+
+#define TRY(expr)                   \
+    do {                            \
+        int rc__ = (expr);          \
+        if (rc__ != 0) return rc__; \
+    } while (0)
+
+namespace {
+
+eoe_gemm_args gemm(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, int lda, int ldb,
+                   int ldc, int dtype) {
+    eoe_gemm_args g;
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = nullptr; g.aux_out = nullptr;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = 0;
+    g.dtype = dtype; g.epilogue = EOE_EPI_NONE; g.out_f32 = 0; g.accumulate = 0; g.alpha = 1.0f;
+    return g;
+}
+
+int check_fwd(const eoe_vit_block_fwd_args* a) {
+    if (!a) return eoe_set_error(EOE_ERR_ARG, "vit_block: null args");
+    if (a->n <= 0 || a->L <= 0 || a->L > 64 || a->heads <= 0 || a->D != a->heads * 64)
+        return eoe_set_error(EOE_ERR_ARG, "vit_block: unsupported shape n=%d L=%d D=%d heads=%d (need D = 64*heads, L <= 64)",
+                             a->n, a->L, a->D, a->heads);
+    if (!a->ln1_g || !a->ln1_b || !a->ln2_g || !a->ln2_b || !a->b_in || !a->b_out || !a->b_fc || !a->b_proj || !a->w_in ||
+        !a->w_out || !a->w_fc || !a->w_proj || !a->x_in || !a->x_mid || !a->x_out || !a->xn1 || !a->qkv || !a->att ||
+        !a->xn2 || !a->hpre || !a->hact || !a->stats1 || !a->stats2)
+        return eoe_set_error(EOE_ERR_ARG, "vit_block: null pointer in arguments");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int eoe_vit_block_fwd(const eoe_vit_block_fwd_args* a, void* stream) {
+    TRY(check_fwd(a));
+    const int M = a->n * a->L, D = a->D, H = 4 * a->D, dt = a->dtype;
+    // x_mid = x_in + out_proj(attn(ln_1(x_in)))
+    TRY(eoe_layernorm_fwd(a->x_in, D, a->ln1_g, a->ln1_b, a->xn1, a->stats1, M, D, a->eps, dt, 0, stream));
+    eoe_gemm_args g = gemm(a->xn1, a->w_in, a->qkv, a->b_in, M, 3 * D, D, D, D, 3 * D, dt);
+    TRY(eoe_gemm_nt(&g, stream));
+    TRY(eoe_attn_fwd(a->qkv, a->att, a->n, a->L, a->heads, dt, stream));
+    g = gemm(a->att, a->w_out, a->x_mid, a->b_out, M, D, D, D, D, D, dt);
+    g.epilogue = EOE_EPI_RESIDUAL; g.aux = a->x_in; g.ldaux = D; g.out_f32 = 1;
+    TRY(eoe_gemm_nt(&g, stream));
+    // x_out = x_mid + c_proj(quick_gelu(c_fc(ln_2(x_mid))))
+    TRY(eoe_layernorm_fwd(a->x_mid, D, a->ln2_g, a->ln2_b, a->xn2, a->stats2, M, D, a->eps, dt, 0, stream));
+    g = gemm(a->xn2, a->w_fc, a->hact, a->b_fc, M, H, D, D, D, H, dt);
+    g.epilogue = EOE_EPI_GELU; g.aux_out = a->hpre;
+    TRY(eoe_gemm_nt(&g, stream));
+    g = gemm(a->hact, a->w_proj, a->x_out, a->b_proj, M, D, H, H, H, D, dt);
+    g.epilogue = EOE_EPI_RESIDUAL; g.aux = a->x_mid; g.ldaux = D; g.out_f32 = 1;
+    TRY(eoe_gemm_nt(&g, stream));
+    return 0;
+}
+
+extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) {
+    if (!b) return eoe_set_error(EOE_ERR_ARG, "vit_block_bwd: null args");
+    const eoe_vit_block_fwd_args* a = &b->f;
+    TRY(check_fwd(a));
+    if (!a->w_in_t || !a->w_out_t || !a->w_fc_t || !a->w_proj_t || !b->dx_out || !b->dx_in || !b->g_ln1_g || !b->g_ln1_b ||
+        !b->g_ln2_g || !b->g_ln2_b || !b->g_b_in || !b->g_b_out || !b->g_b_fc || !b->g_b_proj || !b->g_w_in || !b->g_w_out ||
+        !b->g_w_fc || !b->g_w_proj || !b->d16_a || !b->d16_b || !b->dh || !b->dqkv || !b->dx_mid)
+        return eoe_set_error(EOE_ERR_ARG, "vit_block_bwd: null pointer in arguments");
+    const int M = a->n * a->L, D = a->D, H = 4 * a->D, dt = a->dtype, acc = b->accumulate;
+    hipStream_t s = (hipStream_t)stream;
+    if (!acc) {
+        // LayerNorm parameter gradients are accumulated with atomics
+        if (hipMemsetAsync(b->g_ln1_g, 0, D * sizeof(float), s) != hipSuccess || hipMemsetAsync(b->g_ln1_b, 0, D * sizeof(float), s) != hipSuccess ||
+            hipMemsetAsync(b->g_ln2_g, 0, D * sizeof(float), s) != hipSuccess || hipMemsetAsync(b->g_ln2_b, 0, D * sizeof(float), s) != hipSuccess)
+            return eoe_set_error(EOE_ERR_LAUNCH, "vit_block_bwd: memset failed");
+    }
+    eoe_gemm_args g;
+    // ---- MLP branch:  x_out = x_mid + c_proj(gelu(c_fc(ln_2(x_mid))))
+    TRY(eoe_cast(b->dx_out, b->d16_a, (size_t)M * D, dt, stream));
+    g = gemm(b->d16_a, a->w_proj_t, b->dh, nullptr, M, H, D, D, D, H, dt);                  // d hact, then * gelu'(hpre)
+    g.epilogue = EOE_EPI_GELU_BWD; g.aux = a->hpre; g.ldaux = H;
+    TRY(eoe_gemm_nt(&g, stream));
+    g = gemm(b->d16_a, a->hact, b->g_w_proj, nullptr, D, H, M, D, H, H, dt);                // dW_proj[D,4D] = dY^T hact
+    g.out_f32 = 1; g.accumulate = acc;
+    TRY(eoe_gemm_tn(&g, stream));
+    TRY(eoe_colsum(b->d16_a, D, b->g_b_proj, M, D, dt, acc, stream));
+    g = gemm(b->dh, a->w_fc_t, b->d16_b, nullptr, M, D, H, H, H, D, dt);                    // d xn2
+    TRY(eoe_gemm_nt(&g, stream));
+    g = gemm(b->dh, a->xn2, b->g_w_fc, nullptr, H, D, M, H, D, D, dt);                      // dW_fc[4D,D] = dh^T xn2
+    g.out_f32 = 1; g.accumulate = acc;
+    TRY(eoe_gemm_tn(&g, stream));
+    TRY(eoe_colsum(b->dh, H, b->g_b_fc, M, H, dt, acc, stream));
+    TRY(eoe_layernorm_bwd(b->d16_b, 0, a->x_mid, D, a->stats2, a->ln2_g, b->dx_out, b->dx_mid, D, b->d16_a, b->g_ln2_g,
+                          b->g_ln2_b, M, D, dt, stream));
+    // ---- attention branch:  x_mid = x_in + out_proj(attn(ln_1(x_in)))
+    g = gemm(b->d16_a, a->w_out_t, b->d16_b, nullptr, M, D, D, D, D, D, dt);                // d att
+    TRY(eoe_gemm_nt(&g, stream));
+    g = gemm(b->d16_a, a->att, b->g_w_out, nullptr, D, D, M, D, D, D, dt);                  // dW_out[D,D]
+    g.out_f32 = 1; g.accumulate = acc;
+    TRY(eoe_gemm_tn(&g, stream));
+    TRY(eoe_colsum(b->d16_a, D, b->g_b_out, M, D, dt, acc, stream));
+    TRY(eoe_attn_bwd(a->qkv, b->d16_b, b->dqkv, a->n, a->L, a->heads, dt, stream));
+    g = gemm(b->dqkv, a->w_in_t, b->d16_b, nullptr, M, D, 3 * D, 3 * D, 3 * D, D, dt);      // d xn1
+    TRY(eoe_gemm_nt(&g, stream));
+    g = gemm(b->dqkv, a->xn1, b->g_w_in, nullptr, 3 * D, D, M, 3 * D, D, D, dt);            // dW_in[3D,D]
+    g.out_f32 = 1; g.accumulate = acc;
+    TRY(eoe_gemm_tn(&g, stream));
+    TRY(eoe_colsum(b->dqkv, 3 * D, b->g_b_in, M, 3 * D, dt, acc, stream));
+    TRY(eoe_layernorm_bwd(b->d16_b, 0, a->x_in, D, a->stats1, a->ln1_g, b->dx_mid, b->dx_in, D, nullptr, b->g_ln1_g,
+                          b->g_ln1_b, M, D, dt, stream));
+    return 0;
+}

@@ -1,0 +1,3 @@
+from .clip_vit import VisualTransformer, ResidualAttentionBlock      # noqa: F401
+from .custom_base import CustomNet                                   # noqa: F401
+from .custom import ClipViTB32Custom                                 # noqa: F401

@@ -1,0 +1,483 @@
+"""Tensor-level wrappers and torch.autograd.Function bindings over the C ABI of libeoe_hip.so.
+
+PyTorch is used here for device memory, streams and the autograd tape only: every arithmetic operation below
+is a hand-written HIP kernel reached through ctypes (eoe_amd._lib).  All functions require CUDA (ROCm) tensors
+and raise otherwise -- there is no CPU path in this package.
+"""
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import lib, check, GemmArgs, EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_GELU_BWD
+
+# ------------------------------------------------------------------------------------------------ config
+_compute_dtype = torch.bfloat16
+
+
+def set_compute_dtype(dt):
+    """16-bit storage / MFMA operand type of activations and weight copies: torch.bfloat16 or torch.float16"""
+    global _compute_dtype
+    if isinstance(dt, str):
+        dt = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp16": torch.float16, "f16": torch.float16,
+              "float16": torch.float16}[dt]
+    if dt not in (torch.bfloat16, torch.float16):
+        raise ValueError(f"unsupported compute dtype {dt}")
+    _compute_dtype = dt
+
+
+def compute_dtype():
+    return _compute_dtype
+
+
+def dtype_code(dt) -> int:
+    if dt == torch.float16:
+        return _lib.EOE_F16
+    if dt == torch.bfloat16:
+        return _lib.EOE_BF16
+    raise ValueError(f"not a 16-bit compute dtype: {dt}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("eoe_amd ops need tensors on the GPU (there is no CPU fallback)")
+
+
+# ------------------------------------------------------------------------------------------------ raw ops
+def gemm_nt(a, b, out, bias=None, epilogue=EPI_NONE, aux=None, aux_out=None, accumulate=False, alpha=1.0):
+    """out[M,N] = a[M,K] @ b[N,K]^T  (+ epilogue); a, b 16-bit row-major (row stride may exceed K)"""
+    _chk(a, b, out, bias, aux, aux_out)
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K and out.shape == (M, N), (a.shape, b.shape, out.shape)
+    assert a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1 and a.dtype == b.dtype
+    g = GemmArgs(_p(a), _p(b), _p(out), _p(bias), _p(aux), _p(aux_out), M, N, K, a.stride(0), b.stride(0),
+                 out.stride(0), aux.stride(0) if aux is not None else 0, dtype_code(a.dtype), epilogue,
+                 1 if out.dtype == torch.float32 else 0, 1 if accumulate else 0, float(alpha))
+    check(lib.eoe_gemm_nt(C.byref(g), _stream()), "eoe_gemm_nt")
+    return out
+
+
+def gemm_tn(a, b, out, accumulate=False, alpha=1.0):
+    """out[M,N] (fp32) = a[T,M]^T @ b[T,N]; a, b 16-bit row-major"""
+    _chk(a, b, out)
+    T, M = a.shape
+    N = b.shape[1]
+    assert b.shape[0] == T and out.shape == (M, N) and out.dtype == torch.float32
+    assert a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1 and a.dtype == b.dtype
+    g = GemmArgs(_p(a), _p(b), _p(out), None, None, None, M, N, T, a.stride(0), b.stride(0), out.stride(0), 0,
+                 dtype_code(a.dtype), EPI_NONE, 1, 1 if accumulate else 0, float(alpha))
+    check(lib.eoe_gemm_tn(C.byref(g), _stream()), "eoe_gemm_tn")
+    return out
+
+
+def cast16(src: torch.Tensor, dtype=None, out=None):
+    _chk(src)
+    dtype = dtype or _compute_dtype
+    src = src.contiguous()
+    if out is None:
+        out = torch.empty(src.shape, dtype=dtype, device=src.device)
+    check(lib.eoe_cast(_p(src), _p(out), src.numel(), dtype_code(out.dtype), _stream()), "eoe_cast")
+    return out
+
+
+def cast_transpose(src: torch.Tensor, dtype=None, want=True, want_t=True):
+    """fp32 [R,C] -> (16-bit [R,C], 16-bit [C,R])"""
+    _chk(src)
+    dtype = dtype or _compute_dtype
+    src = src.contiguous()
+    R, Cc = src.shape
+    d = torch.empty((R, Cc), dtype=dtype, device=src.device) if want else None
+    dt = torch.empty((Cc, R), dtype=dtype, device=src.device) if want_t else None
+    check(lib.eoe_cast_transpose(_p(src), _p(d), _p(dt), R, Cc, dtype_code(dtype), _stream()), "eoe_cast_transpose")
+    return d, dt
+
+
+def colsum(x16: torch.Tensor, out: torch.Tensor, accumulate=False):
+    _chk(x16, out)
+    rows, cols = x16.shape
+    check(lib.eoe_colsum(_p(x16), x16.stride(0), _p(out), rows, cols, dtype_code(x16.dtype), 1 if accumulate else 0,
+                         _stream()), "eoe_colsum")
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, rows, D, ldx, out, stats, eps=1e-5):
+    _chk(x, gamma, beta, out, stats)
+    out_f32 = 1 if out.dtype == torch.float32 else 0
+    code = dtype_code(out.dtype) if not out_f32 else _lib.EOE_BF16
+    check(lib.eoe_layernorm_fwd(_p(x), ldx, _p(gamma), _p(beta), _p(out), _p(stats), rows, D, float(eps), code,
+                                out_f32, _stream()), "eoe_layernorm_fwd")
+    return out
+
+
+def layernorm_bwd(dy, x, stats, gamma, rows, D, ldx, dx_out, ld_out, dres=None, dx16=None, dgamma=None, dbeta=None):
+    _chk(dy, x, stats, gamma, dx_out, dres, dx16, dgamma, dbeta)
+    dy_f32 = 1 if dy.dtype == torch.float32 else 0
+    code = dtype_code(dy.dtype) if not dy_f32 else (dtype_code(dx16.dtype) if dx16 is not None else _lib.EOE_BF16)
+    check(lib.eoe_layernorm_bwd(_p(dy), dy_f32, _p(x), ldx, _p(stats), _p(gamma), _p(dres), _p(dx_out), ld_out,
+                                _p(dx16), _p(dgamma), _p(dbeta), rows, D, code, _stream()), "eoe_layernorm_bwd")
+    return dx_out
+
+
+def attn_fwd(qkv, out, n, L, heads):
+    _chk(qkv, out)
+    check(lib.eoe_attn_fwd(_p(qkv), _p(out), n, L, heads, dtype_code(qkv.dtype), _stream()), "eoe_attn_fwd")
+    return out
+
+
+def attn_bwd(qkv, dout, dqkv, n, L, heads):
+    _chk(qkv, dout, dqkv)
+    check(lib.eoe_attn_bwd(_p(qkv), _p(dout), _p(dqkv), n, L, heads, dtype_code(qkv.dtype), _stream()), "eoe_attn_bwd")
+    return dqkv
+
+
+def patchify(x, patch, mean=None, std=None, dtype=None):
+    _chk(x, mean, std)
+    dtype = dtype or _compute_dtype
+    x = x.contiguous().float()
+    n, c, res, res2 = x.shape
+    assert c == 3 and res == res2
+    g = res // patch
+    out = torch.empty((n * g * g, 3 * patch * patch), dtype=dtype, device=x.device)
+    check(lib.eoe_patchify(_p(x), _p(mean), _p(std), _p(out), n, res, patch, dtype_code(dtype), _stream()),
+          "eoe_patchify")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ weight copies
+class _Shadow:
+    """16-bit MFMA operand copies of fp32 master weights ([out,in] and transposed [in,out]), refreshed when the
+    parameter's version counter or storage changes (the fused optimiser bumps the counter)."""
+
+    def __init__(self):
+        self.cache = {}
+
+    def get(self, p: torch.Tensor, want=True, want_t=True, view2d=None):
+        key = id(p)
+        tag = (p._version, p.data_ptr(), _compute_dtype, want, want_t)
+        hit = self.cache.get(key)
+        if hit is not None and hit[0] == tag:
+            return hit[1], hit[2]
+        src = p.detach()
+        if view2d is not None:
+            src = src.reshape(view2d)
+        d, dt = cast_transpose(src, _compute_dtype, want, want_t)
+        self.cache[key] = (tag, d, dt)
+        return d, dt
+
+
+shadow = _Shadow()
+
+_scratch = {}
+
+
+def scratch(name, shape, dtype, device):
+    """persistent scratch buffers reused across calls (backward is sequential, one set per shape is enough)"""
+    key = (name, tuple(shape), dtype, device)
+    t = _scratch.get(key)
+    if t is None:
+        t = torch.empty(shape, dtype=dtype, device=device)
+        _scratch[key] = t
+    return t
+
+
+def _grad_target(p: torch.Tensor):
+    """where a parameter gradient is written: the parameter's registered arena view if it has one and is free
+    (p.grad is None), else a fresh tensor"""
+    buf = getattr(p, "_eoe_grad_buf", None)
+    if buf is not None and p.grad is None:
+        return buf
+    return torch.empty_like(p, memory_format=torch.contiguous_format)
+
+
+# ------------------------------------------------------------------------------------------------ autograd: linear
+class LinearFunction(torch.autograd.Function):
+    """y = x @ W^T + b with fp32 in/out, 16-bit MFMA operands (custom_base.py:25-26,47-48 final_linear)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _chk(x, weight, bias)
+        x2 = x.reshape(-1, x.shape[-1])
+        x16 = x2 if x2.dtype == _compute_dtype else cast16(x2.float())
+        w16, _ = shadow.get(weight, True, True)
+        out = torch.empty((x2.shape[0], weight.shape[0]), dtype=torch.float32, device=x.device)
+        gemm_nt(x16, w16, out, bias=bias)
+        ctx.save_for_backward(x16, weight, bias)
+        ctx.in_shape = x.shape
+        ctx.x_dtype = x.dtype
+        return out.reshape(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x16, weight, bias = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous().float()
+        d16 = cast16(dy2)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            _, w16t = shadow.get(weight, True, True)
+            dx = torch.empty((d16.shape[0], weight.shape[1]), dtype=torch.float32, device=dy.device)
+            gemm_nt(d16, w16t, dx)
+            dx = dx.reshape(ctx.in_shape).to(ctx.x_dtype)
+        if ctx.needs_input_grad[1]:
+            dw = _grad_target(weight)
+            gemm_tn(d16, x16, dw)
+        if bias is not None and ctx.needs_input_grad[2]:
+            db = _grad_target(bias)
+            colsum(d16, db)
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    return LinearFunction.apply(x, weight, bias)
+
+
+# ------------------------------------------------------------------------------------------------ autograd: ViT
+class VitEmbedFunction(torch.autograd.Function):
+    """images -> residual stream entering block 0 (clip/model.py:220-225): [normalise +] patchify, conv1 as a
+    GEMM, class/positional embedding, ln_pre.  Output fp32 [n*L, D]."""
+
+    @staticmethod
+    def forward(ctx, x, conv_w, cls, pos, g, b, patch, mean, std):
+        _chk(x, conv_w, cls, pos, g, b)
+        n = x.shape[0]
+        D = conv_w.shape[0]
+        L = pos.shape[0]
+        patches = patchify(x, patch, mean, std)
+        w16, _ = shadow.get(conv_w, True, False, view2d=(D, -1))
+        tok = torch.empty((patches.shape[0], D), dtype=torch.float32, device=x.device)
+        gemm_nt(patches, w16, tok)
+        x0 = torch.empty((n * L, D), dtype=torch.float32, device=x.device)
+        y = torch.empty_like(x0)
+        stats = torch.empty((n * L, 2), dtype=torch.float32, device=x.device)
+        check(lib.eoe_embed_lnpre_fwd(_p(tok), _p(cls), _p(pos), _p(g), _p(b), _p(x0), _p(y), _p(stats), n, L, D, 1e-5,
+                                      _stream()), "eoe_embed_lnpre_fwd")
+        ctx.save_for_backward(patches, x0, stats, conv_w, cls, pos, g, b)
+        ctx.dims = (n, L, D)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        patches, x0, stats, conv_w, cls, pos, g, b = ctx.saved_tensors
+        n, L, D = ctx.dims
+        dy = dy.contiguous()
+        dtok = torch.empty((n * (L - 1), D), dtype=patches.dtype, device=dy.device)
+        dcls, dpos, dg, db = (_grad_target(t) for t in (cls, pos, g, b))
+        for t in (dcls, dpos, dg, db):
+            t.zero_()
+        check(lib.eoe_embed_lnpre_bwd(_p(dy), _p(x0), _p(stats), _p(g), _p(dtok), _p(dcls), _p(dpos), _p(dg), _p(db),
+                                      n, L, D, dtype_code(patches.dtype), _stream()), "eoe_embed_lnpre_bwd")
+        dw = _grad_target(conv_w)
+        gemm_tn(dtok, patches, dw.view(D, -1))
+        return None, dw, dcls, dpos, dg, db, None, None, None
+
+
+_BLOCK_PARAMS = ("ln1_g", "ln1_b", "w_in", "b_in", "w_out", "b_out", "ln2_g", "ln2_b", "w_fc", "b_fc", "w_proj", "b_proj")
+
+
+def _block_ws(M, D, device, dtype):
+    """one allocation holding every activation a block saves for backward"""
+    es = 2
+    sizes = [("xn1", M * D * es), ("qkv", M * 3 * D * es), ("att", M * D * es), ("xn2", M * D * es),
+             ("hpre", M * 4 * D * es), ("hact", M * 4 * D * es), ("stats1", M * 2 * 4), ("stats2", M * 2 * 4),
+             ("x_mid", M * D * 4)]
+    offs, tot = {}, 0
+    for k, s in sizes:
+        offs[k] = tot
+        tot += (s + 255) // 256 * 256
+    buf = torch.empty(tot, dtype=torch.uint8, device=device)
+    base = buf.data_ptr()
+    return buf, {k: base + o for k, o in offs.items()}
+
+
+class VitBlockFunction(torch.autograd.Function):
+    """one ResidualAttentionBlock (clip/model.py:167-188) on the batch-major token matrix, fp32 residual stream
+    [n*L, D] in and out; a single C call launches the whole kernel chain."""
+
+    @staticmethod
+    def forward(ctx, x, n, heads, ln1_g, ln1_b, w_in, b_in, w_out, b_out, ln2_g, ln2_b, w_fc, b_fc, w_proj, b_proj):
+        _chk(x)
+        x = x.contiguous()
+        M, D = x.shape
+        L = M // n
+        ws, ptr = _block_ws(M, D, x.device, _compute_dtype)
+        x_out = torch.empty_like(x)
+        need_t = torch.is_grad_enabled()
+        sh = {k: shadow.get(w, True, True) for k, w in (("in", w_in), ("out", w_out), ("fc", w_fc), ("proj", w_proj))}
+        a = _lib.VitBlockFwdArgs()
+        a.n, a.L, a.D, a.heads, a.dtype, a.eps = n, L, D, heads, dtype_code(_compute_dtype), 1e-5
+        a.ln1_g, a.ln1_b, a.ln2_g, a.ln2_b = _p(ln1_g), _p(ln1_b), _p(ln2_g), _p(ln2_b)
+        a.b_in, a.b_out, a.b_fc, a.b_proj = _p(b_in), _p(b_out), _p(b_fc), _p(b_proj)
+        a.w_in, a.w_out, a.w_fc, a.w_proj = (_p(sh[k][0]) for k in ("in", "out", "fc", "proj"))
+        a.w_in_t, a.w_out_t, a.w_fc_t, a.w_proj_t = (_p(sh[k][1]) for k in ("in", "out", "fc", "proj"))
+        a.x_in, a.x_mid, a.x_out = _p(x), ptr["x_mid"], _p(x_out)
+        a.xn1, a.qkv, a.att, a.xn2, a.hpre, a.hact = (ptr[k] for k in ("xn1", "qkv", "att", "xn2", "hpre", "hact"))
+        a.stats1, a.stats2 = ptr["stats1"], ptr["stats2"]
+        check(lib.eoe_vit_block_fwd(C.byref(a), _stream()), "eoe_vit_block_fwd")
+        ctx.save_for_backward(x, ws, ln1_g, ln1_b, w_in, b_in, w_out, b_out, ln2_g, ln2_b, w_fc, b_fc, w_proj, b_proj)
+        ctx.args = a
+        ctx.shadows = sh          # keep the 16-bit copies used by this forward alive until backward
+        return x_out
+
+    @staticmethod
+    def backward(ctx, dx_out):
+        saved = ctx.saved_tensors
+        x, ws = saved[0], saved[1]
+        params = dict(zip(_BLOCK_PARAMS, saved[2:]))
+        M, D = x.shape
+        dev, dt = x.device, _compute_dtype if ctx.args.dtype == dtype_code(_compute_dtype) else None
+        dt = torch.float16 if ctx.args.dtype == _lib.EOE_F16 else torch.bfloat16
+        dx_out = dx_out.contiguous()
+        dx_in = torch.empty_like(x)
+        grads = {k: _grad_target(p) for k, p in params.items()}
+        b = _lib.VitBlockBwdArgs()
+        b.f = ctx.args
+        b.dx_out, b.dx_in = _p(dx_out), _p(dx_in)
+        b.g_ln1_g, b.g_ln1_b, b.g_ln2_g, b.g_ln2_b = (_p(grads[k]) for k in ("ln1_g", "ln1_b", "ln2_g", "ln2_b"))
+        b.g_b_in, b.g_b_out, b.g_b_fc, b.g_b_proj = (_p(grads[k]) for k in ("b_in", "b_out", "b_fc", "b_proj"))
+        b.g_w_in, b.g_w_out, b.g_w_fc, b.g_w_proj = (_p(grads[k]) for k in ("w_in", "w_out", "w_fc", "w_proj"))
+        b.accumulate = 0
+        b.d16_a = _p(scratch("d16_a", (M, D), dt, dev))
+        b.d16_b = _p(scratch("d16_b", (M, D), dt, dev))
+        b.dh = _p(scratch("dh", (M, 4 * D), dt, dev))
+        b.dqkv = _p(scratch("dqkv", (M, 3 * D), dt, dev))
+        b.dx_mid = _p(scratch("dx_mid", (M, D), torch.float32, dev))
+        check(lib.eoe_vit_block_bwd(C.byref(b), _stream()), "eoe_vit_block_bwd")
+        return (dx_in, None, None) + tuple(grads[k] for k in _BLOCK_PARAMS)
+
+
+class VitHeadFunction(torch.autograd.Function):
+    """ln_post on the class token + projection (clip/model.py:231-234): [n*L, D] fp32 -> [n, out] fp32"""
+
+    @staticmethod
+    def forward(ctx, x, n, g, b, proj):
+        _chk(x, g, b, proj)
+        x = x.contiguous()
+        M, D = x.shape
+        L = M // n
+        cls16 = torch.empty((n, D), dtype=_compute_dtype, device=x.device)
+        stats = torch.empty((n, 2), dtype=torch.float32, device=x.device)
+        layernorm_fwd(x, g, b, n, D, L * D, cls16, stats)
+        if proj is None:
+            raise RuntimeError("VisualTransformer without proj is not supported")
+        p16, p16t = shadow.get(proj, True, True)          # proj [D, out]; p16t [out, D]
+        out = torch.empty((n, proj.shape[1]), dtype=torch.float32, device=x.device)
+        gemm_nt(cls16, p16t, out)
+        ctx.save_for_backward(x, stats, cls16, g, b, proj)
+        ctx.dims = (n, L, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, stats, cls16, g, b, proj = ctx.saved_tensors
+        n, L, D = ctx.dims
+        d16 = cast16(dout.contiguous().float())
+        p16, _ = shadow.get(proj, True, True)
+        dcls = torch.empty((n, D), dtype=d16.dtype, device=x.device)
+        gemm_nt(d16, p16, dcls)                            # [n, out] @ proj[D, out]^T
+        dproj = _grad_target(proj)
+        gemm_tn(cls16, d16, dproj)                         # [D, out] = cls16^T d16
+        dx = torch.zeros_like(x)
+        dg, db = _grad_target(g), _grad_target(b)
+        dg.zero_()
+        db.zero_()
+        layernorm_bwd(dcls, x, stats, g, n, D, L * D, dx, L * D, dgamma=dg, dbeta=db)
+        return dx, None, dg, db, dproj
+
+
+# ------------------------------------------------------------------------------------------------ autograd: objectives
+class HscLossFunction(torch.autograd.Function):
+    """HSCTrainer.loss (hsc.py:17-21) as one fused head; inv_count = 1/N (or 1/global N under data parallel)"""
+
+    @staticmethod
+    def forward(ctx, feats, labels, nominal_label, inv_count):
+        _chk(feats, labels)
+        f = feats.contiguous().float()
+        n, d = f.shape
+        labels = labels.contiguous().to(torch.int64)
+        loss = torch.empty(1, dtype=torch.float32, device=f.device)
+        losses = torch.empty(n, dtype=torch.float32, device=f.device)
+        inv = float(inv_count) if inv_count is not None else 1.0 / n
+        check(lib.eoe_hsc_fwd(_p(f), _p(labels), int(nominal_label), _p(loss), None, None, _p(losses), n, d, inv,
+                              _stream()), "eoe_hsc_fwd")
+        ctx.save_for_backward(f, labels)
+        ctx.cfg = (int(nominal_label), inv)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        f, labels = ctx.saved_tensors
+        nominal, inv = ctx.cfg
+        n, d = f.shape
+        df = torch.empty_like(f)
+        gs = gout.contiguous().float().reshape(1)
+        check(lib.eoe_hsc_bwd(_p(f), _p(labels), nominal, _p(gs), _p(df), None, n, d, inv, _lib.EOE_BF16, _stream()),
+              "eoe_hsc_bwd")
+        return df, None, None, None
+
+
+def hsc_loss(feats, labels, nominal_label=0, inv_count=None):
+    return HscLossFunction.apply(feats, labels, nominal_label, inv_count)
+
+
+def hsc_score(feats):
+    """HSCTrainer.compute_anomaly_score (hsc.py:12-15)"""
+    _chk(feats)
+    f = feats.detach().contiguous().float()
+    n, d = f.shape
+    out = torch.empty(n, dtype=torch.float32, device=f.device)
+    check(lib.eoe_hsc_score(_p(f), _p(out), n, d, _stream()), "eoe_hsc_score")
+    return out
+
+
+class BceLossFunction(torch.autograd.Function):
+    """BCETrainer.loss (bce.py:19-20)"""
+
+    @staticmethod
+    def forward(ctx, feats, labels, inv_count):
+        _chk(feats, labels)
+        x = feats.contiguous().float().reshape(-1)
+        n = x.shape[0]
+        labels = labels.contiguous().to(torch.int64)
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        losses = torch.empty(n, dtype=torch.float32, device=x.device)
+        inv = float(inv_count) if inv_count is not None else 1.0 / n
+        check(lib.eoe_bce_fwd(_p(x), _p(labels), 0, _p(loss), None, _p(losses), n, inv, _stream()), "eoe_bce_fwd")
+        ctx.save_for_backward(x, labels)
+        ctx.inv = inv
+        ctx.shape = feats.shape
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, labels = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        gs = gout.contiguous().float().reshape(1)
+        check(lib.eoe_bce_bwd(_p(x), _p(labels), _p(gs), _p(dx), x.shape[0], ctx.inv, _stream()), "eoe_bce_bwd")
+        return dx.reshape(ctx.shape), None, None
+
+
+def bce_loss(feats, labels, inv_count=None):
+    return BceLossFunction.apply(feats, labels, inv_count)
+
+
+def bce_score(feats, nominal_label=0):
+    """BCETrainer.compute_anomaly_score (bce.py:15-17)"""
+    _chk(feats)
+    x = feats.detach().contiguous().float().reshape(-1)
+    n = x.shape[0]
+    out = torch.empty(n, dtype=torch.float32, device=x.device)
+    dummy = torch.zeros(n, dtype=torch.int64, device=x.device)
+    check(lib.eoe_bce_fwd(_p(x), _p(dummy), int(nominal_label), None, _p(out), None, n, 1.0, _stream()), "eoe_bce_fwd")
+    return out

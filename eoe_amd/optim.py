@@ -1,0 +1,108 @@
+"""Fused multi-tensor Adam: one kernel launch per step over a chunk table (C ABI `eoe_adam_multi`).
+
+Replaces `torch.optim.Adam(model.parameters(), lr=lr, weight_decay=wdk, amsgrad=False)` constructed inside the
+reference's `train_cls` (`src/eoe/training/ad_trainer.py:383`) with the same `torch.optim.Optimizer` API
+(`zero_grad / step / state_dict / load_state_dict / param_groups`, so `MultiStepLR` (:384) drives it unchanged)
+and the same arithmetic: L2-in-gradient weight decay, bias correction, eps 1e-8; parameters whose grad is None
+(frozen by `freeze_parts`, `ad_trainer.py:593-596`) are skipped and their step count does not advance.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+_CHUNK_DT = np.dtype([("p_off", "<i8"), ("g_off", "<i8"), ("m_off", "<i8"), ("v_off", "<i8"), ("n", "<i4"),
+                      ("group", "<i4")])
+assert _CHUNK_DT.itemsize == C.sizeof(_lib.AdamChunk)
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False):
+        if amsgrad:
+            raise NotImplementedError("amsgrad is not used by the reference trainer (ad_trainer.py:383)")
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False)
+        super().__init__(params, defaults)
+        self._tables = {}
+
+    def _init_state(self, group):
+        """exp_avg / exp_avg_sq of a whole group live in two flat arenas (one allocation each)"""
+        need = [p for p in group["params"] if p.requires_grad and "exp_avg" not in self.state[p]]
+        if not need:
+            return
+        tot = sum((p.numel() + 3) // 4 * 4 for p in need)
+        dev = need[0].device
+        m_arena = torch.zeros(tot, dtype=torch.float32, device=dev)
+        v_arena = torch.zeros(tot, dtype=torch.float32, device=dev)
+        off = 0
+        for p in need:
+            n = p.numel()
+            st = self.state[p]
+            st["step"] = torch.tensor(0.0, dtype=torch.float32)
+            st["exp_avg"] = m_arena[off:off + n].view(p.shape)
+            st["exp_avg_sq"] = v_arena[off:off + n].view(p.shape)
+            off += (n + 3) // 4 * 4
+
+    def _table(self, gi, active, steps):
+        """device chunk table for the active parameters of group gi, cached on pointers and step grouping"""
+        distinct = sorted(set(steps))
+        sig = (tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), p.numel()) for p in active),
+               tuple(distinct.index(s) for s in steps))
+        hit = self._tables.get(gi)
+        if hit is not None and hit[0] == sig:
+            return hit[1:], distinct
+        pb = min(p.data_ptr() for p in active)
+        gb = min(p.grad.data_ptr() for p in active)
+        mb = min(self.state[p]["exp_avg"].data_ptr() for p in active)
+        vb = min(self.state[p]["exp_avg_sq"].data_ptr() for p in active)
+        rows = []
+        for p, s in zip(active, steps):
+            st = self.state[p]
+            po, go = (p.data_ptr() - pb) // 4, (p.grad.data_ptr() - gb) // 4
+            mo, vo = (st["exp_avg"].data_ptr() - mb) // 4, (st["exp_avg_sq"].data_ptr() - vb) // 4
+            n = p.numel()
+            for c0 in range(0, n, _lib.ADAM_CHUNK):
+                rows.append((po + c0, go + c0, mo + c0, vo + c0, min(_lib.ADAM_CHUNK, n - c0), distinct.index(s)))
+        arr = np.array(rows, dtype=_CHUNK_DT)
+        tab = torch.from_numpy(arr.view(np.uint8).copy()).to(active[0].device)
+        self._tables[gi] = (sig, tab, len(rows), (pb, gb, mb, vb))
+        return (tab, len(rows), (pb, gb, mb, vb)), distinct
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            active = [p for p in group["params"] if p.grad is not None]
+            if not active:
+                continue
+            for p in active:
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
+                    raise RuntimeError("FusedAdam needs contiguous fp32 parameters and gradients on the GPU")
+            self._init_state(group)
+            steps = []
+            for p in active:
+                st = self.state[p]
+                st["step"] += 1
+                steps.append(int(st["step"].item()))
+            beta1, beta2 = group["betas"]
+            lr = float(group["lr"])
+            (tab, n_chunks, bases), distinct = self._table(gi, active, steps)
+            if len(distinct) > _lib.ADAM_GROUPS:
+                raise RuntimeError("FusedAdam: more than %d distinct step counts in one group" % _lib.ADAM_GROUPS)
+            sc = _lib.AdamScalars()
+            for i, s in enumerate(distinct):
+                bc1 = 1.0 - beta1 ** s
+                bc2 = 1.0 - beta2 ** s
+                sc.step_size[i] = lr / bc1
+                sc.bc2_sqrt[i] = math.sqrt(bc2)
+            check(lib.eoe_adam_multi(bases[0], bases[1], bases[2], bases[3], tab.data_ptr(), n_chunks, C.byref(sc),
+                                     float(beta1), float(beta2), float(group["eps"]), float(group["weight_decay"]),
+                                     None, _lib.EOE_BF16, torch.cuda.current_stream().cuda_stream), "eoe_adam_multi")
+            torch._C._increment_version(active)     # the kernel wrote in place: invalidate 16-bit weight copies
+        return loss

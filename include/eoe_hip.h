@@ -1,0 +1,209 @@
+/* eoe_hip.h -- C ABI of libeoe_hip.so: the MI355X (gfx950) kernels of the outlier-exposure AD training hot path.
+ *
+ * The reference (liznerski/eoe) is pure Python and has no FFI; its boundary for this path is the duck-typed
+ * torch.nn.Module / ADTrainer-hook interface.  Every entry point below names the
+ * reference call it replaces (path:line relative to /root/reference).  Conventions:
+ *   - plain pointers and sizes only; the caller (PyTorch) owns every buffer, including workspaces;
+ *   - every call takes the HIP stream to launch on (`void* stream` = hipStream_t);
+ *   - return 0 on success, non-zero on error; the message is in the thread-local eoe_last_error();
+ *   - "16-bit" buffers hold IEEE fp16 (EOE_F16) or bfloat16 (EOE_BF16), chosen per call with `dtype`;
+ *     accumulation, LayerNorm statistics, the residual stream, losses, gradients of parameters and the
+ *     optimiser state are fp32;
+ *   - token tensors are batch-major:  row = image * L + token  (the reference's LND permute,
+ *     clip/model.py:227,229, is value-preserving).
+ */
+#ifndef EOE_HIP_H
+#define EOE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EOE_ABI_VERSION 1
+
+enum { EOE_OK = 0, EOE_ERR_ARG = 1, EOE_ERR_LAUNCH = 2, EOE_ERR_UNSUPPORTED = 3 };
+enum { EOE_F16 = 1, EOE_BF16 = 2 };
+
+int eoe_abi_version(void);
+const char* eoe_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------
+ * GEMM (MFMA 16x16x32, LDS-staged 128x128x64 tiles, fp32 accumulate)
+ *   replaces: every nn.Linear / F.linear / conv1-as-GEMM / `x @ proj` on the path
+ *   (clip/model.py:171-178,220,233-234; custom_base.py:25-26,47-48) and their autograd backward
+ *   (ad_trainer.py:431).
+ *   NT:  C[M,N] = A[M,K] . B[N,K]^T            (forward: B = weight;  dgrad: B = transposed weight copy)
+ *   TN:  C[M,N] = A[T,M]^T . B[T,N]            (wgrad: A = dY, B = X, reduction over the T tokens)
+ * ---------------------------------------------------------------------------------------------------- */
+enum {
+    EOE_EPI_NONE = 0,      /* C = acc (+ bias)                                                         */
+    EOE_EPI_GELU = 1,      /* pre = acc + bias -> aux_out (16-bit);  C = pre * sigmoid(1.702 pre)      */
+    EOE_EPI_RESIDUAL = 2,  /* C(fp32) = acc + bias + aux(fp32 [M,N], leading dim ldaux)                */
+    EOE_EPI_GELU_BWD = 3   /* C = acc * d/dpre[pre sigmoid(1.702 pre)],  pre = aux (16-bit [M,N])      */
+};
+
+typedef struct {
+    const void* A;      /* 16-bit */
+    const void* B;      /* 16-bit */
+    void* C;            /* 16-bit, or fp32 if out_f32 */
+    const float* bias;  /* [N] fp32 or NULL */
+    const void* aux;    /* see epilogue */
+    void* aux_out;      /* see epilogue */
+    int32_t M, N, K;    /* for TN, K is the reduction length T */
+    int32_t lda, ldb, ldc, ldaux;   /* leading dimensions in elements */
+    int32_t dtype;      /* EOE_F16 | EOE_BF16 */
+    int32_t epilogue;   /* EOE_EPI_* */
+    int32_t out_f32;    /* C is fp32 */
+    int32_t accumulate; /* C += result (C must be fp32) */
+    float alpha;        /* result scale applied to acc before bias/epilogue (1.0 = none) */
+} eoe_gemm_args;
+
+int eoe_gemm_nt(const eoe_gemm_args* args, void* stream);
+int eoe_gemm_tn(const eoe_gemm_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * element-wise / reduction kernels (HBM-bound; wavefront-shuffle reductions)
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* fp32 [rows, cols] -> 16-bit copy [rows, cols] and (if dst_t != NULL) transposed 16-bit copy [cols, rows].
+ * Produces the MFMA operand copies of the fp32 master weights once per optimiser step. */
+int eoe_cast_transpose(const float* src, void* dst, void* dst_t, int rows, int cols, int dtype, void* stream);
+
+/* per-channel affine + patch extraction: x fp32 [n,3,res,res] (NCHW, as the reference feeds it,
+ * ad_trainer.py:411-429) -> 16-bit patch matrix [n*(res/p)^2, 3*p*p], column = c*p*p + ky*p + kx
+ * (the flattened conv1 weight order, clip/model.py:207,220).  mean/std NULL = already normalised
+ * (replaces transformations.py:126-138 applied at ad_trainer.py:413-425). */
+int eoe_patchify(const float* x, const float* mean, const float* std, void* out, int n, int res, int patch,
+                 int dtype, void* stream);
+
+/* token assembly + ln_pre (clip/model.py:223-225): tok fp32 [n*(L-1), D] patch embeddings,
+ * cls [D], pos [L, D] -> x0 fp32 [n*L, D] = cat(cls, tok) + pos (kept for backward),
+ * y fp32 [n*L, D] = LayerNorm(x0) (the residual stream entering block 0), stats [n*L, 2] = (mean, rstd). */
+int eoe_embed_lnpre_fwd(const float* tok, const float* cls, const float* pos, const float* gamma,
+                        const float* beta, float* x0, float* y, float* stats, int n, int L, int D, float eps,
+                        void* stream);
+/* backward of the above: dy fp32 [n*L, D] -> dtok 16-bit [n*(L-1), D] (operand of the conv1 wgrad GEMM),
+ * dcls[D] +=, dpos[L,D] +=, dgamma[D] +=, dbeta[D] += (fp32 atomics; caller zeroes or accumulates). */
+int eoe_embed_lnpre_bwd(const float* dy, const float* x0, const float* stats, const float* gamma, void* dtok,
+                        float* dcls, float* dpos, float* dgamma, float* dbeta, int n, int L, int D, int dtype,
+                        void* stream);
+
+/* LayerNorm over the last dim (clip/model.py:153-159, fp32 statistics, biased variance):
+ * x fp32 [rows, D] (row stride ldx elements) -> y 16-bit [rows, D] (GEMM operand) or fp32 if out_f32,
+ * stats [rows, 2]. */
+int eoe_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, void* y, float* stats,
+                      int rows, int D, float eps, int dtype, int out_f32, void* stream);
+/* dx_out[r, :] (fp32, row stride ld_out) = (dres ? dres[r, :] : 0) + LN'(dy)[r, :];  dx16 (optional) = 16-bit
+ * copy of dx_out (the next GEMM's operand); dgamma/dbeta += column sums.  dy is 16-bit, or fp32 if dy_f32. */
+int eoe_layernorm_bwd(const void* dy, int dy_f32, const float* x, int ldx, const float* stats,
+                      const float* gamma, const float* dres, float* dx_out, int ld_out, void* dx16,
+                      float* dgamma, float* dbeta, int rows, int D, int dtype, void* stream);
+
+/* out[c] (+)= sum_r x[r, c]  -- bias gradients (x 16-bit [rows, cols], row stride ldx). */
+int eoe_colsum(const void* x, int ldx, float* out, int rows, int cols, int dtype, int accumulate, void* stream);
+
+/* fp32 -> 16-bit copy of n contiguous elements */
+int eoe_cast(const float* src, void* dst, size_t n, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * multi-head self-attention over short sequences (L <= 64, head dim 64), one wavefront per (image, head):
+ *   replaces nn.MultiheadAttention(768, 12) inside ResidualAttentionBlock.attention
+ *   (clip/model.py:171,181-183), without mask or dropout.
+ * qkv 16-bit [n*L, 3*D] (q | k | v, each D = heads*64 wide), out 16-bit [n*L, D].
+ * ---------------------------------------------------------------------------------------------------- */
+int eoe_attn_fwd(const void* qkv, void* out, int n, int L, int heads, int dtype, void* stream);
+int eoe_attn_bwd(const void* qkv, const void* dout, void* dqkv, int n, int L, int heads, int dtype,
+                 void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * objectives (fused heads)
+ * ---------------------------------------------------------------------------------------------------- */
+/* HSC (hsc.py:12-21): f fp32 [n, d]; labels int64 [n]; per sample  dist = sqrt(|f|^2+1)-1,
+ * score = 1-exp(-dist), loss_i = dist if label==nominal else -log(score+1e-9);
+ * loss[0] = inv_count * sum_i loss_i  (inv_count = 1/n for the plain mean, 1/global_n under data parallel).
+ * Any of scores / dists / losses may be NULL. */
+int eoe_hsc_fwd(const float* f, const int64_t* labels, int64_t nominal_label, float* loss, float* scores,
+                float* dists, float* losses, int n, int d, float inv_count, void* stream);
+/* df fp32 [n,d] = gscale[0] * inv_count * dloss_i/df (gscale = upstream gradient of the scalar loss, device
+ * pointer or NULL = 1);  df16 (optional) = 16-bit copy. */
+int eoe_hsc_bwd(const float* f, const int64_t* labels, int64_t nominal_label, const float* gscale, float* df,
+                void* df16, int n, int d, float inv_count, int dtype, void* stream);
+/* score only (hsc.py:12-15; ad_trainer.py:434-436,505) */
+int eoe_hsc_score(const float* f, float* scores, int n, int d, void* stream);
+
+/* BCE with logits (bce.py:15-20): x fp32 [n] logits; loss[0] = inv_count * sum_i bce_i; scores = sigmoid(x)
+ * (1 - sigmoid if nominal_label != 0). */
+int eoe_bce_fwd(const float* x, const int64_t* labels, int64_t nominal_label, float* loss, float* scores,
+                float* losses, int n, float inv_count, void* stream);
+int eoe_bce_bwd(const float* x, const int64_t* labels, const float* gscale, float* dx, int n, float inv_count,
+                void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * fused multi-tensor Adam (ad_trainer.py:383: torch.optim.Adam(params, lr, weight_decay=wdk, amsgrad=False))
+ * One launch over a chunk table.  Per chunk: element offset into each of the four fp32 arenas
+ * (p, g, m, v may also be distinct allocations: offsets are relative to the pointers given here) and a length.
+ * L2-in-gradient weight decay, bias correction per step-count group (frozen parameters, whose grad is None,
+ * are simply not in the table and keep their step count: SURVEY.md section 7 "Adam details").
+ * shadow16 (optional, may be NULL): 16-bit copy of the updated parameter written at the same element offset.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int64_t p_off, g_off, m_off, v_off; /* element offsets */
+    int32_t n;                          /* elements in this chunk (<= EOE_ADAM_CHUNK) */
+    int32_t group;                      /* index into eoe_adam_scalars (parameters sharing a step count) */
+} eoe_adam_chunk;
+#define EOE_ADAM_CHUNK 8192
+#define EOE_ADAM_GROUPS 4
+typedef struct {                        /* per step-count group, computed on the host in double as torch does: */
+    float step_size[EOE_ADAM_GROUPS];   /*   lr / (1 - beta1**step)                                            */
+    float bc2_sqrt[EOE_ADAM_GROUPS];    /*   sqrt(1 - beta2**step)                                             */
+} eoe_adam_scalars;
+
+int eoe_adam_multi(float* p, const float* g, float* m, float* v, const eoe_adam_chunk* chunks /*device*/,
+                   int n_chunks, const eoe_adam_scalars* scalars /*host*/, float beta1, float beta2, float eps,
+                   float weight_decay, void* shadow16, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * fused ViT residual block (clip/model.py:167-188 ResidualAttentionBlock.forward and its backward):
+ * one call launches the whole kernel chain of a block on `stream` (no host round trips in between).
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t n, L, D, heads, dtype;   /* rows M = n*L; hidden = 4*D */
+    float eps;
+    /* parameters: fp32 vectors, 16-bit matrices (row-major [out, in]) and their transposes [in, out] */
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *b_in, *b_out, *b_fc, *b_proj;
+    const void *w_in, *w_out, *w_fc, *w_proj;           /* [3D,D] [D,D] [4D,D] [D,4D]   */
+    const void *w_in_t, *w_out_t, *w_fc_t, *w_proj_t;   /* [D,3D] [D,D] [D,4D] [4D,D]   */
+    /* activations (caller-allocated; saved for backward) */
+    const float* x_in;   /* fp32 [M,D] residual stream in */
+    float* x_mid;        /* fp32 [M,D] after attention */
+    float* x_out;        /* fp32 [M,D] residual stream out */
+    void *xn1, *qkv, *att, *xn2, *hpre, *hact;   /* 16-bit [M,D] [M,3D] [M,D] [M,D] [M,4D] [M,4D] */
+    float *stats1, *stats2;                      /* fp32 [M,2] */
+} eoe_vit_block_fwd_args;
+
+typedef struct {
+    eoe_vit_block_fwd_args f;   /* same parameters and saved activations as the forward */
+    const float* dx_out;        /* fp32 [M,D] gradient wrt x_out */
+    float* dx_in;               /* fp32 [M,D] gradient wrt x_in */
+    /* parameter gradients, fp32, overwritten (or += if accumulate) */
+    float *g_ln1_g, *g_ln1_b, *g_ln2_g, *g_ln2_b, *g_b_in, *g_b_out, *g_b_fc, *g_b_proj;
+    float *g_w_in, *g_w_out, *g_w_fc, *g_w_proj;
+    int32_t accumulate;
+    /* scratch (caller-allocated, 16-bit unless noted): */
+    void *d16_a;      /* [M,D]   16-bit copy of a residual-stream gradient */
+    void *d16_b;      /* [M,D]   */
+    void *dh;         /* [M,4D]  */
+    void *dqkv;       /* [M,3D]  */
+    float* dx_mid;    /* fp32 [M,D] */
+} eoe_vit_block_bwd_args;
+
+int eoe_vit_block_fwd(const eoe_vit_block_fwd_args* a, void* stream);
+int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* a, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EOE_HIP_H */

@@ -1,0 +1,244 @@
+"""GPU tier 2: every HIP op, called through the C ABI (ctypes), against the CPU oracle / fp64 math on the same
+seeded inputs; edge cases: ragged M / N / T tails, sequence shorter than the MFMA tile, accumulate, both dtypes."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import DTYPES, EPS16, t16, f32, assert_close, rel_rms   # noqa: E402
+from oracle import objectives, optim as ooptim, models as omodels, fill  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import eoe_amd.ops as o
+    return o
+
+
+def _qgelu(x):
+    return x * torch.sigmoid(1.702 * x)
+
+
+def _qgelu_grad(x):
+    s = torch.sigmoid(1.702 * x)
+    return s * (1 + 1.702 * x * (1 - s))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (200, 256, 192), (130, 136, 64), (50, 8, 64),
+                                   (12800, 768, 768), (392, 768, 3072), (4, 256, 512)])
+def test_gemm_nt_plain(ops, dtype, M, N, K):
+    a, ar = t16(f"nt/a{M}", (M, K), 1.0, dtype)
+    b, br = t16(f"nt/b{N}", (N, K), 1.0, dtype)
+    bias, biasr = f32("nt/bias", (N,), 1.0)
+    ref = ar.double() @ br.double().t() + biasr.double()
+    out = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    ops.gemm_nt(a, b, out, bias=bias)
+    assert_close(out, ref, 2e-6, 2e-5 * math.sqrt(K), f"gemm_nt f32 out {M}x{N}x{K}")
+    out16 = torch.empty((M, N), dtype=dtype, device="cuda")
+    ops.gemm_nt(a, b, out16, bias=bias)
+    assert_close(out16, ref, 2 * EPS16[dtype], 1e-4 * math.sqrt(K), f"gemm_nt 16-bit out {M}x{N}x{K}")
+    # accumulate + alpha
+    base, baser = f32("nt/base", (M, N), 1.0)
+    ops.gemm_nt(a, b, base, accumulate=True, alpha=0.5)
+    assert_close(base, baser.double() + 0.5 * (ar.double() @ br.double().t()), 2e-6, 2e-5 * math.sqrt(K), "gemm_nt accumulate")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_nt_strided_and_epilogues(ops, dtype):
+    M, N, K = 200, 256, 128
+    a, ar = t16("nte/a", (M, K + 64), 1.0, dtype)          # row stride larger than K
+    b, br = t16("nte/b", (N, K), 0.2, dtype)
+    bias, biasr = f32("nte/bias", (N,), 0.5)
+    res, resr = f32("nte/res", (M, N), 1.0)
+    acc = ar[:, :K].double() @ br.double().t() + biasr.double()
+    out = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    ops.gemm_nt(a[:, :K], b, out, bias=bias, epilogue=ops.EPI_RESIDUAL, aux=res)
+    assert_close(out, acc + resr.double(), 2e-6, 1e-4, "residual epilogue")
+    pre = torch.empty((M, N), dtype=dtype, device="cuda")
+    act = torch.empty((M, N), dtype=dtype, device="cuda")
+    ops.gemm_nt(a[:, :K], b, act, bias=bias, epilogue=ops.EPI_GELU, aux_out=pre)
+    assert_close(pre, acc, 2 * EPS16[dtype], 1e-4, "gelu epilogue: pre-activation")
+    assert_close(act, _qgelu(pre.float().cpu().double()), 2 * EPS16[dtype], 1e-4, "gelu epilogue: activation of the stored pre")
+    dz = torch.empty((M, N), dtype=dtype, device="cuda")
+    ops.gemm_nt(a[:, :K], b, dz, epilogue=ops.EPI_GELU_BWD, aux=pre)
+    ref = (ar[:, :K].double() @ br.double().t()) * _qgelu_grad(pre.float().cpu().double())
+    assert_close(dz, ref, 2 * EPS16[dtype], 2e-4, "gelu-backward epilogue")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T,M,N", [(64, 128, 128), (200, 256, 128), (50, 8, 16), (1000, 136, 264), (12800, 768, 768),
+                                   (12544, 768, 3072), (4, 256, 512), (4100, 128, 128)])
+def test_gemm_tn(ops, dtype, T, M, N):
+    a, ar = t16(f"tn/a{T}", (T, M), 1.0, dtype)
+    b, br = t16(f"tn/b{T}", (T, N), 1.0, dtype)
+    ref = ar.double().t() @ br.double()
+    out = torch.full((M, N), 7.0, dtype=torch.float32, device="cuda")
+    ops.gemm_tn(a, b, out)
+    assert_close(out, ref, 2e-6, 3e-5 * math.sqrt(T), f"gemm_tn {T}x{M}x{N}")
+    ops.gemm_tn(a, b, out, accumulate=True)
+    assert_close(out, 2 * ref, 4e-6, 6e-5 * math.sqrt(T), f"gemm_tn accumulate {T}x{M}x{N}")
+
+
+def test_gemm_rejects_bad_shapes(ops):
+    a = torch.zeros((8, 40), dtype=torch.bfloat16, device="cuda")
+    b = torch.zeros((8, 40), dtype=torch.bfloat16, device="cuda")
+    out = torch.zeros((8, 8), dtype=torch.float32, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt(a, b, out)          # K not a multiple of 64
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_cast_transpose_colsum(ops, dtype):
+    w, wr = f32("ct/w", (200, 136), 1.0)
+    d, dt = ops.cast_transpose(w, dtype)
+    assert torch.equal(d.cpu(), wr.to(dtype)) and torch.equal(dt.cpu(), wr.to(dtype).t().contiguous())
+    x, xr = t16("cs/x", (1000, 264), 1.0, dtype)
+    out = torch.full((264,), 3.0, dtype=torch.float32, device="cuda")
+    ops.colsum(x, out)
+    assert_close(out, xr.double().sum(0), 1e-5, 1e-3, "colsum")
+    ops.colsum(x, out, accumulate=True)
+    assert_close(out, 2 * xr.double().sum(0), 1e-5, 2e-3, "colsum accumulate")
+    c = ops.cast16(w, dtype)
+    assert torch.equal(c.cpu(), wr.to(dtype))
+    v, vr = f32("ct/v", (1027,), 1.0)
+    assert torch.equal(ops.cast16(v, dtype).cpu(), vr.to(dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_patchify(ops, dtype):
+    x, xr = f32("pf/x", (3, 3, 64, 64), 1.0)
+    mean = torch.tensor([0.1, -0.2, 0.3], device="cuda")
+    std = torch.tensor([0.5, 2.0, 1.5], device="cuda")
+    for use_norm in (False, True):
+        got = ops.patchify(x, 32, mean if use_norm else None, std if use_norm else None, dtype)
+        xx = (xr - mean.cpu().view(1, 3, 1, 1)) / std.cpu().view(1, 3, 1, 1) if use_norm else xr
+        ref = xx.reshape(3, 3, 2, 32, 2, 32).permute(0, 2, 4, 1, 3, 5).reshape(12, 3072)
+        assert_close(got, ref.to(dtype).float(), 2 * EPS16[dtype], 1e-6, f"patchify norm={use_norm}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,D", [(7, 768), (200, 768), (64, 256), (33, 1024)])
+def test_layernorm(ops, dtype, rows, D):
+    x, xr = f32("ln/x", (rows, D), 2.0, mean=0.5)
+    g, gr = f32("ln/g", (D,), 0.2, mean=1.0)
+    b, br = f32("ln/b", (D,), 0.2)
+    xr = xr.double().requires_grad_(True)
+    gr = gr.double().requires_grad_(True)
+    br = br.double().requires_grad_(True)
+    yr = omodels.layer_norm(xr, gr, br)
+    y32 = torch.empty((rows, D), dtype=torch.float32, device="cuda")
+    stats = torch.empty((rows, 2), dtype=torch.float32, device="cuda")
+    ops.layernorm_fwd(x, g, b, rows, D, D, y32, stats)
+    assert_close(y32, yr, 1e-5, 1e-5, "layernorm fwd f32")
+    y16 = torch.empty((rows, D), dtype=dtype, device="cuda")
+    ops.layernorm_fwd(x, g, b, rows, D, D, y16, stats)
+    assert_close(y16, yr, 2 * EPS16[dtype], 1e-5, "layernorm fwd 16-bit")
+    dy, dyr = t16("ln/dy", (rows, D), 1.0, dtype)
+    res, resr = f32("ln/res", (rows, D), 1.0)
+    (yr * dyr.double()).sum().backward()
+    dx = torch.empty((rows, D), dtype=torch.float32, device="cuda")
+    dx16 = torch.empty((rows, D), dtype=dtype, device="cuda")
+    dg = torch.zeros(D, dtype=torch.float32, device="cuda")
+    db = torch.zeros(D, dtype=torch.float32, device="cuda")
+    ops.layernorm_bwd(dy, x, stats, g, rows, D, D, dx, D, dres=res, dx16=dx16, dgamma=dg, dbeta=db)
+    assert_close(dx, xr.grad + resr.double(), 1e-4, 1e-4, "layernorm bwd dx")
+    assert_close(dx16, xr.grad + resr.double(), 2 * EPS16[dtype], 1e-4, "layernorm bwd dx16")
+    assert_close(dg, gr.grad, 1e-4, 1e-4 * math.sqrt(rows), "layernorm bwd dgamma")
+    assert_close(db, br.grad, 1e-4, 1e-4 * math.sqrt(rows), "layernorm bwd dbeta")
+
+
+def _attn_ref(qkv, n, L, heads):
+    D = heads * 64
+    q, k, v = qkv.reshape(n, L, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) / 8.0
+    return (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(n * L, D)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,L,heads", [(2, 50, 12), (3, 64, 2), (1, 17, 1), (5, 1, 3)])
+def test_attention(ops, dtype, n, L, heads):
+    D = heads * 64
+    qkv, qkvr = t16(f"att/qkv{L}", (n * L, 3 * D), 1.0, dtype)
+    do, dor = t16(f"att/do{L}", (n * L, D), 1.0, dtype)
+    qkvr = qkvr.double().requires_grad_(True)
+    ref = _attn_ref(qkvr, n, L, heads)
+    out = torch.empty((n * L, D), dtype=dtype, device="cuda")
+    ops.attn_fwd(qkv, out, n, L, heads)
+    # probabilities are rounded to 16 bit before P.V: tolerance of a few 16-bit ulps of the value scale
+    assert_close(out, ref, 4 * EPS16[dtype], 6 * EPS16[dtype], f"attention fwd L={L}")
+    (ref * dor.double()).sum().backward()
+    dqkv = torch.full((n * L, 3 * D), float("nan"), dtype=dtype, device="cuda")
+    ops.attn_bwd(qkv, do, dqkv, n, L, heads)
+    scale = qkvr.grad.abs().max().item()
+    assert_close(dqkv, qkvr.grad, 8 * EPS16[dtype], 8 * EPS16[dtype] * scale, f"attention bwd L={L}")
+    assert rel_rms(dqkv, qkvr.grad) < 3 * EPS16[dtype]
+
+
+def test_hsc_bce(ops):
+    import eoe_amd
+    for n, d in ((16, 256), (5, 100), (300, 256)):
+        f, fr = f32(f"hsc/f{n}", (n, d), 0.08)
+        y = torch.from_numpy(fill.fill_int(f"hsc/y{n}", (n,), 0, 2))
+        fg = f.clone().requires_grad_(True)
+        loss = eoe_amd.hsc_loss(fg, y.cuda())
+        (loss * 1.5).backward()
+        frr = fr.double().requires_grad_(True)
+        lref = objectives.hsc_loss(frr, y)
+        (lref * 1.5).backward()
+        assert abs(loss.item() - lref.item()) <= 2e-6 * max(1, abs(lref.item()))
+        assert_close(fg.grad, frr.grad, 1e-5, 1e-9, "hsc grad")
+        assert_close(eoe_amd.hsc_score(f), objectives.hsc_score(fr.double()), 1e-5, 1e-7, "hsc score")
+        # data-parallel normalisation: sum / global count
+        l2 = eoe_amd.hsc_loss(f, y.cuda(), 0, 1.0 / (4 * n))
+        assert abs(l2.item() - lref.item() / 4) <= 2e-6
+    z = torch.zeros(2, 256, device="cuda")
+    assert eoe_amd.hsc_loss(z, torch.zeros(2, dtype=torch.long, device="cuda")).item() == 0.0
+    assert abs(eoe_amd.hsc_loss(z, torch.ones(2, dtype=torch.long, device="cuda")).item() - 20.7233) < 1e-3
+    for n in (16, 300):
+        x, xr = f32(f"bce/x{n}", (n, 1), 3.0)
+        y = torch.from_numpy(fill.fill_int(f"bce/y{n}", (n,), 0, 2))
+        xg = x.clone().requires_grad_(True)
+        loss = eoe_amd.bce_loss(xg, y.cuda())
+        loss.backward()
+        xrr = xr.double().requires_grad_(True)
+        lref = objectives.bce_loss(xrr, y)
+        lref.backward()
+        assert abs(loss.item() - lref.item()) <= 2e-6 * max(1, abs(lref.item()))
+        assert_close(xg.grad, xrr.grad, 1e-5, 1e-9, "bce grad")
+        assert_close(eoe_amd.bce_score(x), objectives.bce_score(xr.double()), 1e-5, 1e-7, "bce score")
+
+
+@pytest.mark.parametrize("wd", [0.0, 1e-3])
+def test_fused_adam(golden, wd):
+    import eoe_amd
+    g = golden("g8_adam")
+    shapes = ((7, 5), (33,), (4, 3, 2))
+    ps = [torch.nn.Parameter(torch.from_numpy(fill.fill(f"g8/p{i}", s, std=0.5)).cuda()) for i, s in enumerate(shapes)]
+    opt = eoe_amd.FusedAdam(ps, lr=1e-2, weight_decay=wd)
+    for t in range(5):
+        opt.zero_grad()
+        for i, p in enumerate(ps):
+            if i == 1 and t in (1, 2):
+                p.grad = None
+            else:
+                p.grad = torch.from_numpy(fill.fill(f"g8/g{i}/t{t}", tuple(p.shape), std=0.1)).cuda()
+        opt.step()
+    for i, p in enumerate(ps):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"wd{wd}/p{i}"], rtol=3e-6, atol=1e-6)
+    # big, unaligned sizes against the oracle
+    big = [torch.nn.Parameter(torch.from_numpy(fill.fill(f"ad/p{i}", (n,), std=0.5)).cuda()) for i, n in enumerate((70001, 8192, 3))]
+    ref = [p.detach().cpu().clone() for p in big]
+    st = ooptim.AdamState(ref)
+    opt = eoe_amd.FusedAdam(big, lr=3e-3, weight_decay=wd)
+    for t in range(3):
+        gs = [torch.from_numpy(fill.fill(f"ad/g{i}/{t}", tuple(p.shape), std=0.1)) for i, p in enumerate(big)]
+        for p, gg in zip(big, gs):
+            p.grad = gg.cuda()
+        opt.step()
+        ooptim.adam_step(ref, gs, st, lr=3e-3, weight_decay=wd)
+    for p, r in zip(big, ref):
+        assert_close(p, r, 3e-6, 1e-6, "fused adam vs oracle")
