@@ -1,0 +1,177 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: training images/sec, CLIP ViT-B/32 + HSC, 224x224 (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the reference's inner loop (`src/eoe/training/ad_trainer.py:428-436`) over one synthetic
+step batch of 128 normal + 128 OE already-normalised images per GPU: zero_grad -> encoder forward -> HSC loss ->
+backward -> (gradient all-reduce) -> Adam -> anomaly scores from the pre-step features.  Inputs are resident in HBM
+before the timed region.  Rank 0 prints ONE JSON line (contract in the task description), with two extra objects:
+  roofline     -- the dominant kernel family's achieved TFLOP/s (algorithmic flops / hipEvent-measured launch time,
+                  collected in a separate profiled pass inside this run) against the dense 16-bit MFMA peak;
+  cpu_baseline -- the CPU oracle (a port of the reference step: oracle/) timed on this host's cores on a bounded
+                  sample (N=1, rank 0 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0    # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+HBM_PEAK_GBS = 8000.0
+FWD_GFLOP_PER_IMG = 8.818    # ViT-B/32 image tower forward, 2 flop per MAC
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="normal images per GPU per step (an equal OE half is added)")
+    ap.add_argument("--mode", choices=["full", "frozen"], default="full",
+                    help="full fine-tune (config 5 style) or frozen encoder + trained head (config 4)")
+    ap.add_argument("--dtype", choices=["fp16", "bf16"], default="fp16")
+    ap.add_argument("--layers", type=int, default=12)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--cpu-steps", type=int, default=4)
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """the CPU oracle (port of the reference step) on a bounded sample: N=cpu_batch images, 1 warm-up + cpu_steps"""
+    import torch
+    from oracle import models as omodels, trainer as otrainer
+    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))   # the GPU box grants 16 host cores per GPU
+    m = omodels.ClipViTNet(layers=args.layers, freeze=(args.mode == "frozen"))
+    omodels.deterministic_init(m, tag="bench", layers=args.layers)
+    nh = args.cpu_batch // 2
+    batch = otrainer.synthetic_batch("bench/cpu", nh, nh, 224)
+    otrainer.train_steps(m, [batch], "hsc", lr=1e-4, weight_decay=1e-3)          # warm-up
+    t0 = time.perf_counter()
+    otrainer.train_steps(m, [batch] * args.cpu_steps, "hsc", lr=1e-4, weight_decay=1e-3)
+    dt = time.perf_counter() - t0
+    return {"value": round(args.cpu_steps * 2 * nh / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{args.cpu_steps} steps of {2 * nh} images (ViT-B/32 {args.layers} layers, {args.mode}, fp32 oracle)"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import eoe_amd
+    from eoe_amd import _lib, parallel
+    from eoe_amd.models import ClipViTB32Custom
+
+    rank, world, local = parallel.init_from_env("nccl")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    eoe_amd.set_compute_dtype(args.dtype)
+
+    torch.manual_seed(0)
+    model = ClipViTB32Custom(prediction_head=True, clf=False, freeze=(args.mode == "frozen"), layers=args.layers).to(dev).train()
+    opt = eoe_amd.FusedAdam(model.parameters(), lr=1e-4, weight_decay=1e-3)     # train_clip_imagenet.py:13-14
+    model.freeze_parts()
+    arena = parallel.GradArena(model)
+    if world > 1:
+        arena.install_hooks()
+
+    nb = args.batch
+    n_local = 2 * nb
+    n_global = n_local * world
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    imgs = torch.randn((n_local, 3, 224, 224), generator=gen, device=dev)
+    imgs[nb:] += 0.5 * torch.randn((1, 3, 224, 224), generator=torch.Generator(device=dev).manual_seed(7), device=dev)
+    lbls = torch.cat([torch.zeros(nb, dtype=torch.int64), torch.ones(nb, dtype=torch.int64)]).to(dev)
+    score_buf = torch.empty((args.steps + args.warmup + 8, n_local), dtype=torch.float32, device=dev)
+
+    def step(i):
+        opt.zero_grad()
+        feats = model(imgs)
+        loss = eoe_amd.hsc_loss(feats, lbls, 0, 1.0 / n_global)
+        loss.backward()
+        arena.finish()
+        opt.step()
+        score_buf[i % score_buf.shape[0]] = eoe_amd.hsc_score(feats)
+        return loss
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        loss = step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    final_loss = loss.item()
+    assert final_loss == final_loss, "NaN loss"
+
+    roof = None
+    if not args.no_roofline:
+        # separate profiled pass: hipEvents around every kernel launch (inside the library, on the launch stream)
+        _lib.prof_enable(True)
+        for i in range(3):
+            step(i)
+        torch.cuda.synchronize()
+        _lib.prof_enable(False)
+        prof = _lib.prof_collect()
+        gemm = {k: v for k, v in prof.items() if k.startswith("gemm")}
+        tot_ms = sum(v["total_ms"] for v in prof.values())
+        dom = max(gemm, key=lambda k: gemm[k]["total_ms"])
+        d = gemm[dom]
+        achieved = d["flops"] / (d["total_ms"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "avg_launch_us": round(d["total_ms"] * 1e3 / d["launches"], 2), "launches_per_step": d["launches"] // 3,
+                "kernels_ms_per_step": {k: round(v["total_ms"] / 3, 3) for k, v in sorted(prof.items())},
+                "profiled_ms_per_step": round(tot_ms / 3, 3)}
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = n_global * args.steps / elapsed
+        flop_per_img = FWD_GFLOP_PER_IMG * (3.0 if args.mode == "full" else 1.0) * args.layers / 12.0
+        out = {
+            "metric": "train images/sec, CLIP ViT-B/32 + HSC, 224x224",
+            "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"CLIP ViT-B/32 ({args.layers} layers) + Linear(512,256) + HSC, "
+                                   f"{'full fine-tune' if args.mode == 'full' else 'frozen encoder'}, Adam lr 1e-4 wd 1e-3, "
+                                   f"224x224, {nb} normal + {nb} OE images per GPU per step",
+                       "global_batch": n_global, "parallelism": f"dp{world}"},
+            "model_tflops": round(value * flop_per_img / 1e3, 1),
+            "mfma_roofline_frac_end_to_end": round(value * flop_per_img / 1e3 / (MFMA_PEAK_TFLOPS * world), 4),
+            "final_loss": round(final_loss, 5),
+        }
+        if roof is not None:
+            out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

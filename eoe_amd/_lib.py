@@ -29,6 +29,11 @@ class AdamScalars(C.Structure):
     _fields_ = [("step_size", _f32 * ADAM_GROUPS), ("bc2_sqrt", _f32 * ADAM_GROUPS)]
 
 
+class ProfEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("launches", _i64), ("total_ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
 class VitBlockFwdArgs(C.Structure):
     _fields_ = [("n", _i32), ("L", _i32), ("D", _i32), ("heads", _i32), ("dtype", _i32), ("eps", _f32),
                 ("ln1_g", _vp), ("ln1_b", _vp), ("ln2_g", _vp), ("ln2_b", _vp),
@@ -75,6 +80,8 @@ SIGNATURES = {
                        _vp],
     "eoe_vit_block_fwd": [C.POINTER(VitBlockFwdArgs), _vp],
     "eoe_vit_block_bwd": [C.POINTER(VitBlockBwdArgs), _vp],
+    "eoe_prof_enable": [C.c_int],
+    "eoe_prof_collect": [C.POINTER(ProfEntry), C.c_int, C.POINTER(C.c_int)],
 }
 _RESTYPES = {"eoe_last_error": C.c_char_p}
 
@@ -116,3 +123,19 @@ def check(rc: int, what: str = ""):
     if rc != 0:
         msg = lib.eoe_last_error()
         raise EoeError(f"{what}: error {rc}: {msg.decode() if msg else ''}")
+
+
+def prof_enable(on: bool):
+    check(lib.eoe_prof_enable(1 if on else 0), "eoe_prof_enable")
+
+
+def prof_collect():
+    """{kernel name: dict(launches, total_ms, flops, bytes)} for everything recorded since prof_enable(True)"""
+    buf = (ProfEntry * 64)()
+    n = C.c_int(0)
+    check(lib.eoe_prof_collect(buf, 64, C.byref(n)), "eoe_prof_collect")
+    return {buf[i].name.decode(): dict(launches=buf[i].launches, total_ms=buf[i].total_ms, flops=buf[i].flops,
+                                       bytes=buf[i].bytes) for i in range(n.value)}
+
+
+

@@ -355,6 +355,7 @@ extern "C" int eoe_attn_fwd(const void* qkv, void* out, int n, int L, int heads,
     EOE_CHECK_ARG(qkv && out && n > 0 && heads > 0, "attn_fwd: bad args");
     EOE_CHECK_ARG(L >= 1 && L <= 64, "attn: sequence length %d not in [1, 64]", L);
     const float scale = 0.125f;   // 1/sqrt(64)
+    ProfScope ps("attn_fwd", 4.0 * n * heads * (double)L * L * 64, 2.0 * (double)n * L * heads * 64 * 4, stream);
     if (dtype == EOE_F16)
         hipLaunchKernelGGL((attn_fwd_kernel<f16_t>), dim3(n * heads), dim3(64), 0, (hipStream_t)stream,
                            (const f16_t*)qkv, (f16_t*)out, L, heads, scale);
@@ -372,6 +373,7 @@ extern "C" int eoe_attn_bwd(const void* qkv, const void* dout, void* dqkv, int n
     EOE_CHECK_ARG(qkv && dout && dqkv && n > 0 && heads > 0, "attn_bwd: bad args");
     EOE_CHECK_ARG(L >= 1 && L <= 64, "attn: sequence length %d not in [1, 64]", L);
     const float scale = 0.125f;
+    ProfScope ps("attn_bwd", 14.0 * n * heads * (double)L * L * 64, 2.0 * (double)n * L * heads * 64 * 7, stream);
     if (dtype == EOE_F16)
         hipLaunchKernelGGL((attn_bwd_kernel<f16_t>), dim3(n * heads), dim3(64), 0, (hipStream_t)stream,
                            (const f16_t*)qkv, (const f16_t*)dout, (f16_t*)dqkv, L, heads, scale);

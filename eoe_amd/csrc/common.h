@@ -31,6 +31,18 @@ int eoe_set_error(int code, const char* fmt, ...);
         if (rc__ != 0) return rc__; \
     } while (0)
 
+// in-library kernel timing (api.cpp): a scope brackets the launches of one entry point with hipEvents
+bool eoe_prof_active();
+int eoe_prof_begin(const char* name, double flops, double bytes, hipStream_t s);
+void eoe_prof_finish(int idx, hipStream_t s);
+struct ProfScope {
+    int idx; hipStream_t s;
+    ProfScope(const char* name, double flops, double bytes, void* stream) : idx(-1), s((hipStream_t)stream) {
+        if (eoe_prof_active()) idx = eoe_prof_begin(name, flops, bytes, s);
+    }
+    ~ProfScope() { if (idx >= 0) eoe_prof_finish(idx, s); }
+};
+
 // ---------------------------------------------------------------------------------------------------
 // 16-bit element types: one code path templated on the storage/MFMA type
 // ---------------------------------------------------------------------------------------------------

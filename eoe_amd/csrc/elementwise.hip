@@ -514,6 +514,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(float* __restrict__ p, 
 
 extern "C" int eoe_cast(const float* src, void* dst, size_t n, int dtype, void* stream) {
     EOE_CHECK_ARG(src && dst, "cast: null pointer");
+    ProfScope ps("cast", 0, 6.0 * n, stream);
     if (n == 0) return 0;
     int grid = (int)((n / 4 + 255) / 256);
     if (grid > 4096) grid = 4096;
@@ -526,6 +527,7 @@ extern "C" int eoe_cast(const float* src, void* dst, size_t n, int dtype, void* 
 extern "C" int eoe_cast_transpose(const float* src, void* dst, void* dst_t, int rows, int cols, int dtype,
                                   void* stream) {
     EOE_CHECK_ARG(src && (dst || dst_t) && rows > 0 && cols > 0, "cast_transpose: bad args");
+    ProfScope ps("cast_transpose", 0, ((dst ? 2.0 : 0.0) + (dst_t ? 2.0 : 0.0) + 4.0) * rows * cols, stream);
     dim3 grid(cdiv(cols, 64), cdiv(rows, 64));
     DISPATCH_T(dtype, hipLaunchKernelGGL((cast_transpose_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, src,
                                          (T*)dst, (T*)dst_t, rows, cols));
@@ -538,6 +540,7 @@ extern "C" int eoe_patchify(const float* x, const float* mean, const float* stdv
     EOE_CHECK_ARG(x && out && n > 0, "patchify: bad args");
     EOE_CHECK_ARG(res % patch == 0 && patch % 4 == 0, "patchify: res %% patch != 0 or patch %% 4 != 0");
     EOE_CHECK_ARG((mean == nullptr) == (stdv == nullptr), "patchify: mean/std must both be given or both NULL");
+    ProfScope ps("patchify", 0, 6.0 * n * 3 * res * res, stream);
     const int g = res / patch;
     DISPATCH_T(dtype, hipLaunchKernelGGL((patchify_kernel<T>), dim3(n * g), dim3(256), 0, (hipStream_t)stream, x, mean,
                                          stdv, (T*)out, res, patch));
@@ -549,6 +552,7 @@ extern "C" int eoe_layernorm_fwd(const float* x, int ldx, const float* gamma, co
                                  float* stats, int rows, int D, float eps, int dtype, int out_f32, void* stream) {
     EOE_CHECK_ARG(x && gamma && beta && y && rows > 0, "layernorm_fwd: bad args");
     EOE_CHECK_ARG(D % 256 == 0 && D <= 1024 && ldx % 4 == 0, "layernorm: D must be a multiple of 256, <= 1024");
+    ProfScope ps("layernorm_fwd", 0, (4.0 + (out_f32 ? 4.0 : 2.0)) * rows * D, stream);
     DISPATCH_T(dtype, DISPATCH_NV(D, hipLaunchKernelGGL((layernorm_fwd_kernel<T, NV>), dim3(cdiv(rows, 4)), dim3(256), 0,
                                          (hipStream_t)stream, x, ldx, gamma, beta, y, stats, rows, D, eps, out_f32)));
     EOE_CHECK_LAUNCH("layernorm_fwd");
@@ -561,6 +565,7 @@ extern "C" int eoe_layernorm_bwd(const void* dy, int dy_f32, const float* x, int
     EOE_CHECK_ARG(dy && x && stats && gamma && dx_out && rows > 0, "layernorm_bwd: bad args");
     EOE_CHECK_ARG(D % 256 == 0 && D <= 1024 && ldx % 4 == 0 && ld_out % 4 == 0, "layernorm: D must be a multiple of 256, <= 1024");
     EOE_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma/dbeta must both be given or both NULL");
+    ProfScope ps("layernorm_bwd", 0, ((dy_f32 ? 4.0 : 2.0) + 4.0 + (dres ? 4.0 : 0.0) + 4.0 + (dx16 ? 2.0 : 0.0)) * rows * D, stream);
     int grid = cdiv(rows, 4);
     if (grid > 512) grid = 512;
     DISPATCH_T(dtype, DISPATCH_NV(D, hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy,
@@ -597,6 +602,7 @@ extern "C" int eoe_colsum(const void* x, int ldx, float* out, int rows, int cols
                           void* stream) {
     EOE_CHECK_ARG(x && out && rows > 0 && cols > 0, "colsum: bad args");
     EOE_CHECK_ARG(cols % 4 == 0 && ldx % 4 == 0, "colsum: cols and ldx must be multiples of 4");
+    ProfScope ps("colsum", 0, 2.0 * rows * cols, stream);
     if (!accumulate) {
         if (hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), (hipStream_t)stream) != hipSuccess)
             return eoe_set_error(EOE_ERR_LAUNCH, "colsum: memset failed");
@@ -668,6 +674,7 @@ extern "C" int eoe_adam_multi(float* p, const float* g, float* m, float* v, cons
                               int n_chunks, const eoe_adam_scalars* scalars, float beta1, float beta2, float eps,
                               float weight_decay, void* shadow16, int dtype, void* stream) {
     EOE_CHECK_ARG(p && g && m && v && chunks && scalars && n_chunks > 0, "adam_multi: bad args");
+    ProfScope ps("adam_multi", 0, 28.0 * n_chunks * EOE_ADAM_CHUNK, stream);
     if (!shadow16) dtype = EOE_BF16;
     const eoe_adam_scalars sc = *scalars;
     DISPATCH_T(dtype, hipLaunchKernelGGL((adam_multi_kernel<T>), dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, p, g,

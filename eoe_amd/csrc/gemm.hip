@@ -12,6 +12,7 @@
 // consecutive output COLUMNS of one output row (D: col = lane&15 -> m, row = 4*(lane>>4)+r -> n): epilogue
 // loads/stores are 8-B (16-bit) or 16-B (fp32) vectors along the contiguous dimension.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -370,6 +371,10 @@ int fill_params(const eoe_gemm_args* a, GemmP& p, bool tn) {
     }
     EOE_CHECK_ARG(ba < 0x7fffffffull && bb < 0x7fffffffull, "gemm: operand larger than 2 GiB");
     p.bytesA = (unsigned)ba; p.bytesB = (unsigned)bb;
+    // diagnostics only: EOE_GEMM_DEBUG=1 makes every operand load out of range (zero-filled, nothing fetched), which
+    // times the LDS/MFMA/epilogue side of the kernel alone (results are then wrong by construction)
+    static const int dbg = getenv("EOE_GEMM_DEBUG") ? atoi(getenv("EOE_GEMM_DEBUG")) : 0;
+    if (dbg & 1) { p.bytesA = 0; p.bytesB = 0; }
     if (a->epilogue == EOE_EPI_GELU) EOE_CHECK_ARG(a->aux_out && !a->out_f32, "gemm: GELU epilogue needs aux_out, 16-bit C");
     if (a->epilogue == EOE_EPI_RESIDUAL) EOE_CHECK_ARG(a->aux && a->out_f32, "gemm: RESIDUAL epilogue needs aux, fp32 C");
     if (a->epilogue == EOE_EPI_GELU_BWD) EOE_CHECK_ARG(a->aux, "gemm: GELU_BWD epilogue needs aux");
@@ -382,13 +387,18 @@ int fill_params(const eoe_gemm_args* a, GemmP& p, bool tn) {
 int eoe_gemm_tn_splits(int M, int N, int T) {
     const int tiles = cdiv(M, BM) * cdiv(N, BN);
     int s = 1;
-    while (tiles * s < 384 && s < 16 && T / (s * 2) >= 512) s *= 2;
+    while (tiles * s < 200 && s < 16 && T / (s * 2) >= 512) s *= 2;
     return s;
 }
 
 extern "C" int eoe_gemm_nt(const eoe_gemm_args* a, void* stream) {
     GemmP p;
     EOE_TRY(fill_params(a, p, false));
+    const int osz = a->out_f32 ? 4 : 2;
+    ProfScope ps("gemm_nt", 2.0 * a->M * a->N * a->K,
+                 2.0 * ((double)a->M * a->K + (double)a->N * a->K) + (double)osz * a->M * a->N *
+                     (a->epilogue == EOE_EPI_GELU ? 2 : 1) + (a->epilogue == EOE_EPI_RESIDUAL ? 4.0 * a->M * a->N : 0.0) +
+                     (a->epilogue == EOE_EPI_GELU_BWD ? 2.0 * a->M * a->N : 0.0), stream);
     return a->dtype == EOE_F16 ? launch_nt<f16_t>(p, a->epilogue, (hipStream_t)stream)
                                : launch_nt<bf16_t>(p, a->epilogue, (hipStream_t)stream);
 }
@@ -398,6 +408,8 @@ extern "C" int eoe_gemm_tn(const eoe_gemm_args* a, void* stream) {
     EOE_TRY(fill_params(a, p, true));
     EOE_CHECK_ARG(a->epilogue == EOE_EPI_NONE && a->out_f32, "gemm_tn: only plain fp32 output is supported");
     int splits = eoe_gemm_tn_splits(a->M, a->N, a->K);
+    ProfScope ps("gemm_tn", 2.0 * a->M * a->N * a->K,
+                 2.0 * ((double)a->K * a->M + (double)a->K * a->N) + 4.0 * a->M * a->N, stream);
     if (splits > 1 && !a->accumulate) {
         // atomically combined partial sums need a zeroed destination
         EOE_CHECK_ARG(a->ldc == a->N, "gemm_tn: split reduction needs a dense C");

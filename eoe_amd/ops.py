@@ -13,7 +13,9 @@ from . import _lib
 from ._lib import lib, check, GemmArgs, EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_GELU_BWD
 
 # ------------------------------------------------------------------------------------------------ config
-_compute_dtype = torch.bfloat16
+# fp16 operands (11-bit significand) meet the 1e-3 parity bar against the fp32 reference and are what the
+# reference's own GPU CLIP path stores its weights in (clip/model.py:371-392); bf16 is selectable.
+_compute_dtype = torch.float16
 
 
 def set_compute_dtype(dt):
@@ -193,12 +195,18 @@ def scratch(name, shape, dtype, device):
     return t
 
 
+# id(first parameter of a fused block) -> callable invoked right after that block's backward kernels were enqueued
+# (eoe_amd.parallel.GradArena uses it to start the bucket's all-reduce while backward continues)
+grad_ready_hooks = {}
+
+
 def _grad_target(p: torch.Tensor):
-    """where a parameter gradient is written: the parameter's registered arena view if it has one and is free
-    (p.grad is None), else a fresh tensor"""
+    """where a parameter gradient is written: a fresh alias of the parameter's registered arena view if it has one
+    and is free (p.grad is None) -- a new tensor object over the same memory, so that autograd's AccumulateGrad
+    adopts it without a copy -- else a fresh tensor"""
     buf = getattr(p, "_eoe_grad_buf", None)
     if buf is not None and p.grad is None:
-        return buf
+        return buf.detach()
     return torch.empty_like(p, memory_format=torch.contiguous_format)
 
 
@@ -336,7 +344,7 @@ class VitBlockFunction(torch.autograd.Function):
         x, ws = saved[0], saved[1]
         params = dict(zip(_BLOCK_PARAMS, saved[2:]))
         M, D = x.shape
-        dev, dt = x.device, _compute_dtype if ctx.args.dtype == dtype_code(_compute_dtype) else None
+        dev = x.device
         dt = torch.float16 if ctx.args.dtype == _lib.EOE_F16 else torch.bfloat16
         dx_out = dx_out.contiguous()
         dx_in = torch.empty_like(x)
@@ -354,6 +362,9 @@ class VitBlockFunction(torch.autograd.Function):
         b.dqkv = _p(scratch("dqkv", (M, 3 * D), dt, dev))
         b.dx_mid = _p(scratch("dx_mid", (M, D), torch.float32, dev))
         check(lib.eoe_vit_block_bwd(C.byref(b), _stream()), "eoe_vit_block_bwd")
+        hook = grad_ready_hooks.get(id(params["ln1_g"]))
+        if hook is not None:
+            hook()
         return (dx_in, None, None) + tuple(grads[k] for k in _BLOCK_PARAMS)
 
 

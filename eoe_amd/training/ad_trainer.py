@@ -1,0 +1,348 @@
+"""Counterpart of the reference trainer base class, `src/eoe/training/ad_trainer.py:93-662`, for the hot path:
+`train_cls` (:356-471) and `eval_cls` (:473-550) inner loops, the class x seed `run` loop (:177-354) with
+`weight_reset` copies (:31-34,232-243), NaN retry (:257-280), snapshot loading (:552-615), and the three
+abstract objective hooks (:624-662) with unchanged signatures.
+
+What differs, deliberately (SURVEY.md sections 3.1 and 8):
+  * the optimiser is eoe_amd.FusedAdam (one kernel per step) -- constructed here exactly where the reference
+    constructs torch.optim.Adam (:383), same hyper-parameters, driven by the stock MultiStepLR (:384);
+  * anomaly scores and the loss stay on the device during an epoch; they are copied to the host once per epoch
+    for the NaN check and the AUC (:447-455) instead of forcing two host syncs per step (:436,442);
+  * the per-half masked Normalize (:413-425) is one affine with the normal class's statistics, fused into the
+    encoder's first kernel when the encoder supports it (SURVEY.md section 8a note 1);
+  * optional data parallelism (one process per GPU): each rank trains on its rows of every step batch,
+    loss = sum(local) / global batch, gradients summed over RCCL, scores/labels all-gathered for the AUC.
+Datasets, loggers with tensorboard/PDF output, MSMs and the CLIP text objective are out of scope.
+"""
+import json
+import os
+from abc import ABC, abstractmethod
+from copy import deepcopy
+from typing import List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from .. import ops, parallel
+from ..metrics import ROC, PRC, roc_auc, average_precision
+from ..optim import FusedAdam
+
+
+class NanGradientsError(RuntimeError):
+    pass
+
+
+def weight_reset(m: torch.nn.Module):
+    # ad_trainer.py:31-34
+    reset_parameters = getattr(m, "reset_parameters", None)
+    if callable(reset_parameters):
+        m.reset_parameters()
+
+
+class JsonLogger:
+    """minimal stand-in for `src/eoe/utils/logger.py` (out of scope): JSON lines + snapshots with the reference's
+    snapshot dict layout {net, opt, sched, epoch, ds_statistics} (`logger.py:318-340`)"""
+
+    def __init__(self, logdir: Optional[str] = None, active: bool = True):
+        self.dir, self.active = logdir, active and logdir is not None
+        if self.active:
+            os.makedirs(os.path.join(logdir, "snapshots"), exist_ok=True)
+
+    def print(self, msg: str):
+        print(msg, flush=True)
+
+    warning = logtxt = print
+
+    def logjson(self, name: str, obj):
+        if self.active:
+            with open(os.path.join(self.dir, name + ".json"), "w") as f:
+                json.dump(obj, f, default=lambda o: None if (isinstance(o, float) and o != o) else o)
+
+    def add_scalar(self, *a, **k):
+        pass
+
+    def snapshot(self, name: str, net: torch.nn.Module, opt=None, sched=None, epoch: int = None, **kwargs):
+        if not self.active:
+            return None
+        path = os.path.join(self.dir, "snapshots", name + ".pt")
+        data = {"net": net.state_dict(), "opt": opt.state_dict() if opt is not None else None,
+                "sched": sched.state_dict() if sched is not None else None, "epoch": epoch}
+        data.update(kwargs)
+        torch.save(data, path)
+        return path
+
+
+class ADTrainer(ABC):
+    AD_MODES = ("one_vs_rest", "leave_one_out")
+    KEEP_SNAPSHOT_IN_RAM = False
+
+    def __init__(self, model: torch.nn.Module, train_transform=None, test_transform=None, dataset=None,
+                 oe_dataset=None, datapath: str = None, logger: JsonLogger = None, epochs: int = 1, lr: float = 1e-3,
+                 wdk: float = 0.0, milestones: List[int] = (), batch_size: int = 128, ad_mode: str = "one_vs_rest",
+                 device: Union[str, torch.device] = "cuda", oe_limit_samples=np.inf, oe_limit_classes=np.inf,
+                 msms=(), workers: int = 2, classes: List[str] = None, data_parallel: bool = False):
+        """same parameters as the reference (`ad_trainer.py:98-164`).  `dataset` is either a step-batch source
+        (eoe_amd.data: an object with `.loaders(batch_size)`, `.nominal_label`, `.normalize`) or a callable
+        `(cls, seed) -> source`; `classes` names the classes to iterate (default: one class "0")."""
+        self.model = model.cpu() if model is not None else model
+        self.train_transform, self.test_transform = train_transform, test_transform
+        self.dsstr, self.oe_dsstr, self.datapath = dataset, oe_dataset, datapath
+        self.logger = logger if logger is not None else JsonLogger(None)
+        self.device = torch.device(device)
+        self.epochs, self.lr, self.wdk, self.milestones, self.batch_size = epochs, lr, wdk, list(milestones), batch_size
+        self.ad_mode = ad_mode
+        self.center = None
+        self.workers = workers
+        self.ds = dataset if hasattr(dataset, "loaders") else None
+        self.classes = classes if classes is not None else ["0"]
+        self.data_parallel = data_parallel
+        if msms:
+            raise NotImplementedError("multi-scale modes (MSM) are out of scope")
+
+    # ------------------------------------------------------------------------------------------- run
+    def get_nominal_classes(self, cur_class: int):
+        # ad_trainer.py:166-175
+        if self.ad_mode == "one_vs_rest":
+            return [cur_class]
+        elif self.ad_mode == "leave_one_out":
+            return [c for c in range(len(self.classes)) if c != cur_class]
+        raise NotImplementedError(f"AD mode {self.ad_mode} unknown. Known modes are {ADTrainer.AD_MODES}.")
+
+    def _dataset(self, c: int, seed: int):
+        if self.ds is not None:
+            return self.ds
+        if callable(self.dsstr):
+            return self.dsstr(c, seed)
+        raise ValueError("dataset must be a step-batch source or a callable (cls, seed) -> source")
+
+    def run(self, run_classes: List[int] = None, run_seeds: int = 1, load: List[List] = None, test: bool = True,
+            train: bool = True) -> Tuple[List[List[torch.nn.Module]], dict]:
+        """class x seed loop (`ad_trainer.py:177-354`); returns (models, results) with the reference's keys"""
+        classes = self.classes
+        run_classes = run_classes if run_classes is not None else list(range(len(classes)))
+        train_rocs = [[] for _ in classes]
+        eval_rocs = [[] for _ in classes]
+        eval_prcs = [[] for _ in classes]
+        models = [[] for _ in classes]
+        for c, cstr in ((c, cstr) for c, cstr in enumerate(classes) if c in run_classes):
+            for seed in range(run_seeds):
+                self.logger.print(f'------ start training cls {c} "{cstr}" ------')
+                cur_load = load[c][seed] if (load is not None and len(load) > c and len(load[c]) > seed) else None
+
+                def copy_model():
+                    # ad_trainer.py:232-243: deepcopy of the CPU master + reset_parameters on every module
+                    if cur_load is not None and isinstance(cur_load, torch.nn.Module):
+                        model = deepcopy(cur_load)
+                    else:
+                        model = deepcopy(self.model)
+                        model.apply(weight_reset)
+                    for n, p in model.named_parameters():
+                        p.detach_().requires_grad_()
+                    return model
+
+                ds = self._dataset(c, seed)
+                model, roc = None, None
+                for i in range(5):
+                    try:
+                        model = copy_model()
+                        if train:
+                            model, roc = self.train_cls(model, ds, c, cstr, seed, cur_load)
+                        break
+                    except NanGradientsError:
+                        self.logger.warning(f'Gradients got NaN for class {c} "{cstr}" and seed {seed}. '
+                                            f'Happened {i} times so far. Try once more.')
+                        ds = self._dataset(c, seed)
+                        if i == 3 - 1:
+                            model, roc = None, None
+                models[c].append(model)
+                train_rocs[c].append(roc)
+                if test and model is not None:
+                    roc, prc = self.eval_cls(model, ds, c, cstr, seed)
+                else:
+                    roc, prc = None, None
+                eval_rocs[c].append(roc)
+                eval_prcs[c].append(prc)
+                if model is not None:
+                    self.logger.snapshot(f"snapshot_cls{c}_it{seed}", model, epoch=self.epochs,
+                                         ds_statistics=getattr(ds, "ds_statistics", None))
+                    if not ADTrainer.KEEP_SNAPSHOT_IN_RAM:
+                        models[c][-1] = None
+
+        def cls_means(rocs, attr):
+            out = []
+            for lst in rocs:
+                vals = [getattr(r, attr) for r in lst if r is not None]
+                out.append((float(np.mean(vals)), float(np.std(vals))) if vals else None)
+            return out
+
+        if test:
+            m = [x for x in cls_means(eval_rocs, "auc") if x is not None]
+            pm = [x for x in cls_means(eval_prcs, "avg_prec") if x is not None]
+            mean_auc = float(np.mean([a for a, _ in m])) if m else float("nan")
+            std_auc = float(np.std([a for a, _ in m])) if m else float("nan")
+            mean_avg_prec = float(np.mean([a for a, _ in pm])) if pm else float("nan")
+            self.logger.logtxt(f"Eval: Overall {mean_auc * 100:04.2f}% +- {std_auc * 100:04.2f}% AUC.")
+        else:
+            mean_auc = std_auc = mean_avg_prec = float("nan")
+        cls_aucs = [[roc.get_score() if roc is not None else None for roc in cls_roc] for cls_roc in eval_rocs]
+        self.logger.logjson("results", {"eval_mean_auc": mean_auc, "eval_std_auc": std_auc,
+                                        "eval_mean_avg_prec": mean_avg_prec, "eval_cls_rocs": cls_aucs,
+                                        "classes": classes})
+        return models, {"mean_auc": mean_auc, "mean_avg_prec": mean_avg_prec, "std_auc": std_auc, "cls_aucs": cls_aucs}
+
+    # ------------------------------------------------------------------------------------------- hot loop
+    def _normalize_hook(self, model, ds):
+        """install the (mean, std) of the normal class on an encoder that fuses it; returns a fallback callable for
+        encoders that do not"""
+        norm = getattr(ds, "normalize", None)
+        enc = getattr(model, "feature_model", model)
+        if hasattr(enc, "set_normalize"):
+            enc.set_normalize(*(norm if norm is not None else (None, None)))
+            return None
+        if norm is None:
+            return None
+        mean = torch.as_tensor(norm[0], dtype=torch.float32, device=self.device).view(1, -1, 1, 1)
+        std = torch.as_tensor(norm[1], dtype=torch.float32, device=self.device).view(1, -1, 1, 1)
+        raise NotImplementedError("this encoder has no fused normalise; add one to its first kernel")
+
+    def train_cls(self, model: torch.nn.Module, ds, cls: int, clsstr: str, seed: int,
+                  load: Union[torch.nn.Module, str] = None):
+        """the inner loop, `ad_trainer.py:356-471`; returns (model on the CPU in eval mode, training ROC)"""
+        model = model.to(self.device).train()
+        epochs = self.epochs
+        cls_roc = None
+        opt = FusedAdam(model.parameters(), lr=self.lr, weight_decay=self.wdk, amsgrad=False)          # :383
+        sched = torch.optim.lr_scheduler.MultiStepLR(opt, self.milestones, 0.1)                       # :384
+        loader, _ = ds.loaders(self.batch_size, num_workers=self.workers, persistent=True)              # :385
+        ep = self.load(load if isinstance(load, str) else None, model, opt, sched)                      # :396
+        center = self.center = self.prepare_metric(clsstr, loader, model, seed)                         # :397
+        self._normalize_hook(model, ds)
+        rank, world = 0, 1
+        arena = None
+        if self.data_parallel and torch.distributed.is_initialized():
+            rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
+            arena = parallel.GradArena(model)
+            arena.install_hooks()
+        nominal = getattr(ds, "nominal_label", 0)
+        self.last_losses = []
+        try:
+            for ep in range(ep, epochs):
+                ep_labels, ep_scores, ep_losses = [], [], []
+                for batch in loader:                                                                    # :410
+                    imgs, lbls = batch[0], batch[1]
+                    n_norm = int((lbls == nominal).sum())
+                    n_glob = lbls.shape[0]
+                    if world > 1:
+                        rows = parallel.shard_rows(n_norm, n_glob - n_norm, rank, world)
+                        imgs, lbls = imgs[rows], lbls[rows]
+                    imgs = imgs.to(self.device, non_blocking=True)                                      # :411
+                    lbls = lbls.to(self.device, non_blocking=True)                                      # :412
+                    opt.zero_grad()                                                                     # :428
+                    feats = model(imgs)                                                                 # :429
+                    loss = self.loss(feats, lbls, center, inputs=imgs, nominal_label=nominal,
+                                     inv_count=(1.0 / n_glob))                                          # :430
+                    loss.backward()                                                                     # :431
+                    if arena is not None:
+                        arena.finish()
+                    opt.step()                                                                          # :432
+                    opt.zero_grad()                                                                     # :433
+                    scores = self.compute_anomaly_score(feats, center, inputs=imgs, nominal_label=nominal)   # :434
+                    ep_labels.append(lbls)
+                    ep_scores.append(scores.detach())
+                    ep_losses.append(loss.detach())
+                # ---- epoch tail (:447-469): one host copy per epoch
+                la, sc = torch.cat(ep_labels), torch.cat(ep_scores).reshape(-1)
+                ls = torch.stack(ep_losses)
+                if world > 1:
+                    la, sc = parallel.all_gather_1d(la), parallel.all_gather_1d(sc)
+                    torch.distributed.all_reduce(ls)          # local losses are already divided by the global batch
+                la, sc = la.cpu().numpy(), sc.cpu().numpy()
+                self.last_losses.extend(ls.cpu().tolist())
+                if np.isnan(sc).sum() > 0:
+                    raise NanGradientsError()                                                           # :448-449
+                if (la == 1).sum() > 0:
+                    cls_roc = ROC(roc_auc(la, sc))                                                      # :452-455
+                sched.step()                                                                            # :468
+        finally:
+            if arena is not None:
+                arena.remove_hooks()
+                for p in model.parameters():
+                    if hasattr(p, "_eoe_grad_buf"):
+                        del p._eoe_grad_buf
+        return model.cpu().eval(), cls_roc                                                              # :471
+
+    def eval_cls(self, model: torch.nn.Module, ds, cls: int, clsstr: str, seed: int):
+        """forward-only scoring of the test split, `ad_trainer.py:473-550`"""
+        model = model.to(self.device).eval()
+        _, loader = ds.loaders(self.batch_size, num_workers=self.workers, shuffle_test=False)
+        self._normalize_hook(model, ds)
+        center = self.center
+        nominal = getattr(ds, "nominal_label", 0)
+        ep_labels, ep_scores, ep_idcs = [], [], []
+        for batch in loader:
+            imgs, lbls = batch[0].to(self.device), batch[1]
+            with torch.no_grad():
+                feats = model(imgs)
+            ep_scores.append(self.compute_anomaly_score(feats, center, inputs=imgs, nominal_label=nominal))
+            ep_labels.append(lbls)
+            ep_idcs.append(batch[2] if len(batch) > 2 else torch.arange(len(lbls)))
+        la = torch.cat(ep_labels).cpu().numpy()
+        sc = torch.cat(ep_scores).reshape(-1).cpu().numpy()
+        idc = torch.cat(ep_idcs).cpu().numpy()
+        if (la == 0).sum() > 0 and (la == 1).sum() > 0:
+            keep = la >= 0
+            cls_roc = ROC(roc_auc(la[keep], sc[keep]))
+            cls_prc = PRC(average_precision(la[keep], sc[keep]))
+            self.logger.logtxt(f'Eval: class "{clsstr}" yields {cls_roc.auc * 100:04.2f}% AUC and '
+                               f'{cls_prc.avg_prec * 100:04.2f}% average precision (seed {seed}).')
+        else:
+            cls_roc = cls_prc = None
+        self.logger.logjson(f"eval_cls{cls}_it{seed}_anomaly_scores", {int(k): float(v) for k, v in zip(idc, sc)})
+        model.cpu()
+        return cls_roc, cls_prc
+
+    # ------------------------------------------------------------------------------------------- snapshots
+    def load(self, path: str, model: torch.nn.Module, opt=None, sched=None) -> int:
+        """`ad_trainer.py:552-598`: restores {net, opt, sched, epoch} or a bare feature-model state_dict; always
+        triggers freeze_parts() when the model has it"""
+        epoch = 0
+        if path is not None:
+            snapshot = self.unify_snapshot_style(torch.load(path, map_location="cpu"))
+            feature_model_state = snapshot.pop("feature_model", None)
+            if feature_model_state is not None:
+                if not hasattr(model, "load_feature_model_weights"):
+                    raise ValueError(f"Found weights for a pre-trained feature model of a CustomNet at {path}. "
+                                     f"However, the AD model ({model.__class__}) is not a CustomNet!")
+                model.load_feature_model_weights(feature_model_state)
+            net_state, opt_state = snapshot.pop("net", None), snapshot.pop("opt", None)
+            sched_state, epoch = snapshot.pop("sched", None), snapshot.pop("epoch", 0)
+            if net_state is not None:
+                model.load_state_dict(net_state)
+            if opt_state is not None and opt is not None:
+                opt.load_state_dict(opt_state)
+            if sched_state is not None and sched is not None:
+                sched.load_state_dict(sched_state)
+        if hasattr(model, "freeze_parts"):
+            model.freeze_parts()
+        return epoch
+
+    def unify_snapshot_style(self, snapshot: dict) -> dict:
+        # ad_trainer.py:608-615
+        if "net" in snapshot and isinstance(snapshot["net"], dict):
+            return snapshot
+        if all(isinstance(t, torch.Tensor) for t in snapshot.values()):
+            return {"feature_model": snapshot}
+        raise ValueError("Cannot parse snapshot.")
+
+    # ------------------------------------------------------------------------------------------- objective hooks
+    @abstractmethod
+    def prepare_metric(self, cstr: str, loader, model: torch.nn.Module, seed: int, **kwargs) -> torch.Tensor:
+        pass
+
+    @abstractmethod
+    def compute_anomaly_score(self, features: torch.Tensor, center: torch.Tensor, **kwargs) -> torch.Tensor:
+        pass
+
+    @abstractmethod
+    def loss(self, features: torch.Tensor, labels: torch.Tensor, center: torch.Tensor, **kwargs) -> torch.Tensor:
+        pass

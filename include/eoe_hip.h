@@ -203,6 +203,21 @@ typedef struct {
 int eoe_vit_block_fwd(const eoe_vit_block_fwd_args* a, void* stream);
 int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* a, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * in-library kernel timing (used by bench.py for the roofline line): while enabled, every entry point brackets
+ * its kernel launches with hipEvents on the stream it launches on and records the algorithmic flops / bytes.
+ * eoe_prof_collect synchronises the recorded events and aggregates them per kernel name.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct {
+    char name[32];
+    int64_t launches;
+    double total_ms;   /* sum of per-launch durations */
+    double flops;      /* sum of algorithmic floating-point operations (2 per MAC) */
+    double bytes;      /* sum of algorithmic HBM bytes (inputs read once + outputs written once) */
+} eoe_prof_entry;
+int eoe_prof_enable(int on);
+int eoe_prof_collect(eoe_prof_entry* out, int max_entries, int* n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,72 @@
+"""CPU tier: the N>1 path of the data-parallel layer with 2 gloo ranks: row sharding + loss/global-N scaling +
+summed gradients through GradArena reproduce the single-process full-batch gradient; scores gather in rank order."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+
+
+def _per_sample_loss(f, y):
+    d = torch.sqrt((f * f).sum(1) + 1) - 1
+    return torch.where(y == 0, d, -torch.log(1 - torch.exp(-d) + 1e-9))
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from eoe_amd import parallel
+    r, w, _ = parallel.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(10, 6, generator=g)
+    y = torch.cat([torch.zeros(5, dtype=torch.long), torch.ones(5, dtype=torch.long)])
+    m = _model()
+    arena = parallel.GradArena(m)
+    rows = parallel.shard_rows(5, 5, rank, world)
+    loss = _per_sample_loss(m(x[rows]), y[rows]).sum() / 10.0          # sum(local) / GLOBAL batch
+    loss.backward()
+    # half of the parameters sit in the arena (as the fused kernels leave them), half are stray tensors
+    for i, p in enumerate(m.parameters()):
+        if i % 2 == 0:
+            p._eoe_grad_buf.copy_(p.grad)
+            p.grad = p._eoe_grad_buf
+    arena.finish()
+    scores = parallel.all_gather_1d(torch.full((3,), float(rank)))
+    tot = torch.tensor([loss.item()])
+    dist.all_reduce(tot)
+    if rank == 0:
+        torch.save({"grads": [p.grad.clone() for p in m.parameters()], "scores": scores, "loss": tot}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradients_equal_full_batch(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(10, 6, generator=g)
+    y = torch.cat([torch.zeros(5, dtype=torch.long), torch.ones(5, dtype=torch.long)])
+    m = _model()
+    loss = _per_sample_loss(m(x), y).mean()
+    loss.backward()
+    for a, p in zip(got["grads"], m.parameters()):
+        np.testing.assert_allclose(a.numpy(), p.grad.numpy(), rtol=1e-5, atol=1e-7)
+    assert abs(got["loss"].item() - loss.item()) < 1e-6
+    assert got["scores"].tolist() == [0.0] * 3 + [1.0] * 3

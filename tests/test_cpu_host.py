@@ -1,0 +1,115 @@
+"""CPU tier: host-side logic of the product (no GPU compute): the C-ABI library loads and exports every symbol
+include/eoe_hip.h declares, argument validation returns errors (not crashes), the step-batch layout and the
+metrics match the oracle / golden vectors bit-exactly where they are integer paths."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import batching, fill, metrics as ometrics
+
+
+def test_library_exports_every_declared_symbol():
+    from eoe_amd import _lib
+    declared = _lib.header_symbols()
+    assert len(declared) >= 24
+    for name in declared:
+        assert hasattr(_lib.lib, name), f"libeoe_hip.so does not export {name}"
+    assert set(declared) == set(_lib.SIGNATURES), set(declared) ^ set(_lib.SIGNATURES)
+    assert _lib.lib.eoe_abi_version() == _lib.ABI_VERSION
+    # struct layouts the Python side mirrors
+    assert C.sizeof(_lib.AdamChunk) == 40 and C.sizeof(_lib.AdamScalars) == 32
+    assert C.sizeof(_lib.GemmArgs) == 6 * 8 + 12 * 4
+
+
+def test_argument_errors_are_reported_not_fatal():
+    from eoe_amd import _lib
+    g = _lib.GemmArgs()                 # all-null arguments
+    rc = _lib.lib.eoe_gemm_nt(C.byref(g), None)
+    assert rc == 1 and b"null" in _lib.lib.eoe_last_error()
+    rc = _lib.lib.eoe_attn_fwd(None, None, 1, 50, 12, 1, None)
+    assert rc == 1
+    with pytest.raises(_lib.EoeError):
+        _lib.check(_lib.lib.eoe_layernorm_fwd(None, 0, None, None, None, None, 1, 768, 1e-5, 1, 0, None), "ln")
+
+
+def test_ops_refuse_cpu_tensors():
+    import eoe_amd
+    with pytest.raises(RuntimeError):
+        eoe_amd.hsc_loss(torch.zeros(2, 4), torch.zeros(2, dtype=torch.long))
+    from eoe_amd.models import ClipViTB32Custom
+    m = ClipViTB32Custom(layers=1)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 224, 224))
+
+
+def test_batch_layout_matches_oracle_bit_exact():
+    from eoe_amd import data, parallel
+    rng = np.random.default_rng(0)
+    for n_normal_ds, bs, oe_sizes in ((100, 7, [4, 4, 4]), (33, 16, [16, 16]), (10, 5, [2, 2, 2, 2])):
+        normal = (rng.standard_normal((bs, 2)).astype(np.float32), np.zeros(bs, np.int64), rng.integers(0, n_normal_ds, bs))
+        chunks = [(rng.standard_normal((k, 2)).astype(np.float32), np.ones(k, np.int64), rng.integers(0, 50, k)) for k in oe_sizes]
+        want = batching.balanced_concat(normal, iter(chunks), n_normal_ds)
+        got = data.balanced_concat([torch.from_numpy(a) for a in normal],
+                                   iter([[torch.from_numpy(a) for a in c] for c in chunks]), n_normal_ds)
+        for w, g in zip(want, got):
+            assert np.array_equal(w, g.numpy())
+    assert data.tile_oe_indices(torch.tensor([4, 9]), 5).tolist() == batching.tile_oe_indices(np.array([4, 9]), 5).tolist()
+    for nn, no, world in ((128, 128, 8), (5, 5, 2), (7, 3, 4), (1, 1, 2)):
+        for r in range(world):
+            assert parallel.shard_rows(nn, no, r, world).tolist() == batching.shard_rows(nn, no, r, world).tolist()
+
+
+def test_synthetic_source_honours_the_contract():
+    from eoe_amd.data import SyntheticAD
+    ds = SyntheticAD(n_train_normal=20, n_oe=6, n_test=10, res=8, seed=3)
+    train, test = ds.loaders(8)
+    batches = list(train)
+    assert len(batches) == len(train) == 3
+    for imgs, lbls, idcs in batches[:2]:
+        assert lbls.tolist() == [0] * 8 + [1] * 8 and imgs.shape == (16, 3, 8, 8)
+        assert (idcs[:8] < 20).all() and (idcs[8:] >= 20).all() and (idcs[8:] < 26).all()     # OE offset rule
+    imgs, lbls, idcs = batches[2]                                                              # ragged last batch
+    assert lbls.tolist() == [0] * 4 + [1] * 4
+    assert sorted(torch.cat([b[2][: len(b[2]) // 2] for b in batches]).tolist()) == list(range(20))
+    assert sum(len(b[1]) for b in test) == 10
+
+
+def test_metrics_match_golden(golden):
+    from eoe_amd import metrics
+    g = golden("g7_metrics")
+    for i in range(4):
+        n, ties = int(g[f"n{i}"]), bool(g[f"ties{i}"])
+        s = fill.fill(f"g7/s{i}", (n,), std=1.0)
+        if ties:
+            s = np.round(s * 4) / 4
+        y = fill.fill_int(f"g7/y{i}", (n,), 0, 2)
+        y[0], y[1] = 0, 1
+        assert abs(metrics.roc_auc(y, s) - float(g[f"auc{i}"])) < 1e-12
+        assert abs(metrics.average_precision(y, s) - float(g[f"ap{i}"])) < 1e-12
+        assert abs(metrics.roc_auc(y, s) - ometrics.roc_auc(y, s)) < 1e-15
+    assert np.isnan(metrics.roc_auc(np.ones(3), np.arange(3.0)))
+
+
+def test_state_dict_names_match_reference_names():
+    """parameter names/shapes of the drop-in modules equal the oracle's (= the reference's)"""
+    from eoe_amd.models import ClipViTB32Custom
+    from oracle import models as omodels
+    a = {k: tuple(v.shape) for k, v in ClipViTB32Custom(layers=2).state_dict().items()}
+    b = {k: tuple(v.shape) for k, v in omodels.ClipViTNet(layers=2).state_dict().items()}
+    assert a == b
+    a = {k: tuple(v.shape) for k, v in ClipViTB32Custom(layers=1, clf=True).state_dict().items()}
+    assert a["final_linear.weight"] == (1, 512)
+    m = ClipViTB32Custom(layers=1, freeze=True)
+    assert m.freeze_parts() and all(not p.requires_grad for p in m.feature_model.parameters())
+    assert all(p.requires_grad for p in m.final_linear.parameters())
+
+
+def test_trainer_registry_and_hooks():
+    from eoe_amd.training import TRAINER, ADTrainer
+    assert set(TRAINER) == {"hsc", "bce"}
+    for cls in TRAINER.values():
+        assert issubclass(cls, ADTrainer)
+        for hook in ("prepare_metric", "compute_anomaly_score", "loss", "train_cls", "eval_cls", "run", "load"):
+            assert callable(getattr(cls, hook))
