@@ -51,7 +51,7 @@ class VitBlockBwdArgs(C.Structure):
                 ("g_b_in", _vp), ("g_b_out", _vp), ("g_b_fc", _vp), ("g_b_proj", _vp),
                 ("g_w_in", _vp), ("g_w_out", _vp), ("g_w_fc", _vp), ("g_w_proj", _vp),
                 ("accumulate", _i32),
-                ("d16_a", _vp), ("d16_b", _vp), ("dh", _vp), ("dqkv", _vp), ("dx_mid", _vp)]
+                ("d16_a", _vp), ("d16_b", _vp), ("d16_c", _vp), ("dh", _vp), ("dqkv", _vp), ("dx_mid", _vp)]
 
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); must match include/eoe_hip.h
@@ -60,6 +60,7 @@ SIGNATURES = {
     "eoe_last_error": [],
     "eoe_gemm_nt": [C.POINTER(GemmArgs), _vp],
     "eoe_gemm_tn": [C.POINTER(GemmArgs), _vp],
+    "eoe_gemm_tn_grouped": [C.POINTER(GemmArgs), C.c_int, _vp],
     "eoe_cast_transpose": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
     "eoe_patchify": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "eoe_embed_lnpre_fwd": [_vp] * 8 + [C.c_int, C.c_int, C.c_int, _f32, _vp],

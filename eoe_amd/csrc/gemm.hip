@@ -1,6 +1,6 @@
-// MFMA GEMMs for gfx950: 128x128x64 tiles, 4 wavefronts (2x2, 64x64 each), v_mfma_f32_16x16x32_{f16,bf16},
-// operands staged global -> LDS with bounds-checked LDS-DMA (buffer_load ... lds, 16 B per lane; an
-// out-of-range lane reads 0, which is the zero padding of ragged M / N / T tails), two LDS stages.
+// MFMA GEMM (NT) for gfx950: 256x128x64 tiles, 8 wavefronts (4x2, 64x64 each; two per SIMD), one workgroup per CU,
+// v_mfma_f32_16x16x32_{f16,bf16}, operands staged global -> LDS with bounds-checked LDS-DMA (buffer_load ... lds,
+// 16 B per lane; an out-of-range lane reads 0, which is the zero padding of ragged M / N tails), 3-stage LDS ring.
 //
 //   NT:  C[M,N] = A[M,K] . B[N,K]^T   both operands K-contiguous; LDS image [128 rows][64 k] with the 16-B chunk
 //        index XOR-swizzled by (row>>1)&7 (applied on the SOURCE address, LDS-DMA writes linearly), fragments
@@ -16,10 +16,11 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = 128 * 64 * 2;          // one operand tile, 16 KiB
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;       // A + B
-constexpr int SMEM_BYTES = 2 * STAGE_BYTES;       // two stages, 64 KiB -> 2 workgroups per CU
+constexpr int BM = 256, BN = 128, BK = 64, NSTAGE = 3;
+constexpr int A_BYTES = BM * BK * 2;              // 32 KiB
+constexpr int B_BYTES = BN * BK * 2;              // 16 KiB
+constexpr int STAGE_BYTES = A_BYTES + B_BYTES;    // 48 KiB
+constexpr int SMEM_BYTES = NSTAGE * STAGE_BYTES;  // 144 KiB: one 8-wave workgroup per CU
 
 struct GemmP {
     const void* A; const void* B; void* C; const float* bias; const void* aux; void* aux_out;
@@ -45,8 +46,13 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[4][4], int
             for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r] * p.alpha;
             const int nvalid = (p.N - n) < 4 ? (p.N - n) : 4;
             if (p.bias) {
+                if (vec_ok) {
+                    const f32x4 bv = *(const f32x4*)(p.bias + n);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (r < nvalid) v[r] += p.bias[n + r];
+                    for (int r = 0; r < 4; ++r) v[r] += bv[r];
+                } else {
+                    for (int r = 0; r < nvalid; ++r) v[r] += p.bias[n + r];
+                }
             }
             const size_t off = (size_t)m * p.ldc + n;
             if (EPI == EOE_EPI_GELU) {
@@ -116,8 +122,19 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[4][4], int
 }
 
 // ------------------------------------------------------------------------------------------------ NT
+// main loop: 3-stage LDS ring filled by LDS-DMA two k-tiles ahead (counted vmcnt: the newest tile stays in
+// flight across the barrier), ONE raw s_barrier per k-tile, MFMA fragments double-buffered in registers so the
+// ds_reads of the next 32-deep k-step run under the 16 MFMAs of the current one.
+//   iteration kt:  stage(kt+2) | F1 = frags(kt, ks1) | MFMA(F0) | vmcnt -> tile kt+1 landed, lgkmcnt(0), barrier |
+//                  F0 = frags(kt+1, ks0) | MFMA(F1)
+//   WAR: stage(kt+2) overwrites the buffer of tile kt-1, whose last reads (its F1) completed before every wave
+//        passed the barrier of iteration kt-1.   RAW: each wave waits for its own DMA pieces of tile kt+1 before
+//        the barrier; the reads of that tile come after the barrier.
+#define EOE_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define EOE_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
 template <typename T, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
+__global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_n = (p.N + BN - 1) / BN;
@@ -127,190 +144,91 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
     __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.bytesA);
     __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.bytesB);
 
-    // staging: wave-load wl (0..15) covers tile rows 8*wl .. 8*wl+7, 128 B each; lane -> (row, 16-B slot)
-    unsigned offA[4], offB[4];
+    // staging: a wave-load (1 KiB) covers 8 tile rows of 128 B; lane -> (row, 16-B slot); the slot holds logical
+    // chunk slot ^ ((row>>1)&7).  A image: 256 rows = 32 wave-loads (4 per wave); B image: 128 rows = 16 (2 per wave)
+    unsigned offA[4], offB[2];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int wl = wave * 4 + j;
-        const int row = wl * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);            // logical chunk fetched into this slot
-        const int ga = m0 + row, gb = n0 + row;
+        const int row = (wave * 4 + j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const int ga = m0 + row;
         offA[j] = (ga < p.M) ? (unsigned)(((size_t)ga * p.lda + c * 8) * 2) : EOE_OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave * 2 + j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const int gb = n0 + row;
         offB[j] = (gb < p.N) ? (unsigned)(((size_t)gb * p.ldb + c * 8) * 2) : EOE_OOB;
     }
-    auto stage = [&](int buf, int k0) {
+    auto stage = [&](int buf, int k0) {       // 6 LDS-DMA instructions per wave per k-tile
         char* sa = smem + buf * STAGE_BYTES;
-        char* sb = sa + TILE_BYTES;
+        char* sb = sa + A_BYTES;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int wl = wave * 4 + j;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(sa + wl * 1024), 16,
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(sa + (wave * 4 + j) * 1024), 16,
                                                      offA[j] + (unsigned)k0 * 2u, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(sb + wl * 1024), 16,
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(sb + (wave * 2 + j) * 1024), 16,
                                                      offB[j] + (unsigned)k0 * 2u, 0, 0, 0);
-        }
     };
 
     const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
     const int lr = lane & 15, lg = lane >> 4;
     const int sw = (lr >> 1) & 7;
-    // per-lane fragment byte offsets inside a tile for k-step 0 / 1
-    const int fragA = (wm0 + lr) * 128, fragB = (wn0 + lr) * 128;
+    const int fragA = (wm0 + lr) * 128, fragB = A_BYTES + (wn0 + lr) * 128;
     const int ch0 = ((0 + lg) ^ sw) * 16, ch1 = ((4 + lg) ^ sw) * 16;
+    typedef typename T16<T>::v8 V8;
 
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#define EOE_READ(XA, WB, base, ch)                                        \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                       \
+        XA[i] = *(const V8*)((base) + fragA + i * 2048 + (ch));           \
+        WB[i] = *(const V8*)((base) + fragB + i * 2048 + (ch));           \
+    }
+#define EOE_MFMA(XA, WB)                                                  \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                      \
+        _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = T16<T>::mfma16(WB[ni], XA[mi], acc[mi][ni]);
 
     const int nk = p.K / BK;
+    V8 xa0[4], wb0[4], xa1[4], wb1[4];
     stage(0, 0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) stage(buf ^ 1, (kt + 1) * BK);
-        const char* sa = smem + buf * STAGE_BYTES;
-        const char* sb = sa + TILE_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int ch = ks ? ch1 : ch0;
-            typename T16<T>::v8 xa[4], wb[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                xa[i] = *(const typename T16<T>::v8*)(sa + fragA + i * 16 * 128 + ch);
-                wb[i] = *(const typename T16<T>::v8*)(sb + fragB + i * 16 * 128 + ch);
-            }
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = T16<T>::mfma16(wb[ni], xa[mi], acc[mi][ni]);
-        }
-        __syncthreads();
-    }
-    epilogue<T, EPI>(p, acc, m0 + wm0, n0 + wn0, lane);
-}
-
-// ------------------------------------------------------------------------------------------------ TN
-template <typename T>
-__device__ __forceinline__ typename T16<T>::v8 tr_frag(const char* base, int off_lo) {
-    // two transposed 4-row reads (rows +0..3 and +4..7 of this lane group's 8-row k block)
-    i16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4v*)(base + off_lo));
-    i16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4v*)(base + off_lo + 4 * 256));
-    i16x8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return __builtin_bit_cast(typename T16<T>::v8, r);
-}
-
-template <typename T, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p, int t_per_split) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int tiles = tiles_n * ((p.M + BM - 1) / BM);
-    const int split = blockIdx.x / tiles;                 // split-T index (atomic accumulation when > 1 splits)
-    const int tile = xcd_remap(blockIdx.x % tiles, tiles);
-    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-    const int t_begin = split * t_per_split;
-    const int t_end = min(p.K, t_begin + t_per_split);
-
-    __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.bytesA);
-    __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.bytesB);
-
-    // staging: wave-load wl (0..15) covers tile rows (t) 4*wl .. 4*wl+3, 256 B each; lane -> (row, 16-B slot)
-    int srow[4];
-    unsigned colA[4], colB[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int wl = wave * 4 + j;
-        const int row = wl * 4 + (lane >> 4);
-        const int s = lane & 15;
-        const int f = (row & 3) | (((row >> 3) & 1) << 2);
-        const int c16 = ((((s >> 1) ^ f) << 1) | (s & 1));       // logical 16-B chunk (8 columns) fetched
-        srow[j] = row;
-        const int ca = m0 + c16 * 8, cb = n0 + c16 * 8;
-        colA[j] = (ca < p.M) ? (unsigned)(ca * 2) : EOE_OOB;
-        colB[j] = (cb < p.N) ? (unsigned)(cb * 2) : EOE_OOB;
-    }
-    auto stage = [&](int buf, int t0) {
-        char* sa = smem + buf * STAGE_BYTES;
-        char* sb = sa + TILE_BYTES;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int wl = wave * 4 + j;
-            const int t = t0 + srow[j];
-            const bool ok = t < t_end;
-            const unsigned oa = (ok && colA[j] != EOE_OOB) ? (unsigned)((size_t)t * p.lda * 2) + colA[j] : EOE_OOB;
-            const unsigned ob = (ok && colB[j] != EOE_OOB) ? (unsigned)((size_t)t * p.ldb * 2) + colB[j] : EOE_OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(sa + wl * 1024), 16, oa, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(sb + wl * 1024), 16, ob, 0, 0, 0);
-        }
-    };
-
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
-    const int lr = lane & 15, lg = lane >> 4;
-    // transposed read: lane 4q+p of a 16-lane group addresses row q of the group's 4-row block, columns 4p..4p+3
-    const int q = lr >> 2, pp = lr & 3;
-    // k-step ks, read half h: row = 32*ks + 8*lg + 4*h + q ;  f(row) = q | ((lg&1)<<2)  (independent of ks, h)
-    const int f = q | ((lg & 1) << 2);
-    const int row_off = (8 * lg + q) * 256;
-    int colbyteA[4], colbyteB[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        colbyteA[i] = ((((wm0 >> 4) + i) ^ f) << 5) + pp * 8;
-        colbyteB[i] = ((((wn0 >> 4) + i) ^ f) << 5) + pp * 8;
-    }
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int nk = (t_end - t_begin + BK - 1) / BK;
-    if (nk > 0) {
-        stage(0, t_begin);
-        __syncthreads();
-    }
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) stage(buf ^ 1, t_begin + (kt + 1) * BK);
-        const char* sa = smem + buf * STAGE_BYTES;
-        const char* sb = sa + TILE_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            typename T16<T>::v8 xa[4], wb[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                xa[i] = tr_frag<T>(sa, ks * 32 * 256 + row_off + colbyteA[i]);
-                wb[i] = tr_frag<T>(sb, ks * 32 * 256 + row_off + colbyteB[i]);
-            }
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = T16<T>::mfma16(wb[ni], xa[mi], acc[mi][ni]);
-        }
-        __syncthreads();
-    }
-    if (gridDim.x > (unsigned)tiles) {
-        // split-T: fp32 atomic accumulation into C (caller zeroed C or accumulates into it)
-        const int lr2 = lane & 15, lg2 = lane >> 4;
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int m = m0 + wm0 + mi * 16 + lr2;
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int n = n0 + wn0 + ni * 16 + lg2 * 4;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < p.N) atomicAdd((float*)p.C + (size_t)m * p.ldc + n + r, acc[mi][ni][r] * p.alpha);
-            }
-        }
+    if (nk > 1) {
+        stage(1, BK);
+        EOE_WAIT_VM(6);
     } else {
-        epilogue<T, EPI>(p, acc, m0 + wm0, n0 + wn0, lane);
+        EOE_WAIT_VM(0);
     }
+    __builtin_amdgcn_s_barrier();
+    EOE_READ(xa0, wb0, smem, ch0);
+    int cur = 0;                                  // ring slot of tile kt
+    for (int kt = 0; kt < nk; ++kt) {
+        const int nxt = (cur == NSTAGE - 1) ? 0 : cur + 1;
+        const int nx2 = (nxt == NSTAGE - 1) ? 0 : nxt + 1;
+        const char* sc = smem + cur * STAGE_BYTES;
+        if (kt + 2 < nk) stage(nx2, (kt + 2) * BK);
+        EOE_READ(xa1, wb1, sc, ch1);
+        EOE_MFMA(xa0, wb0);
+        if (kt + 2 < nk) { EOE_WAIT_VM(6); } else { EOE_WAIT_VM(0); }
+        EOE_WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
+        {   // unconditional (the last iteration reads a stale ring slot and discards it): keeps the compiler's
+            // lgkmcnt bookkeeping exact, so MFMA(F1) does not wait for these reads
+            const char* sn = smem + nxt * STAGE_BYTES;
+            EOE_READ(xa0, wb0, sn, ch0);
+        }
+        EOE_MFMA(xa1, wb1);
+        cur = nxt;
+    }
+#undef EOE_READ
+#undef EOE_MFMA
+    epilogue<T, EPI>(p, acc, m0 + wm0, n0 + wn0, lane);
 }
 
 template <typename T>
@@ -318,8 +236,8 @@ int launch_nt(const GemmP& p, int epi, hipStream_t s) {
     const int grid = cdiv(p.M, BM) * cdiv(p.N, BN);
 #define EOE_NT_CASE(E)                                                                      \
     case E:                                                                                 \
-        hipFuncSetAttribute((const void*)gemm_nt_kernel<T, E>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES); \
-        hipLaunchKernelGGL((gemm_nt_kernel<T, E>), dim3(grid), dim3(256), SMEM_BYTES, s, p); \
+        { static bool once = (hipFuncSetAttribute((const void*)gemm_nt_kernel<T, E>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES), true); (void)once; } \
+        hipLaunchKernelGGL((gemm_nt_kernel<T, E>), dim3(grid), dim3(512), SMEM_BYTES, s, p); \
         break;
     switch (epi) {
         EOE_NT_CASE(EOE_EPI_NONE)
@@ -333,20 +251,7 @@ int launch_nt(const GemmP& p, int epi, hipStream_t s) {
     return 0;
 }
 
-template <typename T>
-int launch_tn(const GemmP& p, int splits, hipStream_t s) {
-    const int tiles = cdiv(p.M, BM) * cdiv(p.N, BN);
-    int t_per = cdiv(cdiv(p.K, splits), BK) * BK;
-    if (t_per < BK) t_per = BK;
-    splits = cdiv(p.K, t_per);
-    if (splits < 1) splits = 1;
-    hipFuncSetAttribute((const void*)gemm_tn_kernel<T, EOE_EPI_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    hipLaunchKernelGGL((gemm_tn_kernel<T, EOE_EPI_NONE>), dim3(tiles * splits), dim3(256), SMEM_BYTES, s, p, t_per);
-    EOE_CHECK_LAUNCH("gemm_tn");
-    return 0;
-}
-
-int fill_params(const eoe_gemm_args* a, GemmP& p, bool tn) {
+int fill_params(const eoe_gemm_args* a, GemmP& p) {
     EOE_CHECK_ARG(a != nullptr, "gemm: null args");
     EOE_CHECK_ARG(a->A && a->B && a->C, "gemm: null operand");
     EOE_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "gemm: bad shape %d %d %d", a->M, a->N, a->K);
@@ -357,18 +262,10 @@ int fill_params(const eoe_gemm_args* a, GemmP& p, bool tn) {
     p.A = a->A; p.B = a->B; p.C = a->C; p.bias = a->bias; p.aux = a->aux; p.aux_out = a->aux_out;
     p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ldaux = a->ldaux;
     p.out_f32 = a->out_f32; p.accumulate = a->accumulate; p.alpha = a->alpha;
-    size_t ba, bb;
-    if (!tn) {
-        EOE_CHECK_ARG((a->K % BK) == 0, "gemm_nt: K=%d must be a multiple of %d", a->K, BK);
-        EOE_CHECK_ARG(a->lda >= a->K && a->ldb >= a->K, "gemm_nt: leading dims smaller than K");
-        ba = ((size_t)(a->M - 1) * a->lda + a->K) * 2;
-        bb = ((size_t)(a->N - 1) * a->ldb + a->K) * 2;
-    } else {
-        EOE_CHECK_ARG((a->M % 8) == 0 && (a->N % 8) == 0, "gemm_tn: M, N must be multiples of 8");
-        EOE_CHECK_ARG(a->lda >= a->M && a->ldb >= a->N, "gemm_tn: leading dims smaller than M/N");
-        ba = ((size_t)(a->K - 1) * a->lda + a->M) * 2;
-        bb = ((size_t)(a->K - 1) * a->ldb + a->N) * 2;
-    }
+    EOE_CHECK_ARG((a->K % BK) == 0, "gemm_nt: K=%d must be a multiple of %d", a->K, BK);
+    EOE_CHECK_ARG(a->lda >= a->K && a->ldb >= a->K, "gemm_nt: leading dims smaller than K");
+    const size_t ba = ((size_t)(a->M - 1) * a->lda + a->K) * 2;
+    const size_t bb = ((size_t)(a->N - 1) * a->ldb + a->K) * 2;
     EOE_CHECK_ARG(ba < 0x7fffffffull && bb < 0x7fffffffull, "gemm: operand larger than 2 GiB");
     p.bytesA = (unsigned)ba; p.bytesB = (unsigned)bb;
     // diagnostics only: EOE_GEMM_DEBUG=1 makes every operand load out of range (zero-filled, nothing fetched), which
@@ -383,17 +280,9 @@ int fill_params(const eoe_gemm_args* a, GemmP& p, bool tn) {
 
 }  // namespace
 
-// heuristic split of the wgrad reduction so that small outputs still fill the chip (fp32 atomics combine)
-int eoe_gemm_tn_splits(int M, int N, int T) {
-    const int tiles = cdiv(M, BM) * cdiv(N, BN);
-    int s = 1;
-    while (tiles * s < 200 && s < 16 && T / (s * 2) >= 512) s *= 2;
-    return s;
-}
-
 extern "C" int eoe_gemm_nt(const eoe_gemm_args* a, void* stream) {
     GemmP p;
-    EOE_TRY(fill_params(a, p, false));
+    EOE_TRY(fill_params(a, p));
     const int osz = a->out_f32 ? 4 : 2;
     ProfScope ps("gemm_nt", 2.0 * a->M * a->N * a->K,
                  2.0 * ((double)a->M * a->K + (double)a->N * a->K) + (double)osz * a->M * a->N *
@@ -403,20 +292,3 @@ extern "C" int eoe_gemm_nt(const eoe_gemm_args* a, void* stream) {
                                : launch_nt<bf16_t>(p, a->epilogue, (hipStream_t)stream);
 }
 
-extern "C" int eoe_gemm_tn(const eoe_gemm_args* a, void* stream) {
-    GemmP p;
-    EOE_TRY(fill_params(a, p, true));
-    EOE_CHECK_ARG(a->epilogue == EOE_EPI_NONE && a->out_f32, "gemm_tn: only plain fp32 output is supported");
-    int splits = eoe_gemm_tn_splits(a->M, a->N, a->K);
-    ProfScope ps("gemm_tn", 2.0 * a->M * a->N * a->K,
-                 2.0 * ((double)a->K * a->M + (double)a->K * a->N) + 4.0 * a->M * a->N, stream);
-    if (splits > 1 && !a->accumulate) {
-        // atomically combined partial sums need a zeroed destination
-        EOE_CHECK_ARG(a->ldc == a->N, "gemm_tn: split reduction needs a dense C");
-        if (hipMemsetAsync(a->C, 0, (size_t)a->M * a->N * sizeof(float), (hipStream_t)stream) != hipSuccess)
-            return eoe_set_error(EOE_ERR_LAUNCH, "gemm_tn: memset failed");
-    }
-    if (splits > 1 && a->bias) return eoe_set_error(EOE_ERR_ARG, "gemm_tn: bias with split reduction");
-    return a->dtype == EOE_F16 ? launch_tn<f16_t>(p, splits, (hipStream_t)stream)
-                               : launch_tn<bf16_t>(p, splits, (hipStream_t)stream);
-}

@@ -1,0 +1,279 @@
+// Weight-gradient GEMM for gfx950:  C[M,N] (fp32) = A[T,M]^T . B[T,N]   (A = dY, B = X, reduction over T tokens).
+//
+// Design for the wgrad regime (few output tiles, very long reduction: ViT-B/32 has M,N in {768,2304,3072} and
+// T = 12800): 256x128 output tiles, 8 wavefronts (4x2, 64x64 each, two per SIMD so they cover each other's LDS
+// and barrier stalls), ONE workgroup per CU, and a GROUPED launch: up to EOE_TN_MAX_GROUP independent problems
+// (the four weight gradients of a transformer block: 54 + 18 + 72 + 72 = 216 tiles) share one grid, so the chip
+// is filled by plain data parallelism over output tiles -- every tile runs the whole reduction, there is no
+// split-K, no atomics and no zero-init for that case, and the result is bitwise reproducible.  Small stand-alone
+// problems can still split T across workgroups (fp32 atomic accumulation).
+//
+// Operands are staged global -> LDS by bounds-checked LDS-DMA (buffer_load ... lds, 16 B per lane; out-of-range
+// lanes read 0 = zero padding of the ragged T / M / N tails).  The reduction dimension is the row (strided)
+// dimension of both operands, so MFMA fragments are read with the hardware-transposing ds_read_b64_tr_b16 from
+// LDS images [64 t][cols] whose 32-B granules are XOR-swizzled by (t&3)|((t>>3)&1)<<2 (applied on the SOURCE
+// address: LDS-DMA writes linearly), conflict-free for both 4-row halves of a k-step.
+// Workgroup ids are remapped so that each XCD (private L2) gets a contiguous run of tiles, which share A/B panels.
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int BM = 256, BN = 128, BK = 64;
+constexpr int A_BYTES = BK * BM * 2;              // 32 KiB
+constexpr int B_BYTES = BK * BN * 2;              // 16 KiB
+constexpr int STAGE_BYTES = A_BYTES + B_BYTES;    // 48 KiB
+constexpr int NSTAGE = 3;
+constexpr int SMEM_BYTES = NSTAGE * STAGE_BYTES;  // 144 KiB: one 8-wave workgroup per CU
+constexpr int NWAVES = 8;
+
+struct TnProblem {
+    const void* A; const void* B; float* C;
+    int M, N, lda, ldb, ldc, tiles_n, tile_start;
+    unsigned bytesA, bytesB;
+};
+struct TnGroup {
+    TnProblem p[EOE_TN_MAX_GROUP];
+    int count, T, total_tiles, splits, t_per_split, accumulate;
+    float alpha;
+};
+
+__device__ __forceinline__ int swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+template <typename T>
+__device__ __forceinline__ typename T16<T>::v8 tr_frag(const char* base, int off_lo, int row_bytes) {
+    i16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4v*)(base + off_lo));
+    i16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4v*)(base + off_lo + 4 * row_bytes));
+    i16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return __builtin_bit_cast(typename T16<T>::v8, r);
+}
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int split = blockIdx.x / g.total_tiles;
+    const int gt = xcd_remap(blockIdx.x % g.total_tiles, g.total_tiles);
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < EOE_TN_MAX_GROUP; ++i)
+        if (i < g.count && gt >= g.p[i].tile_start) pi = i;
+    const TnProblem& P = g.p[pi];
+    const int lt = gt - P.tile_start;
+    const int m0 = (lt / P.tiles_n) * BM, n0 = (lt % P.tiles_n) * BN;
+    const int t_begin = split * g.t_per_split;
+    const int t_end = min(g.T, t_begin + g.t_per_split);
+
+    __amdgpu_buffer_rsrc_t ra = make_rsrc(P.A, P.bytesA);
+    __amdgpu_buffer_rsrc_t rb = make_rsrc(P.B, P.bytesB);
+    const int lda = P.lda, ldb = P.ldb;
+
+    // staging.  A image: 64 rows x 512 B -> 32 wave-loads (2 rows each), 4 per wave;
+    //           B image: 64 rows x 256 B -> 16 wave-loads (4 rows each), 2 per wave.
+    int rowA[4], rowB[2];
+    unsigned colA[4], colB[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int wl = wave * 4 + j;
+        const int row = wl * 2 + (lane >> 5), s = lane & 31;
+        const int c16 = (((s >> 1) ^ swz(row)) << 1) | (s & 1);      // swz touches the low 3 granule bits only
+        rowA[j] = row;
+        const int c = m0 + c16 * 8;
+        colA[j] = (c < P.M) ? (unsigned)(c * 2) : EOE_OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int wl = wave * 2 + j;
+        const int row = wl * 4 + (lane >> 4), s = lane & 15;
+        const int c16 = (((s >> 1) ^ swz(row)) << 1) | (s & 1);
+        rowB[j] = row;
+        const int c = n0 + c16 * 8;
+        colB[j] = (c < P.N) ? (unsigned)(c * 2) : EOE_OOB;
+    }
+    auto stage = [&](int buf, int t0) {
+        char* sa = smem + buf * STAGE_BYTES;
+        char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = t0 + rowA[j];
+            const unsigned o = (t < t_end && colA[j] != EOE_OOB) ? (unsigned)((size_t)t * lda * 2) + colA[j] : EOE_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(sa + (wave * 4 + j) * 1024), 16, o, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int t = t0 + rowB[j];
+            const unsigned o = (t < t_end && colB[j] != EOE_OOB) ? (unsigned)((size_t)t * ldb * 2) + colB[j] : EOE_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(sb + (wave * 2 + j) * 1024), 16, o, 0, 0, 0);
+        }
+    };
+
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int lr = lane & 15, lg = lane >> 4;
+    // transposed read: lane 4q+p of a 16-lane group addresses row q of the group's 4-row block, columns 4p..4p+3
+    const int q = lr >> 2, pp = lr & 3;
+    const int f = q | ((lg & 1) << 2);                 // swz(row) for row = 32*ks + 8*lg + 4*h + q
+    const int rowsel = 8 * lg + q;
+    int offA[4], offB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        offA[i] = rowsel * (BM * 2) + ((((wm0 >> 4) + i) ^ f) << 5) + pp * 8;
+        offB[i] = rowsel * (BN * 2) + ((((wn0 >> 4) + i) ^ f) << 5) + pp * 8;
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // main loop: 3-stage LDS ring, LDS-DMA two k-tiles ahead behind a counted vmcnt, one raw s_barrier per k-tile,
+    // fragments double-buffered in registers (same schedule and hazard argument as gemm_nt_kernel in gemm.hip)
+    typedef typename T16<T>::v8 V8;
+#define EOE_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define EOE_READ(XA, WB, base, ks)                                                         \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                        \
+        XA[i] = tr_frag<T>((base), (ks) * 32 * (BM * 2) + offA[i], BM * 2);                \
+        WB[i] = tr_frag<T>((base) + A_BYTES, (ks) * 32 * (BN * 2) + offB[i], BN * 2);      \
+    }
+    // D = (B-tile fragment as the A operand) x (A-tile fragment as the B operand): the lane holds 4 consecutive n
+    // (output columns) of one output row m
+#define EOE_MFMA(XA, WB)                                                                   \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                       \
+        _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = T16<T>::mfma16(WB[ni], XA[mi], acc[mi][ni]);
+
+    const int nk = (t_end - t_begin + BK - 1) / BK;
+    if (nk > 0) {
+        V8 xa0[4], wb0[4], xa1[4], wb1[4];
+        stage(0, t_begin);
+        if (nk > 1) {
+            stage(1, t_begin + BK);
+            EOE_WAIT_VM(6);
+        } else {
+            EOE_WAIT_VM(0);
+        }
+        __builtin_amdgcn_s_barrier();
+        EOE_READ(xa0, wb0, smem, 0);
+        int cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int nxt = (cur == NSTAGE - 1) ? 0 : cur + 1;
+            const int nx2 = (nxt == NSTAGE - 1) ? 0 : nxt + 1;
+            const char* sc = smem + cur * STAGE_BYTES;
+            if (kt + 2 < nk) stage(nx2, t_begin + (kt + 2) * BK);
+            EOE_READ(xa1, wb1, sc, 1);
+            EOE_MFMA(xa0, wb0);
+            if (kt + 2 < nk) { EOE_WAIT_VM(6); } else { EOE_WAIT_VM(0); }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const char* sn = smem + nxt * STAGE_BYTES;
+            EOE_READ(xa0, wb0, sn, 0);          // unconditional: the last one reads a stale slot and is discarded
+            EOE_MFMA(xa1, wb1);
+            cur = nxt;
+        }
+    }
+#undef EOE_READ
+#undef EOE_MFMA
+
+    const bool atomic = g.splits > 1;
+    const bool vec = ((P.ldc & 3) == 0) && ((P.N & 3) == 0) && !atomic;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wm0 + mi * 16 + lr;
+        if (m >= P.M) continue;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wn0 + ni * 16 + lg * 4;
+            if (n >= P.N) continue;
+            float* c = P.C + (size_t)m * P.ldc + n;
+            f32x4 v = acc[mi][ni] * g.alpha;
+            if (vec) {
+                if (g.accumulate) v += *(const f32x4*)c;
+                *(f32x4*)c = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (n + r >= P.N) break;
+                    if (atomic) atomicAdd(c + r, v[r]);
+                    else c[r] = g.accumulate ? c[r] + v[r] : v[r];
+                }
+            }
+        }
+    }
+}
+
+int check_problem(const eoe_gemm_args* a, int T, int dtype) {
+    EOE_CHECK_ARG(a->A && a->B && a->C, "gemm_tn: null operand");
+    EOE_CHECK_ARG(a->M > 0 && a->N > 0 && a->K == T, "gemm_tn: bad shape %d %d %d (group T = %d)", a->M, a->N, a->K, T);
+    EOE_CHECK_ARG(a->dtype == dtype, "gemm_tn: mixed dtypes in a group");
+    EOE_CHECK_ARG((a->lda % 8) == 0 && (a->ldb % 8) == 0, "gemm_tn: lda/ldb must be multiples of 8 (16-B rows)");
+    EOE_CHECK_ARG((((uintptr_t)a->A | (uintptr_t)a->B) & 15) == 0, "gemm_tn: A/B must be 16-B aligned");
+    EOE_CHECK_ARG((a->M % 8) == 0 && (a->N % 8) == 0, "gemm_tn: M, N must be multiples of 8");
+    EOE_CHECK_ARG(a->lda >= a->M && a->ldb >= a->N && a->ldc >= a->N, "gemm_tn: leading dims too small");
+    EOE_CHECK_ARG(a->epilogue == EOE_EPI_NONE && a->out_f32 && !a->bias, "gemm_tn: only plain fp32 output is supported");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int eoe_gemm_tn_grouped(const eoe_gemm_args* args, int count, void* stream) {
+    EOE_CHECK_ARG(args && count >= 1 && count <= EOE_TN_MAX_GROUP, "gemm_tn_grouped: count %d not in [1, %d]", count,
+                  EOE_TN_MAX_GROUP);
+    const int T = args[0].K, dtype = args[0].dtype;
+    EOE_CHECK_ARG(dtype == EOE_F16 || dtype == EOE_BF16, "gemm_tn: bad dtype %d", dtype);
+    EOE_CHECK_ARG(T > 0, "gemm_tn: empty reduction");
+    TnGroup g;
+    memset(&g, 0, sizeof(g));
+    int tiles = 0;
+    double flops = 0, bytes = 0;
+    for (int i = 0; i < count; ++i) {
+        const eoe_gemm_args* a = &args[i];
+        EOE_TRY(check_problem(a, T, dtype));
+        EOE_CHECK_ARG(a->accumulate == args[0].accumulate && a->alpha == args[0].alpha,
+                      "gemm_tn_grouped: accumulate / alpha must agree within a group");
+        TnProblem& p = g.p[i];
+        p.A = a->A; p.B = a->B; p.C = (float*)a->C; p.M = a->M; p.N = a->N; p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc;
+        p.tiles_n = cdiv(a->N, BN);
+        p.tile_start = tiles;
+        tiles += cdiv(a->M, BM) * p.tiles_n;
+        const size_t ba = ((size_t)(T - 1) * a->lda + a->M) * 2, bb = ((size_t)(T - 1) * a->ldb + a->N) * 2;
+        EOE_CHECK_ARG(ba < 0x7fffffffull && bb < 0x7fffffffull, "gemm_tn: operand larger than 2 GiB");
+        p.bytesA = (unsigned)ba; p.bytesB = (unsigned)bb;
+        flops += 2.0 * a->M * a->N * T;
+        bytes += 2.0 * ((double)T * a->M + (double)T * a->N) + 4.0 * a->M * a->N;
+    }
+    static const int dbg = getenv("EOE_GEMM_DEBUG") ? atoi(getenv("EOE_GEMM_DEBUG")) : 0;
+    if (dbg & 1) for (int i = 0; i < count; ++i) { g.p[i].bytesA = 0; g.p[i].bytesB = 0; }
+    g.count = count; g.T = T; g.total_tiles = tiles; g.accumulate = args[0].accumulate; g.alpha = args[0].alpha;
+    // split the reduction only when the whole group leaves most of the chip idle
+    int splits = 1;
+    while (tiles * splits < 128 && splits < 32 && T / (splits * 2) >= 256) splits *= 2;
+    int t_per = cdiv(cdiv(T, splits), BK) * BK;
+    splits = cdiv(T, t_per);
+    g.splits = splits; g.t_per_split = t_per;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("gemm_tn", flops, bytes, stream);
+    if (splits > 1 && !g.accumulate) {
+        for (int i = 0; i < count; ++i) {
+            EOE_CHECK_ARG(args[i].ldc == args[i].N, "gemm_tn: split reduction needs a dense C");
+            if (hipMemsetAsync(args[i].C, 0, (size_t)args[i].M * args[i].N * sizeof(float), s) != hipSuccess)
+                return eoe_set_error(EOE_ERR_LAUNCH, "gemm_tn: memset failed");
+        }
+    }
+    if (dtype == EOE_F16) {
+        static bool once = (hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES), true);
+        (void)once;
+        hipLaunchKernelGGL((gemm_tn_grouped_kernel<f16_t>), dim3(tiles * splits), dim3(512), SMEM_BYTES, s, g);
+    } else {
+        static bool once = (hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES), true);
+        (void)once;
+        hipLaunchKernelGGL((gemm_tn_grouped_kernel<bf16_t>), dim3(tiles * splits), dim3(512), SMEM_BYTES, s, g);
+    }
+    EOE_CHECK_LAUNCH("gemm_tn_grouped");
+    return 0;
+}
+
+extern "C" int eoe_gemm_tn(const eoe_gemm_args* a, void* stream) {
+    EOE_CHECK_ARG(a != nullptr, "gemm_tn: null args");
+    return eoe_gemm_tn_grouped(a, 1, stream);
+}

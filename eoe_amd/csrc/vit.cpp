@@ -64,7 +64,7 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
     TRY(check_fwd(a));
     if (!a->w_in_t || !a->w_out_t || !a->w_fc_t || !a->w_proj_t || !b->dx_out || !b->dx_in || !b->g_ln1_g || !b->g_ln1_b ||
         !b->g_ln2_g || !b->g_ln2_b || !b->g_b_in || !b->g_b_out || !b->g_b_fc || !b->g_b_proj || !b->g_w_in || !b->g_w_out ||
-        !b->g_w_fc || !b->g_w_proj || !b->d16_a || !b->d16_b || !b->dh || !b->dqkv || !b->dx_mid)
+        !b->g_w_fc || !b->g_w_proj || !b->d16_a || !b->d16_b || !b->d16_c || !b->dh || !b->dqkv || !b->dx_mid)
         return eoe_set_error(EOE_ERR_ARG, "vit_block_bwd: null pointer in arguments");
     const int M = a->n * a->L, D = a->D, H = 4 * a->D, dt = a->dtype, acc = b->accumulate;
     hipStream_t s = (hipStream_t)stream;
@@ -74,38 +74,33 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
             hipMemsetAsync(b->g_ln2_g, 0, D * sizeof(float), s) != hipSuccess || hipMemsetAsync(b->g_ln2_b, 0, D * sizeof(float), s) != hipSuccess)
             return eoe_set_error(EOE_ERR_LAUNCH, "vit_block_bwd: memset failed");
     }
-    eoe_gemm_args g;
+    eoe_gemm_args g, w[4];
     // ---- MLP branch:  x_out = x_mid + c_proj(gelu(c_fc(ln_2(x_mid))))
     TRY(eoe_cast(b->dx_out, b->d16_a, (size_t)M * D, dt, stream));
     g = gemm(b->d16_a, a->w_proj_t, b->dh, nullptr, M, H, D, D, D, H, dt);                  // d hact, then * gelu'(hpre)
     g.epilogue = EOE_EPI_GELU_BWD; g.aux = a->hpre; g.ldaux = H;
     TRY(eoe_gemm_nt(&g, stream));
-    g = gemm(b->d16_a, a->hact, b->g_w_proj, nullptr, D, H, M, D, H, H, dt);                // dW_proj[D,4D] = dY^T hact
-    g.out_f32 = 1; g.accumulate = acc;
-    TRY(eoe_gemm_tn(&g, stream));
     TRY(eoe_colsum(b->d16_a, D, b->g_b_proj, M, D, dt, acc, stream));
     g = gemm(b->dh, a->w_fc_t, b->d16_b, nullptr, M, D, H, H, H, D, dt);                    // d xn2
     TRY(eoe_gemm_nt(&g, stream));
-    g = gemm(b->dh, a->xn2, b->g_w_fc, nullptr, H, D, M, H, D, D, dt);                      // dW_fc[4D,D] = dh^T xn2
-    g.out_f32 = 1; g.accumulate = acc;
-    TRY(eoe_gemm_tn(&g, stream));
     TRY(eoe_colsum(b->dh, H, b->g_b_fc, M, H, dt, acc, stream));
-    TRY(eoe_layernorm_bwd(b->d16_b, 0, a->x_mid, D, a->stats2, a->ln2_g, b->dx_out, b->dx_mid, D, b->d16_a, b->g_ln2_g,
+    TRY(eoe_layernorm_bwd(b->d16_b, 0, a->x_mid, D, a->stats2, a->ln2_g, b->dx_out, b->dx_mid, D, b->d16_c, b->g_ln2_g,
                           b->g_ln2_b, M, D, dt, stream));
     // ---- attention branch:  x_mid = x_in + out_proj(attn(ln_1(x_in)))
-    g = gemm(b->d16_a, a->w_out_t, b->d16_b, nullptr, M, D, D, D, D, D, dt);                // d att
+    g = gemm(b->d16_c, a->w_out_t, b->d16_b, nullptr, M, D, D, D, D, D, dt);                // d att
     TRY(eoe_gemm_nt(&g, stream));
-    g = gemm(b->d16_a, a->att, b->g_w_out, nullptr, D, D, M, D, D, D, dt);                  // dW_out[D,D]
-    g.out_f32 = 1; g.accumulate = acc;
-    TRY(eoe_gemm_tn(&g, stream));
-    TRY(eoe_colsum(b->d16_a, D, b->g_b_out, M, D, dt, acc, stream));
+    TRY(eoe_colsum(b->d16_c, D, b->g_b_out, M, D, dt, acc, stream));
     TRY(eoe_attn_bwd(a->qkv, b->d16_b, b->dqkv, a->n, a->L, a->heads, dt, stream));
     g = gemm(b->dqkv, a->w_in_t, b->d16_b, nullptr, M, D, 3 * D, 3 * D, 3 * D, D, dt);      // d xn1
     TRY(eoe_gemm_nt(&g, stream));
-    g = gemm(b->dqkv, a->xn1, b->g_w_in, nullptr, 3 * D, D, M, 3 * D, D, D, dt);            // dW_in[3D,D]
-    g.out_f32 = 1; g.accumulate = acc;
-    TRY(eoe_gemm_tn(&g, stream));
     TRY(eoe_colsum(b->dqkv, 3 * D, b->g_b_in, M, 3 * D, dt, acc, stream));
+    // ---- the four weight gradients of the block in one grouped launch (every dY and X is still live)
+    w[0] = gemm(b->dh, a->xn2, b->g_w_fc, nullptr, H, D, M, H, D, D, dt);                    // dW_fc[4D,D]   = dh^T xn2
+    w[1] = gemm(b->d16_a, a->hact, b->g_w_proj, nullptr, D, H, M, D, H, H, dt);             // dW_proj[D,4D] = dY^T hact
+    w[2] = gemm(b->dqkv, a->xn1, b->g_w_in, nullptr, 3 * D, D, M, 3 * D, D, D, dt);         // dW_in[3D,D]   = dqkv^T xn1
+    w[3] = gemm(b->d16_c, a->att, b->g_w_out, nullptr, D, D, M, D, D, D, dt);               // dW_out[D,D]   = dmid^T att
+    for (int i = 0; i < 4; ++i) { w[i].out_f32 = 1; w[i].accumulate = acc; }
+    TRY(eoe_gemm_tn_grouped(w, 4, stream));
     TRY(eoe_layernorm_bwd(b->d16_b, 0, a->x_in, D, a->stats1, a->ln1_g, b->dx_mid, b->dx_in, D, nullptr, b->g_ln1_g,
                           b->g_ln1_b, M, D, dt, stream));
     return 0;

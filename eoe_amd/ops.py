@@ -358,6 +358,7 @@ class VitBlockFunction(torch.autograd.Function):
         b.accumulate = 0
         b.d16_a = _p(scratch("d16_a", (M, D), dt, dev))
         b.d16_b = _p(scratch("d16_b", (M, D), dt, dev))
+        b.d16_c = _p(scratch("d16_c", (M, D), dt, dev))
         b.dh = _p(scratch("dh", (M, 4 * D), dt, dev))
         b.dqkv = _p(scratch("dqkv", (M, 3 * D), dt, dev))
         b.dx_mid = _p(scratch("dx_mid", (M, D), torch.float32, dev))

@@ -63,6 +63,10 @@ typedef struct {
 
 int eoe_gemm_nt(const eoe_gemm_args* args, void* stream);
 int eoe_gemm_tn(const eoe_gemm_args* args, void* stream);
+/* up to EOE_TN_MAX_GROUP independent TN problems with the same reduction length T, dtype, accumulate and alpha in
+ * ONE launch (the four weight gradients of a transformer block fill the chip together: no split-K, no atomics) */
+#define EOE_TN_MAX_GROUP 4
+int eoe_gemm_tn_grouped(const eoe_gemm_args* args, int count, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * element-wise / reduction kernels (HBM-bound; wavefront-shuffle reductions)
@@ -193,8 +197,9 @@ typedef struct {
     float *g_w_in, *g_w_out, *g_w_fc, *g_w_proj;
     int32_t accumulate;
     /* scratch (caller-allocated, 16-bit unless noted): */
-    void *d16_a;      /* [M,D]   16-bit copy of a residual-stream gradient */
-    void *d16_b;      /* [M,D]   */
+    void *d16_a;      /* [M,D]   16-bit copy of dx_out (dY of c_proj)          */
+    void *d16_b;      /* [M,D]   dgrad outputs (d xn2, d att, d xn1 in turn)   */
+    void *d16_c;      /* [M,D]   16-bit copy of dx_mid (dY of out_proj)        */
     void *dh;         /* [M,4D]  */
     void *dqkv;       /* [M,3D]  */
     float* dx_mid;    /* fp32 [M,D] */

@@ -83,6 +83,34 @@ def test_gemm_tn(ops, dtype, T, M, N):
     assert_close(out, 2 * ref, 4e-6, 6e-5 * math.sqrt(T), f"gemm_tn accumulate {T}x{M}x{N}")
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_tn_grouped(ops, dtype):
+    """the four weight gradients of a (small) block in one launch, ragged T, against fp64"""
+    import ctypes as C
+    from eoe_amd import _lib
+    T = 456
+    shapes = [(264, 136), (128, 520), (768, 256), (8, 8)]
+    args = (_lib.GemmArgs * 4)()
+    keep, outs, refs = [], [], []
+    for i, (m, n) in enumerate(shapes):
+        a, ar = t16(f"tng/a{i}", (T, m), 1.0, dtype)
+        b, br = t16(f"tng/b{i}", (T, n), 1.0, dtype)
+        out = torch.full((m, n), 3.0, dtype=torch.float32, device="cuda")
+        keep += [a, b]
+        outs.append(out)
+        refs.append(ar.double().t() @ br.double())
+        args[i] = _lib.GemmArgs(a.data_ptr(), b.data_ptr(), out.data_ptr(), None, None, None, m, n, T, m, n, n, 0,
+                                ops.dtype_code(dtype), 0, 1, 0, 1.0)
+    _lib.check(_lib.lib.eoe_gemm_tn_grouped(args, 4, torch.cuda.current_stream().cuda_stream), "grouped")
+    for out, ref in zip(outs, refs):
+        assert_close(out, ref, 2e-6, 3e-5 * math.sqrt(T), "gemm_tn_grouped")
+    for i in range(4):
+        args[i].accumulate = 1
+    _lib.check(_lib.lib.eoe_gemm_tn_grouped(args, 4, torch.cuda.current_stream().cuda_stream), "grouped acc")
+    for out, ref in zip(outs, refs):
+        assert_close(out, 2 * ref, 4e-6, 6e-5 * math.sqrt(T), "gemm_tn_grouped accumulate")
+
+
 def test_gemm_rejects_bad_shapes(ops):
     a = torch.zeros((8, 40), dtype=torch.bfloat16, device="cuda")
     b = torch.zeros((8, 40), dtype=torch.bfloat16, device="cuda")

@@ -70,3 +70,20 @@ for name, m, n, t in shapes_tn:
         tot_us += us; tot_fl += fl
     print(f"TN {name:9s} {m:6d}x{n:5d}x{t:5d}        {us:8.1f} us  {fl / us / 1e6:7.1f} TF")
 print(f"TN layer total {tot_us:.1f} us  {tot_fl / tot_us / 1e6:.1f} TF")
+# the four wgrads of a block as one grouped launch
+import ctypes as C
+from eoe_amd import _lib
+args = (_lib.GemmArgs * 4)()
+keep = []
+fl = 0
+for i, (name, m, n, t) in enumerate(shapes_tn[:4]):
+    a = torch.randn(t, m, device="cuda").to(dt)
+    b = torch.randn(t, n, device="cuda").to(dt)
+    out = torch.empty(m, n, device="cuda", dtype=torch.float32)
+    keep += [a, b, out]
+    args[i] = _lib.GemmArgs(a.data_ptr(), b.data_ptr(), out.data_ptr(), None, None, None, m, n, t, m, n, n, 0,
+                            ops.dtype_code(dt), 0, 1, 0, 1.0)
+    fl += 2.0 * m * n * t
+st = torch.cuda.current_stream().cuda_stream
+us = timeit(lambda: _lib.check(_lib.lib.eoe_gemm_tn_grouped(args, 4, st), "g"))
+print(f"TN grouped block wgrad (216 tiles)           {us:8.1f} us  {fl / us / 1e6:7.1f} TF")
