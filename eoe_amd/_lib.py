@@ -15,7 +15,7 @@ _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_si
 
 
 class GemmArgs(C.Structure):
-    _fields_ = [("A", _vp), ("B", _vp), ("C", _vp), ("bias", _vp), ("aux", _vp), ("aux_out", _vp),
+    _fields_ = [("A", _vp), ("B", _vp), ("C", _vp), ("bias", _vp), ("aux", _vp), ("aux_out", _vp), ("colsum", _vp),
                 ("M", _i32), ("N", _i32), ("K", _i32),
                 ("lda", _i32), ("ldb", _i32), ("ldc", _i32), ("ldaux", _i32),
                 ("dtype", _i32), ("epilogue", _i32), ("out_f32", _i32), ("accumulate", _i32), ("alpha", _f32)]
@@ -66,8 +66,9 @@ SIGNATURES = {
     "eoe_embed_lnpre_fwd": [_vp] * 8 + [C.c_int, C.c_int, C.c_int, _f32, _vp],
     "eoe_embed_lnpre_bwd": [_vp] * 9 + [C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "eoe_layernorm_fwd": [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, C.c_int, C.c_int, _vp],
-    "eoe_layernorm_bwd": [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int,
-                          C.c_int, _vp],
+    "eoe_layernorm_bwd": [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int,
+                          C.c_int, C.c_int, _vp],
+    "eoe_cast_colsum": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "eoe_colsum": [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "eoe_cast": [_vp, _vp, _sz, C.c_int, _vp],
     "eoe_attn_fwd": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],

@@ -47,6 +47,60 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
     }
 }
 
+// vectorised variant (rows, cols multiples of 4): float4 reads, 8-byte writes on both copies
+template <typename T>
+__global__ __launch_bounds__(256) void cast_transpose_vec_kernel(const float* __restrict__ src, T* __restrict__ dst,
+                                                                 T* __restrict__ dst_t, int rows, int cols) {
+    __shared__ T tile[64][68];
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int sub = threadIdx.x >> 4, q4 = (threadIdx.x & 15) * 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = p * 16 + sub, gr = r0 + r, gc = c0 + q4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gr < rows && gc < cols) {
+            v = *(const f32x4*)(src + (size_t)gr * cols + gc);
+            if (dst) *(u32x2*)(dst + (size_t)gr * cols + gc) = pack4<T>(v[0], v[1], v[2], v[3]);
+        }
+        tile[r][q4 + 0] = (T)v[0]; tile[r][q4 + 1] = (T)v[1]; tile[r][q4 + 2] = (T)v[2]; tile[r][q4 + 3] = (T)v[3];
+    }
+    __syncthreads();
+    if (dst_t) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int c = p * 16 + sub, gc = c0 + c, gr = r0 + q4;
+            if (gc < cols && gr < rows) {
+                typename T16<T>::v4 o;
+                o[0] = tile[q4 + 0][c]; o[1] = tile[q4 + 1][c]; o[2] = tile[q4 + 2][c]; o[3] = tile[q4 + 3][c];
+                *(u32x2*)(dst_t + (size_t)gc * rows + gr) = __builtin_bit_cast(u32x2, o);
+            }
+        }
+    }
+}
+
+// fp32 [rows, cols] -> 16-bit copy + column sums (bias gradient of the layer whose dY this is), one pass
+template <typename T>
+__global__ __launch_bounds__(256) void cast_colsum_kernel(const float* __restrict__ x, T* __restrict__ dst,
+                                                          float* __restrict__ out, int rows, int cols) {
+    __shared__ float red[4][256];
+    const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 256 + cg * 4;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < cols) {
+        for (int r = blockIdx.y * 4 + rl; r < rows; r += gridDim.y * 4) {
+            const f32x4 v = *(const f32x4*)(x + (size_t)r * cols + c);
+            *(u32x2*)(dst + (size_t)r * cols + c) = pack4<T>(v[0], v[1], v[2], v[3]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] += v[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[rl][cg * 4 + k] = a[k];
+    __syncthreads();
+    const int cc = blockIdx.x * 256 + threadIdx.x;
+    if (cc < cols) atomicAdd(out + cc, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 // ------------------------------------------------------------------------------------------ patchify
 // one block per (image, patch-row py): reads 3 * p rows of res floats (coalesced), writes g patches.
 template <typename T>
@@ -140,15 +194,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
                                      const float* __restrict__ stats, const float* __restrict__ gamma,
                                      const float* __restrict__ dres, float* __restrict__ dx_out, int ld_out,
                                      T* __restrict__ dx16, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                     int rows, int D) {
-    __shared__ float red[2][4][1024];
+                                     float* __restrict__ dxsum, int rows, int D) {
+    __shared__ float red[3][4][1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int nv = NV;
-    f32x4 ag[NV], ab[NV], gm[NV];
+    f32x4 ag[NV], ab[NV], ax[NV], gm[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         ag[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         ab[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        ax[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (i < nv) gm[i] = *(const f32x4*)(gamma + i * 256 + lane * 4);
     }
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
@@ -194,9 +249,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
                 }
                 *(f32x4*)(dx_out + (size_t)row * ld_out + c) = (f32x4){o[0], o[1], o[2], o[3]};
                 if (dx16) *(u32x2*)(dx16 + (size_t)row * D + c) = pack4<T>(o[0], o[1], o[2], o[3]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ax[i][r] += o[r];
             }
     }
-    if (!dgamma) return;
+    if (!dgamma && !dxsum) return;
 #pragma unroll
     for (int i = 0; i < NV; ++i)
         if (i < nv) {
@@ -204,14 +261,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
             for (int r = 0; r < 4; ++r) {
                 red[0][wave][i * 256 + lane * 4 + r] = ag[i][r];
                 red[1][wave][i * 256 + lane * 4 + r] = ab[i][r];
+                red[2][wave][i * 256 + lane * 4 + r] = ax[i][r];
             }
         }
     __syncthreads();
     for (int c = threadIdx.x; c < D; c += blockDim.x) {
-        const float sg = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
-        const float sb = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
-        atomicAdd(dgamma + c, sg);
-        atomicAdd(dbeta + c, sb);
+        if (dgamma) {
+            atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+            atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+        }
+        if (dxsum) atomicAdd(dxsum + c, red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c]);
     }
 }
 
@@ -529,8 +588,13 @@ extern "C" int eoe_cast_transpose(const float* src, void* dst, void* dst_t, int 
     EOE_CHECK_ARG(src && (dst || dst_t) && rows > 0 && cols > 0, "cast_transpose: bad args");
     ProfScope ps("cast_transpose", 0, ((dst ? 2.0 : 0.0) + (dst_t ? 2.0 : 0.0) + 4.0) * rows * cols, stream);
     dim3 grid(cdiv(cols, 64), cdiv(rows, 64));
-    DISPATCH_T(dtype, hipLaunchKernelGGL((cast_transpose_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, src,
-                                         (T*)dst, (T*)dst_t, rows, cols));
+    if ((rows & 3) == 0 && (cols & 3) == 0) {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((cast_transpose_vec_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, src,
+                                             (T*)dst, (T*)dst_t, rows, cols));
+    } else {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((cast_transpose_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, src,
+                                             (T*)dst, (T*)dst_t, rows, cols));
+    }
     EOE_CHECK_LAUNCH("cast_transpose");
     return 0;
 }
@@ -561,7 +625,8 @@ extern "C" int eoe_layernorm_fwd(const float* x, int ldx, const float* gamma, co
 
 extern "C" int eoe_layernorm_bwd(const void* dy, int dy_f32, const float* x, int ldx, const float* stats,
                                  const float* gamma, const float* dres, float* dx_out, int ld_out, void* dx16,
-                                 float* dgamma, float* dbeta, int rows, int D, int dtype, void* stream) {
+                                 float* dgamma, float* dbeta, float* dxsum, int rows, int D, int dtype,
+                                 void* stream) {
     EOE_CHECK_ARG(dy && x && stats && gamma && dx_out && rows > 0, "layernorm_bwd: bad args");
     EOE_CHECK_ARG(D % 256 == 0 && D <= 1024 && ldx % 4 == 0 && ld_out % 4 == 0, "layernorm: D must be a multiple of 256, <= 1024");
     EOE_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma/dbeta must both be given or both NULL");
@@ -570,7 +635,7 @@ extern "C" int eoe_layernorm_bwd(const void* dy, int dy_f32, const float* x, int
     if (grid > 512) grid = 512;
     DISPATCH_T(dtype, DISPATCH_NV(D, hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy,
                                          dy_f32, x, ldx, stats, gamma, dres, dx_out, ld_out, (T*)dx16, dgamma, dbeta,
-                                         rows, D)));
+                                         dxsum, rows, D)));
     EOE_CHECK_LAUNCH("layernorm_bwd");
     return 0;
 }
@@ -613,6 +678,23 @@ extern "C" int eoe_colsum(const void* x, int ldx, float* out, int rows, int cols
     DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), dim3(cdiv(cols, 256), gy), dim3(256), 0,
                                          (hipStream_t)stream, (const T*)x, ldx, out, rows, cols));
     EOE_CHECK_LAUNCH("colsum");
+    return 0;
+}
+
+extern "C" int eoe_cast_colsum(const float* x, void* dst, float* out, int rows, int cols, int dtype, int accumulate,
+                               void* stream) {
+    EOE_CHECK_ARG(x && dst && out && rows > 0 && cols > 0, "cast_colsum: bad args");
+    EOE_CHECK_ARG(cols % 4 == 0, "cast_colsum: cols must be a multiple of 4");
+    ProfScope ps("cast_colsum", 0, 6.0 * rows * cols, stream);
+    if (!accumulate) {
+        if (hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), (hipStream_t)stream) != hipSuccess)
+            return eoe_set_error(EOE_ERR_LAUNCH, "cast_colsum: memset failed");
+    }
+    int gy = cdiv(rows, 4 * 8);
+    if (gy > 256) gy = 256;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((cast_colsum_kernel<T>), dim3(cdiv(cols, 256), gy), dim3(256), 0,
+                                         (hipStream_t)stream, x, (T*)dst, out, rows, cols));
+    EOE_CHECK_LAUNCH("cast_colsum");
     return 0;
 }
 

@@ -23,7 +23,7 @@ constexpr int STAGE_BYTES = A_BYTES + B_BYTES;    // 48 KiB
 constexpr int SMEM_BYTES = NSTAGE * STAGE_BYTES;  // 144 KiB: one 8-wave workgroup per CU
 
 struct GemmP {
-    const void* A; const void* B; void* C; const float* bias; const void* aux; void* aux_out;
+    const void* A; const void* B; void* C; const float* bias; const void* aux; void* aux_out; float* colsum;
     int M, N, K, lda, ldb, ldc, ldaux, out_f32, accumulate;
     float alpha;
     unsigned bytesA, bytesB;
@@ -33,6 +33,9 @@ template <typename T, int EPI>
 __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[4][4], int m_base, int n_base, int lane) {
     const int lr = lane & 15, lg = lane >> 4;
     const bool vec_ok = ((p.ldc & 3) == 0) && ((p.N & 3) == 0);
+    f32x4 cs[4];                       // per-ni column sums of this lane's rows (bias gradient of the producer)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) cs[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int m = m_base + mi * 16 + lr;
@@ -97,6 +100,10 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[4][4], int
                     for (int r = 0; r < nvalid; ++r) v[r] *= quick_gelu_grad_f((float)pre[r]);
                 }
             }
+            if (EPI != EOE_EPI_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cs[ni][r] += v[r];
+            }
             if (p.out_f32) {
                 float* c = (float*)p.C + off;
                 if (vec_ok) {
@@ -116,6 +123,19 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[4][4], int
                 } else {
                     for (int r = 0; r < nvalid; ++r) c[r] = (T)v[r];
                 }
+            }
+        }
+    }
+    if (EPI != EOE_EPI_GELU && p.colsum) {
+        // rows of this wave's 64x64 sub-tile live on the 16 lanes sharing lane>>4: xor-reduce over lane&15
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = cs[ni][r];
+                t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+                const int n = n_base + ni * 16 + lg * 4 + r;
+                if (lr == 0 && n < p.N) atomicAdd(p.colsum + n, t);
             }
         }
     }
@@ -259,7 +279,7 @@ int fill_params(const eoe_gemm_args* a, GemmP& p) {
     EOE_CHECK_ARG((a->lda % 8) == 0 && (a->ldb % 8) == 0, "gemm: lda/ldb must be multiples of 8 (16-B rows)");
     EOE_CHECK_ARG((((uintptr_t)a->A | (uintptr_t)a->B) & 15) == 0, "gemm: A/B must be 16-B aligned");
     EOE_CHECK_ARG(!a->accumulate || a->out_f32, "gemm: accumulate needs an fp32 C");
-    p.A = a->A; p.B = a->B; p.C = a->C; p.bias = a->bias; p.aux = a->aux; p.aux_out = a->aux_out;
+    p.A = a->A; p.B = a->B; p.C = a->C; p.bias = a->bias; p.aux = a->aux; p.aux_out = a->aux_out; p.colsum = a->colsum;
     p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ldaux = a->ldaux;
     p.out_f32 = a->out_f32; p.accumulate = a->accumulate; p.alpha = a->alpha;
     EOE_CHECK_ARG((a->K % BK) == 0, "gemm_nt: K=%d must be a multiple of %d", a->K, BK);

@@ -16,7 +16,7 @@ namespace {
 eoe_gemm_args gemm(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, int lda, int ldb,
                    int ldc, int dtype) {
     eoe_gemm_args g;
-    g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = nullptr; g.aux_out = nullptr;
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = nullptr; g.aux_out = nullptr; g.colsum = nullptr;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = 0;
     g.dtype = dtype; g.epilogue = EOE_EPI_NONE; g.out_f32 = 0; g.accumulate = 0; g.alpha = 1.0f;
     return g;
@@ -76,20 +76,22 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
     }
     eoe_gemm_args g, w[4];
     // ---- MLP branch:  x_out = x_mid + c_proj(gelu(c_fc(ln_2(x_mid))))
-    TRY(eoe_cast(b->dx_out, b->d16_a, (size_t)M * D, dt, stream));
+    // bias gradients are column sums of the dY tensors: fused into the kernels that produce them (fp32 atomics)
+    if (!acc) {
+        if (hipMemsetAsync(b->g_b_fc, 0, H * sizeof(float), s) != hipSuccess || hipMemsetAsync(b->g_b_out, 0, D * sizeof(float), s) != hipSuccess)
+            return eoe_set_error(EOE_ERR_LAUNCH, "vit_block_bwd: memset failed");
+    }
+    TRY(eoe_cast_colsum(b->dx_out, b->d16_a, b->g_b_proj, M, D, dt, acc, stream));          // dY of c_proj + db_proj
     g = gemm(b->d16_a, a->w_proj_t, b->dh, nullptr, M, H, D, D, D, H, dt);                  // d hact, then * gelu'(hpre)
-    g.epilogue = EOE_EPI_GELU_BWD; g.aux = a->hpre; g.ldaux = H;
+    g.epilogue = EOE_EPI_GELU_BWD; g.aux = a->hpre; g.ldaux = H; g.colsum = b->g_b_fc;      // + db_fc
     TRY(eoe_gemm_nt(&g, stream));
-    TRY(eoe_colsum(b->d16_a, D, b->g_b_proj, M, D, dt, acc, stream));
     g = gemm(b->dh, a->w_fc_t, b->d16_b, nullptr, M, D, H, H, H, D, dt);                    // d xn2
     TRY(eoe_gemm_nt(&g, stream));
-    TRY(eoe_colsum(b->dh, H, b->g_b_fc, M, H, dt, acc, stream));
     TRY(eoe_layernorm_bwd(b->d16_b, 0, a->x_mid, D, a->stats2, a->ln2_g, b->dx_out, b->dx_mid, D, b->d16_c, b->g_ln2_g,
-                          b->g_ln2_b, M, D, dt, stream));
+                          b->g_ln2_b, b->g_b_out, M, D, dt, stream));                       // + db_out = colsum(dx_mid)
     // ---- attention branch:  x_mid = x_in + out_proj(attn(ln_1(x_in)))
     g = gemm(b->d16_c, a->w_out_t, b->d16_b, nullptr, M, D, D, D, D, D, dt);                // d att
     TRY(eoe_gemm_nt(&g, stream));
-    TRY(eoe_colsum(b->d16_c, D, b->g_b_out, M, D, dt, acc, stream));
     TRY(eoe_attn_bwd(a->qkv, b->d16_b, b->dqkv, a->n, a->L, a->heads, dt, stream));
     g = gemm(b->dqkv, a->w_in_t, b->d16_b, nullptr, M, D, 3 * D, 3 * D, 3 * D, D, dt);      // d xn1
     TRY(eoe_gemm_nt(&g, stream));
@@ -102,6 +104,6 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
     for (int i = 0; i < 4; ++i) { w[i].out_f32 = 1; w[i].accumulate = acc; }
     TRY(eoe_gemm_tn_grouped(w, 4, stream));
     TRY(eoe_layernorm_bwd(b->d16_b, 0, a->x_in, D, a->stats1, a->ln1_g, b->dx_mid, b->dx_in, D, nullptr, b->g_ln1_g,
-                          b->g_ln1_b, M, D, dt, stream));
+                          b->g_ln1_b, nullptr, M, D, dt, stream));
     return 0;
 }

@@ -5,6 +5,7 @@ is a hand-written HIP kernel reached through ctypes (eoe_amd._lib).  All functio
 and raise otherwise -- there is no CPU path in this package.
 """
 import ctypes as C
+import weakref
 from typing import Optional
 
 import torch
@@ -58,14 +59,15 @@ def _chk(*ts):
 
 
 # ------------------------------------------------------------------------------------------------ raw ops
-def gemm_nt(a, b, out, bias=None, epilogue=EPI_NONE, aux=None, aux_out=None, accumulate=False, alpha=1.0):
+def gemm_nt(a, b, out, bias=None, epilogue=EPI_NONE, aux=None, aux_out=None, accumulate=False, alpha=1.0,
+            colsum_out=None):
     """out[M,N] = a[M,K] @ b[N,K]^T  (+ epilogue); a, b 16-bit row-major (row stride may exceed K)"""
-    _chk(a, b, out, bias, aux, aux_out)
+    _chk(a, b, out, bias, aux, aux_out, colsum_out)
     M, K = a.shape
     N = b.shape[0]
     assert b.shape[1] == K and out.shape == (M, N), (a.shape, b.shape, out.shape)
     assert a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1 and a.dtype == b.dtype
-    g = GemmArgs(_p(a), _p(b), _p(out), _p(bias), _p(aux), _p(aux_out), M, N, K, a.stride(0), b.stride(0),
+    g = GemmArgs(_p(a), _p(b), _p(out), _p(bias), _p(aux), _p(aux_out), _p(colsum_out), M, N, K, a.stride(0), b.stride(0),
                  out.stride(0), aux.stride(0) if aux is not None else 0, dtype_code(a.dtype), epilogue,
                  1 if out.dtype == torch.float32 else 0, 1 if accumulate else 0, float(alpha))
     check(lib.eoe_gemm_nt(C.byref(g), _stream()), "eoe_gemm_nt")
@@ -79,7 +81,7 @@ def gemm_tn(a, b, out, accumulate=False, alpha=1.0):
     N = b.shape[1]
     assert b.shape[0] == T and out.shape == (M, N) and out.dtype == torch.float32
     assert a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1 and a.dtype == b.dtype
-    g = GemmArgs(_p(a), _p(b), _p(out), None, None, None, M, N, T, a.stride(0), b.stride(0), out.stride(0), 0,
+    g = GemmArgs(_p(a), _p(b), _p(out), None, None, None, None, M, N, T, a.stride(0), b.stride(0), out.stride(0), 0,
                  dtype_code(a.dtype), EPI_NONE, 1, 1 if accumulate else 0, float(alpha))
     check(lib.eoe_gemm_tn(C.byref(g), _stream()), "eoe_gemm_tn")
     return out
@@ -107,6 +109,15 @@ def cast_transpose(src: torch.Tensor, dtype=None, want=True, want_t=True):
     return d, dt
 
 
+def cast_colsum(x: torch.Tensor, out16: torch.Tensor, colsum_out: torch.Tensor, accumulate=False):
+    """out16 = 16-bit copy of x (fp32 [rows, cols]); colsum_out[c] (+)= sum_r x[r, c]"""
+    _chk(x, out16, colsum_out)
+    rows, cols = x.shape
+    check(lib.eoe_cast_colsum(_p(x), _p(out16), _p(colsum_out), rows, cols, dtype_code(out16.dtype),
+                              1 if accumulate else 0, _stream()), "eoe_cast_colsum")
+    return out16
+
+
 def colsum(x16: torch.Tensor, out: torch.Tensor, accumulate=False):
     _chk(x16, out)
     rows, cols = x16.shape
@@ -124,12 +135,13 @@ def layernorm_fwd(x, gamma, beta, rows, D, ldx, out, stats, eps=1e-5):
     return out
 
 
-def layernorm_bwd(dy, x, stats, gamma, rows, D, ldx, dx_out, ld_out, dres=None, dx16=None, dgamma=None, dbeta=None):
-    _chk(dy, x, stats, gamma, dx_out, dres, dx16, dgamma, dbeta)
+def layernorm_bwd(dy, x, stats, gamma, rows, D, ldx, dx_out, ld_out, dres=None, dx16=None, dgamma=None, dbeta=None,
+                  dxsum=None):
+    _chk(dy, x, stats, gamma, dx_out, dres, dx16, dgamma, dbeta, dxsum)
     dy_f32 = 1 if dy.dtype == torch.float32 else 0
     code = dtype_code(dy.dtype) if not dy_f32 else (dtype_code(dx16.dtype) if dx16 is not None else _lib.EOE_BF16)
     check(lib.eoe_layernorm_bwd(_p(dy), dy_f32, _p(x), ldx, _p(stats), _p(gamma), _p(dres), _p(dx_out), ld_out,
-                                _p(dx16), _p(dgamma), _p(dbeta), rows, D, code, _stream()), "eoe_layernorm_bwd")
+                                _p(dx16), _p(dgamma), _p(dbeta), _p(dxsum), rows, D, code, _stream()), "eoe_layernorm_bwd")
     return dx_out
 
 
@@ -164,19 +176,21 @@ class _Shadow:
     parameter's version counter or storage changes (the fused optimiser bumps the counter)."""
 
     def __init__(self):
+        # id(param) -> (weakref(param), tag, copy, transposed copy).  The weak reference guards against a dead
+        # model's copies being handed to a new parameter that reuses the address, version and storage.
         self.cache = {}
 
     def get(self, p: torch.Tensor, want=True, want_t=True, view2d=None):
         key = id(p)
         tag = (p._version, p.data_ptr(), _compute_dtype, want, want_t)
         hit = self.cache.get(key)
-        if hit is not None and hit[0] == tag:
-            return hit[1], hit[2]
+        if hit is not None and hit[0]() is p and hit[1] == tag:
+            return hit[2], hit[3]
         src = p.detach()
         if view2d is not None:
             src = src.reshape(view2d)
         d, dt = cast_transpose(src, _compute_dtype, want, want_t)
-        self.cache[key] = (tag, d, dt)
+        self.cache[key] = (weakref.ref(p, lambda _r, k=key, c=self.cache: c.pop(k, None)), tag, d, dt)
         return d, dt
 
 
@@ -364,8 +378,8 @@ class VitBlockFunction(torch.autograd.Function):
         b.dx_mid = _p(scratch("dx_mid", (M, D), torch.float32, dev))
         check(lib.eoe_vit_block_bwd(C.byref(b), _stream()), "eoe_vit_block_bwd")
         hook = grad_ready_hooks.get(id(params["ln1_g"]))
-        if hook is not None:
-            hook()
+        if hook is not None and hook[0]() is params["ln1_g"]:      # (weakref to the parameter, callable)
+            hook[1]()
         return (dx_in, None, None) + tuple(grads[k] for k in _BLOCK_PARAMS)
 
 

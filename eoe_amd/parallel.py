@@ -9,6 +9,7 @@ backward (RCCL runs it on its own stream, overlapped with the remaining backward
 head / remaining parameters form the last bucket.
 """
 import os
+import weakref
 from typing import List, Optional
 
 import torch
@@ -69,7 +70,7 @@ class GradArena:
                 hi = max(self.offsets[id(p)] + (p.numel() + 63) // 64 * 64 for p in ps)
                 if hi - lo != sum((p.numel() + 63) // 64 * 64 for p in ps):
                     continue                              # not contiguous in the arena: leave to the final bucket
-                self.block_buckets.append((id(ps[0]), lo, hi))
+                self.block_buckets.append((ps[0], lo, hi))
                 covered.update(id(p) for p in ps)
         self.rest = [p for p in params if id(p) not in covered]
         self.handles: List = []
@@ -77,13 +78,13 @@ class GradArena:
 
     # -- overlap: called from VitBlockFunction.backward right after the block's kernels were enqueued
     def install_hooks(self):
-        for key, lo, hi in self.block_buckets:
-            ops.grad_ready_hooks[key] = (lambda lo=lo, hi=hi: self._reduce_slice(lo, hi))
+        for first, lo, hi in self.block_buckets:
+            ops.grad_ready_hooks[id(first)] = (weakref.ref(first), (lambda lo=lo, hi=hi: self._reduce_slice(lo, hi)))
         self._installed = True
 
     def remove_hooks(self):
-        for key, _, _ in self.block_buckets:
-            ops.grad_ready_hooks.pop(key, None)
+        for first, _, _ in self.block_buckets:
+            ops.grad_ready_hooks.pop(id(first), None)
         self._installed = False
 
     def _reduce_slice(self, lo, hi):

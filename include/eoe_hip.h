@@ -52,6 +52,7 @@ typedef struct {
     const float* bias;  /* [N] fp32 or NULL */
     const void* aux;    /* see epilogue */
     void* aux_out;      /* see epilogue */
+    float* colsum;      /* optional (NT only): colsum[n] += sum_m C[m,n] of the epilogue result (fp32 atomics) */
     int32_t M, N, K;    /* for TN, K is the reduction length T */
     int32_t lda, ldb, ldc, ldaux;   /* leading dimensions in elements */
     int32_t dtype;      /* EOE_F16 | EOE_BF16 */
@@ -101,13 +102,18 @@ int eoe_embed_lnpre_bwd(const float* dy, const float* x0, const float* stats, co
 int eoe_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, void* y, float* stats,
                       int rows, int D, float eps, int dtype, int out_f32, void* stream);
 /* dx_out[r, :] (fp32, row stride ld_out) = (dres ? dres[r, :] : 0) + LN'(dy)[r, :];  dx16 (optional) = 16-bit
- * copy of dx_out (the next GEMM's operand); dgamma/dbeta += column sums.  dy is 16-bit, or fp32 if dy_f32. */
+ * copy of dx_out (the next GEMM's operand); dgamma/dbeta += column sums of dy*xhat / dy;  dxsum (optional) +=
+ * column sums of dx_out (the bias gradient of the layer that produced the LayerNorm input's residual branch).
+ * dy is 16-bit, or fp32 if dy_f32. */
 int eoe_layernorm_bwd(const void* dy, int dy_f32, const float* x, int ldx, const float* stats,
                       const float* gamma, const float* dres, float* dx_out, int ld_out, void* dx16,
-                      float* dgamma, float* dbeta, int rows, int D, int dtype, void* stream);
+                      float* dgamma, float* dbeta, float* dxsum, int rows, int D, int dtype, void* stream);
 
 /* out[c] (+)= sum_r x[r, c]  -- bias gradients (x 16-bit [rows, cols], row stride ldx). */
 int eoe_colsum(const void* x, int ldx, float* out, int rows, int cols, int dtype, int accumulate, void* stream);
+
+/* dst = 16-bit copy of x fp32 [rows, cols] and out[c] (+)= sum_r x[r, c] in one pass */
+int eoe_cast_colsum(const float* x, void* dst, float* out, int rows, int cols, int dtype, int accumulate, void* stream);
 
 /* fp32 -> 16-bit copy of n contiguous elements */
 int eoe_cast(const float* src, void* dst, size_t n, int dtype, void* stream);

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib.eoe_abi_version() == _lib.ABI_VERSION
     # struct layouts the Python side mirrors
     assert C.sizeof(_lib.AdamChunk) == 40 and C.sizeof(_lib.AdamScalars) == 32
-    assert C.sizeof(_lib.GemmArgs) == 6 * 8 + 12 * 4
+    assert C.sizeof(_lib.GemmArgs) == 7 * 8 + 12 * 4
 
 
 def test_argument_errors_are_reported_not_fatal():

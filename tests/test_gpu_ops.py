@@ -64,9 +64,11 @@ def test_gemm_nt_strided_and_epilogues(ops, dtype):
     assert_close(pre, acc, 2 * EPS16[dtype], 1e-4, "gelu epilogue: pre-activation")
     assert_close(act, _qgelu(pre.float().cpu().double()), 2 * EPS16[dtype], 1e-4, "gelu epilogue: activation of the stored pre")
     dz = torch.empty((M, N), dtype=dtype, device="cuda")
-    ops.gemm_nt(a[:, :K], b, dz, epilogue=ops.EPI_GELU_BWD, aux=pre)
+    cs = torch.full((N,), 2.0, dtype=torch.float32, device="cuda")
+    ops.gemm_nt(a[:, :K], b, dz, epilogue=ops.EPI_GELU_BWD, aux=pre, colsum_out=cs)
     ref = (ar[:, :K].double() @ br.double().t()) * _qgelu_grad(pre.float().cpu().double())
     assert_close(dz, ref, 2 * EPS16[dtype], 2e-4, "gelu-backward epilogue")
+    assert_close(cs, 2.0 + ref.sum(0), 1e-4, 1e-3, "fused column sums of the epilogue result (M tail masked)")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -99,7 +101,7 @@ def test_gemm_tn_grouped(ops, dtype):
         keep += [a, b]
         outs.append(out)
         refs.append(ar.double().t() @ br.double())
-        args[i] = _lib.GemmArgs(a.data_ptr(), b.data_ptr(), out.data_ptr(), None, None, None, m, n, T, m, n, n, 0,
+        args[i] = _lib.GemmArgs(a.data_ptr(), b.data_ptr(), out.data_ptr(), None, None, None, None, m, n, T, m, n, n, 0,
                                 ops.dtype_code(dtype), 0, 1, 0, 1.0)
     _lib.check(_lib.lib.eoe_gemm_tn_grouped(args, 4, torch.cuda.current_stream().cuda_stream), "grouped")
     for out, ref in zip(outs, refs):
@@ -132,6 +134,15 @@ def test_cast_transpose_colsum(ops, dtype):
     assert_close(out, 2 * xr.double().sum(0), 1e-5, 2e-3, "colsum accumulate")
     c = ops.cast16(w, dtype)
     assert torch.equal(c.cpu(), wr.to(dtype))
+    big, bigr = f32("ct/big", (1001, 264), 1.0)
+    o16 = torch.empty((1001, 264), dtype=dtype, device="cuda")
+    cs = torch.full((264,), 1.0, dtype=torch.float32, device="cuda")
+    ops.cast_colsum(big, o16, cs)
+    assert torch.equal(o16.cpu(), bigr.to(dtype))
+    assert_close(cs, bigr.double().sum(0), 1e-5, 1e-3, "cast_colsum")
+    w2, w2r = f32("ct/w2", (130, 67), 1.0)          # odd sizes take the scalar transpose kernel
+    d2, dt2 = ops.cast_transpose(w2, dtype)
+    assert torch.equal(d2.cpu(), w2r.to(dtype)) and torch.equal(dt2.cpu(), w2r.to(dtype).t().contiguous())
     v, vr = f32("ct/v", (1027,), 1.0)
     assert torch.equal(ops.cast16(v, dtype).cpu(), vr.to(dtype))
 
@@ -172,7 +183,9 @@ def test_layernorm(ops, dtype, rows, D):
     dx16 = torch.empty((rows, D), dtype=dtype, device="cuda")
     dg = torch.zeros(D, dtype=torch.float32, device="cuda")
     db = torch.zeros(D, dtype=torch.float32, device="cuda")
-    ops.layernorm_bwd(dy, x, stats, g, rows, D, D, dx, D, dres=res, dx16=dx16, dgamma=dg, dbeta=db)
+    dxs = torch.zeros(D, dtype=torch.float32, device="cuda")
+    ops.layernorm_bwd(dy, x, stats, g, rows, D, D, dx, D, dres=res, dx16=dx16, dgamma=dg, dbeta=db, dxsum=dxs)
+    assert_close(dxs, (xr.grad + resr.double()).sum(0), 1e-4, 1e-4 * math.sqrt(rows), "layernorm bwd column sums of dx")
     assert_close(dx, xr.grad + resr.double(), 1e-4, 1e-4, "layernorm bwd dx")
     assert_close(dx16, xr.grad + resr.double(), 2 * EPS16[dtype], 1e-4, "layernorm bwd dx16")
     assert_close(dg, gr.grad, 1e-4, 1e-4 * math.sqrt(rows), "layernorm bwd dgamma")

@@ -81,7 +81,7 @@ for i, (name, m, n, t) in enumerate(shapes_tn[:4]):
     b = torch.randn(t, n, device="cuda").to(dt)
     out = torch.empty(m, n, device="cuda", dtype=torch.float32)
     keep += [a, b, out]
-    args[i] = _lib.GemmArgs(a.data_ptr(), b.data_ptr(), out.data_ptr(), None, None, None, m, n, t, m, n, n, 0,
+    args[i] = _lib.GemmArgs(a.data_ptr(), b.data_ptr(), out.data_ptr(), None, None, None, None, m, n, t, m, n, n, 0,
                             ops.dtype_code(dt), 0, 1, 0, 1.0)
     fl += 2.0 * m * n * t
 st = torch.cuda.current_stream().cuda_stream

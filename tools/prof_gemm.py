@@ -23,7 +23,7 @@ for i, (m, n, t) in enumerate([(3072, 768, M), (768, 3072, M), (2304, 768, M), (
     b = torch.randn(t, n, device="cuda").to(dt)
     out = torch.empty(m, n, device="cuda", dtype=torch.float32)
     keep += [a, b, out]
-    args[i] = _lib.GemmArgs(a.data_ptr(), b.data_ptr(), out.data_ptr(), None, None, None, m, n, t, m, n, n, 0,
+    args[i] = _lib.GemmArgs(a.data_ptr(), b.data_ptr(), out.data_ptr(), None, None, None, None, m, n, t, m, n, n, 0,
                             ops.dtype_code(dt), 0, 1, 0, 1.0)
 for _ in range(reps):
     _lib.check(_lib.lib.eoe_gemm_tn_grouped(args, 4, torch.cuda.current_stream().cuda_stream), "g")
