@@ -68,6 +68,9 @@ SIGNATURES = {
     "eoe_layernorm_fwd": [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, C.c_int, C.c_int, _vp],
     "eoe_layernorm_bwd": [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int,
                           C.c_int, C.c_int, _vp],
+    "eoe_linear_small_fwd": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
+    "eoe_linear_small_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "eoe_zero_multi": [C.POINTER(_vp), C.POINTER(C.c_int), C.c_int, _vp],
     "eoe_cast_colsum": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "eoe_colsum": [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "eoe_cast": [_vp, _vp, _sz, C.c_int, _vp],
@@ -82,6 +85,14 @@ SIGNATURES = {
                        _vp],
     "eoe_vit_block_fwd": [C.POINTER(VitBlockFwdArgs), _vp],
     "eoe_vit_block_bwd": [C.POINTER(VitBlockBwdArgs), _vp],
+    "eoe_im2col5": [_vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "eoe_col2im5": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "eoe_conv5_pack_weight": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "eoe_conv5_unpack_wgrad": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "eoe_bn_stats": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _f32, C.c_int, _vp],
+    "eoe_bn_act_pool_fwd": [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "eoe_bn_act_pool_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                            C.c_int, C.c_int, C.c_int, _vp],
     "eoe_prof_enable": [C.c_int],
     "eoe_prof_collect": [C.POINTER(ProfEntry), C.c_int, C.POINTER(C.c_int)],
 }

@@ -1,0 +1,433 @@
+// CNN backbone kernels (reference `src/eoe/models/cnn.py:44-86`, CNN32 / CNN28): 5x5 stride-1 pad-2 convolutions
+// as im2col + the MFMA GEMMs of gemm.hip / gemm_tn.hip, BatchNorm (training statistics) + LeakyReLU + 2x2 MaxPool
+// fused into one apply kernel per direction.  Activations between layers are NHWC 16-bit; pre-BatchNorm conv
+// outputs are fp32 [N*H*W, C] (the GEMM's fp32 epilogue) so that batch statistics are taken in fp32.
+// All of these are HBM-bound (or launch-latency-bound at 32x32): coalesced 16-byte accesses along the channel dim.
+#include "common.h"
+
+namespace {
+
+constexpr float LRELU = 0.01f;   // F.leaky_relu default negative_slope (cnn.py:76-82)
+
+// ---------------------------------------------------------------------------------------------- im2col
+// image layer: x fp32 NCHW [n,cin,H,W] (+ optional per-channel normalise) -> patches [n*H*W, Kp] 16-bit,
+// column = (ky*5+kx)*cin + c, zero padded to Kp
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_img_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                         const float* __restrict__ stdv, T* __restrict__ out, int n,
+                                                         int cin, int H, int W, int Kp) {
+    const size_t total = (size_t)n * H * W * Kp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int col = (int)(i % Kp);
+        const size_t row = i / Kp;
+        float v = 0.f;
+        if (col < 25 * cin) {
+            const int tap = col / cin, c = col % cin;
+            const int w = (int)(row % W), h = (int)((row / W) % H), img = (int)(row / ((size_t)W * H));
+            const int hh = h + tap / 5 - 2, ww = w + tap % 5 - 2;
+            if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
+                v = x[(((size_t)img * cin + c) * H + hh) * W + ww];
+                if (mean) v = (v - mean[c]) / stdv[c];
+            }
+        }
+        out[i] = (T)v;
+    }
+}
+
+// hidden layers: x NHWC [n,H,W,C] (C multiple of 8; 16-bit, or fp32 if XF32) -> patches [n*H*W, Kp], one 16-byte
+// output chunk per thread
+template <typename T, bool XF32>
+__global__ __launch_bounds__(256) void im2col_nhwc_kernel(const void* __restrict__ xv, T* __restrict__ out, int n, int H,
+                                                          int W, int C, int Kp) {
+    const int cpr = Kp / 8;                       // 16-B chunks per output row
+    const int cc = C / 8;                         // chunks per tap
+    const size_t total = (size_t)n * H * W * cpr;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cpr);
+        const size_t row = i / cpr;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        const int tap = ch / cc;
+        if (tap < 25) {
+            const int c8 = ch % cc;
+            const int w = (int)(row % W), h = (int)((row / W) % H), img = (int)(row / ((size_t)W * H));
+            const int hh = h + tap / 5 - 2, ww = w + tap % 5 - 2;
+            if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
+                const size_t o = (((size_t)img * H + hh) * W + ww) * C + c8 * 8;
+                if (XF32) {
+                    const f32x4 a = *(const f32x4*)((const float*)xv + o), b = *(const f32x4*)((const float*)xv + o + 4);
+                    const float t[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+                    v = pack8<T>(t);
+                } else {
+                    v = *(const u32x4*)((const T*)xv + o);
+                }
+            }
+        }
+        *(u32x4*)(out + row * Kp + (size_t)ch * 8) = v;
+    }
+}
+
+// gradient wrt the layer input: dx fp32 NHWC [n,H,W,C] = gather over the 25 taps of dpatches 16-bit [n*H*W, Kp]
+template <typename T>
+__global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dp, float* __restrict__ dx, int n, int H, int W,
+                                                     int C, int Kp) {
+    const int cc = C / 4;
+    const size_t total = (size_t)n * H * W * cc;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % cc);
+        const size_t pix = i / cc;
+        const int w = (int)(pix % W), h = (int)((pix / W) % H), img = (int)(pix / ((size_t)W * H));
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 5
+        for (int tap = 0; tap < 25; ++tap) {
+            const int hh = h - (tap / 5 - 2), ww = w - (tap % 5 - 2);      // output position whose tap reads this pixel
+            if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+            float t[4];
+            unpack4<T>(*(const u32x2*)(dp + (((size_t)img * H + hh) * W + ww) * Kp + tap * C + c4 * 4), t);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] += t[r];
+        }
+        *(f32x4*)(dx + pix * C + c4 * 4) = (f32x4){a[0], a[1], a[2], a[3]};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- weights
+// w fp32 [cout, cin, 5, 5] -> w16 [cout, Kp] (column = tap*cin + c) and w16t [Kp, cout]
+template <typename T>
+__global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict__ w, T* __restrict__ w16, T* __restrict__ w16t,
+                                                        int cout, int cin, int Kp) {
+    const int total = cout * Kp;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int o = i / Kp, col = i % Kp;
+        float v = 0.f;
+        if (col < 25 * cin) v = w[((size_t)o * cin + col % cin) * 25 + col / cin];
+        w16[i] = (T)v;
+        if (w16t) w16t[(size_t)col * cout + o] = (T)v;
+    }
+}
+// g fp32 [cout, Kp] -> dw fp32 [cout, cin, 5, 5] (+= if accumulate)
+__global__ __launch_bounds__(256) void conv_unpack_kernel(const float* __restrict__ g, float* __restrict__ dw, int cout, int cin,
+                                                          int Kp, int accumulate) {
+    const int total = cout * cin * 25;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int tap = i % 25, c = (i / 25) % cin, o = i / (25 * cin);
+        const float v = g[(size_t)o * Kp + tap * cin + c];
+        dw[i] = accumulate ? dw[i] + v : v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- BatchNorm
+// column sums of y and y^2 over M rows, y fp32 [M, C]; sums[0..C) += sum, sums[C..2C) += sumsq (fp32 atomics of
+// per-workgroup partial sums accumulated in double)
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ y, float* __restrict__ sums, int M, int C) {
+    __shared__ double red[2][256];
+    const int cpb = C < 256 ? C : 256;            // columns per block
+    const int rpb = 256 / cpb;                    // row lanes per block
+    const int c = blockIdx.x * cpb + threadIdx.x % cpb;
+    const int rl = threadIdx.x / cpb;
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+        for (int r = blockIdx.y * rpb + rl; r < M; r += gridDim.y * rpb) {
+            const float v = y[(size_t)r * C + c];
+            s += v;
+            q += (double)v * v;
+        }
+    }
+    red[0][threadIdx.x] = s;
+    red[1][threadIdx.x] = q;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        for (int k = 1; k < rpb; ++k) {
+            s += red[0][threadIdx.x + k * cpb];
+            q += red[1][threadIdx.x + k * cpb];
+        }
+        atomicAdd(sums + c, (float)s);
+        atomicAdd(sums + C + c, (float)q);
+    }
+}
+
+// sums -> stats[0..C) = mean, stats[C..2C) = rstd; running buffers updated as nn.BatchNorm does (momentum 0.1,
+// unbiased variance for the running estimate)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ sums, float* __restrict__ stats,
+                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                          int64_t* __restrict__ nbt, int M, int C, float eps, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) nbt[0] += 1;
+    if (c >= C) return;
+    const double mean = (double)sums[c] / M;
+    double var = (double)sums[C + c] / M - mean * mean;
+    if (var < 0) var = 0;
+    stats[c] = (float)mean;
+    stats[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * M / (M > 1 ? M - 1 : 1));
+    }
+}
+// eval mode: stats from the running buffers
+__global__ __launch_bounds__(256) void bn_running_stats_kernel(const float* __restrict__ rm, const float* __restrict__ rv,
+                                                               float* __restrict__ stats, int C, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    stats[c] = rm[c];
+    stats[C + c] = 1.0f / sqrtf(rv[c] + eps);
+}
+
+__device__ __forceinline__ float lrelu(float z) { return z > 0.f ? z : LRELU * z; }
+
+// out = maxpool_P(leaky_relu(bn(y))); y fp32 [n,H,W,C] ; out 16-bit [n,H/P,W/P,C], or (nchw_flat) [n, C*(H/P)*(W/P)] in the
+// reference's NCHW flatten order (cnn.py:83), or fp32 if out_f32.  P in {1,2}.  4 channels per thread.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ stats,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              void* __restrict__ out, int n, int H, int W, int C, int P,
+                                                              int nchw_flat, int out_f32) {
+    const int Ho = H / P, Wo = W / P, cc = C / 4;
+    const size_t total = (size_t)n * Ho * Wo * cc;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cc) * 4;
+        const size_t op = i / cc;
+        const int wo = (int)(op % Wo), ho = (int)((op / Wo) % Ho), img = (int)(op / ((size_t)Wo * Ho));
+        const f32x4 mu = *(const f32x4*)(stats + c), rs = *(const f32x4*)(stats + C + c);
+        f32x4 g = {1.f, 1.f, 1.f, 1.f}, b = {0.f, 0.f, 0.f, 0.f};
+        if (gamma) { g = *(const f32x4*)(gamma + c); b = *(const f32x4*)(beta + c); }
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int dy = 0; dy < P; ++dy)
+            for (int dx = 0; dx < P; ++dx) {
+                const f32x4 v = *(const f32x4*)(y + (((size_t)img * H + ho * P + dy) * W + wo * P + dx) * C + c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) best[r] = fmaxf(best[r], lrelu((v[r] - mu[r]) * rs[r] * g[r] + b[r]));
+            }
+        if (nchw_flat) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const size_t o = ((size_t)img * C + c + r) * Ho * Wo + (size_t)ho * Wo + wo;
+                if (out_f32) ((float*)out)[o] = best[r];
+                else ((T*)out)[o] = (T)best[r];
+            }
+        } else if (out_f32) {
+            *(f32x4*)((float*)out + op * C + c) = (f32x4){best[0], best[1], best[2], best[3]};
+        } else {
+            *(u32x2*)((T*)out + op * C + c) = pack4<T>(best[0], best[1], best[2], best[3]);
+        }
+    }
+}
+
+// upstream gradient of one pooled output element (dout fp32, NHWC or NCHW-flat)
+__device__ __forceinline__ float load_dout(const float* dout, int nchw_flat, int img, int ho, int wo, int c, int Ho, int Wo, int C) {
+    return nchw_flat ? dout[((size_t)img * C + c) * Ho * Wo + (size_t)ho * Wo + wo]
+                     : dout[(((size_t)img * Ho + ho) * Wo + wo) * C + c];
+}
+
+// backward pass 1: per-channel sums of g and g*xhat, where g is the gradient at the BatchNorm OUTPUT (un-pooled through
+// the first maximum of each window, times LeakyReLU').  One thread per (pooled position, 4 channels); LDS + atomics.
+// mode 0 = reduce into red[0..C)=sum g, red[C..2C)=sum g*xhat;  mode 1 = write dy (16-bit [n*H*W, C]) using those sums.
+template <typename T, int MODE, int P>
+__global__ __launch_bounds__(256) void bn_act_pool_bwd_kernel(const float* __restrict__ y, const float* __restrict__ stats,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ dout, float* __restrict__ red,
+                                                              void* __restrict__ dy, int dy_f32, int n, int H, int W, int C,
+                                                              int nchw_flat, int use_batch_stats) {
+    extern __shared__ float lds[];                // MODE 0: [2][C] partial sums
+    const int Ho = H / P, Wo = W / P, cc = C / 4;
+    const size_t total = (size_t)n * Ho * Wo * cc;
+    const float invM = 1.0f / ((float)n * H * W);
+    if (MODE == 0) {
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lds[i] = 0.f;
+        __syncthreads();
+    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cc) * 4;
+        const size_t op = i / cc;
+        const int wo = (int)(op % Wo), ho = (int)((op / Wo) % Ho), img = (int)(op / ((size_t)Wo * Ho));
+        const f32x4 mu = *(const f32x4*)(stats + c), rs = *(const f32x4*)(stats + C + c);
+        f32x4 g = {1.f, 1.f, 1.f, 1.f}, b = {0.f, 0.f, 0.f, 0.f};
+        if (gamma) { g = *(const f32x4*)(gamma + c); b = *(const f32x4*)(beta + c); }
+        f32x4 xh[P * P], z[P * P];
+        int arg[4] = {0, 0, 0, 0};
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int k = 0; k < P * P; ++k) {
+            const int dy_ = k / P, dx_ = k % P;
+            const f32x4 v = *(const f32x4*)(y + (((size_t)img * H + ho * P + dy_) * W + wo * P + dx_) * C + c);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                xh[k][r] = (v[r] - mu[r]) * rs[r];
+                z[k][r] = xh[k][r] * g[r] + b[r];
+                const float a = lrelu(z[k][r]);
+                if (a > best[r]) { best[r] = a; arg[r] = k; }      // first maximum wins, as max_pool2d does
+            }
+        }
+        float d[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[r] = load_dout(dout, nchw_flat, img, ho, wo, c + r, Ho, Wo, C);
+        if (MODE == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = arg[r];
+                float gz = 0.f, xk = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < P * P; ++kk)
+                    if (kk == k) { gz = d[r] * (z[kk][r] > 0.f ? 1.f : LRELU); xk = xh[kk][r]; }
+                atomicAdd(&lds[c + r], gz);
+                atomicAdd(&lds[C + c + r], gz * xk);
+            }
+        } else {
+            const f32x4 s1 = *(const f32x4*)(red + c), s2 = *(const f32x4*)(red + C + c);
+#pragma unroll
+            for (int k = 0; k < P * P; ++k) {
+                const int dy_ = k / P, dx_ = k % P;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float gz = (k == arg[r]) ? d[r] * (z[k][r] > 0.f ? 1.f : LRELU) : 0.f;
+                    // training: dy = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)); eval (running stats): gamma*rstd*g
+                    o[r] = use_batch_stats ? g[r] * rs[r] * (gz - s1[r] * invM - xh[k][r] * s2[r] * invM) : g[r] * rs[r] * gz;
+                }
+                const size_t oo = (((size_t)img * H + ho * P + dy_) * W + wo * P + dx_) * C + c;
+                if (dy_f32) *(f32x4*)((float*)dy + oo) = (f32x4){o[0], o[1], o[2], o[3]};
+                else *(u32x2*)((T*)dy + oo) = pack4<T>(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+    if (MODE == 0) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(red + i, lds[i]);
+    }
+}
+
+__global__ __launch_bounds__(256) void add_copy_kernel(float* __restrict__ dst, const float* __restrict__ src, int n, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = accumulate ? dst[i] + src[i] : src[i];
+}
+
+int grid_for(size_t total) {
+    size_t g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, ...)                                  \
+    do {                                                        \
+        if ((dtype) == EOE_F16) { typedef f16_t T; __VA_ARGS__; } \
+        else if ((dtype) == EOE_BF16) { typedef bf16_t T; __VA_ARGS__; } \
+        else return eoe_set_error(EOE_ERR_ARG, "bad dtype %d", (int)(dtype)); \
+    } while (0)
+
+extern "C" int eoe_im2col5(const void* x, int x_kind, const float* mean, const float* stdv, void* out, int n, int cin,
+                           int H, int W, int Kp, int dtype, void* stream) {
+    EOE_CHECK_ARG(x && out && n > 0 && cin > 0 && H > 0 && W > 0, "im2col5: bad args");
+    EOE_CHECK_ARG(Kp >= 25 * cin && Kp % 64 == 0, "im2col5: Kp = %d must be a multiple of 64 and >= 25*cin", Kp);
+    EOE_CHECK_ARG((mean == nullptr) == (stdv == nullptr), "im2col5: mean/std must both be given or both NULL");
+    ProfScope ps("im2col5", 0, 2.0 * n * H * W * Kp, stream);
+    if (x_kind == 1) {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((im2col_img_kernel<T>), dim3(grid_for((size_t)n * H * W * Kp)), dim3(256), 0,
+                                             (hipStream_t)stream, (const float*)x, mean, stdv, (T*)out, n, cin, H, W, Kp));
+    } else {
+        EOE_CHECK_ARG(cin % 8 == 0, "im2col5: hidden layers need cin %% 8 == 0");
+        EOE_CHECK_ARG(x_kind == 0 || x_kind == 2, "im2col5: x_kind must be 0 (16-bit NHWC), 1 (fp32 NCHW image) or 2 (fp32 NHWC)");
+        if (x_kind == 2) {
+            DISPATCH_T(dtype, hipLaunchKernelGGL((im2col_nhwc_kernel<T, true>), dim3(grid_for((size_t)n * H * W * Kp / 8)), dim3(256), 0,
+                                                 (hipStream_t)stream, x, (T*)out, n, H, W, cin, Kp));
+        } else {
+            DISPATCH_T(dtype, hipLaunchKernelGGL((im2col_nhwc_kernel<T, false>), dim3(grid_for((size_t)n * H * W * Kp / 8)), dim3(256), 0,
+                                                 (hipStream_t)stream, x, (T*)out, n, H, W, cin, Kp));
+        }
+    }
+    EOE_CHECK_LAUNCH("im2col5");
+    return 0;
+}
+
+extern "C" int eoe_col2im5(const void* dpatches, float* dx, int n, int C, int H, int W, int Kp, int dtype, void* stream) {
+    EOE_CHECK_ARG(dpatches && dx && n > 0 && C % 4 == 0 && Kp >= 25 * C, "col2im5: bad args");
+    ProfScope ps("col2im5", 0, 2.0 * n * H * W * 25 * C + 4.0 * n * H * W * C, stream);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((col2im_kernel<T>), dim3(grid_for((size_t)n * H * W * C / 4)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)dpatches, dx, n, H, W, C, Kp));
+    EOE_CHECK_LAUNCH("col2im5");
+    return 0;
+}
+
+extern "C" int eoe_conv5_pack_weight(const float* w, void* w16, void* w16t, int cout, int cin, int Kp, int dtype, void* stream) {
+    EOE_CHECK_ARG(w && w16 && cout > 0 && cin > 0 && Kp >= 25 * cin, "conv5_pack_weight: bad args");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((conv_pack_kernel<T>), dim3(grid_for((size_t)cout * Kp)), dim3(256), 0,
+                                         (hipStream_t)stream, w, (T*)w16, (T*)w16t, cout, cin, Kp));
+    EOE_CHECK_LAUNCH("conv5_pack_weight");
+    return 0;
+}
+
+extern "C" int eoe_conv5_unpack_wgrad(const float* g, float* dw, int cout, int cin, int Kp, int accumulate, void* stream) {
+    EOE_CHECK_ARG(g && dw && cout > 0 && cin > 0 && Kp >= 25 * cin, "conv5_unpack_wgrad: bad args");
+    hipLaunchKernelGGL(conv_unpack_kernel, dim3(grid_for((size_t)cout * cin * 25)), dim3(256), 0, (hipStream_t)stream, g, dw,
+                       cout, cin, Kp, accumulate);
+    EOE_CHECK_LAUNCH("conv5_unpack_wgrad");
+    return 0;
+}
+
+extern "C" int eoe_bn_stats(const float* y, float* sums_scratch, float* stats, float* running_mean, float* running_var,
+                            int64_t* num_batches_tracked, int M, int C, float eps, float momentum, int training, void* stream) {
+    EOE_CHECK_ARG(stats && M > 0 && C > 0, "bn_stats: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    if (!training) {
+        EOE_CHECK_ARG(running_mean && running_var, "bn_stats: eval mode needs the running buffers");
+        hipLaunchKernelGGL(bn_running_stats_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, running_mean, running_var, stats, C, eps);
+        EOE_CHECK_LAUNCH("bn_running_stats");
+        return 0;
+    }
+    EOE_CHECK_ARG(y && sums_scratch, "bn_stats: bad args");
+    EOE_CHECK_ARG(C <= 256 ? (256 % C == 0) : (C % 256 == 0), "bn_stats: C = %d must divide or be a multiple of 256", C);
+    ProfScope ps("bn_stats", 0, 4.0 * M * C, stream);
+    if (hipMemsetAsync(sums_scratch, 0, 2 * C * sizeof(float), s) != hipSuccess) return eoe_set_error(EOE_ERR_LAUNCH, "bn_stats: memset failed");
+    const int cpb = C < 256 ? C : 256, rpb = 256 / cpb;
+    int gy = cdiv(M, rpb * 64);
+    if (gy > 512) gy = 512;
+    if (gy < 1) gy = 1;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(cdiv(C, cpb), gy), dim3(256), 0, s, y, sums_scratch, M, C);
+    EOE_CHECK_LAUNCH("bn_stats");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, sums_scratch, stats, running_mean, running_var,
+                       num_batches_tracked, M, C, eps, momentum);
+    EOE_CHECK_LAUNCH("bn_finalize");
+    return 0;
+}
+
+extern "C" int eoe_bn_act_pool_fwd(const float* y, const float* stats, const float* gamma, const float* beta, void* out, int n,
+                                   int H, int W, int C, int pool, int nchw_flat, int out_f32, int dtype, void* stream) {
+    EOE_CHECK_ARG(y && stats && out && n > 0 && C % 4 == 0, "bn_act_pool_fwd: bad args");
+    EOE_CHECK_ARG((pool == 1 || pool == 2) && H % pool == 0 && W % pool == 0, "bn_act_pool: pool must be 1 or 2 and divide H, W");
+    EOE_CHECK_ARG((gamma == nullptr) == (beta == nullptr), "bn_act_pool: gamma/beta must both be given or both NULL");
+    ProfScope ps("bn_act_pool_fwd", 0, 4.0 * n * H * W * C + 2.0 * n * H * W * C / (pool * pool), stream);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_pool_fwd_kernel<T>), dim3(grid_for((size_t)n * (H / pool) * (W / pool) * C / 4)),
+                                         dim3(256), 0, (hipStream_t)stream, y, stats, gamma, beta, out, n, H, W, C, pool,
+                                         nchw_flat, out_f32));
+    EOE_CHECK_LAUNCH("bn_act_pool_fwd");
+    return 0;
+}
+
+extern "C" int eoe_bn_act_pool_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* dout,
+                                   float* red_scratch, void* dy, int dy_f32, float* dgamma, float* dbeta, int n, int H, int W,
+                                   int C, int pool, int nchw_flat, int training, int accumulate, int dtype, void* stream) {
+    EOE_CHECK_ARG(y && stats && dout && red_scratch && dy && n > 0 && C % 4 == 0, "bn_act_pool_bwd: bad args");
+    EOE_CHECK_ARG((pool == 1 || pool == 2) && H % pool == 0 && W % pool == 0, "bn_act_pool: pool must be 1 or 2 and divide H, W");
+    EOE_CHECK_ARG((gamma == nullptr) == (beta == nullptr) && (dgamma == nullptr) == (dbeta == nullptr), "bn_act_pool_bwd: gamma/beta pairs");
+    EOE_CHECK_ARG(C <= 4096, "bn_act_pool_bwd: C too large");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("bn_act_pool_bwd", 0, 2 * 4.0 * n * H * W * C + 2.0 * n * H * W * C, stream);
+    if (hipMemsetAsync(red_scratch, 0, 2 * C * sizeof(float), s) != hipSuccess) return eoe_set_error(EOE_ERR_LAUNCH, "bn_act_pool_bwd: memset failed");
+    const int grid = grid_for((size_t)n * (H / pool) * (W / pool) * C / 4);
+    const int g0 = grid > 512 ? 512 : grid;
+#define EOE_BNB(MODE, PP, GRID, LDS)                                                                                  \
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_pool_bwd_kernel<T, MODE, PP>), dim3(GRID), dim3(256), LDS, s, y, stats, gamma, \
+                                         beta, dout, red_scratch, dy, dy_f32, n, H, W, C, nchw_flat, training))
+    if (pool == 1) { EOE_BNB(0, 1, g0, 2 * C * sizeof(float)); } else { EOE_BNB(0, 2, g0, 2 * C * sizeof(float)); }
+    EOE_CHECK_LAUNCH("bn_act_pool_bwd_reduce");
+    if (pool == 1) { EOE_BNB(1, 1, grid, 0); } else { EOE_BNB(1, 2, grid, 0); }
+    EOE_CHECK_LAUNCH("bn_act_pool_bwd_apply");
+#undef EOE_BNB
+    if (dgamma) {     // dbeta = sum g, dgamma = sum g*xhat
+        hipLaunchKernelGGL(add_copy_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, dbeta, (const float*)red_scratch, C, accumulate);
+        hipLaunchKernelGGL(add_copy_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, dgamma, (const float*)(red_scratch + C), C, accumulate);
+        EOE_CHECK_LAUNCH("bn_act_pool_bwd_params");
+    }
+    return 0;
+}

@@ -101,6 +101,15 @@ __global__ __launch_bounds__(256) void cast_colsum_kernel(const float* __restric
     if (cc < cols) atomicAdd(out + cc, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// zero up to EOE_ZERO_MAX small fp32 buffers in one launch (gradient accumulators filled by atomics)
+struct ZeroArgs { float* p[EOE_ZERO_MAX]; int n[EOE_ZERO_MAX]; int count; };
+__global__ __launch_bounds__(256) void zero_multi_kernel(ZeroArgs a) {
+    const int b = blockIdx.y;
+    if (b >= a.count) return;
+    float* p = a.p[b];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n[b]; i += gridDim.x * blockDim.x) p[i] = 0.f;
+}
+
 // ------------------------------------------------------------------------------------------ patchify
 // one block per (image, patch-row py): reads 3 * p rows of res floats (coalesced), writes g patches.
 template <typename T>
@@ -495,6 +504,80 @@ __global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ 
     dx[i] = (s - (float)labels[i]) * inv_count * (gscale ? gscale[0] : 1.0f);
 }
 
+// ------------------------------------------------------------------------------------------ narrow linear head
+// y[M,N] = x[M,K] w[N,K]^T + b for N <= 8 (the 1-wide classification head of CustomNet(clf=True),
+// custom_base.py:25-26): exact fp32, one wavefront per row.  Latency-bound by construction.
+constexpr int SMALL_N = 8;
+__global__ __launch_bounds__(256) void linear_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ y,
+                                                               int M, int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float acc[SMALL_N];
+#pragma unroll
+    for (int n = 0; n < SMALL_N; ++n) acc[n] = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float xv = x[(size_t)row * K + k];
+#pragma unroll
+        for (int n = 0; n < SMALL_N; ++n)
+            if (n < N) acc[n] += xv * w[(size_t)n * K + k];
+    }
+#pragma unroll
+    for (int n = 0; n < SMALL_N; ++n)
+        if (n < N) {
+            const float t = wave_sum(acc[n]);
+            if (lane == 0) y[(size_t)row * N + n] = t + (bias ? bias[n] : 0.f);
+        }
+}
+
+__global__ __launch_bounds__(256) void linear_small_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                              float* __restrict__ dx, int M, int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float d[SMALL_N];
+#pragma unroll
+    for (int n = 0; n < SMALL_N; ++n) d[n] = (n < N) ? dy[(size_t)row * N + n] : 0.f;
+    for (int k = lane; k < K; k += 64) {
+        float a = 0.f;
+#pragma unroll
+        for (int n = 0; n < SMALL_N; ++n)
+            if (n < N) a += d[n] * w[(size_t)n * K + k];
+        dx[(size_t)row * K + k] = a;
+    }
+}
+
+// dw[n,k] += sum_m dy[m,n] x[m,k] (thread per k, rows strided over grid.y), db[n] += sum_m dy[m,n]
+__global__ __launch_bounds__(256) void linear_small_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              float* __restrict__ dw, float* __restrict__ db, int M, int N,
+                                                              int K) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    float acc[SMALL_N], accb[SMALL_N];
+#pragma unroll
+    for (int n = 0; n < SMALL_N; ++n) { acc[n] = 0.f; accb[n] = 0.f; }
+    for (int m = blockIdx.y; m < M; m += gridDim.y) {
+        const float xv = (k < K) ? x[(size_t)m * K + k] : 0.f;
+#pragma unroll
+        for (int n = 0; n < SMALL_N; ++n)
+            if (n < N) {
+                const float d = dy[(size_t)m * N + n];
+                acc[n] += d * xv;
+                accb[n] += d;
+            }
+    }
+    if (k < K) {
+#pragma unroll
+        for (int n = 0; n < SMALL_N; ++n)
+            if (n < N) atomicAdd(dw + (size_t)n * K + k, acc[n]);
+    }
+    if (db && k == 0) {
+#pragma unroll
+        for (int n = 0; n < SMALL_N; ++n)
+            if (n < N) atomicAdd(db + n, accb[n]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ Adam
 // one block per chunk of <= EOE_ADAM_CHUNK elements; float4 accesses (chunk offsets are multiples of 4 for
 // 16-B aligned parameter starts; scalar path otherwise).
@@ -678,6 +761,56 @@ extern "C" int eoe_colsum(const void* x, int ldx, float* out, int rows, int cols
     DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), dim3(cdiv(cols, 256), gy), dim3(256), 0,
                                          (hipStream_t)stream, (const T*)x, ldx, out, rows, cols));
     EOE_CHECK_LAUNCH("colsum");
+    return 0;
+}
+
+extern "C" int eoe_linear_small_fwd(const float* x, const float* w, const float* bias, float* y, int M, int N, int K,
+                                    void* stream) {
+    EOE_CHECK_ARG(x && w && y && M > 0 && K > 0, "linear_small_fwd: bad args");
+    EOE_CHECK_ARG(N >= 1 && N <= SMALL_N, "linear_small: N = %d not in [1, %d]", N, SMALL_N);
+    hipLaunchKernelGGL(linear_small_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, M, N, K);
+    EOE_CHECK_LAUNCH("linear_small_fwd");
+    return 0;
+}
+
+extern "C" int eoe_linear_small_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
+                                    int M, int N, int K, int accumulate, void* stream) {
+    EOE_CHECK_ARG(x && w && dy && M > 0 && K > 0, "linear_small_bwd: bad args");
+    EOE_CHECK_ARG(N >= 1 && N <= SMALL_N, "linear_small: N = %d not in [1, %d]", N, SMALL_N);
+    hipStream_t s = (hipStream_t)stream;
+    if (dx) {
+        hipLaunchKernelGGL(linear_small_dx_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, dy, w, dx, M, N, K);
+        EOE_CHECK_LAUNCH("linear_small_dx");
+    }
+    if (dw) {
+        if (!accumulate) {
+            if (hipMemsetAsync(dw, 0, (size_t)N * K * sizeof(float), s) != hipSuccess ||
+                (db && hipMemsetAsync(db, 0, (size_t)N * sizeof(float), s) != hipSuccess))
+                return eoe_set_error(EOE_ERR_LAUNCH, "linear_small_bwd: memset failed");
+        }
+        int gy = cdiv(M, 32);
+        if (gy > 64) gy = 64;
+        hipLaunchKernelGGL(linear_small_dw_kernel, dim3(cdiv(K, 256), gy), dim3(256), 0, s, x, dy, dw, db, M, N, K);
+        EOE_CHECK_LAUNCH("linear_small_dw");
+    }
+    return 0;
+}
+
+extern "C" int eoe_zero_multi(float* const* ptrs, const int* counts, int n, void* stream) {
+    EOE_CHECK_ARG(ptrs && counts && n >= 1 && n <= EOE_ZERO_MAX, "zero_multi: n %d not in [1, %d]", n, EOE_ZERO_MAX);
+    ZeroArgs a;
+    int mx = 0;
+    for (int i = 0; i < n; ++i) {
+        EOE_CHECK_ARG(ptrs[i] && counts[i] >= 0, "zero_multi: bad buffer %d", i);
+        a.p[i] = ptrs[i]; a.n[i] = counts[i];
+        if (counts[i] > mx) mx = counts[i];
+    }
+    a.count = n;
+    int gx = cdiv(mx, 256);
+    if (gx > 64) gx = 64;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(zero_multi_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, a);
+    EOE_CHECK_LAUNCH("zero_multi");
     return 0;
 }
 

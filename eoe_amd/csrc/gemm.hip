@@ -17,6 +17,7 @@
 namespace {
 
 constexpr int BM = 256, BN = 128, BK = 64, NSTAGE = 3;
+#define EOE_NT_DEFAULT_B false
 constexpr int A_BYTES = BM * BK * 2;              // 32 KiB
 constexpr int B_BYTES = BN * BK * 2;              // 16 KiB
 constexpr int STAGE_BYTES = A_BYTES + B_BYTES;    // 48 KiB
@@ -158,40 +159,60 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int total_tiles = tiles_n * ((p.M + BM - 1) / BM);
+    const int G = gridDim.x;                       // persistent: this workgroup runs tiles b, b+G, b+2G, ...
+    const int my_tiles = (total_tiles - (int)blockIdx.x + G - 1) / G;
+    const int nk = p.K / BK;
+    const int iters = my_tiles * nk;               // flattened (tile, k-tile) iteration space of this workgroup
 
     __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.bytesA);
     __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.bytesB);
 
-    // staging: a wave-load (1 KiB) covers 8 tile rows of 128 B; lane -> (row, 16-B slot); the slot holds logical
-    // chunk slot ^ ((row>>1)&7).  A image: 256 rows = 32 wave-loads (4 per wave); B image: 128 rows = 16 (2 per wave)
+    // staging cursor: the LDS-DMA ring runs two k-tiles ahead of the MFMAs ACROSS tile boundaries, so the next tile's
+    // first operands are already in flight while this tile's epilogue stores drain.
+    // a wave-load (1 KiB) covers 8 tile rows of 128 B; lane -> (row, 16-B slot); the slot holds logical chunk
+    // slot ^ ((row>>1)&7).  A image: 256 rows = 32 wave-loads (4 per wave); B image: 128 rows = 16 (2 per wave)
     unsigned offA[4], offB[2];
+    int st_tile = blockIdx.x, st_kt = 0, st_slot = 0;
+    auto tile_origin = [&](int t, int& m0, int& n0) {
+        const int r = xcd_remap(t, total_tiles);
+        m0 = (r / tiles_n) * BM;
+        n0 = (r % tiles_n) * BN;
+    };
+    auto set_offsets = [&](int t) {
+        int m0, n0;
+        tile_origin(t, m0, n0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = (wave * 4 + j) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
-        const int ga = m0 + row;
-        offA[j] = (ga < p.M) ? (unsigned)(((size_t)ga * p.lda + c * 8) * 2) : EOE_OOB;
-    }
+        for (int j = 0; j < 4; ++j) {
+            const int row = (wave * 4 + j) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            const int ga = m0 + row;
+            offA[j] = (ga < p.M) ? (unsigned)(((size_t)ga * p.lda + c * 8) * 2) : EOE_OOB;
+        }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = (wave * 2 + j) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
-        const int gb = n0 + row;
-        offB[j] = (gb < p.N) ? (unsigned)(((size_t)gb * p.ldb + c * 8) * 2) : EOE_OOB;
-    }
-    auto stage = [&](int buf, int k0) {       // 6 LDS-DMA instructions per wave per k-tile
-        char* sa = smem + buf * STAGE_BYTES;
+        for (int j = 0; j < 2; ++j) {
+            const int row = (wave * 2 + j) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            const int gb = n0 + row;
+            offB[j] = (gb < p.N) ? (unsigned)(((size_t)gb * p.ldb + c * 8) * 2) : EOE_OOB;
+        }
+    };
+    auto stage_next = [&]() {                      // 6 LDS-DMA instructions per wave per k-tile
+        char* sa = smem + st_slot * STAGE_BYTES;
         char* sb = sa + A_BYTES;
+        const unsigned k0 = (unsigned)st_kt * (BK * 2u);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(sa + (wave * 4 + j) * 1024), 16,
-                                                     offA[j] + (unsigned)k0 * 2u, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(sa + (wave * 4 + j) * 1024), 16, offA[j] + k0, 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(sb + (wave * 2 + j) * 1024), 16,
-                                                     offB[j] + (unsigned)k0 * 2u, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(sb + (wave * 2 + j) * 1024), 16, offB[j] + k0, 0, 0, 0);
+        st_slot = (st_slot == NSTAGE - 1) ? 0 : st_slot + 1;
+        if (++st_kt == nk) {
+            st_kt = 0;
+            st_tile += G;
+            if (st_tile < total_tiles) set_offsets(st_tile);
+        }
     };
 
     const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
@@ -216,26 +237,27 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                      \
         _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = T16<T>::mfma16(WB[ni], XA[mi], acc[mi][ni]);
 
-    const int nk = p.K / BK;
+    if (iters <= 0) return;
     V8 xa0[4], wb0[4], xa1[4], wb1[4];
-    stage(0, 0);
-    if (nk > 1) {
-        stage(1, BK);
+    set_offsets(st_tile);
+    stage_next();
+    if (iters > 1) {
+        stage_next();
         EOE_WAIT_VM(6);
     } else {
         EOE_WAIT_VM(0);
     }
     __builtin_amdgcn_s_barrier();
     EOE_READ(xa0, wb0, smem, ch0);
-    int cur = 0;                                  // ring slot of tile kt
-    for (int kt = 0; kt < nk; ++kt) {
+    int cur = 0;                                   // ring slot of the k-tile being multiplied
+    int c_tile = blockIdx.x, c_kt = 0;
+    for (int it = 0; it < iters; ++it) {
         const int nxt = (cur == NSTAGE - 1) ? 0 : cur + 1;
-        const int nx2 = (nxt == NSTAGE - 1) ? 0 : nxt + 1;
         const char* sc = smem + cur * STAGE_BYTES;
-        if (kt + 2 < nk) stage(nx2, (kt + 2) * BK);
+        if (it + 2 < iters) stage_next();
         EOE_READ(xa1, wb1, sc, ch1);
         EOE_MFMA(xa0, wb0);
-        if (kt + 2 < nk) { EOE_WAIT_VM(6); } else { EOE_WAIT_VM(0); }
+        if (it + 2 < iters) { EOE_WAIT_VM(6); } else { EOE_WAIT_VM(0); }
         EOE_WAIT_LGKM0();
         __builtin_amdgcn_s_barrier();
         {   // unconditional (the last iteration reads a stale ring slot and discards it): keeps the compiler's
@@ -245,15 +267,143 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
         }
         EOE_MFMA(xa1, wb1);
         cur = nxt;
+        if (++c_kt == nk) {                        // tile finished: epilogue while the next tile's DMA is in flight
+            int m0, n0;
+            tile_origin(c_tile, m0, n0);
+            epilogue<T, EPI>(p, acc, m0 + wm0, n0 + wn0, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            c_kt = 0;
+            c_tile += G;
+        }
     }
 #undef EOE_READ
 #undef EOE_MFMA
+}
+
+// ------------------------------------------------------------------------------------------------ NT, variant B
+// Same 256x128 output tile and 8 waves, but BK = 32 and a 3-stage 72 KiB ring so that TWO workgroups share a CU
+// (16 waves, 4 per SIMD, <= 128 VGPRs): while one workgroup is in its prologue, its epilogue (the store burst is
+// HBM-bound when every CU flushes its tile at once) or parked at a barrier, the other one keeps the MFMA pipe busy.
+// Fragments are not double-buffered: with 4 waves per SIMD thread-level parallelism hides the LDS latency.
+namespace vb {
+constexpr int BK2 = 32;
+constexpr int A2 = BM * BK2 * 2;      // 16 KiB
+constexpr int B2 = BN * BK2 * 2;      //  8 KiB
+constexpr int STAGE2 = A2 + B2;       // 24 KiB
+constexpr int SMEM2 = NSTAGE * STAGE2;   // 72 KiB
+}  // namespace vb
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 4) void gemm_nt_kernel_b(GemmP p) {
+    using namespace vb;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+
+    __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.bytesA);
+    __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.bytesB);
+
+    // a wave-load (1 KiB) covers 16 tile rows of 64 B; lane -> (row, 16-B slot); slot holds chunk slot ^ ((row>>2)&3)
+    // A image: 256 rows = 16 wave-loads (2 per wave); B image: 128 rows = 8 wave-loads (1 per wave)
+    unsigned offA[2], offB;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave * 2 + j) * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 2) & 3);
+        const int ga = m0 + row;
+        offA[j] = (ga < p.M) ? (unsigned)(((size_t)ga * p.lda + c * 8) * 2) : EOE_OOB;
+    }
+    {
+        const int row = wave * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 2) & 3);
+        const int gb = n0 + row;
+        offB = (gb < p.N) ? (unsigned)(((size_t)gb * p.ldb + c * 8) * 2) : EOE_OOB;
+    }
+    auto stage = [&](int slot, int k0) {           // 3 LDS-DMA instructions per wave per k-tile
+        char* sa = smem + slot * STAGE2;
+        char* sb = sa + A2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(sa + (wave * 2 + j) * 1024), 16,
+                                                     offA[j] + (unsigned)k0 * 2u, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(sb + wave * 1024), 16, offB + (unsigned)k0 * 2u, 0, 0, 0);
+    };
+
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int chs = (lg ^ ((lr >> 2) & 3)) * 16;            // (row>>2)&3 of row = w?0 + 16 i + lr is (lr>>2)&3
+    const int fragA = (wm0 + lr) * 64 + chs, fragB = A2 + (wn0 + lr) * 64 + chs;
+    typedef typename T16<T>::v8 V8;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK2;
+    stage(0, 0);
+    if (nk > 1) {
+        stage(1, BK2);
+        EOE_WAIT_VM(3);
+    } else {
+        EOE_WAIT_VM(0);
+    }
+    __builtin_amdgcn_s_barrier();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int nxt = (cur == NSTAGE - 1) ? 0 : cur + 1;
+        const int nx2 = (nxt == NSTAGE - 1) ? 0 : nxt + 1;
+        const char* sc = smem + cur * STAGE2;
+        if (kt + 2 < nk) stage(nx2, (kt + 2) * BK2);
+        V8 xa[4], wb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            xa[i] = *(const V8*)(sc + fragA + i * 1024);
+            wb[i] = *(const V8*)(sc + fragB + i * 1024);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = T16<T>::mfma16(wb[ni], xa[mi], acc[mi][ni]);
+        if (kt + 2 < nk) { EOE_WAIT_VM(3); } else { EOE_WAIT_VM(0); }
+        EOE_WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
+        cur = nxt;
+    }
     epilogue<T, EPI>(p, acc, m0 + wm0, n0 + wn0, lane);
 }
 
 template <typename T>
 int launch_nt(const GemmP& p, int epi, hipStream_t s) {
-    const int grid = cdiv(p.M, BM) * cdiv(p.N, BN);
+    const int tiles = cdiv(p.M, BM) * cdiv(p.N, BN);
+    static const int ncu = [] { int d = 0, n = 256; hipDeviceProp_t pr; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) n = pr.multiProcessorCount; return n; }();
+    const int grid = tiles < ncu ? tiles : ncu;      // persistent: one 8-wave workgroup per CU
+    // variant selection: EOE_NT_VARIANT=a forces the persistent 1-WG/CU kernel, =b the 2-WG/CU BK=32 kernel
+    static const char* var = getenv("EOE_NT_VARIANT");
+    const bool use_b = var ? (var[0] == 'b') : EOE_NT_DEFAULT_B;
+    if (use_b && (p.K % vb::BK2) == 0) {
+#define EOE_NTB_CASE(E)                                                                     \
+        case E:                                                                             \
+            { static bool once = (hipFuncSetAttribute((const void*)gemm_nt_kernel_b<T, E>, hipFuncAttributeMaxDynamicSharedMemorySize, vb::SMEM2), true); (void)once; } \
+            hipLaunchKernelGGL((gemm_nt_kernel_b<T, E>), dim3(tiles), dim3(512), vb::SMEM2, s, p); \
+            break;
+        switch (epi) {
+            EOE_NTB_CASE(EOE_EPI_NONE)
+            EOE_NTB_CASE(EOE_EPI_GELU)
+            EOE_NTB_CASE(EOE_EPI_RESIDUAL)
+            EOE_NTB_CASE(EOE_EPI_GELU_BWD)
+            default: return eoe_set_error(EOE_ERR_ARG, "gemm_nt: unknown epilogue %d", epi);
+        }
+#undef EOE_NTB_CASE
+        EOE_CHECK_LAUNCH("gemm_nt_b");
+        return 0;
+    }
 #define EOE_NT_CASE(E)                                                                      \
     case E:                                                                                 \
         { static bool once = (hipFuncSetAttribute((const void*)gemm_nt_kernel<T, E>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES), true); (void)once; } \

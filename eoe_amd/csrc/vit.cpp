@@ -69,19 +69,15 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
     const int M = a->n * a->L, D = a->D, H = 4 * a->D, dt = a->dtype, acc = b->accumulate;
     hipStream_t s = (hipStream_t)stream;
     if (!acc) {
-        // LayerNorm parameter gradients are accumulated with atomics
-        if (hipMemsetAsync(b->g_ln1_g, 0, D * sizeof(float), s) != hipSuccess || hipMemsetAsync(b->g_ln1_b, 0, D * sizeof(float), s) != hipSuccess ||
-            hipMemsetAsync(b->g_ln2_g, 0, D * sizeof(float), s) != hipSuccess || hipMemsetAsync(b->g_ln2_b, 0, D * sizeof(float), s) != hipSuccess)
-            return eoe_set_error(EOE_ERR_LAUNCH, "vit_block_bwd: memset failed");
+        // gradients accumulated with fp32 atomics (LayerNorm parameters, fused bias column sums): one zeroing launch
+        float* zp[8] = {b->g_ln1_g, b->g_ln1_b, b->g_ln2_g, b->g_ln2_b, b->g_b_fc, b->g_b_out, b->g_b_proj, b->g_b_in};
+        const int zn[8] = {D, D, D, D, H, D, D, 3 * D};
+        TRY(eoe_zero_multi(zp, zn, 8, stream));
     }
     eoe_gemm_args g, w[4];
     // ---- MLP branch:  x_out = x_mid + c_proj(gelu(c_fc(ln_2(x_mid))))
     // bias gradients are column sums of the dY tensors: fused into the kernels that produce them (fp32 atomics)
-    if (!acc) {
-        if (hipMemsetAsync(b->g_b_fc, 0, H * sizeof(float), s) != hipSuccess || hipMemsetAsync(b->g_b_out, 0, D * sizeof(float), s) != hipSuccess)
-            return eoe_set_error(EOE_ERR_LAUNCH, "vit_block_bwd: memset failed");
-    }
-    TRY(eoe_cast_colsum(b->dx_out, b->d16_a, b->g_b_proj, M, D, dt, acc, stream));          // dY of c_proj + db_proj
+    TRY(eoe_cast_colsum(b->dx_out, b->d16_a, b->g_b_proj, M, D, dt, 1, stream));          // dY of c_proj + db_proj
     g = gemm(b->d16_a, a->w_proj_t, b->dh, nullptr, M, H, D, D, D, H, dt);                  // d hact, then * gelu'(hpre)
     g.epilogue = EOE_EPI_GELU_BWD; g.aux = a->hpre; g.ldaux = H; g.colsum = b->g_b_fc;      // + db_fc
     TRY(eoe_gemm_nt(&g, stream));
@@ -95,7 +91,7 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
     TRY(eoe_attn_bwd(a->qkv, b->d16_b, b->dqkv, a->n, a->L, a->heads, dt, stream));
     g = gemm(b->dqkv, a->w_in_t, b->d16_b, nullptr, M, D, 3 * D, 3 * D, 3 * D, D, dt);      // d xn1
     TRY(eoe_gemm_nt(&g, stream));
-    TRY(eoe_colsum(b->dqkv, 3 * D, b->g_b_in, M, 3 * D, dt, acc, stream));
+    TRY(eoe_colsum(b->dqkv, 3 * D, b->g_b_in, M, 3 * D, dt, 1, stream));
     // ---- the four weight gradients of the block in one grouped launch (every dY and X is still live)
     w[0] = gemm(b->dh, a->xn2, b->g_w_fc, nullptr, H, D, M, H, D, D, dt);                    // dW_fc[4D,D]   = dh^T xn2
     w[1] = gemm(b->d16_a, a->hact, b->g_w_proj, nullptr, D, H, M, D, H, H, dt);             // dW_proj[D,4D] = dY^T hact

@@ -1,3 +1,4 @@
 from .clip_vit import VisualTransformer, ResidualAttentionBlock      # noqa: F401
 from .custom_base import CustomNet                                   # noqa: F401
 from .custom import ClipViTB32Custom                                 # noqa: F401
+from .cnn import CNN32                                              # noqa: F401

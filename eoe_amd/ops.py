@@ -261,7 +261,41 @@ class LinearFunction(torch.autograd.Function):
         return dx, dw, db
 
 
+class LinearSmallFunction(torch.autograd.Function):
+    """narrow head (N <= 8 outputs, e.g. final_linear(512 -> 1) of CustomNet(clf=True)): exact fp32 kernels"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _chk(x, weight, bias)
+        x2 = x.reshape(-1, x.shape[-1]).contiguous().float()
+        w = weight.contiguous()
+        M, K = x2.shape
+        N = w.shape[0]
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        check(lib.eoe_linear_small_fwd(_p(x2), _p(w), _p(bias), _p(y), M, N, K, _stream()), "eoe_linear_small_fwd")
+        ctx.save_for_backward(x2, weight, bias)
+        ctx.in_shape = x.shape
+        return y.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, bias = ctx.saved_tensors
+        M, K = x2.shape
+        N = weight.shape[0]
+        dy2 = dy.reshape(M, N).contiguous().float()
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        dw = _grad_target(weight) if ctx.needs_input_grad[1] else None
+        db = _grad_target(bias) if (bias is not None and ctx.needs_input_grad[2]) else None
+        if db is not None and dw is None:
+            dw = torch.empty_like(weight)
+        check(lib.eoe_linear_small_bwd(_p(x2), _p(weight.contiguous()), _p(dy2), _p(dx), _p(dw), _p(db), M, N, K, 0,
+                                       _stream()), "eoe_linear_small_bwd")
+        return (dx.reshape(ctx.in_shape) if dx is not None else None), (dw if ctx.needs_input_grad[1] else None), db
+
+
 def linear(x, weight, bias=None):
+    if weight.shape[0] <= 8:
+        return LinearSmallFunction.apply(x, weight, bias)
     return LinearFunction.apply(x, weight, bias)
 
 
@@ -507,3 +541,130 @@ def bce_score(feats, nominal_label=0):
     dummy = torch.zeros(n, dtype=torch.int64, device=x.device)
     check(lib.eoe_bce_fwd(_p(x), _p(dummy), int(nominal_label), None, _p(out), None, n, 1.0, _stream()), "eoe_bce_fwd")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ autograd: CNN backbone
+def _conv_kp(cin: int) -> int:
+    return (25 * cin + 63) // 64 * 64
+
+
+def _conv_weight_copies(w: torch.Tensor):
+    """16-bit [cout, Kp] / [Kp, cout] copies of a 5x5 conv weight in patch-column order, cached like `shadow`"""
+    key = ("conv", id(w))
+    tag = (w._version, w.data_ptr(), _compute_dtype)
+    hit = shadow.cache.get(key)
+    if hit is not None and hit[0]() is w and hit[1] == tag:
+        return hit[2], hit[3]
+    cout, cin = w.shape[0], w.shape[1]
+    kp = _conv_kp(cin)
+    w16 = torch.empty((cout, kp), dtype=_compute_dtype, device=w.device)
+    w16t = torch.empty((kp, cout), dtype=_compute_dtype, device=w.device)
+    check(lib.eoe_conv5_pack_weight(_p(w.detach().contiguous()), _p(w16), _p(w16t), cout, cin, kp, dtype_code(_compute_dtype),
+                                    _stream()), "eoe_conv5_pack_weight")
+    shadow.cache[key] = (weakref.ref(w, lambda _r, k=key, c=shadow.cache: c.pop(k, None)), tag, w16, w16t)
+    return w16, w16t
+
+
+class ConvBnActPoolFunction(torch.autograd.Function):
+    """conv5x5(pad 2) + bias -> BatchNorm2d -> LeakyReLU(0.01) -> MaxPool(pool) of `cnn.py:73-82`, one layer per
+    call.  Input: the fp32 NCHW image batch (first layer; optional fused Normalize) or an fp32 NHWC activation; output:
+    fp32 NHWC [n, H/p, W/p, cout], or the reference's NCHW-flattened [n, cout*(H/p)*(W/p)] (`cnn.py:83`) if flat_out."""
+
+    @staticmethod
+    def forward(ctx, x, conv_w, conv_b, bn_w, bn_b, rm, rv, nbt, cfg):
+        _chk(x, conv_w, conv_b, bn_w, bn_b, rm, rv)
+        training, eps, momentum, pool, is_image, mean, std, flat_out = cfg
+        x = x.contiguous().float()
+        cout, cin = conv_w.shape[0], conv_w.shape[1]
+        if is_image:
+            n, _, H, W = x.shape
+        else:
+            n, H, W, _ = x.shape
+        M, kp, dev, dt = n * H * W, _conv_kp(cin), x.device, _compute_dtype
+        code = dtype_code(dt)
+        patches = torch.empty((M, kp), dtype=dt, device=dev)
+        check(lib.eoe_im2col5(_p(x), 1 if is_image else 2, _p(mean), _p(std), _p(patches), n, cin, H, W, kp, code, _stream()),
+              "eoe_im2col5")
+        w16, _ = _conv_weight_copies(conv_w)
+        y = torch.empty((M, cout), dtype=torch.float32, device=dev)
+        gemm_nt(patches, w16, y, bias=conv_b)
+        stats = torch.empty(2 * cout, dtype=torch.float32, device=dev)
+        sums = scratch("bn_sums", (2 * cout,), torch.float32, dev)
+        check(lib.eoe_bn_stats(_p(y), _p(sums), _p(stats), _p(rm), _p(rv), _p(nbt), M, cout, float(eps), float(momentum),
+                               1 if training else 0, _stream()), "eoe_bn_stats")
+        Ho, Wo = H // pool, W // pool
+        out = torch.empty((n, cout * Ho * Wo) if flat_out else (n, Ho, Wo, cout), dtype=torch.float32, device=dev)
+        check(lib.eoe_bn_act_pool_fwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(out), n, H, W, cout, pool, 1 if flat_out else 0,
+                                      1, code, _stream()), "eoe_bn_act_pool_fwd")
+        ctx.save_for_backward(patches, y, stats, conv_w, conv_b, bn_w, bn_b)
+        ctx.cfg = (n, H, W, cin, cout, kp, pool, flat_out, training, is_image)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        patches, y, stats, conv_w, conv_b, bn_w, bn_b = ctx.saved_tensors
+        n, H, W, cin, cout, kp, pool, flat_out, training, is_image = ctx.cfg
+        dev, dt = y.device, patches.dtype
+        code = dtype_code(dt)
+        M = n * H * W
+        dout = dout.contiguous().float()
+        dy16 = torch.empty((M, cout), dtype=dt, device=dev)
+        dg = _grad_target(bn_w) if bn_w is not None else None
+        db = _grad_target(bn_b) if bn_b is not None else None
+        red = scratch("bn_red", (2 * cout,), torch.float32, dev)
+        check(lib.eoe_bn_act_pool_bwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(dout), _p(red), _p(dy16), 0, _p(dg), _p(db), n, H,
+                                      W, cout, pool, 1 if flat_out else 0, 1 if training else 0, 0, code, _stream()),
+              "eoe_bn_act_pool_bwd")
+        g = torch.empty((cout, kp), dtype=torch.float32, device=dev)
+        gemm_tn(dy16, patches, g)
+        dw = _grad_target(conv_w)
+        check(lib.eoe_conv5_unpack_wgrad(_p(g), _p(dw), cout, cin, kp, 0, _stream()), "eoe_conv5_unpack_wgrad")
+        dcb = None
+        if conv_b is not None:
+            dcb = _grad_target(conv_b)
+            colsum(dy16, dcb)
+        dx = None
+        if ctx.needs_input_grad[0] and not is_image:
+            _, w16t = _conv_weight_copies(conv_w)
+            dpatches = torch.empty((M, kp), dtype=dt, device=dev)
+            gemm_nt(dy16, w16t, dpatches)
+            dx = torch.empty((n, H, W, cin), dtype=torch.float32, device=dev)
+            check(lib.eoe_col2im5(_p(dpatches), _p(dx), n, cin, H, W, kp, code, _stream()), "eoe_col2im5")
+        return dx, dw, dcb, dg, db, None, None, None, None
+
+
+class BnActFunction(torch.autograd.Function):
+    """BatchNorm1d -> LeakyReLU(0.01) on an fp32 [n, C] matrix (`cnn.py:84-85`)"""
+
+    @staticmethod
+    def forward(ctx, y, bn_w, bn_b, rm, rv, nbt, cfg):
+        _chk(y, bn_w, bn_b, rm, rv)
+        training, eps, momentum = cfg
+        y = y.contiguous().float()
+        n, C = y.shape
+        dev = y.device
+        stats = torch.empty(2 * C, dtype=torch.float32, device=dev)
+        sums = scratch("bn_sums", (2 * C,), torch.float32, dev)
+        check(lib.eoe_bn_stats(_p(y), _p(sums), _p(stats), _p(rm), _p(rv), _p(nbt), n, C, float(eps), float(momentum),
+                               1 if training else 0, _stream()), "eoe_bn_stats")
+        out = torch.empty_like(y)
+        check(lib.eoe_bn_act_pool_fwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(out), n, 1, 1, C, 1, 0, 1, dtype_code(_compute_dtype),
+                                      _stream()), "eoe_bn_act_pool_fwd")
+        ctx.save_for_backward(y, stats, bn_w, bn_b)
+        ctx.training = training
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, stats, bn_w, bn_b = ctx.saved_tensors
+        n, C = y.shape
+        dev = y.device
+        dout = dout.contiguous().float()
+        dy = torch.empty_like(y)
+        dg = _grad_target(bn_w) if bn_w is not None else None
+        db = _grad_target(bn_b) if bn_b is not None else None
+        red = scratch("bn_red", (2 * C,), torch.float32, dev)
+        check(lib.eoe_bn_act_pool_bwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(dout), _p(red), _p(dy), 1, _p(dg), _p(db), n, 1, 1,
+                                      C, 1, 0, 1 if ctx.training else 0, 0, dtype_code(_compute_dtype), _stream()),
+              "eoe_bn_act_pool_bwd")
+        return dy, dg, db, None, None, None, None

@@ -115,6 +115,17 @@ int eoe_colsum(const void* x, int ldx, float* out, int rows, int cols, int dtype
 /* dst = 16-bit copy of x fp32 [rows, cols] and out[c] (+)= sum_r x[r, c] in one pass */
 int eoe_cast_colsum(const float* x, void* dst, float* out, int rows, int cols, int dtype, int accumulate, void* stream);
 
+/* narrow linear head, N <= 8 outputs, exact fp32 (the 1-wide `final_linear` of CustomNet(clf=True),
+ * custom_base.py:25-26, used by the BCE objective): y[M,N] = x[M,K] w[N,K]^T + bias;
+ * backward: dx (optional) = dy w, dw (+)= dy^T x, db (optional) (+)= column sums of dy. */
+int eoe_linear_small_fwd(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, void* stream);
+int eoe_linear_small_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int M, int N,
+                         int K, int accumulate, void* stream);
+
+/* zero up to EOE_ZERO_MAX fp32 buffers in one launch (accumulators that the kernels above fill with atomics) */
+#define EOE_ZERO_MAX 12
+int eoe_zero_multi(float* const* ptrs, const int* counts, int n, void* stream);
+
 /* fp32 -> 16-bit copy of n contiguous elements */
 int eoe_cast(const float* src, void* dst, size_t n, int dtype, void* stream);
 
@@ -213,6 +224,37 @@ typedef struct {
 
 int eoe_vit_block_fwd(const eoe_vit_block_fwd_args* a, void* stream);
 int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * CNN backbone (cnn.py:44-86, CNN32 / CNN28): 5x5 stride-1 pad-2 convolution = im2col + eoe_gemm_nt (forward),
+ * eoe_gemm_tn (wgrad), eoe_gemm_nt + col2im (dgrad); BatchNorm(train statistics) + LeakyReLU(0.01) + MaxPool fused.
+ * Activations between layers: 16-bit NHWC; conv outputs before BatchNorm: fp32 [n*H*W, C].
+ * ---------------------------------------------------------------------------------------------------- */
+/* patches [n*H*W, Kp] 16-bit, column = (ky*5+kx)*cin + c, zero padded to Kp (multiple of 64).  x_kind: 1 = the fp32
+ * NCHW input image batch (optional per-channel normalise as ad_trainer.py:413-425), 0 = a 16-bit NHWC activation,
+ * 2 = an fp32 NHWC activation. */
+int eoe_im2col5(const void* x, int x_kind, const float* mean, const float* std, void* out, int n, int cin, int H, int W,
+                int Kp, int dtype, void* stream);
+/* dx fp32 NHWC [n,H,W,C] = transpose of im2col applied to dpatches 16-bit [n*H*W, Kp] */
+int eoe_col2im5(const void* dpatches, float* dx, int n, int C, int H, int W, int Kp, int dtype, void* stream);
+/* conv weight fp32 [cout,cin,5,5] -> 16-bit [cout,Kp] (patch column order) and transposed [Kp,cout]; and the inverse
+ * reorder of the fp32 weight gradient [cout,Kp] -> [cout,cin,5,5] */
+int eoe_conv5_pack_weight(const float* w, void* w16, void* w16t, int cout, int cin, int Kp, int dtype, void* stream);
+int eoe_conv5_unpack_wgrad(const float* g, float* dw, int cout, int cin, int Kp, int accumulate, void* stream);
+/* batch statistics of y fp32 [M,C]: stats[0..C) = mean, stats[C..2C) = 1/sqrt(var+eps) (biased var); training updates
+ * running_mean/var (momentum, unbiased var) and num_batches_tracked as nn.BatchNorm does (cnn.py:57-66); eval reads
+ * the running buffers.  sums_scratch: 2*C floats. */
+int eoe_bn_stats(const float* y, float* sums_scratch, float* stats, float* running_mean, float* running_var,
+                 int64_t* num_batches_tracked, int M, int C, float eps, float momentum, int training, void* stream);
+/* out = maxpool_{pool}(leaky_relu(bn(y))), y fp32 [n,H,W,C]; out 16-bit NHWC (or fp32 if out_f32; or the reference's
+ * NCHW flatten order [n, C*(H/p)*(W/p)] if nchw_flat, cnn.py:83) */
+int eoe_bn_act_pool_fwd(const float* y, const float* stats, const float* gamma, const float* beta, void* out, int n, int H,
+                        int W, int C, int pool, int nchw_flat, int out_f32, int dtype, void* stream);
+/* backward of the above: dout fp32 (layout of `out`) -> dy [n*H*W, C] 16-bit (dY operand of the conv wgrad/dgrad), or
+ * fp32 if dy_f32; dgamma, dbeta */
+int eoe_bn_act_pool_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* dout,
+                        float* red_scratch, void* dy, int dy_f32, float* dgamma, float* dbeta, int n, int H, int W, int C,
+                        int pool, int nchw_flat, int training, int accumulate, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * in-library kernel timing (used by bench.py for the roofline line): while enabled, every entry point brackets

@@ -50,7 +50,7 @@ def test_block_vs_golden(golden, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("layers,n_half,steps,obj,freeze", [
-    (2, 2, 3, "hsc", False), (2, 2, 3, "hsc", True), (12, 1, 2, "hsc", False)])
+    (2, 2, 3, "hsc", False), (2, 2, 3, "hsc", True), (12, 1, 2, "hsc", False), (2, 2, 3, "bce", False)])
 def test_vit_trajectory_vs_golden(golden, dtype, layers, n_half, steps, obj, freeze):
     import eoe_amd
     from eoe_amd.models import ClipViTB32Custom
@@ -69,7 +69,7 @@ def test_vit_trajectory_vs_golden(golden, dtype, layers, n_half, steps, obj, fre
         imgs, lbls = imgs.cuda(), lbls.cuda()
         opt.zero_grad()
         feats = m(imgs)
-        loss = eoe_amd.hsc_loss(feats, lbls, 0)
+        loss = eoe_amd.hsc_loss(feats, lbls, 0) if obj == "hsc" else eoe_amd.bce_loss(feats, lbls)
         loss.backward()
         if it == 0:
             f0 = feats.detach().clone()
@@ -77,7 +77,7 @@ def test_vit_trajectory_vs_golden(golden, dtype, layers, n_half, steps, obj, fre
         opt.step()
         opt.zero_grad()
         losses.append(loss.item())
-        scores.append(eoe_amd.hsc_score(feats).cpu().numpy())
+        scores.append((eoe_amd.hsc_score(feats) if obj == "hsc" else eoe_amd.bce_score(feats)).cpu().numpy())
     tol = TRAJ_TOL[dtype]
     rf = rel_rms(f0, torch.from_numpy(g["features0"]))
     dl = np.abs(np.array(losses) - g["losses"]) / np.maximum(1.0, np.abs(g["losses"]))

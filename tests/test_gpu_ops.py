@@ -253,6 +253,24 @@ def test_hsc_bce(ops):
         assert_close(eoe_amd.bce_score(x), objectives.bce_score(xr.double()), 1e-5, 1e-7, "bce score")
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 1, 512), (7, 3, 100), (300, 8, 64)])
+def test_linear_small(ops, M, N, K):
+    x, xr = f32("ls/x", (M, K), 1.0)
+    w, wr = f32("ls/w", (N, K), 0.1)
+    b, br = f32("ls/b", (N,), 0.5)
+    dy, dyr = f32("ls/dy", (M, N), 1.0)
+    xg, wg, bg = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = ops.linear(xg, wg, bg)
+    (y * dy).sum().backward()
+    xd, wd, bd = xr.double().requires_grad_(True), wr.double().requires_grad_(True), br.double().requires_grad_(True)
+    yr = xd @ wd.t() + bd
+    (yr * dyr.double()).sum().backward()
+    assert_close(y, yr, 1e-5, 1e-5, "linear_small fwd")
+    assert_close(xg.grad, xd.grad, 1e-5, 1e-6, "linear_small dx")
+    assert_close(wg.grad, wd.grad, 1e-4, 1e-4, "linear_small dw")
+    assert_close(bg.grad, bd.grad, 1e-4, 1e-4, "linear_small db")
+
+
 @pytest.mark.parametrize("wd", [0.0, 1e-3])
 def test_fused_adam(golden, wd):
     import eoe_amd
