@@ -72,8 +72,9 @@ def main():
     from eoe_amd import _lib, parallel
     from eoe_amd.models import ClipViTB32Custom
 
-    rank, world, local = parallel.init_from_env("nccl")
+    rank, world, local = parallel.init_from_env(os.environ.get("EOE_DIST_BACKEND", "nccl"))   # "nccl" = RCCL
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     eoe_amd.set_compute_dtype(args.dtype)

@@ -17,7 +17,6 @@
 namespace {
 
 constexpr int BM = 256, BN = 128, BK = 64, NSTAGE = 3;
-#define EOE_NT_DEFAULT_B false
 constexpr int A_BYTES = BM * BK * 2;              // 32 KiB
 constexpr int B_BYTES = BN * BK * 2;              // 16 KiB
 constexpr int STAGE_BYTES = A_BYTES + B_BYTES;    // 48 KiB
@@ -30,19 +29,19 @@ struct GemmP {
     unsigned bytesA, bytesB;
 };
 
-template <typename T, int EPI>
-__device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[4][4], int m_base, int n_base, int lane) {
+template <typename T, int EPI, int NI>
+__device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[4][NI], int m_base, int n_base, int lane) {
     const int lr = lane & 15, lg = lane >> 4;
     const bool vec_ok = ((p.ldc & 3) == 0) && ((p.N & 3) == 0);
-    f32x4 cs[4];                       // per-ni column sums of this lane's rows (bias gradient of the producer)
+    f32x4 cs[NI];                      // per-ni column sums of this lane's rows (bias gradient of the producer)
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) cs[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ni = 0; ni < NI; ++ni) cs[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int m = m_base + mi * 16 + lr;
         if (m >= p.M) continue;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
             const int n = n_base + ni * 16 + lg * 4;
             if (n >= p.N) continue;
             float v[4];
@@ -130,7 +129,7 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[4][4], int
     if (EPI != EOE_EPI_GELU && p.colsum) {
         // rows of this wave's 64x64 sub-tile live on the 16 lanes sharing lane>>4: xor-reduce over lane&15
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float t = cs[ni][r];
@@ -154,11 +153,15 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[4][4], int
 #define EOE_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define EOE_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-template <typename T, int EPI>
+// NI = 16-column MFMA tiles per wave along N: the workgroup tile is 256 x (32*NI).  NI = 4 (256x128) is the default;
+// NI = 3 (256x96) is chosen when it quantises better over the CUs (e.g. N = 768, M = 12800: 400 tiles instead of 300
+// -> 2 rounds of 3/4-size tiles).  The LDS image keeps the 128-row B slot; rows >= 32*NI are never fetched.
+template <typename T, int EPI, int NI>
 __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_n = (p.N + BN - 1) / BN;
+    constexpr int BNI = 32 * NI;
+    const int tiles_n = (p.N + BNI - 1) / BNI;
     const int total_tiles = tiles_n * ((p.M + BM - 1) / BM);
     const int G = gridDim.x;                       // persistent: this workgroup runs tiles b, b+G, b+2G, ...
     const int my_tiles = (total_tiles - (int)blockIdx.x + G - 1) / G;
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
     auto tile_origin = [&](int t, int& m0, int& n0) {
         const int r = xcd_remap(t, total_tiles);
         m0 = (r / tiles_n) * BM;
-        n0 = (r % tiles_n) * BN;
+        n0 = (r % tiles_n) * BNI;
     };
     auto set_offsets = [&](int t) {
         int m0, n0;
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
             const int row = (wave * 2 + j) * 8 + (lane >> 3);
             const int c = (lane & 7) ^ ((row >> 1) & 7);
             const int gb = n0 + row;
-            offB[j] = (gb < p.N) ? (unsigned)(((size_t)gb * p.ldb + c * 8) * 2) : EOE_OOB;
+            offB[j] = (row < BNI && gb < p.N) ? (unsigned)(((size_t)gb * p.ldb + c * 8) * 2) : EOE_OOB;
         }
     };
     auto stage_next = [&]() {                      // 6 LDS-DMA instructions per wave per k-tile
@@ -215,30 +218,32 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
         }
     };
 
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * (16 * NI);
     const int lr = lane & 15, lg = lane >> 4;
-    const int sw = (lr >> 1) & 7;
+    // B rows of this wave start at wn0 = 0 or 16*NI: (row>>1)&7 of row = wn0 + 16 i + lr depends on wn0 when NI is odd
+    const int swA = (lr >> 1) & 7, swB = ((wn0 + lr) >> 1) & 7;
     const int fragA = (wm0 + lr) * 128, fragB = A_BYTES + (wn0 + lr) * 128;
-    const int ch0 = ((0 + lg) ^ sw) * 16, ch1 = ((4 + lg) ^ sw) * 16;
+    const int chA0 = ((0 + lg) ^ swA) * 16, chA1 = ((4 + lg) ^ swA) * 16;
+    const int chB0 = ((0 + lg) ^ swB) * 16, chB1 = ((4 + lg) ^ swB) * 16;
     typedef typename T16<T>::v8 V8;
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][NI];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-#define EOE_READ(XA, WB, base, ch)                                        \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                       \
-        XA[i] = *(const V8*)((base) + fragA + i * 2048 + (ch));           \
-        WB[i] = *(const V8*)((base) + fragB + i * 2048 + (ch));           \
-    }
+#define EOE_READ(XA, WB, base, ks)                                                        \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                         \
+        XA[i] = *(const V8*)((base) + fragA + i * 2048 + ((ks) ? chA1 : chA0));           \
+    _Pragma("unroll") for (int i = 0; i < NI; ++i)                                        \
+        WB[i] = *(const V8*)((base) + fragB + i * 2048 + ((ks) ? chB1 : chB0));
 #define EOE_MFMA(XA, WB)                                                  \
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                      \
-        _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = T16<T>::mfma16(WB[ni], XA[mi], acc[mi][ni]);
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T16<T>::mfma16(WB[ni], XA[mi], acc[mi][ni]);
 
     if (iters <= 0) return;
-    V8 xa0[4], wb0[4], xa1[4], wb1[4];
+    V8 xa0[4], wb0[NI], xa1[4], wb1[NI];
     set_offsets(st_tile);
     stage_next();
     if (iters > 1) {
@@ -248,14 +253,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
         EOE_WAIT_VM(0);
     }
     __builtin_amdgcn_s_barrier();
-    EOE_READ(xa0, wb0, smem, ch0);
+    EOE_READ(xa0, wb0, smem, 0);
     int cur = 0;                                   // ring slot of the k-tile being multiplied
     int c_tile = blockIdx.x, c_kt = 0;
     for (int it = 0; it < iters; ++it) {
         const int nxt = (cur == NSTAGE - 1) ? 0 : cur + 1;
         const char* sc = smem + cur * STAGE_BYTES;
         if (it + 2 < iters) stage_next();
-        EOE_READ(xa1, wb1, sc, ch1);
+        EOE_READ(xa1, wb1, sc, 1);
         EOE_MFMA(xa0, wb0);
         if (it + 2 < iters) { EOE_WAIT_VM(6); } else { EOE_WAIT_VM(0); }
         EOE_WAIT_LGKM0();
@@ -263,18 +268,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
         {   // unconditional (the last iteration reads a stale ring slot and discards it): keeps the compiler's
             // lgkmcnt bookkeeping exact, so MFMA(F1) does not wait for these reads
             const char* sn = smem + nxt * STAGE_BYTES;
-            EOE_READ(xa0, wb0, sn, ch0);
+            EOE_READ(xa0, wb0, sn, 0);
         }
         EOE_MFMA(xa1, wb1);
         cur = nxt;
         if (++c_kt == nk) {                        // tile finished: epilogue while the next tile's DMA is in flight
             int m0, n0;
             tile_origin(c_tile, m0, n0);
-            epilogue<T, EPI>(p, acc, m0 + wm0, n0 + wn0, lane);
+            epilogue<T, EPI, NI>(p, acc, m0 + wm0, n0 + wn0, lane);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             c_kt = 0;
             c_tile += G;
         }
@@ -283,131 +288,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
 #undef EOE_MFMA
 }
 
-// ------------------------------------------------------------------------------------------------ NT, variant B
-// Same 256x128 output tile and 8 waves, but BK = 32 and a 3-stage 72 KiB ring so that TWO workgroups share a CU
-// (16 waves, 4 per SIMD, <= 128 VGPRs): while one workgroup is in its prologue, its epilogue (the store burst is
-// HBM-bound when every CU flushes its tile at once) or parked at a barrier, the other one keeps the MFMA pipe busy.
-// Fragments are not double-buffered: with 4 waves per SIMD thread-level parallelism hides the LDS latency.
-namespace vb {
-constexpr int BK2 = 32;
-constexpr int A2 = BM * BK2 * 2;      // 16 KiB
-constexpr int B2 = BN * BK2 * 2;      //  8 KiB
-constexpr int STAGE2 = A2 + B2;       // 24 KiB
-constexpr int SMEM2 = NSTAGE * STAGE2;   // 72 KiB
-}  // namespace vb
-
-template <typename T, int EPI>
-__global__ __launch_bounds__(512, 4) void gemm_nt_kernel_b(GemmP p) {
-    using namespace vb;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-
-    __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.bytesA);
-    __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.bytesB);
-
-    // a wave-load (1 KiB) covers 16 tile rows of 64 B; lane -> (row, 16-B slot); slot holds chunk slot ^ ((row>>2)&3)
-    // A image: 256 rows = 16 wave-loads (2 per wave); B image: 128 rows = 8 wave-loads (1 per wave)
-    unsigned offA[2], offB;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = (wave * 2 + j) * 16 + (lane >> 2);
-        const int c = (lane & 3) ^ ((row >> 2) & 3);
-        const int ga = m0 + row;
-        offA[j] = (ga < p.M) ? (unsigned)(((size_t)ga * p.lda + c * 8) * 2) : EOE_OOB;
-    }
-    {
-        const int row = wave * 16 + (lane >> 2);
-        const int c = (lane & 3) ^ ((row >> 2) & 3);
-        const int gb = n0 + row;
-        offB = (gb < p.N) ? (unsigned)(((size_t)gb * p.ldb + c * 8) * 2) : EOE_OOB;
-    }
-    auto stage = [&](int slot, int k0) {           // 3 LDS-DMA instructions per wave per k-tile
-        char* sa = smem + slot * STAGE2;
-        char* sb = sa + A2;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(sa + (wave * 2 + j) * 1024), 16,
-                                                     offA[j] + (unsigned)k0 * 2u, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(sb + wave * 1024), 16, offB + (unsigned)k0 * 2u, 0, 0, 0);
-    };
-
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
-    const int lr = lane & 15, lg = lane >> 4;
-    const int chs = (lg ^ ((lr >> 2) & 3)) * 16;            // (row>>2)&3 of row = w?0 + 16 i + lr is (lr>>2)&3
-    const int fragA = (wm0 + lr) * 64 + chs, fragB = A2 + (wn0 + lr) * 64 + chs;
-    typedef typename T16<T>::v8 V8;
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int nk = p.K / BK2;
-    stage(0, 0);
-    if (nk > 1) {
-        stage(1, BK2);
-        EOE_WAIT_VM(3);
-    } else {
-        EOE_WAIT_VM(0);
-    }
-    __builtin_amdgcn_s_barrier();
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int nxt = (cur == NSTAGE - 1) ? 0 : cur + 1;
-        const int nx2 = (nxt == NSTAGE - 1) ? 0 : nxt + 1;
-        const char* sc = smem + cur * STAGE2;
-        if (kt + 2 < nk) stage(nx2, (kt + 2) * BK2);
-        V8 xa[4], wb[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            xa[i] = *(const V8*)(sc + fragA + i * 1024);
-            wb[i] = *(const V8*)(sc + fragB + i * 1024);
-        }
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = T16<T>::mfma16(wb[ni], xa[mi], acc[mi][ni]);
-        if (kt + 2 < nk) { EOE_WAIT_VM(3); } else { EOE_WAIT_VM(0); }
-        EOE_WAIT_LGKM0();
-        __builtin_amdgcn_s_barrier();
-        cur = nxt;
-    }
-    epilogue<T, EPI>(p, acc, m0 + wm0, n0 + wn0, lane);
-}
-
-template <typename T>
-int launch_nt(const GemmP& p, int epi, hipStream_t s) {
-    const int tiles = cdiv(p.M, BM) * cdiv(p.N, BN);
-    static const int ncu = [] { int d = 0, n = 256; hipDeviceProp_t pr; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) n = pr.multiProcessorCount; return n; }();
-    const int grid = tiles < ncu ? tiles : ncu;      // persistent: one 8-wave workgroup per CU
-    // variant selection: EOE_NT_VARIANT=a forces the persistent 1-WG/CU kernel, =b the 2-WG/CU BK=32 kernel
-    static const char* var = getenv("EOE_NT_VARIANT");
-    const bool use_b = var ? (var[0] == 'b') : EOE_NT_DEFAULT_B;
-    if (use_b && (p.K % vb::BK2) == 0) {
-#define EOE_NTB_CASE(E)                                                                     \
-        case E:                                                                             \
-            { static bool once = (hipFuncSetAttribute((const void*)gemm_nt_kernel_b<T, E>, hipFuncAttributeMaxDynamicSharedMemorySize, vb::SMEM2), true); (void)once; } \
-            hipLaunchKernelGGL((gemm_nt_kernel_b<T, E>), dim3(tiles), dim3(512), vb::SMEM2, s, p); \
-            break;
-        switch (epi) {
-            EOE_NTB_CASE(EOE_EPI_NONE)
-            EOE_NTB_CASE(EOE_EPI_GELU)
-            EOE_NTB_CASE(EOE_EPI_RESIDUAL)
-            EOE_NTB_CASE(EOE_EPI_GELU_BWD)
-            default: return eoe_set_error(EOE_ERR_ARG, "gemm_nt: unknown epilogue %d", epi);
-        }
-#undef EOE_NTB_CASE
-        EOE_CHECK_LAUNCH("gemm_nt_b");
-        return 0;
-    }
+template <typename T, int NI>
+int launch_nt_ni(const GemmP& p, int epi, int grid, hipStream_t s) {
 #define EOE_NT_CASE(E)                                                                      \
     case E:                                                                                 \
-        { static bool once = (hipFuncSetAttribute((const void*)gemm_nt_kernel<T, E>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES), true); (void)once; } \
-        hipLaunchKernelGGL((gemm_nt_kernel<T, E>), dim3(grid), dim3(512), SMEM_BYTES, s, p); \
+        { static bool once = (hipFuncSetAttribute((const void*)gemm_nt_kernel<T, E, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES), true); (void)once; } \
+        hipLaunchKernelGGL((gemm_nt_kernel<T, E, NI>), dim3(grid), dim3(512), SMEM_BYTES, s, p); \
         break;
     switch (epi) {
         EOE_NT_CASE(EOE_EPI_NONE)
@@ -419,6 +305,19 @@ int launch_nt(const GemmP& p, int epi, hipStream_t s) {
 #undef EOE_NT_CASE
     EOE_CHECK_LAUNCH("gemm_nt");
     return 0;
+}
+
+template <typename T>
+int launch_nt(const GemmP& p, int epi, hipStream_t s) {
+    static const int ncu = [] { int d = 0, n = 256; hipDeviceProp_t pr; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) n = pr.multiProcessorCount; return n; }();
+    // tile width: 256x128 unless 256x96 needs >= 10 % fewer (rounds x width) units over the CUs
+    const int t4 = cdiv(p.M, BM) * cdiv(p.N, 128), t3 = cdiv(p.M, BM) * cdiv(p.N, 96);
+    const int c4 = cdiv(t4, ncu) * 4, c3 = cdiv(t3, ncu) * 3;
+    static const char* force = getenv("EOE_NT_NI");
+    const bool use3 = force ? (force[0] == '3') : (c3 * 10 <= c4 * 9);
+    const int tiles = use3 ? t3 : t4;
+    const int grid = tiles < ncu ? tiles : ncu;      // persistent: one 8-wave workgroup per CU
+    return use3 ? launch_nt_ni<T, 3>(p, epi, grid, s) : launch_nt_ni<T, 4>(p, epi, grid, s);
 }
 
 int fill_params(const eoe_gemm_args* a, GemmP& p) {
