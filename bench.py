@@ -39,6 +39,8 @@ def parse():
                     help="full fine-tune (config 5 style) or frozen encoder + trained head (config 4)")
     ap.add_argument("--dtype", choices=["fp16", "bf16"], default="fp16")
     ap.add_argument("--layers", type=int, default=12)
+    ap.add_argument("--model", choices=["vit", "cnn32"], default="vit",
+                    help="vit = the BASELINE.json metric config; cnn32 = secondary (config 1/2 backbone, 32x32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32)
@@ -80,9 +82,16 @@ def main():
     eoe_amd.set_compute_dtype(args.dtype)
 
     torch.manual_seed(0)
-    model = ClipViTB32Custom(prediction_head=True, clf=False, freeze=(args.mode == "frozen"), layers=args.layers).to(dev).train()
-    opt = eoe_amd.FusedAdam(model.parameters(), lr=1e-4, weight_decay=1e-3)     # train_clip_imagenet.py:13-14
-    model.freeze_parts()
+    res = 224
+    if args.model == "vit":
+        model = ClipViTB32Custom(prediction_head=True, clf=False, freeze=(args.mode == "frozen"), layers=args.layers).to(dev).train()
+        opt = eoe_amd.FusedAdam(model.parameters(), lr=1e-4, weight_decay=1e-3)     # train_clip_imagenet.py:13-14
+        model.freeze_parts()
+    else:
+        from eoe_amd.models import CNN32
+        res = 32
+        model = CNN32(bias=True).to(dev).train()                                     # train_cifar.py:44
+        opt = eoe_amd.FusedAdam(model.parameters(), lr=1e-3, weight_decay=0.0)       # train_cifar.py:17-18
     arena = parallel.GradArena(model)
     if world > 1:
         arena.install_hooks()
@@ -92,8 +101,8 @@ def main():
     n_global = n_local * world
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
-    imgs = torch.randn((n_local, 3, 224, 224), generator=gen, device=dev)
-    imgs[nb:] += 0.5 * torch.randn((1, 3, 224, 224), generator=torch.Generator(device=dev).manual_seed(7), device=dev)
+    imgs = torch.randn((n_local, 3, res, res), generator=gen, device=dev)
+    imgs[nb:] += 0.5 * torch.randn((1, 3, res, res), generator=torch.Generator(device=dev).manual_seed(7), device=dev)
     lbls = torch.cat([torch.zeros(nb, dtype=torch.int64), torch.ones(nb, dtype=torch.int64)]).to(dev)
     score_buf = torch.empty((args.steps + args.warmup + 8, n_local), dtype=torch.float32, device=dev)
 
@@ -151,14 +160,17 @@ def main():
         ms = elapsed / args.steps * 1e3
         value = n_global * args.steps / elapsed
         flop_per_img = FWD_GFLOP_PER_IMG * (3.0 if args.mode == "full" else 1.0) * args.layers / 12.0
+        if args.model == "cnn32":
+            flop_per_img = 0.179
         out = {
-            "metric": "train images/sec, CLIP ViT-B/32 + HSC, 224x224",
+            "metric": "train images/sec, CLIP ViT-B/32 + HSC, 224x224" if args.model == "vit" else "train images/sec, CNN32 + HSC, 32x32",
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"CLIP ViT-B/32 ({args.layers} layers) + Linear(512,256) + HSC, "
-                                   f"{'full fine-tune' if args.mode == 'full' else 'frozen encoder'}, Adam lr 1e-4 wd 1e-3, "
-                                   f"224x224, {nb} normal + {nb} OE images per GPU per step",
+            "config": {"workload": (f"CLIP ViT-B/32 ({args.layers} layers) + Linear(512,256) + HSC, "
+                                    f"{'full fine-tune' if args.mode == 'full' else 'frozen encoder'}, Adam lr 1e-4 wd 1e-3, "
+                                    f"224x224, {nb} normal + {nb} OE images per GPU per step") if args.model == "vit" else
+                                   f"CNN32(bias=True) + HSC, Adam lr 1e-3, 32x32, {nb} normal + {nb} OE images per GPU per step",
                        "global_batch": n_global, "parallelism": f"dp{world}"},
             "model_tflops": round(value * flop_per_img / 1e3, 1),
             "mfma_roofline_frac_end_to_end": round(value * flop_per_img / 1e3 / (MFMA_PEAK_TFLOPS * world), 4),
@@ -166,7 +178,7 @@ def main():
         }
         if roof is not None:
             out["roofline"] = roof
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model == "vit":
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -199,12 +199,15 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 // backward: rows are strided over the grid; each wave accumulates dgamma/dbeta partials in registers,
 // the block combines its 4 waves through LDS and issues one fp32 atomic per column.
 template <typename T, int NV>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restrict__ dy, int dy_f32, const float* __restrict__ x, int ldx,
+__global__ __launch_bounds__(512) void layernorm_bwd_kernel(const void* __restrict__ dy, int dy_f32, const float* __restrict__ x, int ldx,
                                      const float* __restrict__ stats, const float* __restrict__ gamma,
                                      const float* __restrict__ dres, float* __restrict__ dx_out, int ld_out,
                                      T* __restrict__ dx16, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                      float* __restrict__ dxsum, int rows, int D) {
-    __shared__ float red[3][4][1024];
+    // 8 waves per workgroup (16 waves per CU at 2 workgroups: enough loads in flight for an HBM-bound kernel)
+    constexpr int NW = 8;
+    extern __shared__ float red_raw[];               // [3][NW][256*NV]
+    float (*red)[NW][256 * NV] = (float (*)[NW][256 * NV])red_raw;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int nv = NV;
     f32x4 ag[NV], ab[NV], ax[NV], gm[NV];
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
         ax[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (i < nv) gm[i] = *(const f32x4*)(gamma + i * 256 + lane * 4);
     }
-    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    for (int row = blockIdx.x * NW + wave; row < rows; row += gridDim.x * NW) {
         const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
         f32x4 g[NV], xh[NV];
         float s1 = 0.f, s2 = 0.f;
@@ -275,11 +278,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
         }
     __syncthreads();
     for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { a0 += red[0][w][c]; a1 += red[1][w][c]; a2 += red[2][w][c]; }
         if (dgamma) {
-            atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-            atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+            atomicAdd(dgamma + c, a0);
+            atomicAdd(dbeta + c, a1);
         }
-        if (dxsum) atomicAdd(dxsum + c, red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c]);
+        if (dxsum) atomicAdd(dxsum + c, a2);
     }
 }
 
@@ -714,9 +720,10 @@ extern "C" int eoe_layernorm_bwd(const void* dy, int dy_f32, const float* x, int
     EOE_CHECK_ARG(D % 256 == 0 && D <= 1024 && ldx % 4 == 0 && ld_out % 4 == 0, "layernorm: D must be a multiple of 256, <= 1024");
     EOE_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma/dbeta must both be given or both NULL");
     ProfScope ps("layernorm_bwd", 0, ((dy_f32 ? 4.0 : 2.0) + 4.0 + (dres ? 4.0 : 0.0) + 4.0 + (dx16 ? 2.0 : 0.0)) * rows * D, stream);
-    int grid = cdiv(rows, 4);
+    int grid = cdiv(rows, 8);
     if (grid > 512) grid = 512;
-    DISPATCH_T(dtype, DISPATCH_NV(D, hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy,
+    DISPATCH_T(dtype, DISPATCH_NV(D, hipFuncSetAttribute((const void*)layernorm_bwd_kernel<T, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 8 * 256 * NV * 4);
+                                  hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV>), dim3(grid), dim3(512), 3 * 8 * 256 * NV * 4, (hipStream_t)stream, dy,
                                          dy_f32, x, ldx, stats, gamma, dres, dx_out, ld_out, (T*)dx16, dgamma, dbeta,
                                          dxsum, rows, D)));
     EOE_CHECK_LAUNCH("layernorm_bwd");

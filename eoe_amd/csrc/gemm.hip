@@ -29,15 +29,15 @@ struct GemmP {
     unsigned bytesA, bytesB;
 };
 
-template <typename T, int EPI, int NI>
-__device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[4][NI], int m_base, int n_base, int lane) {
+template <typename T, int EPI, int NI, int MI = 4>
+__device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][NI], int m_base, int n_base, int lane) {
     const int lr = lane & 15, lg = lane >> 4;
     const bool vec_ok = ((p.ldc & 3) == 0) && ((p.N & 3) == 0);
     f32x4 cs[NI];                      // per-ni column sums of this lane's rows (bias gradient of the producer)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) cs[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
         const int m = m_base + mi * 16 + lr;
         if (m >= p.M) continue;
 #pragma unroll
