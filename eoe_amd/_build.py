@@ -39,7 +39,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in SOURCES:
         obj = os.path.join(objdir, src.rsplit(".", 1)[0] + ".o")
         objs.append(obj)
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-x", "hip", "-c",
+        extra = ["-DEOE_AB"] if os.environ.get("EOE_AB") else []
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + extra + ["-x", "hip", "-c",
                os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

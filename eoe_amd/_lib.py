@@ -94,6 +94,8 @@ SIGNATURES = {
     "eoe_bn_act_pool_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                             C.c_int, C.c_int, C.c_int, _vp],
     "eoe_prof_enable": [C.c_int],
+    "eoe_set_option": [C.c_char_p, C.c_int],
+    "eoe_debug_gemm_stamps": [_vp, C.c_int],
     "eoe_prof_collect": [C.POINTER(ProfEntry), C.c_int, C.POINTER(C.c_int)],
 }
 _RESTYPES = {"eoe_last_error": C.c_char_p}

@@ -14,9 +14,14 @@
 #include "common.h"
 #include <stdlib.h>
 
+unsigned long long* g_stamp_buf = nullptr;
+
 namespace {
 
 constexpr int BM = 256, BN = 128, BK = 64, NSTAGE = 3;
+#ifndef EOE_NT_DEFAULT_FLAGS
+#define EOE_NT_DEFAULT_FLAGS 1     // measured (tools/gemm_ab.py, one device, interleaved): f0 669 us, f1 551 us, f2 795 us, f3 613 us per layer
+#endif
 constexpr int A_BYTES = BM * BK * 2;              // 32 KiB
 constexpr int B_BYTES = BN * BK * 2;              // 16 KiB
 constexpr int STAGE_BYTES = A_BYTES + B_BYTES;    // 48 KiB
@@ -27,10 +32,13 @@ struct GemmP {
     int M, N, K, lda, ldb, ldc, ldaux, out_f32, accumulate;
     float alpha;
     unsigned bytesA, bytesB;
+    unsigned long long* stamp;     // diagnostics (EOE_GEMM_STAMP=1): per-workgroup s_memtime stamps, else NULL
 };
 
+// General (slow) epilogue: straight from the MFMA accumulator layout (lane = output row within a 16-row band, 4
+// consecutive columns per 16x16 tile) -- 8/16-byte pieces, 16 rows per store instruction.  Handles any N / ldc.
 template <typename T, int EPI, int NI, int MI = 4>
-__device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][NI], int m_base, int n_base, int lane) {
+__device__ __forceinline__ void epilogue_generic(const GemmP& p, f32x4 (&acc)[MI][NI], int m_base, int n_base, int lane) {
     const int lr = lane & 15, lg = lane >> 4;
     const bool vec_ok = ((p.ldc & 3) == 0) && ((p.N & 3) == 0);
     f32x4 cs[NI];                      // per-ni column sums of this lane's rows (bias gradient of the producer)
@@ -141,6 +149,113 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][NI], i
     }
 }
 
+// Fast epilogue (N % 16 == 0, 16-byte aligned rows).  The generic form above is store-ISSUE-bound: one store
+// instruction writes 16 rows x 32 B, and it cost 15-21 k cycles per 256x128 tile -- as long as the 12 k-iterations of a
+// K = 768 GEMM.  Here every 16-row band of the wave's 64 x (16*NI) sub-tile is transposed through a 4-KiB LDS scratch
+// (the wave's OWN 4-KiB piece of the ring slot that was just consumed: only this wave's later LDS-DMA writes there, in
+// program order after these reads), so that a lane holds 16 consecutive columns of one row: bias / residual / saved
+// pre-activation are read, and the result is written, as 64-byte (fp32) or 32-byte (16-bit) contiguous pieces, 4 lanes
+// per row = whole 128/256-byte lines per row.
+template <typename T, int EPI, int NI>
+__device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[4][NI], int m_base, int n_base, int lane, char* scr) {
+    const bool fast = ((p.N & 15) == 0) && ((p.ldc & 7) == 0) && ((p.ldaux & 7) == 0) && ((((uintptr_t)p.C) & 15) == 0);
+    if (!fast) {
+        epilogue_generic<T, EPI, NI, 4>(p, acc, m_base, n_base, lane);
+        return;
+    }
+    const int lr = lane & 15, lg = lane >> 4;
+    const int rrow = lane >> 2, rq = lane & 3;                 // read side: row of the band, 16-column group
+    const int n = n_base + rq * 16;
+    const bool col_ok = (rq < NI) && (n < p.N);
+    float cs[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) cs[c] = 0.f;
+    float bias[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) bias[c] = 0.f;
+    if (p.bias && col_ok) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bv = *(const f32x4*)(p.bias + n + q * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bias[q * 4 + r] = bv[r];
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        // accumulator layout -> LDS [16 rows][64 cols] fp32, 16-B chunk index XOR row (bank spread)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) *(f32x4*)(scr + lr * 256 + (((ni * 4 + lg) ^ lr) << 4)) = acc[mi][ni];
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 t = *(const f32x4*)(scr + rrow * 256 + (((rq * 4 + q) ^ rrow) << 4));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[q * 4 + r] = t[r] * p.alpha + bias[q * 4 + r];
+        }
+        const int m = m_base + mi * 16 + rrow;
+        if (m >= p.M || !col_ok) continue;
+        const size_t off = (size_t)m * p.ldc + n;
+        if (EPI == EOE_EPI_GELU) {
+            T* pre = (T*)p.aux_out + off;
+            T* act = (T*)p.C + off;
+            float pr[16], ac[16];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const u32x4 pk = pack8<T>(v + 8 * h);          // the saved pre-activation is what backward differentiates:
+                unpack8<T>(pk, pr + 8 * h);                    // activate its ROUNDED value
+                *(u32x4*)(pre + 8 * h) = pk;
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) ac[c] = quick_gelu_f(pr[c]);
+            *(u32x4*)(act) = pack8<T>(ac);
+            *(u32x4*)(act + 8) = pack8<T>(ac + 8);
+            continue;
+        }
+        if (EPI == EOE_EPI_RESIDUAL) {
+            const float* res = (const float*)p.aux + (size_t)m * p.ldaux + n;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 rv = *(const f32x4*)(res + q * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[q * 4 + r] += rv[r];
+            }
+        }
+        if (EPI == EOE_EPI_GELU_BWD) {
+            const T* pre = (const T*)p.aux + (size_t)m * p.ldaux + n;
+            float pr[16];
+            unpack8<T>(*(const u32x4*)pre, pr);
+            unpack8<T>(*(const u32x4*)(pre + 8), pr + 8);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) v[c] *= quick_gelu_grad_f(pr[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) cs[c] += v[c];
+        if (p.out_f32) {
+            float* c = (float*)p.C + off;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 o = {v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]};
+                if (p.accumulate) o += *(const f32x4*)(c + q * 4);
+                *(f32x4*)(c + q * 4) = o;
+            }
+        } else {
+            T* c = (T*)p.C + off;
+            *(u32x4*)(c) = pack8<T>(v);
+            *(u32x4*)(c + 8) = pack8<T>(v + 8);
+        }
+    }
+    if (EPI != EOE_EPI_GELU && p.colsum) {
+        // the 16 rows of a band sit on lanes with equal lane&3: xor-reduce over lane>>2, then 4 lanes x 16 atomics
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            float t = cs[c];
+            t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+            if (rrow == 0 && col_ok) atomicAdd(p.colsum + n + c, t);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ NT
 // main loop: 3-stage LDS ring filled by LDS-DMA two k-tiles ahead (counted vmcnt: the newest tile stays in
 // flight across the barrier), ONE raw s_barrier per k-tile, MFMA fragments double-buffered in registers so the
@@ -156,15 +271,17 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][NI], i
 // NI = 16-column MFMA tiles per wave along N: the workgroup tile is 256 x (32*NI).  NI = 4 (256x128) is the default;
 // NI = 3 (256x96) is chosen when it quantises better over the CUs (e.g. N = 768, M = 12800: 400 tiles instead of 300
 // -> 2 rounds of 3/4-size tiles).  The LDS image keeps the 128-row B slot; rows >= 32*NI are never fetched.
-template <typename T, int EPI, int NI>
+// FLAGS (tuning switches, A/B-able in one binary when built with -DEOE_AB): bit 0 = LDS-transposed fast epilogue,
+// bit 1 = sched_barrier pins "all fragment reads, then the 16 MFMAs" in each half iteration
+template <typename T, int EPI, int NI, int FLAGS>
 __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int BNI = 32 * NI;
     const int tiles_n = (p.N + BNI - 1) / BNI;
     const int total_tiles = tiles_n * ((p.M + BM - 1) / BM);
-    const int G = gridDim.x;                       // persistent: this workgroup runs tiles b, b+G, b+2G, ...
-    const int my_tiles = (total_tiles - (int)blockIdx.x + G - 1) / G;
+    const int G = gridDim.x;                       // persistent: this workgroup runs a strided sequence of tiles
+    const int my_tiles = (total_tiles - (int)blockIdx.x + G - 1) / G;     // tiles b, b+G, b+2G, ... (XCD-remapped)
     const int nk = p.K / BK;
     const int iters = my_tiles * nk;               // flattened (tile, k-tile) iteration space of this workgroup
 
@@ -176,9 +293,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
     // a wave-load (1 KiB) covers 8 tile rows of 128 B; lane -> (row, 16-B slot); the slot holds logical chunk
     // slot ^ ((row>>1)&7).  A image: 256 rows = 32 wave-loads (4 per wave); B image: 128 rows = 16 (2 per wave)
     unsigned offA[4], offB[2];
-    int st_tile = blockIdx.x, st_kt = 0, st_slot = 0;
-    auto tile_origin = [&](int t, int& m0, int& n0) {
-        const int r = xcd_remap(t, total_tiles);
+    int st_tile = 0, st_kt = 0, st_slot = 0;       // st_tile / c_tile count this workgroup's tiles (0 .. my_tiles)
+    // (tried and rejected, measured interleaved on one device: giving each XCD a band of whole tile rows swept
+    //  column-major to keep A panels L2-resident -- 587 vs 551 us per layer stand-alone, 10.6 vs 8.2 ms in the step)
+    auto tile_origin = [&](int seq, int& m0, int& n0) {
+        const int r = xcd_remap((int)blockIdx.x + seq * G, total_tiles);
         m0 = (r / tiles_n) * BM;
         n0 = (r % tiles_n) * BNI;
     };
@@ -213,8 +332,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
         st_slot = (st_slot == NSTAGE - 1) ? 0 : st_slot + 1;
         if (++st_kt == nk) {
             st_kt = 0;
-            st_tile += G;
-            if (st_tile < total_tiles) set_offsets(st_tile);
+            st_tile += 1;
+            if (st_tile < my_tiles) set_offsets(st_tile);
         }
     };
 
@@ -243,6 +362,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
         _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T16<T>::mfma16(WB[ni], XA[mi], acc[mi][ni]);
 
     if (iters <= 0) return;
+    unsigned long long* stp = p.stamp ? p.stamp + (size_t)blockIdx.x * 16 : nullptr;
+    int sti = 0;
+#define EOE_STAMP() do { if (stp && tid == 0 && sti < 15) stp[sti++] = __builtin_amdgcn_s_memtime(); } while (0)
+    if (stp && tid == 0) stp[15] = __builtin_amdgcn_s_memrealtime();
+    EOE_STAMP();                                   // [0] kernel entry
     V8 xa0[4], wb0[NI], xa1[4], wb1[NI];
     set_offsets(st_tile);
     stage_next();
@@ -253,15 +377,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
         EOE_WAIT_VM(0);
     }
     __builtin_amdgcn_s_barrier();
+    EOE_STAMP();                                   // [1] first operands landed
     EOE_READ(xa0, wb0, smem, 0);
     int cur = 0;                                   // ring slot of the k-tile being multiplied
-    int c_tile = blockIdx.x, c_kt = 0;
+    int c_tile = 0, c_kt = 0;
     for (int it = 0; it < iters; ++it) {
         const int nxt = (cur == NSTAGE - 1) ? 0 : cur + 1;
         const char* sc = smem + cur * STAGE_BYTES;
         if (it + 2 < iters) stage_next();
         EOE_READ(xa1, wb1, sc, 1);
+        if (FLAGS & 2) __builtin_amdgcn_sched_barrier(0);   // keep all 8 fragment reads AHEAD of the 16 MFMAs they overlap with
         EOE_MFMA(xa0, wb0);
+        if (FLAGS & 2) __builtin_amdgcn_sched_barrier(0);
         if (it + 2 < iters) { EOE_WAIT_VM(6); } else { EOE_WAIT_VM(0); }
         EOE_WAIT_LGKM0();
         __builtin_amdgcn_s_barrier();
@@ -270,30 +397,49 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
             const char* sn = smem + nxt * STAGE_BYTES;
             EOE_READ(xa0, wb0, sn, 0);
         }
+        if (FLAGS & 2) __builtin_amdgcn_sched_barrier(0);
         EOE_MFMA(xa1, wb1);
+        if (FLAGS & 2) __builtin_amdgcn_sched_barrier(0);
         cur = nxt;
         if (++c_kt == nk) {                        // tile finished: epilogue while the next tile's DMA is in flight
             int m0, n0;
             tile_origin(c_tile, m0, n0);
-            epilogue<T, EPI, NI>(p, acc, m0 + wm0, n0 + wn0, lane);
+            EOE_STAMP();                           // [2+2i] main loop of tile i done
+            // the epilogue-only arguments are re-read from the kernarg segment HERE (behind an opaque pointer), so
+            // that they do not occupy ~40 SGPRs across the k-loop (the loop otherwise carries SGPR spills and waits)
+#if defined(__HIP_DEVICE_COMPILE__)
+            const __attribute__((address_space(4))) char* kp =
+                (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(kp));
+            GemmP ep;
+            __builtin_memcpy(&ep, (const void*)kp, sizeof(GemmP));
+#else
+            const GemmP ep = p;
+#endif
+            if (FLAGS & 1) epilogue<T, EPI, NI>(ep, acc, m0 + wm0, n0 + wn0, lane, (char*)sc + wave * 4096);
+            else epilogue_generic<T, EPI, NI, 4>(ep, acc, m0 + wm0, n0 + wn0, lane);
+            if (stp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            EOE_STAMP();                           // [3+2i] epilogue of tile i issued and drained
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             c_kt = 0;
-            c_tile += G;
+            c_tile += 1;
         }
     }
 #undef EOE_READ
 #undef EOE_MFMA
 }
 
-template <typename T, int NI>
-int launch_nt_ni(const GemmP& p, int epi, int grid, hipStream_t s) {
+int g_nt_flags = EOE_NT_DEFAULT_FLAGS;
+
+template <typename T, int NI, int FLAGS>
+int launch_nt_f(const GemmP& p, int epi, int grid, hipStream_t s) {
 #define EOE_NT_CASE(E)                                                                      \
     case E:                                                                                 \
-        { static bool once = (hipFuncSetAttribute((const void*)gemm_nt_kernel<T, E, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES), true); (void)once; } \
-        hipLaunchKernelGGL((gemm_nt_kernel<T, E, NI>), dim3(grid), dim3(512), SMEM_BYTES, s, p); \
+        { static bool once = (hipFuncSetAttribute((const void*)gemm_nt_kernel<T, E, NI, FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES), true); (void)once; } \
+        hipLaunchKernelGGL((gemm_nt_kernel<T, E, NI, FLAGS>), dim3(grid), dim3(512), SMEM_BYTES, s, p); \
         break;
     switch (epi) {
         EOE_NT_CASE(EOE_EPI_NONE)
@@ -307,14 +453,28 @@ int launch_nt_ni(const GemmP& p, int epi, int grid, hipStream_t s) {
     return 0;
 }
 
+template <typename T, int NI>
+int launch_nt_ni(const GemmP& p, int epi, int grid, hipStream_t s) {
+#ifdef EOE_AB
+    switch (g_nt_flags & 3) {
+        case 0: return launch_nt_f<T, NI, 0>(p, epi, grid, s);
+        case 1: return launch_nt_f<T, NI, 1>(p, epi, grid, s);
+        case 2: return launch_nt_f<T, NI, 2>(p, epi, grid, s);
+        default: return launch_nt_f<T, NI, 3>(p, epi, grid, s);
+    }
+#else
+    return launch_nt_f<T, NI, EOE_NT_DEFAULT_FLAGS>(p, epi, grid, s);
+#endif
+}
+
 template <typename T>
 int launch_nt(const GemmP& p, int epi, hipStream_t s) {
     static const int ncu = [] { int d = 0, n = 256; hipDeviceProp_t pr; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) n = pr.multiProcessorCount; return n; }();
     // tile width: 256x128 unless 256x96 needs >= 10 % fewer (rounds x width) units over the CUs
     const int t4 = cdiv(p.M, BM) * cdiv(p.N, 128), t3 = cdiv(p.M, BM) * cdiv(p.N, 96);
     const int c4 = cdiv(t4, ncu) * 4, c3 = cdiv(t3, ncu) * 3;
-    static const char* force = getenv("EOE_NT_NI");
-    const bool use3 = force ? (force[0] == '3') : (c3 * 10 <= c4 * 9);
+    const int force = (g_nt_flags >> 4) & 7;          // option bits 4-6: 0 = heuristic, 3 / 4 = force the tile width
+    const bool use3 = force ? (force == 3) : (c3 * 10 <= c4 * 9);
     const int tiles = use3 ? t3 : t4;
     const int grid = tiles < ncu ? tiles : ncu;      // persistent: one 8-wave workgroup per CU
     return use3 ? launch_nt_ni<T, 3>(p, epi, grid, s) : launch_nt_ni<T, 4>(p, epi, grid, s);
@@ -341,6 +501,14 @@ int fill_params(const eoe_gemm_args* a, GemmP& p) {
     // times the LDS/MFMA/epilogue side of the kernel alone (results are then wrong by construction)
     static const int dbg = getenv("EOE_GEMM_DEBUG") ? atoi(getenv("EOE_GEMM_DEBUG")) : 0;
     if (dbg & 1) { p.bytesA = 0; p.bytesB = 0; }
+    p.stamp = nullptr;
+    static const int stampon = getenv("EOE_GEMM_STAMP") ? atoi(getenv("EOE_GEMM_STAMP")) : 0;
+    if (stampon) {
+        static unsigned long long* buf = [] { void* b = nullptr; (void)hipMalloc(&b, 1024 * 16 * 8); return (unsigned long long*)b; }();
+        (void)hipMemsetAsync(buf, 0, 1024 * 16 * 8, 0);
+        p.stamp = buf;
+        g_stamp_buf = buf;
+    }
     if (a->epilogue == EOE_EPI_GELU) EOE_CHECK_ARG(a->aux_out && !a->out_f32, "gemm: GELU epilogue needs aux_out, 16-bit C");
     if (a->epilogue == EOE_EPI_RESIDUAL) EOE_CHECK_ARG(a->aux && a->out_f32, "gemm: RESIDUAL epilogue needs aux, fp32 C");
     if (a->epilogue == EOE_EPI_GELU_BWD) EOE_CHECK_ARG(a->aux, "gemm: GELU_BWD epilogue needs aux");
@@ -361,3 +529,18 @@ extern "C" int eoe_gemm_nt(const eoe_gemm_args* a, void* stream) {
                                : launch_nt<bf16_t>(p, a->epilogue, (hipStream_t)stream);
 }
 
+
+// diagnostics: copies the per-workgroup s_memtime stamps of the last gemm_nt launch (EOE_GEMM_STAMP=1) to the host
+extern "C" int eoe_debug_gemm_stamps(unsigned long long* out, int n_words) {
+    if (!g_stamp_buf || !out) return eoe_set_error(EOE_ERR_ARG, "gemm stamps are not enabled (EOE_GEMM_STAMP=1)");
+    if (hipDeviceSynchronize() != hipSuccess) return eoe_set_error(EOE_ERR_LAUNCH, "sync failed");
+    if (hipMemcpy(out, g_stamp_buf, (size_t)n_words * 8, hipMemcpyDeviceToHost) != hipSuccess)
+        return eoe_set_error(EOE_ERR_LAUNCH, "copy failed");
+    return 0;
+}
+
+// tuning switches (see gemm_nt_kernel FLAGS; bits 4-6 force the tile width); all four variants exist only in -DEOE_AB builds
+extern "C" int eoe_set_option(const char* name, int value) {
+    if (name && !strcmp(name, "nt_flags")) { g_nt_flags = value; return 0; }
+    return eoe_set_error(EOE_ERR_ARG, "unknown option");
+}

@@ -269,6 +269,10 @@ typedef struct {
     double bytes;      /* sum of algorithmic HBM bytes (inputs read once + outputs written once) */
 } eoe_prof_entry;
 int eoe_prof_enable(int on);
+/* tuning switches for A/B measurements inside one process ("nt_flags": see gemm.hip) */
+int eoe_set_option(const char* name, int value);
+/* diagnostics only (EOE_GEMM_STAMP=1): in-kernel s_memtime stamps of the last eoe_gemm_nt launch, 16 words per workgroup */
+int eoe_debug_gemm_stamps(unsigned long long* out, int n_words);
 int eoe_prof_collect(eoe_prof_entry* out, int max_entries, int* n_out);
 
 #ifdef __cplusplus
