@@ -256,6 +256,19 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[4][NI], in
     }
 }
 
+// the epilogue-only arguments are re-read from the kernarg segment at the point of use (behind an opaque pointer), so
+// that they do not occupy ~40 SGPRs across the k-loop (the loop otherwise carries SGPR spills and extra waits)
+__device__ __forceinline__ void load_epilogue_args(GemmP& ep, const GemmP& p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __attribute__((address_space(4))) char* kp =
+        (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    __builtin_memcpy(&ep, (const void*)kp, sizeof(GemmP));
+#else
+    ep = p;
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------ NT
 // main loop: 3-stage LDS ring filled by LDS-DMA two k-tiles ahead (counted vmcnt: the newest tile stays in
 // flight across the barrier), ONE raw s_barrier per k-tile, MFMA fragments double-buffered in registers so the
@@ -405,17 +418,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
             int m0, n0;
             tile_origin(c_tile, m0, n0);
             EOE_STAMP();                           // [2+2i] main loop of tile i done
-            // the epilogue-only arguments are re-read from the kernarg segment HERE (behind an opaque pointer), so
-            // that they do not occupy ~40 SGPRs across the k-loop (the loop otherwise carries SGPR spills and waits)
-#if defined(__HIP_DEVICE_COMPILE__)
-            const __attribute__((address_space(4))) char* kp =
-                (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
-            asm volatile("" : "+s"(kp));
             GemmP ep;
-            __builtin_memcpy(&ep, (const void*)kp, sizeof(GemmP));
-#else
-            const GemmP ep = p;
-#endif
+            load_epilogue_args(ep, p);
             if (FLAGS & 1) epilogue<T, EPI, NI>(ep, acc, m0 + wm0, n0 + wn0, lane, (char*)sc + wave * 4096);
             else epilogue_generic<T, EPI, NI, 4>(ep, acc, m0 + wm0, n0 + wn0, lane);
             if (stp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -431,6 +435,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
 #undef EOE_READ
 #undef EOE_MFMA
 }
+
+// Variants measured and rejected (interleaved A/B on one device with tools/gemm_ab.py, layer total of the 8 forward +
+// dgrad GEMMs of a ViT-B/32 block at M = 12800; the kept kernel = 546 us stand-alone, 8.1 ms/step in the full step):
+//   * sched_barrier pinning "8 fragment reads, then 16 MFMAs" per half iteration ........ 613 us (-11 %)
+//   * BK = 32, five-stage ring (LDS-DMA 4 barrier intervals ahead), one barrier / 16 MFMAs  743 us, 10.6 ms/step
+//   * BK = 32, two 8-wave workgroups per CU (no fragment double-buffering) ................ 772 us
+//   * four waves of 128x64 (12 fragment reads / 32 MFMAs), BK = 32, two workgroups per CU .. 835 us
+//   * per-XCD bands of whole tile rows swept column-major (A panels L2-resident) .......... 587 us, 10.6 ms/step
+//   * non-persistent grid (one tile per workgroup, prologue exposed) ..................... within noise of persistent
 
 int g_nt_flags = EOE_NT_DEFAULT_FLAGS;
 
