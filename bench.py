@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--model", choices=["vit", "cnn32"], default="vit",
                     help="vit = the BASELINE.json metric config; cnn32 = secondary (config 1/2 backbone, 32x32)")
     ap.add_argument("--nt-flags", type=int, default=None, help="tuning switch of the NT GEMM (A/B builds only)")
+    ap.add_argument("--tn-flags", type=int, default=None, help="tuning switch of the wgrad GEMM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32)
@@ -81,6 +82,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     eoe_amd.set_compute_dtype(args.dtype)
+    if args.tn_flags is not None:
+        _lib.check(_lib.lib.eoe_set_option(b"tn_flags", args.tn_flags), "eoe_set_option")
     if args.nt_flags is not None:
         _lib.check(_lib.lib.eoe_set_option(b"nt_flags", args.nt_flags), "eoe_set_option")
 

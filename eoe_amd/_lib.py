@@ -85,14 +85,15 @@ SIGNATURES = {
                        _vp],
     "eoe_vit_block_fwd": [C.POINTER(VitBlockFwdArgs), _vp],
     "eoe_vit_block_bwd": [C.POINTER(VitBlockBwdArgs), _vp],
-    "eoe_im2col5": [_vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
-    "eoe_col2im5": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
-    "eoe_conv5_pack_weight": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
-    "eoe_conv5_unpack_wgrad": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "eoe_im2col": [_vp, C.c_int, _vp, _vp, _vp] + [C.c_int] * 10 + [_vp],
+    "eoe_col2im": [_vp, _vp] + [C.c_int] * 10 + [_vp],
+    "eoe_conv_pack_weight": [_vp, _vp, _vp] + [C.c_int] * 6 + [_vp],
+    "eoe_conv_unpack_wgrad": [_vp, _vp] + [C.c_int] * 6 + [_vp],
     "eoe_bn_stats": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _f32, C.c_int, _vp],
-    "eoe_bn_act_pool_fwd": [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "eoe_bn_act_pool_fwd": [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32,
+                            C.c_int, _vp],
     "eoe_bn_act_pool_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                            C.c_int, C.c_int, C.c_int, _vp],
+                            C.c_int, C.c_int, _f32, C.c_int, _vp],
     "eoe_prof_enable": [C.c_int],
     "eoe_set_option": [C.c_char_p, C.c_int],
     "eoe_debug_gemm_stamps": [_vp, C.c_int],

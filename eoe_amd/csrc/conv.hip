@@ -1,5 +1,5 @@
-// CNN backbone kernels (reference `src/eoe/models/cnn.py:44-86`, CNN32 / CNN28): 5x5 stride-1 pad-2 convolutions
-// as im2col + the MFMA GEMMs of gemm.hip / gemm_tn.hip, BatchNorm (training statistics) + LeakyReLU + 2x2 MaxPool
+// CNN backbone kernels (reference `src/eoe/models/cnn.py:44-86` CNN32 and `src/eoe/models/resnet.py:25-152` WideResNet):
+// convolutions (any kernel / stride / padding) as im2col + the MFMA GEMMs of gemm.hip / gemm_tn.hip, BatchNorm (training statistics) + LeakyReLU/ReLU + 2x2 MaxPool
 // fused into one apply kernel per direction.  Activations between layers are NHWC 16-bit; pre-BatchNorm conv
 // outputs are fp32 [N*H*W, C] (the GEMM's fp32 epilogue) so that batch statistics are taken in fp32.
 // All of these are HBM-bound (or launch-latency-bound at 32x32): coalesced 16-byte accesses along the channel dim.
@@ -7,7 +7,7 @@
 
 namespace {
 
-constexpr float LRELU = 0.01f;   // F.leaky_relu default negative_slope (cnn.py:76-82)
+struct Geo { int kh, kw, stride, pad, Ho, Wo; };   // convolution geometry (square stride / padding)
 
 // ---------------------------------------------------------------------------------------------- im2col
 // image layer: x fp32 NCHW [n,cin,H,W] (+ optional per-channel normalise) -> patches [n*H*W, Kp] 16-bit,
@@ -15,16 +15,16 @@ constexpr float LRELU = 0.01f;   // F.leaky_relu default negative_slope (cnn.py:
 template <typename T>
 __global__ __launch_bounds__(256) void im2col_img_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                          const float* __restrict__ stdv, T* __restrict__ out, int n,
-                                                         int cin, int H, int W, int Kp) {
-    const size_t total = (size_t)n * H * W * Kp;
+                                                         int cin, int H, int W, int Kp, Geo g) {
+    const size_t total = (size_t)n * g.Ho * g.Wo * Kp;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int col = (int)(i % Kp);
         const size_t row = i / Kp;
         float v = 0.f;
-        if (col < 25 * cin) {
+        if (col < g.kh * g.kw * cin) {
             const int tap = col / cin, c = col % cin;
-            const int w = (int)(row % W), h = (int)((row / W) % H), img = (int)(row / ((size_t)W * H));
-            const int hh = h + tap / 5 - 2, ww = w + tap % 5 - 2;
+            const int w = (int)(row % g.Wo), h = (int)((row / g.Wo) % g.Ho), img = (int)(row / ((size_t)g.Wo * g.Ho));
+            const int hh = h * g.stride + tap / g.kw - g.pad, ww = w * g.stride + tap % g.kw - g.pad;
             if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
                 v = x[(((size_t)img * cin + c) * H + hh) * W + ww];
                 if (mean) v = (v - mean[c]) / stdv[c];
@@ -38,19 +38,19 @@ __global__ __launch_bounds__(256) void im2col_img_kernel(const float* __restrict
 // output chunk per thread
 template <typename T, bool XF32>
 __global__ __launch_bounds__(256) void im2col_nhwc_kernel(const void* __restrict__ xv, T* __restrict__ out, int n, int H,
-                                                          int W, int C, int Kp) {
+                                                          int W, int C, int Kp, Geo g) {
     const int cpr = Kp / 8;                       // 16-B chunks per output row
     const int cc = C / 8;                         // chunks per tap
-    const size_t total = (size_t)n * H * W * cpr;
+    const size_t total = (size_t)n * g.Ho * g.Wo * cpr;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int ch = (int)(i % cpr);
         const size_t row = i / cpr;
         u32x4 v = {0u, 0u, 0u, 0u};
         const int tap = ch / cc;
-        if (tap < 25) {
+        if (tap < g.kh * g.kw) {
             const int c8 = ch % cc;
-            const int w = (int)(row % W), h = (int)((row / W) % H), img = (int)(row / ((size_t)W * H));
-            const int hh = h + tap / 5 - 2, ww = w + tap % 5 - 2;
+            const int w = (int)(row % g.Wo), h = (int)((row / g.Wo) % g.Ho), img = (int)(row / ((size_t)g.Wo * g.Ho));
+            const int hh = h * g.stride + tap / g.kw - g.pad, ww = w * g.stride + tap % g.kw - g.pad;
             if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
                 const size_t o = (((size_t)img * H + hh) * W + ww) * C + c8 * 8;
                 if (XF32) {
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void im2col_nhwc_kernel(const void* __restrict
 // gradient wrt the layer input: dx fp32 NHWC [n,H,W,C] = gather over the 25 taps of dpatches 16-bit [n*H*W, Kp]
 template <typename T>
 __global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dp, float* __restrict__ dx, int n, int H, int W,
-                                                     int C, int Kp) {
+                                                     int C, int Kp, Geo g) {
     const int cc = C / 4;
     const size_t total = (size_t)n * H * W * cc;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -77,12 +77,14 @@ __global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dp, f
         const size_t pix = i / cc;
         const int w = (int)(pix % W), h = (int)((pix / W) % H), img = (int)(pix / ((size_t)W * H));
         float a[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 5
-        for (int tap = 0; tap < 25; ++tap) {
-            const int hh = h - (tap / 5 - 2), ww = w - (tap % 5 - 2);      // output position whose tap reads this pixel
-            if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+        for (int tap = 0; tap < g.kh * g.kw; ++tap) {
+            // output position (ho, wo) whose tap (ky, kx) reads this pixel: ho*stride + ky - pad == h
+            const int th = h + g.pad - tap / g.kw, tw = w + g.pad - tap % g.kw;
+            if (th < 0 || tw < 0 || th % g.stride || tw % g.stride) continue;
+            const int hh = th / g.stride, ww = tw / g.stride;
+            if (hh >= g.Ho || ww >= g.Wo) continue;
             float t[4];
-            unpack4<T>(*(const u32x2*)(dp + (((size_t)img * H + hh) * W + ww) * Kp + tap * C + c4 * 4), t);
+            unpack4<T>(*(const u32x2*)(dp + (((size_t)img * g.Ho + hh) * g.Wo + ww) * Kp + tap * C + c4 * 4), t);
 #pragma unroll
             for (int r = 0; r < 4; ++r) a[r] += t[r];
         }
@@ -94,22 +96,22 @@ __global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dp, f
 // w fp32 [cout, cin, 5, 5] -> w16 [cout, Kp] (column = tap*cin + c) and w16t [Kp, cout]
 template <typename T>
 __global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict__ w, T* __restrict__ w16, T* __restrict__ w16t,
-                                                        int cout, int cin, int Kp) {
+                                                        int cout, int cin, int Kp, int taps) {
     const int total = cout * Kp;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int o = i / Kp, col = i % Kp;
         float v = 0.f;
-        if (col < 25 * cin) v = w[((size_t)o * cin + col % cin) * 25 + col / cin];
+        if (col < taps * cin) v = w[((size_t)o * cin + col % cin) * taps + col / cin];
         w16[i] = (T)v;
         if (w16t) w16t[(size_t)col * cout + o] = (T)v;
     }
 }
 // g fp32 [cout, Kp] -> dw fp32 [cout, cin, 5, 5] (+= if accumulate)
 __global__ __launch_bounds__(256) void conv_unpack_kernel(const float* __restrict__ g, float* __restrict__ dw, int cout, int cin,
-                                                          int Kp, int accumulate) {
-    const int total = cout * cin * 25;
+                                                          int Kp, int taps, int accumulate) {
+    const int total = cout * cin * taps;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int tap = i % 25, c = (i / 25) % cin, o = i / (25 * cin);
+        const int tap = i % taps, c = (i / taps) % cin, o = i / (taps * cin);
         const float v = g[(size_t)o * Kp + tap * cin + c];
         dw[i] = accumulate ? dw[i] + v : v;
     }
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(256) void bn_running_stats_kernel(const float* __re
     stats[C + c] = 1.0f / sqrtf(rv[c] + eps);
 }
 
-__device__ __forceinline__ float lrelu(float z) { return z > 0.f ? z : LRELU * z; }
+__device__ __forceinline__ float lrelu(float z, float slope) { return z > 0.f ? z : slope * z; }
 
 // out = maxpool_P(leaky_relu(bn(y))); y fp32 [n,H,W,C] ; out 16-bit [n,H/P,W/P,C], or (nchw_flat) [n, C*(H/P)*(W/P)] in the
 // reference's NCHW flatten order (cnn.py:83), or fp32 if out_f32.  P in {1,2}.  4 channels per thread.
@@ -180,7 +182,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ stats,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               void* __restrict__ out, int n, int H, int W, int C, int P,
-                                                              int nchw_flat, int out_f32) {
+                                                              int nchw_flat, int out_f32, float slope) {
     const int Ho = H / P, Wo = W / P, cc = C / 4;
     const size_t total = (size_t)n * Ho * Wo * cc;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __res
             for (int dx = 0; dx < P; ++dx) {
                 const f32x4 v = *(const f32x4*)(y + (((size_t)img * H + ho * P + dy) * W + wo * P + dx) * C + c);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) best[r] = fmaxf(best[r], lrelu((v[r] - mu[r]) * rs[r] * g[r] + b[r]));
+                for (int r = 0; r < 4; ++r) best[r] = fmaxf(best[r], lrelu((v[r] - mu[r]) * rs[r] * g[r] + b[r], slope));
             }
         if (nchw_flat) {
 #pragma unroll
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_bwd_kernel(const float* __res
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               const float* __restrict__ dout, float* __restrict__ red,
                                                               void* __restrict__ dy, int dy_f32, int n, int H, int W, int C,
-                                                              int nchw_flat, int use_batch_stats) {
+                                                              int nchw_flat, int use_batch_stats, float slope) {
     extern __shared__ float lds[];                // MODE 0: [2][C] partial sums
     const int Ho = H / P, Wo = W / P, cc = C / 4;
     const size_t total = (size_t)n * Ho * Wo * cc;
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_bwd_kernel(const float* __res
             for (int r = 0; r < 4; ++r) {
                 xh[k][r] = (v[r] - mu[r]) * rs[r];
                 z[k][r] = xh[k][r] * g[r] + b[r];
-                const float a = lrelu(z[k][r]);
+                const float a = lrelu(z[k][r], slope);
                 if (a > best[r]) { best[r] = a; arg[r] = k; }      // first maximum wins, as max_pool2d does
             }
         }
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_bwd_kernel(const float* __res
                 float gz = 0.f, xk = 0.f;
 #pragma unroll
                 for (int kk = 0; kk < P * P; ++kk)
-                    if (kk == k) { gz = d[r] * (z[kk][r] > 0.f ? 1.f : LRELU); xk = xh[kk][r]; }
+                    if (kk == k) { gz = d[r] * (z[kk][r] > 0.f ? 1.f : slope); xk = xh[kk][r]; }
                 atomicAdd(&lds[c + r], gz);
                 atomicAdd(&lds[C + c + r], gz * xk);
             }
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_bwd_kernel(const float* __res
                 float o[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float gz = (k == arg[r]) ? d[r] * (z[k][r] > 0.f ? 1.f : LRELU) : 0.f;
+                    const float gz = (k == arg[r]) ? d[r] * (z[k][r] > 0.f ? 1.f : slope) : 0.f;
                     // training: dy = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)); eval (running stats): gamma*rstd*g
                     o[r] = use_batch_stats ? g[r] * rs[r] * (gz - s1[r] * invM - xh[k][r] * s2[r] * invM) : g[r] * rs[r] * gz;
                 }
@@ -316,52 +318,69 @@ int grid_for(size_t total) {
         else return eoe_set_error(EOE_ERR_ARG, "bad dtype %d", (int)(dtype)); \
     } while (0)
 
-extern "C" int eoe_im2col5(const void* x, int x_kind, const float* mean, const float* stdv, void* out, int n, int cin,
-                           int H, int W, int Kp, int dtype, void* stream) {
-    EOE_CHECK_ARG(x && out && n > 0 && cin > 0 && H > 0 && W > 0, "im2col5: bad args");
-    EOE_CHECK_ARG(Kp >= 25 * cin && Kp % 64 == 0, "im2col5: Kp = %d must be a multiple of 64 and >= 25*cin", Kp);
-    EOE_CHECK_ARG((mean == nullptr) == (stdv == nullptr), "im2col5: mean/std must both be given or both NULL");
-    ProfScope ps("im2col5", 0, 2.0 * n * H * W * Kp, stream);
+static int check_geo(const char* who, int H, int W, int kh, int kw, int stride, int pad, Geo& g) {
+    EOE_CHECK_ARG(kh >= 1 && kw >= 1 && stride >= 1 && pad >= 0, "%s: bad geometry", who);
+    g.kh = kh; g.kw = kw; g.stride = stride; g.pad = pad;
+    g.Ho = (H + 2 * pad - kh) / stride + 1;
+    g.Wo = (W + 2 * pad - kw) / stride + 1;
+    EOE_CHECK_ARG(g.Ho >= 1 && g.Wo >= 1, "%s: empty output", who);
+    return 0;
+}
+
+extern "C" int eoe_im2col(const void* x, int x_kind, const float* mean, const float* stdv, void* out, int n, int cin,
+                          int H, int W, int kh, int kw, int stride, int pad, int Kp, int dtype, void* stream) {
+    EOE_CHECK_ARG(x && out && n > 0 && cin > 0 && H > 0 && W > 0, "im2col: bad args");
+    Geo g;
+    EOE_TRY(check_geo("im2col", H, W, kh, kw, stride, pad, g));
+    EOE_CHECK_ARG(Kp >= kh * kw * cin && Kp % 64 == 0, "im2col: Kp = %d must be a multiple of 64 and >= kh*kw*cin", Kp);
+    EOE_CHECK_ARG((mean == nullptr) == (stdv == nullptr), "im2col: mean/std must both be given or both NULL");
+    const size_t rows = (size_t)n * g.Ho * g.Wo;
+    ProfScope ps("im2col", 0, 2.0 * rows * Kp, stream);
     if (x_kind == 1) {
-        DISPATCH_T(dtype, hipLaunchKernelGGL((im2col_img_kernel<T>), dim3(grid_for((size_t)n * H * W * Kp)), dim3(256), 0,
-                                             (hipStream_t)stream, (const float*)x, mean, stdv, (T*)out, n, cin, H, W, Kp));
+        DISPATCH_T(dtype, hipLaunchKernelGGL((im2col_img_kernel<T>), dim3(grid_for(rows * Kp)), dim3(256), 0,
+                                             (hipStream_t)stream, (const float*)x, mean, stdv, (T*)out, n, cin, H, W, Kp, g));
     } else {
-        EOE_CHECK_ARG(cin % 8 == 0, "im2col5: hidden layers need cin %% 8 == 0");
-        EOE_CHECK_ARG(x_kind == 0 || x_kind == 2, "im2col5: x_kind must be 0 (16-bit NHWC), 1 (fp32 NCHW image) or 2 (fp32 NHWC)");
+        EOE_CHECK_ARG(cin % 8 == 0, "im2col: hidden layers need cin %% 8 == 0");
+        EOE_CHECK_ARG(x_kind == 0 || x_kind == 2, "im2col: x_kind must be 0 (16-bit NHWC), 1 (fp32 NCHW image) or 2 (fp32 NHWC)");
         if (x_kind == 2) {
-            DISPATCH_T(dtype, hipLaunchKernelGGL((im2col_nhwc_kernel<T, true>), dim3(grid_for((size_t)n * H * W * Kp / 8)), dim3(256), 0,
-                                                 (hipStream_t)stream, x, (T*)out, n, H, W, cin, Kp));
+            DISPATCH_T(dtype, hipLaunchKernelGGL((im2col_nhwc_kernel<T, true>), dim3(grid_for(rows * Kp / 8)), dim3(256), 0,
+                                                 (hipStream_t)stream, x, (T*)out, n, H, W, cin, Kp, g));
         } else {
-            DISPATCH_T(dtype, hipLaunchKernelGGL((im2col_nhwc_kernel<T, false>), dim3(grid_for((size_t)n * H * W * Kp / 8)), dim3(256), 0,
-                                                 (hipStream_t)stream, x, (T*)out, n, H, W, cin, Kp));
+            DISPATCH_T(dtype, hipLaunchKernelGGL((im2col_nhwc_kernel<T, false>), dim3(grid_for(rows * Kp / 8)), dim3(256), 0,
+                                                 (hipStream_t)stream, x, (T*)out, n, H, W, cin, Kp, g));
         }
     }
-    EOE_CHECK_LAUNCH("im2col5");
+    EOE_CHECK_LAUNCH("im2col");
     return 0;
 }
 
-extern "C" int eoe_col2im5(const void* dpatches, float* dx, int n, int C, int H, int W, int Kp, int dtype, void* stream) {
-    EOE_CHECK_ARG(dpatches && dx && n > 0 && C % 4 == 0 && Kp >= 25 * C, "col2im5: bad args");
-    ProfScope ps("col2im5", 0, 2.0 * n * H * W * 25 * C + 4.0 * n * H * W * C, stream);
+extern "C" int eoe_col2im(const void* dpatches, float* dx, int n, int C, int H, int W, int kh, int kw, int stride, int pad,
+                          int Kp, int dtype, void* stream) {
+    EOE_CHECK_ARG(dpatches && dx && n > 0 && C % 4 == 0 && Kp >= kh * kw * C, "col2im: bad args");
+    Geo g;
+    EOE_TRY(check_geo("col2im", H, W, kh, kw, stride, pad, g));
+    ProfScope ps("col2im", 0, 2.0 * n * g.Ho * g.Wo * kh * kw * C + 4.0 * n * H * W * C, stream);
     DISPATCH_T(dtype, hipLaunchKernelGGL((col2im_kernel<T>), dim3(grid_for((size_t)n * H * W * C / 4)), dim3(256), 0,
-                                         (hipStream_t)stream, (const T*)dpatches, dx, n, H, W, C, Kp));
-    EOE_CHECK_LAUNCH("col2im5");
+                                         (hipStream_t)stream, (const T*)dpatches, dx, n, H, W, C, Kp, g));
+    EOE_CHECK_LAUNCH("col2im");
     return 0;
 }
 
-extern "C" int eoe_conv5_pack_weight(const float* w, void* w16, void* w16t, int cout, int cin, int Kp, int dtype, void* stream) {
-    EOE_CHECK_ARG(w && w16 && cout > 0 && cin > 0 && Kp >= 25 * cin, "conv5_pack_weight: bad args");
+extern "C" int eoe_conv_pack_weight(const float* w, void* w16, void* w16t, int cout, int cin, int kh, int kw, int Kp, int dtype,
+                                    void* stream) {
+    EOE_CHECK_ARG(w && w16 && cout > 0 && cin > 0 && Kp >= kh * kw * cin, "conv_pack_weight: bad args");
     DISPATCH_T(dtype, hipLaunchKernelGGL((conv_pack_kernel<T>), dim3(grid_for((size_t)cout * Kp)), dim3(256), 0,
-                                         (hipStream_t)stream, w, (T*)w16, (T*)w16t, cout, cin, Kp));
-    EOE_CHECK_LAUNCH("conv5_pack_weight");
+                                         (hipStream_t)stream, w, (T*)w16, (T*)w16t, cout, cin, Kp, kh * kw));
+    EOE_CHECK_LAUNCH("conv_pack_weight");
     return 0;
 }
 
-extern "C" int eoe_conv5_unpack_wgrad(const float* g, float* dw, int cout, int cin, int Kp, int accumulate, void* stream) {
-    EOE_CHECK_ARG(g && dw && cout > 0 && cin > 0 && Kp >= 25 * cin, "conv5_unpack_wgrad: bad args");
-    hipLaunchKernelGGL(conv_unpack_kernel, dim3(grid_for((size_t)cout * cin * 25)), dim3(256), 0, (hipStream_t)stream, g, dw,
-                       cout, cin, Kp, accumulate);
-    EOE_CHECK_LAUNCH("conv5_unpack_wgrad");
+extern "C" int eoe_conv_unpack_wgrad(const float* g, float* dw, int cout, int cin, int kh, int kw, int Kp, int accumulate,
+                                     void* stream) {
+    EOE_CHECK_ARG(g && dw && cout > 0 && cin > 0 && Kp >= kh * kw * cin, "conv_unpack_wgrad: bad args");
+    hipLaunchKernelGGL(conv_unpack_kernel, dim3(grid_for((size_t)cout * cin * kh * kw)), dim3(256), 0, (hipStream_t)stream, g, dw,
+                       cout, cin, Kp, kh * kw, accumulate);
+    EOE_CHECK_LAUNCH("conv_unpack_wgrad");
     return 0;
 }
 
@@ -392,21 +411,23 @@ extern "C" int eoe_bn_stats(const float* y, float* sums_scratch, float* stats, f
 }
 
 extern "C" int eoe_bn_act_pool_fwd(const float* y, const float* stats, const float* gamma, const float* beta, void* out, int n,
-                                   int H, int W, int C, int pool, int nchw_flat, int out_f32, int dtype, void* stream) {
+                                   int H, int W, int C, int pool, int nchw_flat, int out_f32, float slope, int dtype,
+                                   void* stream) {
     EOE_CHECK_ARG(y && stats && out && n > 0 && C % 4 == 0, "bn_act_pool_fwd: bad args");
     EOE_CHECK_ARG((pool == 1 || pool == 2) && H % pool == 0 && W % pool == 0, "bn_act_pool: pool must be 1 or 2 and divide H, W");
     EOE_CHECK_ARG((gamma == nullptr) == (beta == nullptr), "bn_act_pool: gamma/beta must both be given or both NULL");
     ProfScope ps("bn_act_pool_fwd", 0, 4.0 * n * H * W * C + 2.0 * n * H * W * C / (pool * pool), stream);
     DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_pool_fwd_kernel<T>), dim3(grid_for((size_t)n * (H / pool) * (W / pool) * C / 4)),
                                          dim3(256), 0, (hipStream_t)stream, y, stats, gamma, beta, out, n, H, W, C, pool,
-                                         nchw_flat, out_f32));
+                                         nchw_flat, out_f32, slope));
     EOE_CHECK_LAUNCH("bn_act_pool_fwd");
     return 0;
 }
 
 extern "C" int eoe_bn_act_pool_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* dout,
                                    float* red_scratch, void* dy, int dy_f32, float* dgamma, float* dbeta, int n, int H, int W,
-                                   int C, int pool, int nchw_flat, int training, int accumulate, int dtype, void* stream) {
+                                   int C, int pool, int nchw_flat, int training, int accumulate, float slope, int dtype,
+                                   void* stream) {
     EOE_CHECK_ARG(y && stats && dout && red_scratch && dy && n > 0 && C % 4 == 0, "bn_act_pool_bwd: bad args");
     EOE_CHECK_ARG((pool == 1 || pool == 2) && H % pool == 0 && W % pool == 0, "bn_act_pool: pool must be 1 or 2 and divide H, W");
     EOE_CHECK_ARG((gamma == nullptr) == (beta == nullptr) && (dgamma == nullptr) == (dbeta == nullptr), "bn_act_pool_bwd: gamma/beta pairs");
@@ -418,7 +439,7 @@ extern "C" int eoe_bn_act_pool_bwd(const float* y, const float* stats, const flo
     const int g0 = grid > 512 ? 512 : grid;
 #define EOE_BNB(MODE, PP, GRID, LDS)                                                                                  \
     DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_pool_bwd_kernel<T, MODE, PP>), dim3(GRID), dim3(256), LDS, s, y, stats, gamma, \
-                                         beta, dout, red_scratch, dy, dy_f32, n, H, W, C, nchw_flat, training))
+                                         beta, dout, red_scratch, dy, dy_f32, n, H, W, C, nchw_flat, training, slope))
     if (pool == 1) { EOE_BNB(0, 1, g0, 2 * C * sizeof(float)); } else { EOE_BNB(0, 2, g0, 2 * C * sizeof(float)); }
     EOE_CHECK_LAUNCH("bn_act_pool_bwd_reduce");
     if (pool == 1) { EOE_BNB(1, 1, grid, 0); } else { EOE_BNB(1, 2, grid, 0); }

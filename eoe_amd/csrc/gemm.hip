@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 unsigned long long* g_stamp_buf = nullptr;
+extern int g_tn_flags;     // gemm_tn.hip
 
 namespace {
 
@@ -285,7 +286,7 @@ __device__ __forceinline__ void load_epilogue_args(GemmP& ep, const GemmP& p) {
 // NI = 3 (256x96) is chosen when it quantises better over the CUs (e.g. N = 768, M = 12800: 400 tiles instead of 300
 // -> 2 rounds of 3/4-size tiles).  The LDS image keeps the 128-row B slot; rows >= 32*NI are never fetched.
 // FLAGS (tuning switches, A/B-able in one binary when built with -DEOE_AB): bit 0 = LDS-transposed fast epilogue,
-// bit 1 = sched_barrier pins "all fragment reads, then the 16 MFMAs" in each half iteration
+// bit 1 = sched_group_barrier interleave of fragment reads with MFMAs (2:1)
 template <typename T, int EPI, int NI, int FLAGS>
 __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -374,11 +375,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                      \
         _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T16<T>::mfma16(WB[ni], XA[mi], acc[mi][ni]);
 
+    // FLAGS bit 1: spread the 8 fragment reads of the NEXT half iteration between the 16 MFMAs of this one (2 MFMA : 1
+    // ds_read), instead of a read burst of all 8 waves at once (64 KiB = 256 LDS cycles during which no MFMA issues)
+#define EOE_INTERLEAVE()                                                   \
+    _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                     \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                 \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                 \
+    }
     if (iters <= 0) return;
     unsigned long long* stp = p.stamp ? p.stamp + (size_t)blockIdx.x * 16 : nullptr;
     int sti = 0;
-#define EOE_STAMP() do { if (stp && tid == 0 && sti < 15) stp[sti++] = __builtin_amdgcn_s_memtime(); } while (0)
-    if (stp && tid == 0) stp[15] = __builtin_amdgcn_s_memrealtime();
+    unsigned long long acc_vm = 0, acc_bar = 0;    // diagnostics: cycles this wave spent in the DMA wait / at the barrier
+#define EOE_STAMP() do { if (stp && tid == 0 && sti < 12) stp[sti++] = __builtin_amdgcn_s_memtime(); } while (0)
     EOE_STAMP();                                   // [0] kernel entry
     V8 xa0[4], wb0[NI], xa1[4], wb1[NI];
     set_offsets(st_tile);
@@ -399,20 +407,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
         const char* sc = smem + cur * STAGE_BYTES;
         if (it + 2 < iters) stage_next();
         EOE_READ(xa1, wb1, sc, 1);
-        if (FLAGS & 2) __builtin_amdgcn_sched_barrier(0);   // keep all 8 fragment reads AHEAD of the 16 MFMAs they overlap with
         EOE_MFMA(xa0, wb0);
-        if (FLAGS & 2) __builtin_amdgcn_sched_barrier(0);
+        if (FLAGS & 2) { EOE_INTERLEAVE(); }
+        unsigned long long tq0 = 0, tq1 = 0;
+        if (stp) tq0 = __builtin_amdgcn_s_memtime();
         if (it + 2 < iters) { EOE_WAIT_VM(6); } else { EOE_WAIT_VM(0); }
         EOE_WAIT_LGKM0();
+        if (stp) tq1 = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_barrier();
+        if (stp) { const unsigned long long tq2 = __builtin_amdgcn_s_memtime(); acc_vm += tq1 - tq0; acc_bar += tq2 - tq1; }
         {   // unconditional (the last iteration reads a stale ring slot and discards it): keeps the compiler's
             // lgkmcnt bookkeeping exact, so MFMA(F1) does not wait for these reads
             const char* sn = smem + nxt * STAGE_BYTES;
             EOE_READ(xa0, wb0, sn, 0);
         }
-        if (FLAGS & 2) __builtin_amdgcn_sched_barrier(0);
         EOE_MFMA(xa1, wb1);
-        if (FLAGS & 2) __builtin_amdgcn_sched_barrier(0);
+        if (FLAGS & 2) { EOE_INTERLEAVE(); }
         cur = nxt;
         if (++c_kt == nk) {                        // tile finished: epilogue while the next tile's DMA is in flight
             int m0, n0;
@@ -434,6 +444,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
     }
 #undef EOE_READ
 #undef EOE_MFMA
+    if (stp && lane == 0 && wave < 2) { stp[12 + wave * 2 - 0] = acc_vm; stp[13 + wave * 2 - 0] = acc_bar; }
 }
 
 // Variants measured and rejected (interleaved A/B on one device with tools/gemm_ab.py, layer total of the 8 forward +
@@ -555,5 +566,6 @@ extern "C" int eoe_debug_gemm_stamps(unsigned long long* out, int n_words) {
 // tuning switches (see gemm_nt_kernel FLAGS; bits 4-6 force the tile width); all four variants exist only in -DEOE_AB builds
 extern "C" int eoe_set_option(const char* name, int value) {
     if (name && !strcmp(name, "nt_flags")) { g_nt_flags = value; return 0; }
+    if (name && !strcmp(name, "tn_flags")) { g_tn_flags = value; return 0; }
     return eoe_set_error(EOE_ERR_ARG, "unknown option");
 }

@@ -17,6 +17,8 @@
 #include "common.h"
 #include <stdlib.h>
 
+int g_tn_flags = 0;     // bit 0: L2 prefetcher wave (option "tn_flags")
+
 namespace {
 
 constexpr int BM = 256, BN = 128, BK = 64;
@@ -50,8 +52,12 @@ __device__ __forceinline__ typename T16<T>::v8 tr_frag(const char* base, int off
     return __builtin_bit_cast(typename T16<T>::v8, r);
 }
 
-template <typename T>
-__global__ __launch_bounds__(512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
+// PF: a ninth wavefront per workgroup does nothing but touch the operand lines of k-tile kt+PFD (one dword per 128-B
+// line, results discarded), PFD-2 barrier intervals before the LDS-DMA of that tile is issued: the DMA then hits L2
+// instead of waiting ~an HBM-miss latency behind a one-iteration lead.  It joins every barrier, so it stays in step.
+constexpr int PFD = 6;
+template <typename T, bool PF>
+__global__ __launch_bounds__(PF ? 576 : 512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int split = blockIdx.x / g.total_tiles;
@@ -69,6 +75,43 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
     __amdgpu_buffer_rsrc_t ra = make_rsrc(P.A, P.bytesA);
     __amdgpu_buffer_rsrc_t rb = make_rsrc(P.B, P.bytesB);
     const int lda = P.lda, ldb = P.ldb;
+
+    if (PF && wave == NWAVES) {
+        // ---- L2 prefetcher wave: lane = row of the k-tile; 4 lines of the A slice (512 B) + 2 of the B slice (256 B)
+        const int nkp = (t_end - t_begin + BK - 1) / BK;
+        unsigned sink = 0;
+        const char* pa = (const char*)P.A;
+        const char* pb = (const char*)P.B;
+        const int ca = min(m0, P.M - 1), cb = min(n0, P.N - 1);
+        auto touch = [&](int kt) {
+            int t = t_begin + kt * BK + lane;
+            if (t > t_end - 1) t = t_end - 1;                       // clamp: touching a valid line twice is harmless
+            const char* ra_ = pa + ((size_t)t * lda + ca) * 2;
+            const char* rb_ = pb + ((size_t)t * ldb + cb) * 2;
+            const size_t la = (size_t)(min(256, P.M - ca) * 2 - 4), lb = (size_t)(min(128, P.N - cb) * 2 - 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const char* q = ra_ + min((size_t)j * 128, la);
+                asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(q) : "memory");
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const char* q = rb_ + min((size_t)j * 128, lb);
+                asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(q) : "memory");
+            }
+        };
+        if (nkp > 0) {
+            for (int kt = 2; kt < PFD && kt < nkp; ++kt) touch(kt);
+            __builtin_amdgcn_s_barrier();                            // prologue barrier of the compute waves
+            for (int kt = 0; kt < nkp; ++kt) {
+                if (kt + PFD < nkp) touch(kt + PFD);
+                __builtin_amdgcn_s_barrier();                        // one per k-tile
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" :: "v"(sink));
+        return;
+    }
 
     // staging.  A image: 64 rows x 512 B -> 32 wave-loads (2 rows each), 4 per wave;
     //           B image: 64 rows x 256 B -> 16 wave-loads (4 rows each), 2 per wave.
@@ -261,13 +304,25 @@ extern "C" int eoe_gemm_tn_grouped(const eoe_gemm_args* args, int count, void* s
         }
     }
     if (dtype == EOE_F16) {
-        static bool once = (hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES), true);
-        (void)once;
-        hipLaunchKernelGGL((gemm_tn_grouped_kernel<f16_t>), dim3(tiles * splits), dim3(512), SMEM_BYTES, s, g);
+        if (g_tn_flags & 1) {
+            static bool once = (hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel<f16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES), true);
+            (void)once;
+            hipLaunchKernelGGL((gemm_tn_grouped_kernel<f16_t, true>), dim3(tiles * splits), dim3(576), SMEM_BYTES, s, g);
+        } else {
+            static bool once = (hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel<f16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES), true);
+            (void)once;
+            hipLaunchKernelGGL((gemm_tn_grouped_kernel<f16_t, false>), dim3(tiles * splits), dim3(512), SMEM_BYTES, s, g);
+        }
     } else {
-        static bool once = (hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES), true);
-        (void)once;
-        hipLaunchKernelGGL((gemm_tn_grouped_kernel<bf16_t>), dim3(tiles * splits), dim3(512), SMEM_BYTES, s, g);
+        if (g_tn_flags & 1) {
+            static bool once = (hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel<bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES), true);
+            (void)once;
+            hipLaunchKernelGGL((gemm_tn_grouped_kernel<bf16_t, true>), dim3(tiles * splits), dim3(576), SMEM_BYTES, s, g);
+        } else {
+            static bool once = (hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel<bf16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES), true);
+            (void)once;
+            hipLaunchKernelGGL((gemm_tn_grouped_kernel<bf16_t, false>), dim3(tiles * splits), dim3(512), SMEM_BYTES, s, g);
+        }
     }
     EOE_CHECK_LAUNCH("gemm_tn_grouped");
     return 0;

@@ -544,47 +544,52 @@ def bce_score(feats, nominal_label=0):
 
 
 # ------------------------------------------------------------------------------------------------ autograd: CNN backbone
-def _conv_kp(cin: int) -> int:
-    return (25 * cin + 63) // 64 * 64
+def _conv_kp(cin: int, taps: int = 25) -> int:
+    return (taps * cin + 63) // 64 * 64
 
 
 def _conv_weight_copies(w: torch.Tensor):
-    """16-bit [cout, Kp] / [Kp, cout] copies of a 5x5 conv weight in patch-column order, cached like `shadow`"""
+    """16-bit [cout, Kp] / [Kp, cout] copies of a conv weight in patch-column order, cached like `shadow`"""
     key = ("conv", id(w))
     tag = (w._version, w.data_ptr(), _compute_dtype)
     hit = shadow.cache.get(key)
     if hit is not None and hit[0]() is w and hit[1] == tag:
         return hit[2], hit[3]
-    cout, cin = w.shape[0], w.shape[1]
-    kp = _conv_kp(cin)
+    cout, cin, kh, kw = w.shape
+    kp = _conv_kp(cin, kh * kw)
     w16 = torch.empty((cout, kp), dtype=_compute_dtype, device=w.device)
     w16t = torch.empty((kp, cout), dtype=_compute_dtype, device=w.device)
-    check(lib.eoe_conv5_pack_weight(_p(w.detach().contiguous()), _p(w16), _p(w16t), cout, cin, kp, dtype_code(_compute_dtype),
-                                    _stream()), "eoe_conv5_pack_weight")
+    check(lib.eoe_conv_pack_weight(_p(w.detach().contiguous()), _p(w16), _p(w16t), cout, cin, kh, kw, kp,
+                                   dtype_code(_compute_dtype), _stream()), "eoe_conv_pack_weight")
     shadow.cache[key] = (weakref.ref(w, lambda _r, k=key, c=shadow.cache: c.pop(k, None)), tag, w16, w16t)
     return w16, w16t
 
 
 class ConvBnActPoolFunction(torch.autograd.Function):
-    """conv5x5(pad 2) + bias -> BatchNorm2d -> LeakyReLU(0.01) -> MaxPool(pool) of `cnn.py:73-82`, one layer per
-    call.  Input: the fp32 NCHW image batch (first layer; optional fused Normalize) or an fp32 NHWC activation; output:
-    fp32 NHWC [n, H/p, W/p, cout], or the reference's NCHW-flattened [n, cout*(H/p)*(W/p)] (`cnn.py:83`) if flat_out."""
+    """conv (+ bias) -> BatchNorm2d -> act -> MaxPool(pool), one layer per call: conv5x5(pad 2) + LeakyReLU(0.01) + pool 2
+    for `cnn.py:73-82` (the default when cfg has 8 entries); cfg[8] = (kh, kw, stride, pad) and cfg[9] = the activation's
+    negative slope (0 = ReLU, 1 = none) give the conv->bn(->relu) units of `resnet.py:93-95,133-141`.
+    Input: the fp32 NCHW image batch (first layer; optional fused Normalize) or an fp32 NHWC activation; output:
+    fp32 NHWC [n, Ho/p, Wo/p, cout], or the reference's NCHW-flattened [n, cout*(Ho/p)*(Wo/p)] (`cnn.py:83`) if flat_out."""
 
     @staticmethod
     def forward(ctx, x, conv_w, conv_b, bn_w, bn_b, rm, rv, nbt, cfg):
         _chk(x, conv_w, conv_b, bn_w, bn_b, rm, rv)
-        training, eps, momentum, pool, is_image, mean, std, flat_out = cfg
+        training, eps, momentum, pool, is_image, mean, std, flat_out = cfg[:8]
+        kh, kw, stride, pad = cfg[8] if len(cfg) > 8 else (5, 5, 1, 2)
+        slope = float(cfg[9]) if len(cfg) > 9 else 0.01
         x = x.contiguous().float()
         cout, cin = conv_w.shape[0], conv_w.shape[1]
         if is_image:
-            n, _, H, W = x.shape
+            n, _, Hi, Wi = x.shape
         else:
-            n, H, W, _ = x.shape
-        M, kp, dev, dt = n * H * W, _conv_kp(cin), x.device, _compute_dtype
+            n, Hi, Wi, _ = x.shape
+        H, W = (Hi + 2 * pad - kh) // stride + 1, (Wi + 2 * pad - kw) // stride + 1       # conv output grid
+        M, kp, dev, dt = n * H * W, _conv_kp(cin, kh * kw), x.device, _compute_dtype
         code = dtype_code(dt)
         patches = torch.empty((M, kp), dtype=dt, device=dev)
-        check(lib.eoe_im2col5(_p(x), 1 if is_image else 2, _p(mean), _p(std), _p(patches), n, cin, H, W, kp, code, _stream()),
-              "eoe_im2col5")
+        check(lib.eoe_im2col(_p(x), 1 if is_image else 2, _p(mean), _p(std), _p(patches), n, cin, Hi, Wi, kh, kw, stride, pad, kp,
+                             code, _stream()), "eoe_im2col")
         w16, _ = _conv_weight_copies(conv_w)
         y = torch.empty((M, cout), dtype=torch.float32, device=dev)
         gemm_nt(patches, w16, y, bias=conv_b)
@@ -595,15 +600,15 @@ class ConvBnActPoolFunction(torch.autograd.Function):
         Ho, Wo = H // pool, W // pool
         out = torch.empty((n, cout * Ho * Wo) if flat_out else (n, Ho, Wo, cout), dtype=torch.float32, device=dev)
         check(lib.eoe_bn_act_pool_fwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(out), n, H, W, cout, pool, 1 if flat_out else 0,
-                                      1, code, _stream()), "eoe_bn_act_pool_fwd")
+                                      1, slope, code, _stream()), "eoe_bn_act_pool_fwd")
         ctx.save_for_backward(patches, y, stats, conv_w, conv_b, bn_w, bn_b)
-        ctx.cfg = (n, H, W, cin, cout, kp, pool, flat_out, training, is_image)
+        ctx.cfg = (n, H, W, cin, cout, kp, pool, flat_out, training, is_image, Hi, Wi, kh, kw, stride, pad, slope)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         patches, y, stats, conv_w, conv_b, bn_w, bn_b = ctx.saved_tensors
-        n, H, W, cin, cout, kp, pool, flat_out, training, is_image = ctx.cfg
+        n, H, W, cin, cout, kp, pool, flat_out, training, is_image, Hi, Wi, kh, kw, stride, pad, slope = ctx.cfg
         dev, dt = y.device, patches.dtype
         code = dtype_code(dt)
         M = n * H * W
@@ -613,12 +618,12 @@ class ConvBnActPoolFunction(torch.autograd.Function):
         db = _grad_target(bn_b) if bn_b is not None else None
         red = scratch("bn_red", (2 * cout,), torch.float32, dev)
         check(lib.eoe_bn_act_pool_bwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(dout), _p(red), _p(dy16), 0, _p(dg), _p(db), n, H,
-                                      W, cout, pool, 1 if flat_out else 0, 1 if training else 0, 0, code, _stream()),
+                                      W, cout, pool, 1 if flat_out else 0, 1 if training else 0, 0, slope, code, _stream()),
               "eoe_bn_act_pool_bwd")
         g = torch.empty((cout, kp), dtype=torch.float32, device=dev)
         gemm_tn(dy16, patches, g)
         dw = _grad_target(conv_w)
-        check(lib.eoe_conv5_unpack_wgrad(_p(g), _p(dw), cout, cin, kp, 0, _stream()), "eoe_conv5_unpack_wgrad")
+        check(lib.eoe_conv_unpack_wgrad(_p(g), _p(dw), cout, cin, kh, kw, kp, 0, _stream()), "eoe_conv_unpack_wgrad")
         dcb = None
         if conv_b is not None:
             dcb = _grad_target(conv_b)
@@ -628,8 +633,8 @@ class ConvBnActPoolFunction(torch.autograd.Function):
             _, w16t = _conv_weight_copies(conv_w)
             dpatches = torch.empty((M, kp), dtype=dt, device=dev)
             gemm_nt(dy16, w16t, dpatches)
-            dx = torch.empty((n, H, W, cin), dtype=torch.float32, device=dev)
-            check(lib.eoe_col2im5(_p(dpatches), _p(dx), n, cin, H, W, kp, code, _stream()), "eoe_col2im5")
+            dx = torch.empty((n, Hi, Wi, cin), dtype=torch.float32, device=dev)
+            check(lib.eoe_col2im(_p(dpatches), _p(dx), n, cin, Hi, Wi, kh, kw, stride, pad, kp, code, _stream()), "eoe_col2im")
         return dx, dw, dcb, dg, db, None, None, None, None
 
 
@@ -648,8 +653,8 @@ class BnActFunction(torch.autograd.Function):
         check(lib.eoe_bn_stats(_p(y), _p(sums), _p(stats), _p(rm), _p(rv), _p(nbt), n, C, float(eps), float(momentum),
                                1 if training else 0, _stream()), "eoe_bn_stats")
         out = torch.empty_like(y)
-        check(lib.eoe_bn_act_pool_fwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(out), n, 1, 1, C, 1, 0, 1, dtype_code(_compute_dtype),
-                                      _stream()), "eoe_bn_act_pool_fwd")
+        check(lib.eoe_bn_act_pool_fwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(out), n, 1, 1, C, 1, 0, 1, 0.01,
+                                      dtype_code(_compute_dtype), _stream()), "eoe_bn_act_pool_fwd")
         ctx.save_for_backward(y, stats, bn_w, bn_b)
         ctx.training = training
         return out
@@ -665,6 +670,6 @@ class BnActFunction(torch.autograd.Function):
         db = _grad_target(bn_b) if bn_b is not None else None
         red = scratch("bn_red", (2 * C,), torch.float32, dev)
         check(lib.eoe_bn_act_pool_bwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(dout), _p(red), _p(dy), 1, _p(dg), _p(db), n, 1, 1,
-                                      C, 1, 0, 1 if ctx.training else 0, 0, dtype_code(_compute_dtype), _stream()),
+                                      C, 1, 0, 1 if ctx.training else 0, 0, 0.01, dtype_code(_compute_dtype), _stream()),
               "eoe_bn_act_pool_bwd")
         return dy, dg, db, None, None, None, None

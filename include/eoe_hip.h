@@ -226,35 +226,38 @@ int eoe_vit_block_fwd(const eoe_vit_block_fwd_args* a, void* stream);
 int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
- * CNN backbone (cnn.py:44-86, CNN32 / CNN28): 5x5 stride-1 pad-2 convolution = im2col + eoe_gemm_nt (forward),
- * eoe_gemm_tn (wgrad), eoe_gemm_nt + col2im (dgrad); BatchNorm(train statistics) + LeakyReLU(0.01) + MaxPool fused.
+ * CNN backbones (cnn.py:44-86 CNN32; resnet.py:25-152 WideResNet): convolution = im2col + eoe_gemm_nt (forward),
+ * eoe_gemm_tn (wgrad), eoe_gemm_nt + col2im (dgrad); BatchNorm(train statistics) + (Leaky)ReLU + MaxPool2 fused.
  * Activations between layers: 16-bit NHWC; conv outputs before BatchNorm: fp32 [n*H*W, C].
  * ---------------------------------------------------------------------------------------------------- */
-/* patches [n*H*W, Kp] 16-bit, column = (ky*5+kx)*cin + c, zero padded to Kp (multiple of 64).  x_kind: 1 = the fp32
- * NCHW input image batch (optional per-channel normalise as ad_trainer.py:413-425), 0 = a 16-bit NHWC activation,
- * 2 = an fp32 NHWC activation. */
-int eoe_im2col5(const void* x, int x_kind, const float* mean, const float* std, void* out, int n, int cin, int H, int W,
-                int Kp, int dtype, void* stream);
-/* dx fp32 NHWC [n,H,W,C] = transpose of im2col applied to dpatches 16-bit [n*H*W, Kp] */
-int eoe_col2im5(const void* dpatches, float* dx, int n, int C, int H, int W, int Kp, int dtype, void* stream);
-/* conv weight fp32 [cout,cin,5,5] -> 16-bit [cout,Kp] (patch column order) and transposed [Kp,cout]; and the inverse
- * reorder of the fp32 weight gradient [cout,Kp] -> [cout,cin,5,5] */
-int eoe_conv5_pack_weight(const float* w, void* w16, void* w16t, int cout, int cin, int Kp, int dtype, void* stream);
-int eoe_conv5_unpack_wgrad(const float* g, float* dw, int cout, int cin, int Kp, int accumulate, void* stream);
+/* patches [n*Ho*Wo, Kp] 16-bit, column = (ky*kw+kx)*cin + c, zero padded to Kp (multiple of 64); Ho = (H+2*pad-kh)/stride+1.
+ * x_kind: 1 = the fp32 NCHW input image batch (optional per-channel normalise as ad_trainer.py:413-425),
+ * 0 = a 16-bit NHWC activation, 2 = an fp32 NHWC activation. */
+int eoe_im2col(const void* x, int x_kind, const float* mean, const float* std, void* out, int n, int cin, int H, int W,
+               int kh, int kw, int stride, int pad, int Kp, int dtype, void* stream);
+/* dx fp32 NHWC [n,H,W,C] = transpose of im2col applied to dpatches 16-bit [n*Ho*Wo, Kp] */
+int eoe_col2im(const void* dpatches, float* dx, int n, int C, int H, int W, int kh, int kw, int stride, int pad, int Kp,
+               int dtype, void* stream);
+/* conv weight fp32 [cout,cin,kh,kw] -> 16-bit [cout,Kp] (patch column order) and transposed [Kp,cout]; and the inverse
+ * reorder of the fp32 weight gradient [cout,Kp] -> [cout,cin,kh,kw] */
+int eoe_conv_pack_weight(const float* w, void* w16, void* w16t, int cout, int cin, int kh, int kw, int Kp, int dtype,
+                         void* stream);
+int eoe_conv_unpack_wgrad(const float* g, float* dw, int cout, int cin, int kh, int kw, int Kp, int accumulate, void* stream);
 /* batch statistics of y fp32 [M,C]: stats[0..C) = mean, stats[C..2C) = 1/sqrt(var+eps) (biased var); training updates
  * running_mean/var (momentum, unbiased var) and num_batches_tracked as nn.BatchNorm does (cnn.py:57-66); eval reads
  * the running buffers.  sums_scratch: 2*C floats. */
 int eoe_bn_stats(const float* y, float* sums_scratch, float* stats, float* running_mean, float* running_var,
                  int64_t* num_batches_tracked, int M, int C, float eps, float momentum, int training, void* stream);
-/* out = maxpool_{pool}(leaky_relu(bn(y))), y fp32 [n,H,W,C]; out 16-bit NHWC (or fp32 if out_f32; or the reference's
- * NCHW flatten order [n, C*(H/p)*(W/p)] if nchw_flat, cnn.py:83) */
+/* out = maxpool_{pool}(act(bn(y))), act(z) = z > 0 ? z : slope*z (slope 0.01 = LeakyReLU of cnn.py, 0 = ReLU of
+ * resnet.py, 1 = identity); y fp32 [n,H,W,C]; out 16-bit NHWC (or fp32 if out_f32; or the reference's NCHW flatten
+ * order [n, C*(H/p)*(W/p)] if nchw_flat, cnn.py:83) */
 int eoe_bn_act_pool_fwd(const float* y, const float* stats, const float* gamma, const float* beta, void* out, int n, int H,
-                        int W, int C, int pool, int nchw_flat, int out_f32, int dtype, void* stream);
+                        int W, int C, int pool, int nchw_flat, int out_f32, float slope, int dtype, void* stream);
 /* backward of the above: dout fp32 (layout of `out`) -> dy [n*H*W, C] 16-bit (dY operand of the conv wgrad/dgrad), or
  * fp32 if dy_f32; dgamma, dbeta */
 int eoe_bn_act_pool_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* dout,
                         float* red_scratch, void* dy, int dy_f32, float* dgamma, float* dbeta, int n, int H, int W, int C,
-                        int pool, int nchw_flat, int training, int accumulate, int dtype, void* stream);
+                        int pool, int nchw_flat, int training, int accumulate, float slope, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * in-library kernel timing (used by bench.py for the roofline line): while enabled, every entry point brackets

@@ -276,3 +276,111 @@ def deterministic_init(model: nn.Module, tag: str = "w", width: int = 768, layer
             arr = _fill.fill(f"{tag}/{name}", tuple(p.shape), std=std, mean=1.0 if is_scale else 0.0)
             p.copy_(torch.from_numpy(arr))
     return model
+
+
+# ---------------------------------------------------------------------------------------------------------
+# WideResNet = ResNet-18 layout + CBAM in every BasicBlock, 224x224 only
+# (`src/eoe/models/resnet.py:25-152`, `src/eoe/models/cbam.py:7-107`)
+# ---------------------------------------------------------------------------------------------------------
+class _BasicConv(nn.Module):
+    # cbam.py:7-23 (conv without bias + BatchNorm momentum 0.01, no relu in the spatial gate)
+    def __init__(self):
+        super().__init__()
+        self.conv = _Conv(2, 1, 7, bias=False)
+        self.bn = _BN(1, 1e-5, True)
+
+    def forward(self, x):
+        y = F.conv2d(x, self.conv.weight, None, stride=1, padding=3)
+        bn = self.bn
+        if bn.training:
+            bn.num_batches_tracked += 1
+        return batch_norm(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, 0.01, bn.eps)
+
+
+class _ChannelGate(nn.Module):
+    # cbam.py:31-66: shared MLP on the global average pool and the global max pool, summed, sigmoid, scale
+    def __init__(self, c, r=16):
+        super().__init__()
+        self.mlp = nn.Sequential(OrderedDict([("1", _Lin(c, c // r)), ("3", _Lin(c // r, c))]))
+
+    def _mlp(self, v):
+        return self.mlp[1](torch.relu(self.mlp[0](v)))
+
+    def forward(self, x):
+        att = self._mlp(x.mean(dim=(2, 3))) + self._mlp(x.amax(dim=(2, 3)))
+        return x * torch.sigmoid(att)[:, :, None, None]
+
+
+class _SpatialGate(nn.Module):
+    # cbam.py:76-92: cat(channel max, channel mean) -> 7x7 conv (2->1) + BN -> sigmoid -> scale
+    def __init__(self):
+        super().__init__()
+        self.spatial = _BasicConv()
+
+    def forward(self, x):
+        comp = torch.cat([x.amax(dim=1, keepdim=True), x.mean(dim=1, keepdim=True)], dim=1)
+        return x * torch.sigmoid(self.spatial(comp))
+
+
+class _CBAM(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.ChannelGate = _ChannelGate(c)
+        self.SpatialGate = _SpatialGate()
+
+    def forward(self, x):
+        return self.SpatialGate(self.ChannelGate(x))
+
+
+class _Downsample(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.add_module("0", _Conv(cin, cout, 1, bias=False))
+        self.add_module("1", _BN(cout, 1e-5, True))
+
+
+class BasicBlock(nn.Module):
+    # resnet.py:112-149
+    def __init__(self, inplanes, planes, stride=1, downsample=False):
+        super().__init__()
+        self.stride = stride
+        self.conv1 = _Conv(inplanes, planes, 3, bias=False)
+        self.bn1 = _BN(planes, 1e-5, True)
+        self.conv2 = _Conv(planes, planes, 3, bias=False)
+        self.bn2 = _BN(planes, 1e-5, True)
+        self.downsample = _Downsample(inplanes, planes) if downsample else None
+        self.cbam = _CBAM(planes)
+
+    def forward(self, x):
+        out = torch.relu(self.bn1(F.conv2d(x, self.conv1.weight, None, stride=self.stride, padding=1)))
+        out = self.bn2(F.conv2d(out, self.conv2.weight, None, stride=1, padding=1))
+        res = x
+        if self.downsample is not None:
+            res = getattr(self.downsample, "1")(F.conv2d(x, getattr(self.downsample, "0").weight, None, stride=self.stride))
+        return torch.relu(self.cbam(out) + res)
+
+
+class WideResNet(nn.Module):
+    # resnet.py:25-109
+    def __init__(self, rep_dim=256, clf=False):
+        super().__init__()
+        self.clf, self.rep_dim = clf, rep_dim
+        self.conv1 = _Conv(3, 64, 7, bias=False)
+        self.bn1 = _BN(64, 1e-5, True)
+        cfg = [(64, 64, 1), (64, 128, 2), (128, 256, 2), (256, 512, 2)]
+        for i, (cin, planes, stride) in enumerate(cfg, start=1):
+            ds = stride != 1 or cin != planes
+            setattr(self, f"layer{i}", nn.Sequential(BasicBlock(cin, planes, stride, ds), BasicBlock(planes, planes)))
+        self.fc = _Lin(512, rep_dim)
+        if clf:
+            self.linear = _Lin(rep_dim, 1)
+
+    def forward(self, x):
+        x = x.reshape(-1, 3, 224, 224)
+        x = torch.relu(self.bn1(F.conv2d(x, self.conv1.weight, None, stride=2, padding=3)))
+        x = F.max_pool2d(x, 3, 2, 1)
+        for i in range(1, 5):
+            x = getattr(self, f"layer{i}")(x)
+        x = F.avg_pool2d(x, 7).reshape(x.shape[0], -1)
+        x = self.fc(x)
+        return self.linear(x) if self.clf else x

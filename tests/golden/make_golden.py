@@ -173,6 +173,34 @@ def g4():
     save("g4_block", y=y.detach().numpy(), dx=x.grad.numpy(), **grad_summary(blk))
 
 
+# ----------------------------------------------------------------------------------------------- G5 WideResNet
+def g5():
+    import types
+    # resnet.py:3 imports torchvision.models.wide_resnet50_2 only for the out-of-scope WideResNet50Pretrained
+    tv, tvm = types.ModuleType("torchvision"), types.ModuleType("torchvision.models")
+    tvm.wide_resnet50_2 = None
+    tv.models = tvm
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.models", tvm)
+    from eoe.models.resnet import WideResNet as RefWRN
+    from eoe.models.cbam import CBAM as RefCBAM
+    m = RefWRN()
+    omodels.deterministic_init(m, tag="wrn")
+    batches = [otrainer.synthetic_batch(f"g5/b{i}", 2, 2, 224) for i in range(2)]
+    losses, scores, first = run_trajectory(m, batches, "hsc", lr=1e-3, wd=0.0)      # train_imagenet.py:16-17
+    save("g5_wideresnet_hsc", losses=losses, scores=scores, **first)
+    # one CBAM(64) block on a 2x64x14x14 map, forward + all gradients
+    cb = RefCBAM(64, 16)
+    omodels.deterministic_init(cb, tag="cbam")
+    cb.train()
+    x = torch.from_numpy(fill.fill("g5/cbam_x", (2, 64, 14, 14), std=1.0)).requires_grad_(True)
+    w = torch.from_numpy(fill.fill("g5/cbam_dy", (2, 64, 14, 14), std=1.0))
+    y = cb(x)
+    (y * w).sum().backward()
+    extra = {f"buf/{n}": b.numpy().copy() for n, b in cb.named_buffers()}
+    save("g5_cbam", y=y.detach().numpy(), dx=x.grad.numpy(), **grad_summary(cb), **extra)
+
+
 # ----------------------------------------------------------------------------------------------- G7 metrics
 def g7():
     from sklearn.metrics import roc_curve, auc, average_precision_score
@@ -221,6 +249,6 @@ def g8():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g7", "g8"]
     for w in which:
         globals()[w]()

@@ -32,7 +32,7 @@ for (name, m, n, k, epi) in [("qkv", 12800, 2304, 768, "none"), ("out", 12800, 7
     st = st[used]
     t0 = st[:, 0].min()
     rel = st[:, :15] - t0
-    ntile = int(((st[:, 2:15] > 0).sum(1).max()) // 2)
+    ntile = min(5, int(((st[:, 2:12] > 0).sum(1).max()) // 2))
     print(f"== {name} {m}x{n}x{k} {epi}: {used.sum()} workgroups, up to {ntile} tiles each (cycles of the 100 MHz-independent shader clock)")
     print(f"   start skew (max entry - min entry): {rel[:, 0].max()}")
     print(f"   prologue (entry -> first operands landed): median {np.median(st[:, 1] - st[:, 0]):.0f}")
@@ -45,5 +45,8 @@ for (name, m, n, k, epi) in [("qkv", 12800, 2304, 768, "none"), ("out", 12800, 7
         ep = st[ok, 3 + 2 * i] - st[ok, 2 + 2 * i]
         print(f"   tile {i}: {ok.sum():3d} wgs  main loop median {np.median(main):7.0f} (min {main.min()}, max {main.max()})  "
               f"epilogue median {np.median(ep):7.0f} (max {ep.max()})")
-    end = np.where(st[:, 2:15] > 0, st[:, 2:15], 0).max(1) - t0
+    tot = (st[:, 2:12].max(1) - st[:, 1])
+    print(f"   wave 0: DMA/LDS wait {np.median(st[:, 12] / np.maximum(tot, 1)) * 100:.1f} % of the loop, barrier wait {np.median(st[:, 13] / np.maximum(tot, 1)) * 100:.1f} %;"
+          f"   wave 1: {np.median(st[:, 14] / np.maximum(tot, 1)) * 100:.1f} % / {np.median(st[:, 15] / np.maximum(tot, 1)) * 100:.1f} %")
+    end = np.where(st[:, 2:12] > 0, st[:, 2:12], 0).max(1) - t0
     print(f"   kernel span: {end.max()} cycles; median workgroup finishes at {np.median(end):.0f}")
