@@ -29,6 +29,28 @@ class AdamScalars(C.Structure):
     _fields_ = [("step_size", _f32 * ADAM_GROUPS), ("bc2_sqrt", _f32 * ADAM_GROUPS)]
 
 
+class CGateArgs(C.Structure):
+    _fields_ = [("x", _vp), ("out", _vp), ("w1", _vp), ("b1", _vp), ("w2", _vp), ("b2", _vp), ("pooled", _vp), ("argmax", _vp),
+                ("hidden", _vp), ("scale", _vp), ("n", _i32), ("HW", _i32), ("C", _i32), ("Ch", _i32)]
+
+
+class CGateBwdArgs(C.Structure):
+    _fields_ = [("f", CGateArgs), ("dout", _vp), ("dx", _vp), ("dscale", _vp), ("dpooled", _vp), ("dhidden", _vp),
+                ("dw1", _vp), ("db1", _vp), ("dw2", _vp), ("db2", _vp)]
+
+
+class SGateArgs(C.Structure):
+    _fields_ = [("x", _vp), ("out", _vp), ("w", _vp), ("gamma", _vp), ("beta", _vp), ("running_mean", _vp), ("running_var", _vp),
+                ("num_batches_tracked", _vp), ("comp", _vp), ("argmax", _vp), ("z", _vp), ("stats", _vp), ("scale", _vp),
+                ("sums", _vp), ("n", _i32), ("H", _i32), ("W", _i32), ("C", _i32), ("eps", _f32), ("momentum", _f32),
+                ("training", _i32)]
+
+
+class SGateBwdArgs(C.Structure):
+    _fields_ = [("f", SGateArgs), ("dout", _vp), ("dx", _vp), ("dscale", _vp), ("dcomp", _vp), ("red", _vp), ("dw", _vp),
+                ("dgamma", _vp), ("dbeta", _vp)]
+
+
 class ProfEntry(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("launches", _i64), ("total_ms", C.c_double), ("flops", C.c_double),
                 ("bytes", C.c_double)]
@@ -94,6 +116,16 @@ SIGNATURES = {
                             C.c_int, _vp],
     "eoe_bn_act_pool_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                             C.c_int, C.c_int, _f32, C.c_int, _vp],
+    "eoe_maxpool_fwd": [_vp, _vp, _vp] + [C.c_int] * 7 + [_vp],
+    "eoe_maxpool_bwd": [_vp, _vp, _vp] + [C.c_int] * 7 + [_vp],
+    "eoe_cgate_fwd": [C.POINTER(CGateArgs), _vp],
+    "eoe_cgate_bwd": [C.POINTER(CGateBwdArgs), _vp],
+    "eoe_sgate_fwd": [C.POINTER(SGateArgs), _vp],
+    "eoe_sgate_bwd": [C.POINTER(SGateBwdArgs), _vp],
+    "eoe_add_relu_fwd": [_vp, _vp, _vp, _i64, _vp],
+    "eoe_relu_bwd": [_vp, _vp, _vp, _i64, _vp],
+    "eoe_avgpool_fwd": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
+    "eoe_avgpool_bwd": [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
     "eoe_prof_enable": [C.c_int],
     "eoe_set_option": [C.c_char_p, C.c_int],
     "eoe_debug_gemm_stamps": [_vp, C.c_int],

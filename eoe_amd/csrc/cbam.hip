@@ -1,0 +1,654 @@
+// WideResNet-specific kernels (reference `src/eoe/models/resnet.py:85-109,130-149`, `src/eoe/models/cbam.py:31-107`):
+// MaxPool 3x3/2, the CBAM channel gate (global avg+max pool -> shared MLP -> sigmoid -> scale) and spatial gate
+// (channel max/mean -> 7x7 conv 2->1 -> BatchNorm -> sigmoid -> scale), residual add + ReLU, global average pool.
+// Everything here is HBM-bound elementwise / reduction work on fp32 NHWC activations: 16-B accesses along the channel
+// axis, reductions in LDS, no MFMA.  The 3x3 / 1x1 / 7x7-stem convolutions run as im2col + MFMA GEMM (conv.hip, gemm.hip).
+#include "common.h"
+
+namespace {
+
+int grid_for(size_t total, int cap = 8192) {
+    size_t g = (total + 255) / 256;
+    if (g > (size_t)cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+__device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
+// ---------------------------------------------------------------------------------------------- MaxPool2d(k, stride, pad)
+// out[n,Ho,Wo,C] = max over the window (padding never wins); idx = winning tap ky*k+kx (first maximum, as max_pool2d)
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                          uint8_t* __restrict__ idx, int n, int H, int W, int C, int k, int stride,
+                                                          int pad, int Ho, int Wo) {
+    const int cc = C / 4;
+    const size_t total = (size_t)n * Ho * Wo * cc;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cc) * 4;
+        const size_t op = i / cc;
+        const int wo = (int)(op % Wo), ho = (int)((op / Wo) % Ho), img = (int)(op / ((size_t)Wo * Ho));
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int arg[4] = {0, 0, 0, 0};
+        for (int tap = 0; tap < k * k; ++tap) {
+            const int h = ho * stride + tap / k - pad, w = wo * stride + tap % k - pad;
+            if (h < 0 || h >= H || w < 0 || w >= W) continue;
+            const f32x4 v = *(const f32x4*)(x + (((size_t)img * H + h) * W + w) * C + c);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (v[r] > best[r]) { best[r] = v[r]; arg[r] = tap; }
+        }
+        *(f32x4*)(out + op * C + c) = (f32x4){best[0], best[1], best[2], best[3]};
+        *(uint32_t*)(idx + op * C + c) = (uint32_t)arg[0] | ((uint32_t)arg[1] << 8) | ((uint32_t)arg[2] << 16) | ((uint32_t)arg[3] << 24);
+    }
+}
+// dx[n,H,W,C] (gather form: every input pixel sums the windows it won)
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dout, const uint8_t* __restrict__ idx,
+                                                          float* __restrict__ dx, int n, int H, int W, int C, int k, int stride,
+                                                          int pad, int Ho, int Wo) {
+    const int cc = C / 4;
+    const size_t total = (size_t)n * H * W * cc;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cc) * 4;
+        const size_t ip = i / cc;
+        const int w = (int)(ip % W), h = (int)((ip / W) % H), img = (int)(ip / ((size_t)W * H));
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int tap = 0; tap < k * k; ++tap) {
+            const int th = h + pad - tap / k, tw = w + pad - tap % k;
+            if (th < 0 || tw < 0 || th % stride || tw % stride) continue;
+            const int ho = th / stride, wo = tw / stride;
+            if (ho >= Ho || wo >= Wo) continue;
+            const size_t o = (((size_t)img * Ho + ho) * Wo + wo) * C + c;
+            const uint32_t a = *(const uint32_t*)(idx + o);
+            const f32x4 d = *(const f32x4*)(dout + o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if ((int)((a >> (8 * r)) & 255u) == tap) acc[r] += d[r];
+        }
+        *(f32x4*)(dx + ip * C + c) = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- per-(image, channel) reductions
+// MODE 0: pooled[n,0,C] = mean_hw x, pooled[n,1,C] = max_hw x, argmax[n,C] = position of the max (cbam.py:47-55)
+// MODE 1: red[n,C] = sum_hw a*b  (gradient of the channel scale)
+// grid (n, C / (4*cpb)); 256 threads = cpb thread-columns (4 channels each) x rpb row lanes
+template <int MODE>
+__global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          float* __restrict__ o0, int* __restrict__ oarg, int HW, int C, int cpb) {
+    __shared__ f32x4 ls[256];
+    __shared__ f32x4 lm[256];
+    __shared__ int la[256][4];
+    const int img = blockIdx.x, rpb = 256 / cpb;
+    const int tc = threadIdx.x % cpb, rl = threadIdx.x / cpb;
+    const int c = (blockIdx.y * cpb + tc) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int arg[4] = {0, 0, 0, 0};
+    const float* pa = a + (size_t)img * HW * C + c;
+    const float* pb = MODE == 1 ? b + (size_t)img * HW * C + c : nullptr;
+    for (int hw = rl; hw < HW; hw += rpb) {
+        const f32x4 v = *(const f32x4*)(pa + (size_t)hw * C);
+        if (MODE == 0) {
+            s += v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (v[r] > m[r]) { m[r] = v[r]; arg[r] = hw; }
+        } else {
+            s += v * *(const f32x4*)(pb + (size_t)hw * C);
+        }
+    }
+    ls[threadIdx.x] = s;
+    if (MODE == 0) {
+        lm[threadIdx.x] = m;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) la[threadIdx.x][r] = arg[r];
+    }
+    __syncthreads();
+    if (rl == 0) {
+        for (int k = 1; k < rpb; ++k) {
+            const int t = threadIdx.x + k * cpb;
+            s += ls[t];
+            if (MODE == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = lm[t][r];
+                    const int av = la[t][r];
+                    if (v > m[r] || (v == m[r] && av < arg[r])) { m[r] = v; arg[r] = av; }
+                }
+            }
+        }
+        if (MODE == 0) {
+            const float inv = 1.0f / (float)HW;
+            *(f32x4*)(o0 + ((size_t)img * 2 + 0) * C + c) = s * inv;
+            *(f32x4*)(o0 + ((size_t)img * 2 + 1) * C + c) = m;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) oarg[(size_t)img * C + c + r] = arg[r];
+        } else {
+            *(f32x4*)(o0 + (size_t)img * C + c) = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- channel gate MLP
+// one workgroup per image: hidden[n,k,:] = relu(W1 pooled[n,k,:] + b1) for k in {avg, max};
+// scale[n,:] = sigmoid(W2 (h_avg + h_max) + 2 b2)   (cbam.py:57-66: the two MLP outputs are summed before the sigmoid)
+__global__ __launch_bounds__(256) void cgate_mlp_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ w1,
+                                                            const float* __restrict__ b1, const float* __restrict__ w2,
+                                                            const float* __restrict__ b2, float* __restrict__ hidden,
+                                                            float* __restrict__ scale, int C, int Ch) {
+    extern __shared__ float lds[];                // [2*C] pooled, [2*Ch] hidden
+    float* lp = lds;
+    float* lh = lds + 2 * C;
+    const int img = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) lp[i] = pooled[(size_t)img * 2 * C + i];
+    __syncthreads();
+    for (int o = wave; o < 2 * Ch; o += 4) {
+        const int k = o / Ch, j = o % Ch;
+        float acc = 0.f;
+        for (int c = lane; c < C; c += 64) acc += w1[(size_t)j * C + c] * lp[k * C + c];
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) acc += __shfl_xor(acc, sft, 64);
+        if (lane == 0) {
+            const float h = fmaxf(acc + b1[j], 0.f);
+            lh[o] = h;
+            hidden[(size_t)img * 2 * Ch + o] = h;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float att = 2.f * b2[c];
+        for (int j = 0; j < Ch; ++j) att += w2[(size_t)c * Ch + j] * (lh[j] + lh[Ch + j]);
+        scale[(size_t)img * C + c] = sigmoidf(att);
+    }
+}
+// backward, per image: datt = dscale * s(1-s) (overwrites dscale); dhidden[n,k,:] = (W2^T datt) * (hidden > 0);
+// dpooled[n,k,:] = W1^T dhidden[n,k,:]
+__global__ __launch_bounds__(256) void cgate_mlp_bwd_kernel(const float* __restrict__ scale, const float* __restrict__ hidden,
+                                                            const float* __restrict__ w1, const float* __restrict__ w2,
+                                                            float* __restrict__ dscale, float* __restrict__ dhidden,
+                                                            float* __restrict__ dpooled, int C, int Ch) {
+    extern __shared__ float lds[];                // [C] datt, [2*Ch] dhidden
+    float* ld = lds;
+    float* lh = lds + C;
+    const int img = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float s = scale[(size_t)img * C + c];
+        const float d = dscale[(size_t)img * C + c] * s * (1.f - s);
+        ld[c] = d;
+        dscale[(size_t)img * C + c] = d;
+    }
+    __syncthreads();
+    for (int j = wave; j < Ch; j += 4) {
+        float acc = 0.f;
+        for (int c = lane; c < C; c += 64) acc += w2[(size_t)c * Ch + j] * ld[c];
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) acc += __shfl_xor(acc, sft, 64);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float g = hidden[(size_t)img * 2 * Ch + k * Ch + j] > 0.f ? acc : 0.f;
+                lh[k * Ch + j] = g;
+                dhidden[(size_t)img * 2 * Ch + k * Ch + j] = g;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const int k = i / C, c = i % C;
+        float acc = 0.f;
+        for (int j = 0; j < Ch; ++j) acc += w1[(size_t)j * C + c] * lh[k * Ch + j];
+        dpooled[(size_t)img * 2 * C + i] = acc;
+    }
+}
+// parameter gradients of the MLP, one thread per (c, j): sums over the images
+__global__ __launch_bounds__(256) void cgate_mlp_wgrad_kernel(const float* __restrict__ pooled, const float* __restrict__ hidden,
+                                                              const float* __restrict__ datt, const float* __restrict__ dhidden,
+                                                              float* __restrict__ dw1, float* __restrict__ db1,
+                                                              float* __restrict__ dw2, float* __restrict__ db2, int n, int C, int Ch) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * Ch) return;
+    const int j = i % Ch, c = i / Ch;
+    float a1 = 0.f, a2 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int img = 0; img < n; ++img) {
+        const float da = datt[(size_t)img * C + c];
+        const float* h = hidden + (size_t)img * 2 * Ch;
+        const float* dh = dhidden + (size_t)img * 2 * Ch;
+        const float* p = pooled + (size_t)img * 2 * C;
+        a2 += da * (h[j] + h[Ch + j]);
+        a1 += dh[j] * p[c] + dh[Ch + j] * p[C + c];
+        s2 += da;
+        s1 += dh[j] + dh[Ch + j];
+    }
+    dw2[(size_t)c * Ch + j] = a2;
+    dw1[(size_t)j * C + c] = a1;
+    if (j == 0) db2[c] = 2.f * s2;
+    if (c == 0) db1[j] = s1;
+}
+
+// ---------------------------------------------------------------------------------------------- gate application
+// out = x * sc[img, c] (channel gate) or x * sp[img, hw] (spatial gate)
+__global__ __launch_bounds__(256) void gate_scale_kernel(const float* __restrict__ x, const float* __restrict__ sc,
+                                                         const float* __restrict__ sp, float* __restrict__ out, int n, int HW, int C) {
+    const int cc = C / 4;
+    const size_t total = (size_t)n * HW * cc;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cc) * 4;
+        const size_t p = i / cc;
+        f32x4 v = *(const f32x4*)(x + p * C + c);
+        if (sc) v *= *(const f32x4*)(sc + (p / HW) * C + c);
+        else v *= sp[p];
+        *(f32x4*)(out + p * C + c) = v;
+    }
+}
+// channel gate: dx = dout * s[img,c] + dpooled_avg[img,c] / HW + [hw == argmax[img,c]] * dpooled_max[img,c]
+__global__ __launch_bounds__(256) void cgate_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ scale,
+                                                              const float* __restrict__ dpooled, const int* __restrict__ argmax,
+                                                              float* __restrict__ dx, int n, int HW, int C) {
+    const int cc = C / 4;
+    const size_t total = (size_t)n * HW * cc;
+    const float inv = 1.0f / (float)HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cc) * 4;
+        const size_t p = i / cc;
+        const size_t img = p / HW;
+        const int hw = (int)(p % HW);
+        const f32x4 d = *(const f32x4*)(dout + p * C + c);
+        const f32x4 s = *(const f32x4*)(scale + img * C + c);
+        const f32x4 da = *(const f32x4*)(dpooled + (img * 2 + 0) * C + c);
+        const f32x4 dm = *(const f32x4*)(dpooled + (img * 2 + 1) * C + c);
+        f32x4 o = d * s + da * inv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (argmax[img * C + c + r] == hw) o[r] += dm[r];
+        *(f32x4*)(dx + p * C + c) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- spatial gate
+// 16 lanes per pixel.  MODE 0: comp[p,0] = max_c x, comp[p,1] = mean_c x, argmax[p] = channel of the max (cbam.py:76-79);
+// MODE 1: o0[p] = sum_c a*b  (gradient of the spatial scale)
+template <int MODE>
+__global__ __launch_bounds__(256) void pix_reduce_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         float* __restrict__ o0, int* __restrict__ oarg, size_t P, int C) {
+    const int sub = threadIdx.x & 15;
+    for (size_t p = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4); p < (P + 15) / 16 * 16; p += (size_t)gridDim.x * 16) {
+        const bool live = p < P;
+        float s = 0.f, m = -INFINITY;
+        int arg = 0;
+        if (live) {
+            for (int c = sub * 4; c < C; c += 64) {
+                const f32x4 v = *(const f32x4*)(a + p * C + c);
+                if (MODE == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        s += v[r];
+                        if (v[r] > m) { m = v[r]; arg = c + r; }
+                    }
+                } else {
+                    const f32x4 w = *(const f32x4*)(b + p * C + c);
+                    s += v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3];
+                }
+            }
+        }
+#pragma unroll
+        for (int sft = 8; sft >= 1; sft >>= 1) {
+            s += __shfl_xor(s, sft, 16);
+            if (MODE == 0) {
+                const float om = __shfl_xor(m, sft, 16);
+                const int oa = __shfl_xor(arg, sft, 16);
+                if (om > m || (om == m && oa < arg)) { m = om; arg = oa; }
+            }
+        }
+        if (live && sub == 0) {
+            if (MODE == 0) {
+                o0[p * 2 + 0] = m;
+                o0[p * 2 + 1] = s / (float)C;
+                oarg[p] = arg;
+            } else {
+                o0[p] = s;
+            }
+        }
+    }
+}
+// z[n,H,W] = conv7x7(comp; w[1,2,7,7], pad 3), direct (98 MACs per pixel, operands in L1/L2)
+__global__ __launch_bounds__(256) void sgate_conv_fwd_kernel(const float* __restrict__ comp, const float* __restrict__ w,
+                                                             float* __restrict__ z, int n, int H, int W) {
+    __shared__ float lw[98];
+    if (threadIdx.x < 98) lw[threadIdx.x] = w[threadIdx.x];
+    __syncthreads();
+    const size_t total = (size_t)n * H * W;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(p % W), y = (int)((p / W) % H);
+        const size_t base = p - (size_t)y * W - x;
+        float acc = 0.f;
+        for (int ky = 0; ky < 7; ++ky) {
+            const int yy = y + ky - 3;
+            if (yy < 0 || yy >= H) continue;
+            for (int kx = 0; kx < 7; ++kx) {
+                const int xx = x + kx - 3;
+                if (xx < 0 || xx >= W) continue;
+                const f32x2 v = *(const f32x2*)(comp + (base + (size_t)yy * W + xx) * 2);
+                acc += v[0] * lw[ky * 7 + kx] + v[1] * lw[49 + ky * 7 + kx];
+            }
+        }
+        z[p] = acc;
+    }
+}
+// scale[p] = sigmoid(gamma * (z - mean) * rstd + beta)
+__global__ __launch_bounds__(256) void sgate_sigmoid_kernel(const float* __restrict__ z, const float* __restrict__ stats,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ scale, size_t P) {
+    const float mu = stats[0], rs = stats[1], g = gamma ? gamma[0] : 1.f, b = beta ? beta[0] : 0.f;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x)
+        scale[p] = sigmoidf((z[p] - mu) * rs * g + b);
+}
+// g[p] = dscale[p] * s(1-s) (overwrites dscale); red[0] += sum g, red[1] += sum g*xhat
+__global__ __launch_bounds__(256) void sgate_bn_bwd_reduce_kernel(const float* __restrict__ z, const float* __restrict__ stats,
+                                                                  const float* __restrict__ scale, float* __restrict__ dscale,
+                                                                  float* __restrict__ red, size_t P) {
+    __shared__ float l0[4], l1[4];
+    const float mu = stats[0], rs = stats[1];
+    float s0 = 0.f, s1 = 0.f;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x) {
+        const float s = scale[p];
+        const float g = dscale[p] * s * (1.f - s);
+        dscale[p] = g;
+        s0 += g;
+        s1 += g * (z[p] - mu) * rs;
+    }
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) { s0 += __shfl_xor(s0, sft, 64); s1 += __shfl_xor(s1, sft, 64); }
+    if ((threadIdx.x & 63) == 0) { l0[threadIdx.x >> 6] = s0; l1[threadIdx.x >> 6] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(red + 0, l0[0] + l0[1] + l0[2] + l0[3]);
+        atomicAdd(red + 1, l1[0] + l1[1] + l1[2] + l1[3]);
+    }
+}
+// dz[p] = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)) (training) or gamma*rstd*g (running statistics); in place over g
+__global__ __launch_bounds__(256) void sgate_bn_bwd_apply_kernel(const float* __restrict__ z, const float* __restrict__ stats,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ red,
+                                                                 float* __restrict__ g, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta, size_t P, int training) {
+    const float mu = stats[0], rs = stats[1], ga = gamma ? gamma[0] : 1.f;
+    const float m0 = red[0] / (float)P, m1 = red[1] / (float)P;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && dgamma) { dgamma[0] = red[1]; dbeta[0] = red[0]; }
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x) {
+        const float xh = (z[p] - mu) * rs;
+        g[p] = training ? ga * rs * (g[p] - m0 - xh * m1) : ga * rs * g[p];
+    }
+}
+// dcomp[p, ch] = sum_taps dz[y-ky+3, x-kx+3] * w[ch, ky, kx]
+__global__ __launch_bounds__(256) void sgate_conv_bwd_data_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                                                                  float* __restrict__ dcomp, int n, int H, int W) {
+    __shared__ float lw[98];
+    if (threadIdx.x < 98) lw[threadIdx.x] = w[threadIdx.x];
+    __syncthreads();
+    const size_t total = (size_t)n * H * W;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(p % W), y = (int)((p / W) % H);
+        const size_t base = p - (size_t)y * W - x;
+        float a0 = 0.f, a1 = 0.f;
+        for (int ky = 0; ky < 7; ++ky) {
+            const int yy = y - ky + 3;
+            if (yy < 0 || yy >= H) continue;
+            for (int kx = 0; kx < 7; ++kx) {
+                const int xx = x - kx + 3;
+                if (xx < 0 || xx >= W) continue;
+                const float d = dz[base + (size_t)yy * W + xx];
+                a0 += d * lw[ky * 7 + kx];
+                a1 += d * lw[49 + ky * 7 + kx];
+            }
+        }
+        *(f32x2*)(dcomp + p * 2) = (f32x2){a0, a1};
+    }
+}
+// dw[ch, ky, kx] += sum_p dz[p] * comp[(y+ky-3, x+kx-3), ch]; grid (98, chunks)
+__global__ __launch_bounds__(256) void sgate_conv_bwd_weight_kernel(const float* __restrict__ dz, const float* __restrict__ comp,
+                                                                    float* __restrict__ dw, int n, int H, int W) {
+    __shared__ float l0[4];
+    const int t = blockIdx.x, ch = t / 49, ky = (t % 49) / 7, kx = t % 7;
+    const size_t total = (size_t)n * H * W;
+    float acc = 0.f;
+    for (size_t p = (size_t)blockIdx.y * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.y * blockDim.x) {
+        const int x = (int)(p % W), y = (int)((p / W) % H);
+        const int yy = y + ky - 3, xx = x + kx - 3;
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+        acc += dz[p] * comp[(p + (size_t)(ky - 3) * W + (kx - 3)) * 2 + ch];
+    }
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) acc += __shfl_xor(acc, sft, 64);
+    if ((threadIdx.x & 63) == 0) l0[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(dw + t, l0[0] + l0[1] + l0[2] + l0[3]);
+}
+// dx = dout * scale[p] + [c == argmax[p]] * dcomp[p,0] + dcomp[p,1] / C
+__global__ __launch_bounds__(256) void sgate_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ scale,
+                                                              const float* __restrict__ dcomp, const int* __restrict__ argmax,
+                                                              float* __restrict__ dx, size_t P, int C) {
+    const int cc = C / 4;
+    const size_t total = P * cc;
+    const float inv = 1.0f / (float)C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cc) * 4;
+        const size_t p = i / cc;
+        const f32x4 d = *(const f32x4*)(dout + p * C + c);
+        const f32x2 dc = *(const f32x2*)(dcomp + p * 2);
+        const int am = argmax[p];
+        f32x4 o = d * scale[p] + dc[1] * inv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (c + r == am) o[r] += dc[0];
+        *(f32x4*)(dx + p * C + c) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- residual add + ReLU, avg pool
+__global__ __launch_bounds__(256) void add_relu_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           float* __restrict__ out, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 v = ((const f32x4*)a)[i] + ((const f32x4*)b)[i];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        ((f32x4*)out)[i] = v;
+    }
+}
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                       float* __restrict__ g, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 d = ((const f32x4*)dout)[i];
+        const f32x4 o = ((const f32x4*)out)[i];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[r] = o[r] > 0.f ? d[r] : 0.f;
+        ((f32x4*)g)[i] = d;
+    }
+}
+// dx[n,hw,c] = dout[n,c] / HW
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx, int n, int HW, int C) {
+    const int cc = C / 4;
+    const size_t total = (size_t)n * HW * cc;
+    const float inv = 1.0f / (float)HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cc) * 4;
+        const size_t p = i / cc;
+        *(f32x4*)(dx + p * C + c) = *(const f32x4*)(dout + (p / HW) * C + c) * inv;
+    }
+}
+
+int chan_cpb(int C) { return C / 4 < 64 ? C / 4 : 64; }
+
+}  // namespace
+
+extern "C" int eoe_maxpool_fwd(const float* x, float* out, uint8_t* idx, int n, int H, int W, int C, int k, int stride, int pad,
+                               void* stream) {
+    EOE_CHECK_ARG(x && out && idx && n > 0 && C % 4 == 0 && k >= 1 && k * k <= 255 && stride >= 1 && pad >= 0 && 2 * pad <= k,
+                  "maxpool_fwd: bad args");
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    EOE_CHECK_ARG(Ho >= 1 && Wo >= 1, "maxpool_fwd: empty output");
+    ProfScope ps("maxpool_fwd", 0, 4.0 * n * H * W * C + 5.0 * n * Ho * Wo * C, stream);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((size_t)n * Ho * Wo * C / 4)), dim3(256), 0, (hipStream_t)stream, x, out,
+                       idx, n, H, W, C, k, stride, pad, Ho, Wo);
+    EOE_CHECK_LAUNCH("maxpool_fwd");
+    return 0;
+}
+
+extern "C" int eoe_maxpool_bwd(const float* dout, const uint8_t* idx, float* dx, int n, int H, int W, int C, int k, int stride,
+                               int pad, void* stream) {
+    EOE_CHECK_ARG(dout && dx && idx && n > 0 && C % 4 == 0 && k >= 1 && stride >= 1 && pad >= 0, "maxpool_bwd: bad args");
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    ProfScope ps("maxpool_bwd", 0, 4.0 * n * H * W * C + 5.0 * n * Ho * Wo * C, stream);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((size_t)n * H * W * C / 4)), dim3(256), 0, (hipStream_t)stream, dout, idx,
+                       dx, n, H, W, C, k, stride, pad, Ho, Wo);
+    EOE_CHECK_LAUNCH("maxpool_bwd");
+    return 0;
+}
+
+static int check_cgate(const eoe_cgate_args* a) {
+    EOE_CHECK_ARG(a && a->x && a->w1 && a->b1 && a->w2 && a->b2 && a->pooled && a->argmax && a->hidden && a->scale, "cgate: null args");
+    EOE_CHECK_ARG(a->n > 0 && a->HW > 0 && a->C >= 16 && a->C % 16 == 0 && a->C <= 4096 && a->Ch >= 1 && a->Ch <= 256,
+                  "cgate: bad shape n=%d HW=%d C=%d Ch=%d", a->n, a->HW, a->C, a->Ch);
+    const int cpb = chan_cpb(a->C);
+    EOE_CHECK_ARG(256 % cpb == 0 && (a->C / 4) % cpb == 0, "cgate: C = %d not supported", a->C);
+    return 0;
+}
+
+extern "C" int eoe_cgate_fwd(const eoe_cgate_args* a, void* stream) {
+    EOE_TRY(check_cgate(a));
+    EOE_CHECK_ARG(a->out != nullptr, "cgate_fwd: null out");
+    hipStream_t s = (hipStream_t)stream;
+    const int cpb = chan_cpb(a->C);
+    ProfScope ps("cgate_fwd", 0, 3 * 4.0 * a->n * a->HW * a->C, stream);
+    hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3(a->n, a->C / 4 / cpb), dim3(256), 0, s, a->x, (const float*)nullptr, a->pooled,
+                       a->argmax, a->HW, a->C, cpb);
+    EOE_CHECK_LAUNCH("cgate_pool");
+    hipLaunchKernelGGL(cgate_mlp_fwd_kernel, dim3(a->n), dim3(256), (2 * a->C + 2 * a->Ch) * sizeof(float), s, a->pooled, a->w1, a->b1,
+                       a->w2, a->b2, a->hidden, a->scale, a->C, a->Ch);
+    EOE_CHECK_LAUNCH("cgate_mlp_fwd");
+    hipLaunchKernelGGL(gate_scale_kernel, dim3(grid_for((size_t)a->n * a->HW * a->C / 4)), dim3(256), 0, s, a->x, a->scale,
+                       (const float*)nullptr, a->out, a->n, a->HW, a->C);
+    EOE_CHECK_LAUNCH("cgate_scale");
+    return 0;
+}
+
+extern "C" int eoe_cgate_bwd(const eoe_cgate_bwd_args* b, void* stream) {
+    EOE_CHECK_ARG(b != nullptr, "cgate_bwd: null args");
+    const eoe_cgate_args* a = &b->f;
+    EOE_TRY(check_cgate(a));
+    EOE_CHECK_ARG(b->dout && b->dx && b->dscale && b->dpooled && b->dhidden && b->dw1 && b->db1 && b->dw2 && b->db2,
+                  "cgate_bwd: null args");
+    hipStream_t s = (hipStream_t)stream;
+    const int cpb = chan_cpb(a->C);
+    ProfScope ps("cgate_bwd", 0, 5 * 4.0 * a->n * a->HW * a->C, stream);
+    hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3(a->n, a->C / 4 / cpb), dim3(256), 0, s, b->dout, a->x, b->dscale, (int*)nullptr,
+                       a->HW, a->C, cpb);
+    EOE_CHECK_LAUNCH("cgate_bwd_reduce");
+    hipLaunchKernelGGL(cgate_mlp_bwd_kernel, dim3(a->n), dim3(256), (a->C + 2 * a->Ch) * sizeof(float), s, a->scale, a->hidden, a->w1,
+                       a->w2, b->dscale, b->dhidden, b->dpooled, a->C, a->Ch);
+    EOE_CHECK_LAUNCH("cgate_mlp_bwd");
+    hipLaunchKernelGGL(cgate_mlp_wgrad_kernel, dim3(cdiv(a->C * a->Ch, 256)), dim3(256), 0, s, a->pooled, a->hidden, b->dscale,
+                       b->dhidden, b->dw1, b->db1, b->dw2, b->db2, a->n, a->C, a->Ch);
+    EOE_CHECK_LAUNCH("cgate_mlp_wgrad");
+    hipLaunchKernelGGL(cgate_bwd_apply_kernel, dim3(grid_for((size_t)a->n * a->HW * a->C / 4)), dim3(256), 0, s, b->dout, a->scale,
+                       b->dpooled, a->argmax, b->dx, a->n, a->HW, a->C);
+    EOE_CHECK_LAUNCH("cgate_bwd_apply");
+    return 0;
+}
+
+static int check_sgate(const eoe_sgate_args* a) {
+    EOE_CHECK_ARG(a && a->x && a->w && a->comp && a->argmax && a->z && a->stats && a->scale && a->sums, "sgate: null args");
+    EOE_CHECK_ARG((a->gamma == nullptr) == (a->beta == nullptr), "sgate: gamma/beta must both be given or both NULL");
+    EOE_CHECK_ARG(a->n > 0 && a->H > 0 && a->W > 0 && a->C >= 4 && a->C % 4 == 0, "sgate: bad shape");
+    return 0;
+}
+
+extern "C" int eoe_sgate_fwd(const eoe_sgate_args* a, void* stream) {
+    EOE_TRY(check_sgate(a));
+    EOE_CHECK_ARG(a->out != nullptr, "sgate_fwd: null out");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t P = (size_t)a->n * a->H * a->W;
+    EOE_CHECK_ARG(P < 0x7fffffffull, "sgate: too many pixels");
+    {
+        ProfScope ps("sgate_fwd", 0, 3 * 4.0 * P * a->C, stream);
+        hipLaunchKernelGGL(pix_reduce_kernel<0>, dim3(grid_for(P * 16)), dim3(256), 0, s, a->x, (const float*)nullptr, a->comp,
+                           a->argmax, P, a->C);
+        EOE_CHECK_LAUNCH("sgate_pool");
+        hipLaunchKernelGGL(sgate_conv_fwd_kernel, dim3(grid_for(P)), dim3(256), 0, s, a->comp, a->w, a->z, a->n, a->H, a->W);
+        EOE_CHECK_LAUNCH("sgate_conv_fwd");
+    }
+    EOE_TRY(eoe_bn_stats(a->z, a->sums, a->stats, a->running_mean, a->running_var, a->num_batches_tracked, (int)P, 1, a->eps,
+                         a->momentum, a->training, stream));
+    ProfScope ps("sgate_fwd", 0, 2 * 4.0 * P * a->C, stream);
+    hipLaunchKernelGGL(sgate_sigmoid_kernel, dim3(grid_for(P)), dim3(256), 0, s, a->z, a->stats, a->gamma, a->beta, a->scale, P);
+    EOE_CHECK_LAUNCH("sgate_sigmoid");
+    hipLaunchKernelGGL(gate_scale_kernel, dim3(grid_for(P * a->C / 4)), dim3(256), 0, s, a->x, (const float*)nullptr, a->scale, a->out,
+                       a->n, a->H * a->W, a->C);
+    EOE_CHECK_LAUNCH("sgate_scale");
+    return 0;
+}
+
+extern "C" int eoe_sgate_bwd(const eoe_sgate_bwd_args* b, void* stream) {
+    EOE_CHECK_ARG(b != nullptr, "sgate_bwd: null args");
+    const eoe_sgate_args* a = &b->f;
+    EOE_TRY(check_sgate(a));
+    EOE_CHECK_ARG(b->dout && b->dx && b->dscale && b->dcomp && b->red && b->dw, "sgate_bwd: null args");
+    EOE_CHECK_ARG((b->dgamma == nullptr) == (b->dbeta == nullptr), "sgate_bwd: dgamma/dbeta must both be given or both NULL");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t P = (size_t)a->n * a->H * a->W;
+    ProfScope ps("sgate_bwd", 0, 5 * 4.0 * P * a->C, stream);
+    if (hipMemsetAsync(b->red, 0, 2 * sizeof(float), s) != hipSuccess || hipMemsetAsync(b->dw, 0, 98 * sizeof(float), s) != hipSuccess)
+        return eoe_set_error(EOE_ERR_LAUNCH, "sgate_bwd: memset failed");
+    hipLaunchKernelGGL(pix_reduce_kernel<1>, dim3(grid_for(P * 16)), dim3(256), 0, s, b->dout, a->x, b->dscale, (int*)nullptr, P, a->C);
+    EOE_CHECK_LAUNCH("sgate_bwd_reduce");
+    int g = grid_for(P, 512);
+    hipLaunchKernelGGL(sgate_bn_bwd_reduce_kernel, dim3(g), dim3(256), 0, s, a->z, a->stats, a->scale, b->dscale, b->red, P);
+    EOE_CHECK_LAUNCH("sgate_bn_bwd_reduce");
+    hipLaunchKernelGGL(sgate_bn_bwd_apply_kernel, dim3(grid_for(P)), dim3(256), 0, s, a->z, a->stats, a->gamma, (const float*)b->red,
+                       b->dscale, b->dgamma, b->dbeta, P, a->training);
+    EOE_CHECK_LAUNCH("sgate_bn_bwd_apply");
+    hipLaunchKernelGGL(sgate_conv_bwd_data_kernel, dim3(grid_for(P)), dim3(256), 0, s, (const float*)b->dscale, a->w, b->dcomp, a->n,
+                       a->H, a->W);
+    EOE_CHECK_LAUNCH("sgate_conv_bwd_data");
+    hipLaunchKernelGGL(sgate_conv_bwd_weight_kernel, dim3(98, grid_for(P, 64)), dim3(256), 0, s, (const float*)b->dscale, a->comp, b->dw,
+                       a->n, a->H, a->W);
+    EOE_CHECK_LAUNCH("sgate_conv_bwd_weight");
+    hipLaunchKernelGGL(sgate_bwd_apply_kernel, dim3(grid_for(P * a->C / 4)), dim3(256), 0, s, b->dout, a->scale, (const float*)b->dcomp,
+                       a->argmax, b->dx, P, a->C);
+    EOE_CHECK_LAUNCH("sgate_bwd_apply");
+    return 0;
+}
+
+extern "C" int eoe_add_relu_fwd(const float* a, const float* b, float* out, int64_t count, void* stream) {
+    EOE_CHECK_ARG(a && b && out && count > 0 && count % 4 == 0, "add_relu_fwd: bad args");
+    ProfScope ps("add_relu_fwd", 0, 12.0 * count, stream);
+    hipLaunchKernelGGL(add_relu_fwd_kernel, dim3(grid_for((size_t)count / 4)), dim3(256), 0, (hipStream_t)stream, a, b, out,
+                       (size_t)count / 4);
+    EOE_CHECK_LAUNCH("add_relu_fwd");
+    return 0;
+}
+
+extern "C" int eoe_relu_bwd(const float* dout, const float* out, float* g, int64_t count, void* stream) {
+    EOE_CHECK_ARG(dout && out && g && count > 0 && count % 4 == 0, "relu_bwd: bad args");
+    ProfScope ps("relu_bwd", 0, 12.0 * count, stream);
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for((size_t)count / 4)), dim3(256), 0, (hipStream_t)stream, dout, out, g,
+                       (size_t)count / 4);
+    EOE_CHECK_LAUNCH("relu_bwd");
+    return 0;
+}
+
+extern "C" int eoe_avgpool_fwd(const float* x, float* pooled_scratch, int* argmax_scratch, int n, int HW, int C, void* stream) {
+    EOE_CHECK_ARG(x && pooled_scratch && argmax_scratch && n > 0 && HW > 0 && C >= 16 && C % 16 == 0, "avgpool_fwd: bad args");
+    const int cpb = chan_cpb(C);
+    EOE_CHECK_ARG(256 % cpb == 0 && (C / 4) % cpb == 0, "avgpool_fwd: C = %d not supported", C);
+    ProfScope ps("avgpool_fwd", 0, 4.0 * n * HW * C, stream);
+    hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3(n, C / 4 / cpb), dim3(256), 0, (hipStream_t)stream, x, (const float*)nullptr,
+                       pooled_scratch, argmax_scratch, HW, C, cpb);
+    EOE_CHECK_LAUNCH("avgpool_fwd");
+    return 0;
+}
+
+extern "C" int eoe_avgpool_bwd(const float* dout, float* dx, int n, int HW, int C, void* stream) {
+    EOE_CHECK_ARG(dout && dx && n > 0 && HW > 0 && C % 4 == 0, "avgpool_bwd: bad args");
+    ProfScope ps("avgpool_bwd", 0, 4.0 * n * HW * C, stream);
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for((size_t)n * HW * C / 4)), dim3(256), 0, (hipStream_t)stream, dout, dx, n, HW, C);
+    EOE_CHECK_LAUNCH("avgpool_bwd");
+    return 0;
+}

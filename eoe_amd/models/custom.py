@@ -5,6 +5,7 @@ The reference ships no CLIP CustomNet; "CLIP ViT-B/32 frozen encoder + HSC head"
 (BASELINE.json configs 4/5) are only expressible through this API."""
 from .custom_base import CustomNet
 from .clip_vit import VisualTransformer
+from .resnet import WideResNet
 
 
 class ClipViTB32Custom(CustomNet):
@@ -14,3 +15,11 @@ class ClipViTB32Custom(CustomNet):
                  input_resolution: int = 224):
         super().__init__(512, prediction_head, clf, freeze)
         self.feature_model = VisualTransformer(input_resolution, 32, 768, layers, 12, 512)
+
+
+class WideResNetCustom(CustomNet):
+    """the reference's own example CustomNet (`custom.py:5-8`): feature_model = WideResNet(256, False)"""
+
+    def __init__(self, prediction_head: bool = True, clf: bool = False, freeze: bool = False):
+        super().__init__(256, prediction_head, clf, freeze)
+        self.feature_model = WideResNet(256, False)

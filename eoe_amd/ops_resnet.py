@@ -1,0 +1,171 @@
+"""autograd Functions for the WideResNet + CBAM encoder (reference `src/eoe/models/resnet.py:85-149`,
+`src/eoe/models/cbam.py:31-107`): every forward / backward is one or a few C calls into libeoe_hip.so
+(`include/eoe_hip.h`, section "WideResNet + CBAM").  Activations are fp32 NHWC between the ops; convolutions go
+through `ops.ConvBnActPoolFunction` (im2col + MFMA GEMM + fused BatchNorm/activation)."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, lib
+from .ops import _chk, _grad_target, _p, _stream, scratch
+
+
+class MaxPoolFunction(torch.autograd.Function):
+    """nn.MaxPool2d(k, stride, pad) on fp32 NHWC (`resnet.py:35,96`)"""
+
+    @staticmethod
+    def forward(ctx, x, k, stride, pad):
+        _chk(x)
+        x = x.contiguous().float()
+        n, H, W, Cc = x.shape
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        out = torch.empty((n, Ho, Wo, Cc), dtype=torch.float32, device=x.device)
+        idx = torch.empty((n, Ho, Wo, Cc), dtype=torch.uint8, device=x.device)
+        check(lib.eoe_maxpool_fwd(_p(x), _p(out), _p(idx), n, H, W, Cc, k, stride, pad, _stream()), "eoe_maxpool_fwd")
+        ctx.save_for_backward(idx)
+        ctx.geo = (n, H, W, Cc, k, stride, pad)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        n, H, W, Cc, k, stride, pad = ctx.geo
+        dout = dout.contiguous().float()
+        dx = torch.empty((n, H, W, Cc), dtype=torch.float32, device=dout.device)
+        check(lib.eoe_maxpool_bwd(_p(dout), _p(idx), _p(dx), n, H, W, Cc, k, stride, pad, _stream()), "eoe_maxpool_bwd")
+        return dx, None, None, None
+
+
+class ChannelGateFunction(torch.autograd.Function):
+    """x * sigmoid(mlp(avgpool x) + mlp(maxpool x)) (`cbam.py:31-66`); x fp32 NHWC"""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        _chk(x, w1, b1, w2, b2)
+        x = x.contiguous().float()
+        n, H, W, Cc = x.shape
+        Ch = w1.shape[0]
+        dev = x.device
+        out = torch.empty_like(x)
+        pooled = torch.empty((n, 2, Cc), dtype=torch.float32, device=dev)
+        argmax = torch.empty((n, Cc), dtype=torch.int32, device=dev)
+        hidden = torch.empty((n, 2, Ch), dtype=torch.float32, device=dev)
+        scale = torch.empty((n, Cc), dtype=torch.float32, device=dev)
+        w1c, b1c, w2c, b2c = (t.detach().contiguous() for t in (w1, b1, w2, b2))
+        a = _lib.CGateArgs(_p(x), _p(out), _p(w1c), _p(b1c), _p(w2c), _p(b2c), _p(pooled), _p(argmax), _p(hidden), _p(scale),
+                           n, H * W, Cc, Ch)
+        check(lib.eoe_cgate_fwd(C.byref(a), _stream()), "eoe_cgate_fwd")
+        ctx.save_for_backward(x, w1, b1, w2, b2, pooled, argmax, hidden, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w1, b1, w2, b2, pooled, argmax, hidden, scale = ctx.saved_tensors
+        n, H, W, Cc = x.shape
+        Ch = w1.shape[0]
+        dev = x.device
+        dout = dout.contiguous().float()
+        dx = torch.empty_like(x)
+        dscale = scratch("cg_dscale", (n, Cc), torch.float32, dev)
+        dpooled = scratch("cg_dpooled", (n, 2, Cc), torch.float32, dev)
+        dhidden = scratch("cg_dhidden", (n, 2, Ch), torch.float32, dev)
+        dw1, db1, dw2, db2 = (_grad_target(t) for t in (w1, b1, w2, b2))
+        w1c, b1c, w2c, b2c = (t.detach().contiguous() for t in (w1, b1, w2, b2))
+        f = _lib.CGateArgs(_p(x), None, _p(w1c), _p(b1c), _p(w2c), _p(b2c), _p(pooled), _p(argmax), _p(hidden), _p(scale),
+                           n, H * W, Cc, Ch)
+        b = _lib.CGateBwdArgs(f, _p(dout), _p(dx), _p(dscale), _p(dpooled), _p(dhidden), _p(dw1), _p(db1), _p(dw2), _p(db2))
+        check(lib.eoe_cgate_bwd(C.byref(b), _stream()), "eoe_cgate_bwd")
+        return dx, dw1, db1, dw2, db2
+
+
+class SpatialGateFunction(torch.autograd.Function):
+    """x * sigmoid(bn(conv7x7([max_c x, mean_c x]))) (`cbam.py:76-92`); x fp32 NHWC; cfg = (training, eps, momentum)"""
+
+    @staticmethod
+    def forward(ctx, x, w, bn_w, bn_b, rm, rv, nbt, cfg):
+        _chk(x, w, bn_w, bn_b, rm, rv)
+        training, eps, momentum = cfg
+        x = x.contiguous().float()
+        n, H, W, Cc = x.shape
+        dev = x.device
+        out = torch.empty_like(x)
+        comp = torch.empty((n, H, W, 2), dtype=torch.float32, device=dev)
+        argmax = torch.empty((n, H, W), dtype=torch.int32, device=dev)
+        z = torch.empty((n, H, W), dtype=torch.float32, device=dev)
+        stats = torch.empty(2, dtype=torch.float32, device=dev)
+        scale = torch.empty((n, H, W), dtype=torch.float32, device=dev)
+        sums = scratch("sg_sums", (2,), torch.float32, dev)
+        wc = w.detach().contiguous()
+        a = _lib.SGateArgs(_p(x), _p(out), _p(wc), _p(bn_w), _p(bn_b), _p(rm), _p(rv), _p(nbt), _p(comp), _p(argmax), _p(z),
+                           _p(stats), _p(scale), _p(sums), n, H, W, Cc, float(eps), float(momentum), 1 if training else 0)
+        check(lib.eoe_sgate_fwd(C.byref(a), _stream()), "eoe_sgate_fwd")
+        ctx.save_for_backward(x, w, bn_w, bn_b, comp, argmax, z, stats, scale)
+        ctx.cfg = (training, float(eps), float(momentum))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w, bn_w, bn_b, comp, argmax, z, stats, scale = ctx.saved_tensors
+        training, eps, momentum = ctx.cfg
+        n, H, W, Cc = x.shape
+        dev = x.device
+        dout = dout.contiguous().float()
+        dx = torch.empty_like(x)
+        dscale = scratch("sg_dscale", (n, H, W), torch.float32, dev)
+        dcomp = scratch("sg_dcomp", (n, H, W, 2), torch.float32, dev)
+        red = scratch("sg_red", (2,), torch.float32, dev)
+        sums = scratch("sg_sums", (2,), torch.float32, dev)
+        dw = _grad_target(w)
+        dg = _grad_target(bn_w) if bn_w is not None else None
+        db = _grad_target(bn_b) if bn_b is not None else None
+        wc = w.detach().contiguous()
+        f = _lib.SGateArgs(_p(x), None, _p(wc), _p(bn_w), _p(bn_b), None, None, None, _p(comp), _p(argmax), _p(z), _p(stats),
+                           _p(scale), _p(sums), n, H, W, Cc, eps, momentum, 1 if training else 0)
+        b = _lib.SGateBwdArgs(f, _p(dout), _p(dx), _p(dscale), _p(dcomp), _p(red), _p(dw), _p(dg), _p(db))
+        check(lib.eoe_sgate_bwd(C.byref(b), _stream()), "eoe_sgate_bwd")
+        return dx, dw, dg, db, None, None, None, None
+
+
+class AddReluFunction(torch.autograd.Function):
+    """relu(a + b): the residual junction of a BasicBlock (`resnet.py:146-147`)"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _chk(a, b)
+        a, b = a.contiguous().float(), b.contiguous().float()
+        out = torch.empty_like(a)
+        check(lib.eoe_add_relu_fwd(_p(a), _p(b), _p(out), a.numel(), _stream()), "eoe_add_relu_fwd")
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (out,) = ctx.saved_tensors
+        dout = dout.contiguous().float()
+        g = torch.empty_like(out)
+        check(lib.eoe_relu_bwd(_p(dout), _p(out), _p(g), out.numel(), _stream()), "eoe_relu_bwd")
+        return g, g.view_as(g)
+
+
+class GlobalAvgPoolFunction(torch.autograd.Function):
+    """nn.AvgPool2d(7) on the final 7x7 grid + flatten (`resnet.py:38,104-105`): fp32 NHWC -> [n, C]"""
+
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        x = x.contiguous().float()
+        n, H, W, Cc = x.shape
+        pooled = torch.empty((n, 2, Cc), dtype=torch.float32, device=x.device)
+        argmax = scratch("gap_arg", (n, Cc), torch.int32, x.device)
+        check(lib.eoe_avgpool_fwd(_p(x), _p(pooled), _p(argmax), n, H * W, Cc, _stream()), "eoe_avgpool_fwd")
+        ctx.shape = (n, H, W, Cc)
+        return pooled[:, 0, :]
+
+    @staticmethod
+    def backward(ctx, dout):
+        n, H, W, Cc = ctx.shape
+        dout = dout.contiguous().float()
+        dx = torch.empty((n, H, W, Cc), dtype=torch.float32, device=dout.device)
+        check(lib.eoe_avgpool_bwd(_p(dout), _p(dx), n, H * W, Cc, _stream()), "eoe_avgpool_bwd")
+        return dx

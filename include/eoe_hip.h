@@ -260,6 +260,87 @@ int eoe_bn_act_pool_bwd(const float* y, const float* stats, const float* gamma, 
                         int pool, int nchw_flat, int training, int accumulate, float slope, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
+ * WideResNet + CBAM (resnet.py:85-109,130-149; cbam.py:31-107).  All activations fp32 NHWC.  The 7x7/2 stem,
+ * the 3x3 and the 1x1/2 downsample convolutions are eoe_im2col + eoe_gemm_nt (+ eoe_bn_stats / eoe_bn_act_pool_*
+ * with slope 0 = ReLU or 1 = none); the pieces below are the HBM-bound rest of a BasicBlock.
+ * ---------------------------------------------------------------------------------------------------- */
+/* nn.MaxPool2d(k, stride, pad) (resnet.py:96): out [n,Ho,Wo,C]; idx [n,Ho,Wo,C] = winning tap ky*k+kx (first maximum) */
+int eoe_maxpool_fwd(const float* x, float* out, uint8_t* idx, int n, int H, int W, int C, int k, int stride, int pad,
+                    void* stream);
+int eoe_maxpool_bwd(const float* dout, const uint8_t* idx, float* dx, int n, int H, int W, int C, int k, int stride, int pad,
+                    void* stream);
+
+/* ChannelGate (cbam.py:31-66, pool_types avg+max): out = x * sigmoid(mlp(avgpool x) + mlp(maxpool x)),
+ * mlp = Linear(C, Ch) -> ReLU -> Linear(Ch, C).  The forward fills the saved tensors the backward reads. */
+typedef struct {
+    const float* x;       /* [n, HW, C] */
+    float* out;           /* [n, HW, C] (forward only) */
+    const float* w1;      /* mlp.1.weight [Ch, C] */
+    const float* b1;      /* mlp.1.bias   [Ch]    */
+    const float* w2;      /* mlp.3.weight [C, Ch] */
+    const float* b2;      /* mlp.3.bias   [C]     */
+    float* pooled;        /* [n, 2, C]  avg, max       (saved) */
+    int* argmax;          /* [n, C]     position of the max (saved) */
+    float* hidden;        /* [n, 2, Ch] post-ReLU      (saved) */
+    float* scale;         /* [n, C]     sigmoid output (saved) */
+    int n, HW, C, Ch;
+} eoe_cgate_args;
+typedef struct {
+    eoe_cgate_args f;
+    const float* dout;    /* [n, HW, C] */
+    float* dx;            /* [n, HW, C] */
+    float* dscale;        /* [n, C]     scratch */
+    float* dpooled;       /* [n, 2, C]  scratch */
+    float* dhidden;       /* [n, 2, Ch] scratch */
+    float *dw1, *db1, *dw2, *db2;      /* written (not accumulated) */
+} eoe_cgate_bwd_args;
+int eoe_cgate_fwd(const eoe_cgate_args* a, void* stream);
+int eoe_cgate_bwd(const eoe_cgate_bwd_args* a, void* stream);
+
+/* SpatialGate (cbam.py:76-92): out = x * sigmoid(bn(conv7x7([max_c x, mean_c x]))), conv 2->1 without bias, pad 3,
+ * BatchNorm2d(1) with the module's eps / momentum (cbam.py:14: momentum 0.01) and running buffers. */
+typedef struct {
+    const float* x;       /* [n, H, W, C] */
+    float* out;           /* [n, H, W, C] (forward only) */
+    const float* w;       /* spatial.conv.weight [1, 2, 7, 7] */
+    const float* gamma;   /* spatial.bn.weight [1] or NULL */
+    const float* beta;    /* spatial.bn.bias   [1] or NULL */
+    float* running_mean;  /* [1] or NULL */
+    float* running_var;   /* [1] or NULL */
+    int64_t* num_batches_tracked;   /* [1] or NULL */
+    float* comp;          /* [n, H, W, 2] channel max, channel mean (saved) */
+    int* argmax;          /* [n, H, W]    channel of the max        (saved) */
+    float* z;             /* [n, H, W]    conv output               (saved) */
+    float* stats;         /* [2]          mean, rstd used           (saved) */
+    float* scale;         /* [n, H, W]    sigmoid output            (saved) */
+    float* sums;          /* [2] scratch */
+    int n, H, W, C;
+    float eps, momentum;
+    int training;         /* 1: batch statistics (+ running update), 0: running statistics */
+} eoe_sgate_args;
+typedef struct {
+    eoe_sgate_args f;
+    const float* dout;    /* [n, H, W, C] */
+    float* dx;            /* [n, H, W, C] */
+    float* dscale;        /* [n, H, W]    scratch */
+    float* dcomp;         /* [n, H, W, 2] scratch */
+    float* red;           /* [2] scratch */
+    float* dw;            /* [1, 2, 7, 7] written */
+    float* dgamma;        /* [1] or NULL */
+    float* dbeta;         /* [1] or NULL */
+} eoe_sgate_bwd_args;
+int eoe_sgate_fwd(const eoe_sgate_args* a, void* stream);
+int eoe_sgate_bwd(const eoe_sgate_bwd_args* a, void* stream);
+
+/* out = relu(a + b) (resnet.py:146-147); g = dout * [out > 0] (the gradient of both summands) */
+int eoe_add_relu_fwd(const float* a, const float* b, float* out, int64_t count, void* stream);
+int eoe_relu_bwd(const float* dout, const float* out, float* g, int64_t count, void* stream);
+/* nn.AvgPool2d over the whole HW grid (resnet.py:38,104): pooled_scratch [n,2,C] receives (mean, max), the mean is
+ * pooled_scratch[:,0,:]; backward dx[n,hw,c] = dout[n,c] / HW */
+int eoe_avgpool_fwd(const float* x, float* pooled_scratch, int* argmax_scratch, int n, int HW, int C, void* stream);
+int eoe_avgpool_bwd(const float* dout, float* dx, int n, int HW, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
  * in-library kernel timing (used by bench.py for the roofline line): while enabled, every entry point brackets
  * its kernel launches with hipEvents on the stream it launches on and records the algorithmic flops / bytes.
  * eoe_prof_collect synchronises the recorded events and aggregates them per kernel name.

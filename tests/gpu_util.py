@@ -41,3 +41,12 @@ def rel_rms(got, ref):
     got = got.detach().float().cpu().double()
     ref = ref.detach().double()
     return ((got - ref).pow(2).mean().sqrt() / (ref.pow(2).mean().sqrt() + 1e-30)).item()
+
+
+def conditioned_tol(base, sens32, dtype, k=150.0):
+    """tolerance for a quantity that two fp32 evaluations (reference vs oracle, or oracle fp32 vs fp64) already disagree on
+    by `sens32` (relative): rounding the GEMM operands to 16 bit perturbs the same ill-conditioned sums harder -- measured
+    on WideResNet at N=4 (tools/wrn_sens.py) 50-120 x for fp16, so k = 150 (x 8 for bf16's 3 fewer mantissa bits).
+    Returns None when the allowance exceeds 50 %: the quantity is cancellation noise at this size and pins nothing."""
+    t = max(base, k * (EPS16[dtype] / EPS16[torch.float16]) * sens32)
+    return None if t > 0.5 else t
