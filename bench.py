@@ -39,8 +39,9 @@ def parse():
                     help="full fine-tune (config 5 style) or frozen encoder + trained head (config 4)")
     ap.add_argument("--dtype", choices=["fp16", "bf16"], default="fp16")
     ap.add_argument("--layers", type=int, default=12)
-    ap.add_argument("--model", choices=["vit", "cnn32"], default="vit",
-                    help="vit = the BASELINE.json metric config; cnn32 = secondary (config 1/2 backbone, 32x32)")
+    ap.add_argument("--model", choices=["vit", "cnn32", "wrn"], default="vit",
+                    help="vit = the BASELINE.json metric config; cnn32 = secondary (config 1/2 backbone, 32x32); "
+                         "wrn = secondary (WideResNet+CBAM, 224x224, config 3 backbone)")
     ap.add_argument("--nt-flags", type=int, default=None, help="tuning switch of the NT GEMM (A/B builds only)")
     ap.add_argument("--tn-flags", type=int, default=None, help="tuning switch of the wgrad GEMM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -93,6 +94,10 @@ def main():
         model = ClipViTB32Custom(prediction_head=True, clf=False, freeze=(args.mode == "frozen"), layers=args.layers).to(dev).train()
         opt = eoe_amd.FusedAdam(model.parameters(), lr=1e-4, weight_decay=1e-3)     # train_clip_imagenet.py:13-14
         model.freeze_parts()
+    elif args.model == "wrn":
+        from eoe_amd.models import WideResNet
+        model = WideResNet().to(dev).train()                                         # train_imagenet.py backbone
+        opt = eoe_amd.FusedAdam(model.parameters(), lr=1e-3, weight_decay=0.0)
     else:
         from eoe_amd.models import CNN32
         res = 32
@@ -168,16 +173,23 @@ def main():
         flop_per_img = FWD_GFLOP_PER_IMG * (3.0 if args.mode == "full" else 1.0) * args.layers / 12.0
         if args.model == "cnn32":
             flop_per_img = 0.179
+        if args.model == "wrn":
+            flop_per_img = 10.89                                                     # 3 x 3.63 GFLOP
+        workload = {
+            "vit": (f"CLIP ViT-B/32 ({args.layers} layers) + Linear(512,256) + HSC, "
+                    f"{'full fine-tune' if args.mode == 'full' else 'frozen encoder'}, Adam lr 1e-4 wd 1e-3, "
+                    f"224x224, {nb} normal + {nb} OE images per GPU per step"),
+            "cnn32": f"CNN32(bias=True) + HSC, Adam lr 1e-3, 32x32, {nb} normal + {nb} OE images per GPU per step",
+            "wrn": f"WideResNet(ResNet-18 + CBAM) + HSC, Adam lr 1e-3, 224x224, {nb} normal + {nb} OE images per GPU per step",
+        }[args.model]
+        metric = {"vit": "train images/sec, CLIP ViT-B/32 + HSC, 224x224", "cnn32": "train images/sec, CNN32 + HSC, 32x32",
+                  "wrn": "train images/sec, WideResNet+CBAM + HSC, 224x224"}[args.model]
         out = {
-            "metric": "train images/sec, CLIP ViT-B/32 + HSC, 224x224" if args.model == "vit" else "train images/sec, CNN32 + HSC, 32x32",
+            "metric": metric,
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": (f"CLIP ViT-B/32 ({args.layers} layers) + Linear(512,256) + HSC, "
-                                    f"{'full fine-tune' if args.mode == 'full' else 'frozen encoder'}, Adam lr 1e-4 wd 1e-3, "
-                                    f"224x224, {nb} normal + {nb} OE images per GPU per step") if args.model == "vit" else
-                                   f"CNN32(bias=True) + HSC, Adam lr 1e-3, 32x32, {nb} normal + {nb} OE images per GPU per step",
-                       "global_batch": n_global, "parallelism": f"dp{world}"},
+            "config": {"workload": workload, "global_batch": n_global, "parallelism": f"dp{world}"},
             "model_tflops": round(value * flop_per_img / 1e3, 1),
             "mfma_roofline_frac_end_to_end": round(value * flop_per_img / 1e3 / (MFMA_PEAK_TFLOPS * world), 4),
             "final_loss": round(final_loss, 5),
