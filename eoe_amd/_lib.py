@@ -14,11 +14,17 @@ ADAM_CHUNK, ADAM_GROUPS = 8192, 4
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
 
+class ConvGeometry(C.Structure):
+    _fields_ = [("n", _i32), ("H", _i32), ("W", _i32), ("C", _i32), ("kh", _i32), ("kw", _i32), ("stride", _i32), ("pad", _i32),
+                ("Ho", _i32), ("Wo", _i32)]
+
+
 class GemmArgs(C.Structure):
     _fields_ = [("A", _vp), ("B", _vp), ("C", _vp), ("bias", _vp), ("aux", _vp), ("aux_out", _vp), ("colsum", _vp),
                 ("M", _i32), ("N", _i32), ("K", _i32),
                 ("lda", _i32), ("ldb", _i32), ("ldc", _i32), ("ldaux", _i32),
-                ("dtype", _i32), ("epilogue", _i32), ("out_f32", _i32), ("accumulate", _i32), ("alpha", _f32)]
+                ("dtype", _i32), ("epilogue", _i32), ("out_f32", _i32), ("accumulate", _i32), ("alpha", _f32),
+                ("gather", _i32), ("geo", ConvGeometry)]
 
 
 class AdamChunk(C.Structure):
@@ -109,8 +115,8 @@ SIGNATURES = {
     "eoe_vit_block_bwd": [C.POINTER(VitBlockBwdArgs), _vp],
     "eoe_im2col": [_vp, C.c_int, _vp, _vp, _vp] + [C.c_int] * 10 + [_vp],
     "eoe_col2im": [_vp, _vp] + [C.c_int] * 10 + [_vp],
-    "eoe_conv_pack_weight": [_vp, _vp, _vp] + [C.c_int] * 6 + [_vp],
-    "eoe_conv_unpack_wgrad": [_vp, _vp] + [C.c_int] * 6 + [_vp],
+    "eoe_conv_pack_weight": [_vp, _vp, _vp, _vp] + [C.c_int] * 6 + [_vp],
+    "eoe_conv_unpack_wgrad": [_vp, _vp] + [C.c_int] * 7 + [_vp],
     "eoe_bn_stats": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _f32, C.c_int, _vp],
     "eoe_bn_act_pool_fwd": [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32,
                             C.c_int, _vp],

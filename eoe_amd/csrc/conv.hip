@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dp, f
 // w fp32 [cout, cin, 5, 5] -> w16 [cout, Kp] (column = tap*cin + c) and w16t [Kp, cout]
 template <typename T>
 __global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict__ w, T* __restrict__ w16, T* __restrict__ w16t,
-                                                        int cout, int cin, int Kp, int taps) {
+                                                        T* __restrict__ w16d, int cout, int cin, int Kp, int taps) {
     const int total = cout * Kp;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int o = i / Kp, col = i % Kp;
@@ -104,46 +104,74 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict_
         if (col < taps * cin) v = w[((size_t)o * cin + col % cin) * taps + col / cin];
         w16[i] = (T)v;
         if (w16t) w16t[(size_t)col * cout + o] = (T)v;
+        // dgrad operand of a stride-1 convolution: [cin, (taps reversed) x cout] (dx = conv of dy with the flipped kernel)
+        if (w16d && col < taps * cin) w16d[((size_t)(col % cin) * taps + (taps - 1 - col / cin)) * cout + o] = (T)v;
     }
 }
-// g fp32 [cout, Kp] -> dw fp32 [cout, cin, 5, 5] (+= if accumulate)
+// g fp32 [cout, Kp] (or transposed: [taps*cin, cout]) -> dw fp32 [cout, cin, kh, kw] (+= if accumulate)
 __global__ __launch_bounds__(256) void conv_unpack_kernel(const float* __restrict__ g, float* __restrict__ dw, int cout, int cin,
-                                                          int Kp, int taps, int accumulate) {
+                                                          int Kp, int taps, int transposed, int accumulate) {
     const int total = cout * cin * taps;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int tap = i % taps, c = (i / taps) % cin, o = i / (taps * cin);
-        const float v = g[(size_t)o * Kp + tap * cin + c];
+        const float v = transposed ? g[(size_t)(tap * cin + c) * cout + o] : g[(size_t)o * Kp + tap * cin + c];
         dw[i] = accumulate ? dw[i] + v : v;
     }
 }
 
 // ---------------------------------------------------------------------------------------------- BatchNorm
 // column sums of y and y^2 over M rows, y fp32 [M, C]; sums[0..C) += sum, sums[C..2C) += sumsq (fp32 atomics of
-// per-workgroup partial sums accumulated in double)
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ y, float* __restrict__ sums, int M, int C) {
-    __shared__ double red[2][256];
-    const int cpb = C < 256 ? C : 256;            // columns per block
-    const int rpb = 256 / cpb;                    // row lanes per block
-    const int c = blockIdx.x * cpb + threadIdx.x % cpb;
+// per-workgroup partial sums accumulated in double).  VEC = 4: a thread owns 4 adjacent channels (16-B loads), cpb
+// thread-columns x rpb row lanes per workgroup; VEC = 1 for C not a multiple of 4 (the 1-channel gate BatchNorm).
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ y, float* __restrict__ sums, int M, int C, int cpb) {
+    __shared__ double red[2][256][VEC];
+    const int rpb = 256 / cpb;
+    const int c = (blockIdx.x * cpb + threadIdx.x % cpb) * VEC;
     const int rl = threadIdx.x / cpb;
-    double s = 0.0, q = 0.0;
+    double s[VEC], q[VEC];
+#pragma unroll
+    for (int r = 0; r < VEC; ++r) { s[r] = 0.0; q[r] = 0.0; }
     if (c < C) {
-        for (int r = blockIdx.y * rpb + rl; r < M; r += gridDim.y * rpb) {
-            const float v = y[(size_t)r * C + c];
-            s += v;
-            q += (double)v * v;
+        int row = blockIdx.y * rpb + rl;
+        const int step = gridDim.y * rpb;
+        if (VEC == 4) {
+            // four independent 16-B loads in flight per thread (one outstanding load per thread cannot cover HBM latency)
+            for (; row + 3 * step < M; row += 4 * step) {
+                f32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)(y + (size_t)(row + u * step) * C + c);
+#pragma unroll
+                for (int r = 0; r < VEC; ++r) {
+                    s[r] += (double)((v[0][r] + v[1][r]) + (v[2][r] + v[3][r]));
+                    q[r] += (double)v[0][r] * v[0][r] + (double)v[1][r] * v[1][r] + (double)v[2][r] * v[2][r] + (double)v[3][r] * v[3][r];
+                }
+            }
+        }
+        for (; row < M; row += step) {
+            if (VEC == 4) {
+                const f32x4 v = *(const f32x4*)(y + (size_t)row * C + c);
+#pragma unroll
+                for (int r = 0; r < VEC; ++r) { s[r] += v[r]; q[r] += (double)v[r] * v[r]; }
+            } else {
+                const float v = y[(size_t)row * C + c];
+                s[0] += v;
+                q[0] += (double)v * v;
+            }
         }
     }
-    red[0][threadIdx.x] = s;
-    red[1][threadIdx.x] = q;
+#pragma unroll
+    for (int r = 0; r < VEC; ++r) { red[0][threadIdx.x][r] = s[r]; red[1][threadIdx.x][r] = q[r]; }
     __syncthreads();
     if (rl == 0 && c < C) {
-        for (int k = 1; k < rpb; ++k) {
-            s += red[0][threadIdx.x + k * cpb];
-            q += red[1][threadIdx.x + k * cpb];
+        for (int k = 1; k < rpb; ++k)
+#pragma unroll
+            for (int r = 0; r < VEC; ++r) { s[r] += red[0][threadIdx.x + k * cpb][r]; q[r] += red[1][threadIdx.x + k * cpb][r]; }
+#pragma unroll
+        for (int r = 0; r < VEC; ++r) {
+            atomicAdd(sums + c + r, (float)s[r]);
+            atomicAdd(sums + C + c + r, (float)q[r]);
         }
-        atomicAdd(sums + c, (float)s);
-        atomicAdd(sums + C + c, (float)q);
     }
 }
 
@@ -237,6 +265,9 @@ __global__ __launch_bounds__(256) void bn_act_pool_bwd_kernel(const float* __res
         for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lds[i] = 0.f;
         __syncthreads();
     }
+    // MODE 0: the launch keeps gridDim.x * 256 a multiple of C/4, so a thread sees ONE channel quad for its whole loop
+    // and sums in registers; LDS / global atomics only once per thread / workgroup at the end
+    float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % cc) * 4;
         const size_t op = i / cc;
@@ -270,8 +301,8 @@ __global__ __launch_bounds__(256) void bn_act_pool_bwd_kernel(const float* __res
 #pragma unroll
                 for (int kk = 0; kk < P * P; ++kk)
                     if (kk == k) { gz = d[r] * (z[kk][r] > 0.f ? 1.f : slope); xk = xh[kk][r]; }
-                atomicAdd(&lds[c + r], gz);
-                atomicAdd(&lds[C + c + r], gz * xk);
+                acc0[r] += gz;
+                acc1[r] += gz * xk;
             }
         } else {
             const f32x4 s1 = *(const f32x4*)(red + c), s2 = *(const f32x4*)(red + C + c);
@@ -292,6 +323,15 @@ __global__ __launch_bounds__(256) void bn_act_pool_bwd_kernel(const float* __res
         }
     }
     if (MODE == 0) {
+        const size_t first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (first < total) {
+            const int c = (int)(first % cc) * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                atomicAdd(&lds[c + r], acc0[r]);
+                atomicAdd(&lds[C + c + r], acc1[r]);
+            }
+        }
         __syncthreads();
         for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(red + i, lds[i]);
     }
@@ -366,20 +406,20 @@ extern "C" int eoe_col2im(const void* dpatches, float* dx, int n, int C, int H, 
     return 0;
 }
 
-extern "C" int eoe_conv_pack_weight(const float* w, void* w16, void* w16t, int cout, int cin, int kh, int kw, int Kp, int dtype,
-                                    void* stream) {
+extern "C" int eoe_conv_pack_weight(const float* w, void* w16, void* w16t, void* w16d, int cout, int cin, int kh, int kw, int Kp,
+                                    int dtype, void* stream) {
     EOE_CHECK_ARG(w && w16 && cout > 0 && cin > 0 && Kp >= kh * kw * cin, "conv_pack_weight: bad args");
     DISPATCH_T(dtype, hipLaunchKernelGGL((conv_pack_kernel<T>), dim3(grid_for((size_t)cout * Kp)), dim3(256), 0,
-                                         (hipStream_t)stream, w, (T*)w16, (T*)w16t, cout, cin, Kp, kh * kw));
+                                         (hipStream_t)stream, w, (T*)w16, (T*)w16t, (T*)w16d, cout, cin, Kp, kh * kw));
     EOE_CHECK_LAUNCH("conv_pack_weight");
     return 0;
 }
 
-extern "C" int eoe_conv_unpack_wgrad(const float* g, float* dw, int cout, int cin, int kh, int kw, int Kp, int accumulate,
-                                     void* stream) {
+extern "C" int eoe_conv_unpack_wgrad(const float* g, float* dw, int cout, int cin, int kh, int kw, int Kp, int transposed,
+                                     int accumulate, void* stream) {
     EOE_CHECK_ARG(g && dw && cout > 0 && cin > 0 && Kp >= kh * kw * cin, "conv_unpack_wgrad: bad args");
     hipLaunchKernelGGL(conv_unpack_kernel, dim3(grid_for((size_t)cout * cin * kh * kw)), dim3(256), 0, (hipStream_t)stream, g, dw,
-                       cout, cin, Kp, kh * kw, accumulate);
+                       cout, cin, Kp, kh * kw, transposed, accumulate);
     EOE_CHECK_LAUNCH("conv_unpack_wgrad");
     return 0;
 }
@@ -395,14 +435,19 @@ extern "C" int eoe_bn_stats(const float* y, float* sums_scratch, float* stats, f
         return 0;
     }
     EOE_CHECK_ARG(y && sums_scratch, "bn_stats: bad args");
-    EOE_CHECK_ARG(C <= 256 ? (256 % C == 0) : (C % 256 == 0), "bn_stats: C = %d must divide or be a multiple of 256", C);
+    const int vec = (C % 4 == 0) ? 4 : 1;
+    const int cols = C / vec;                     // thread-columns needed
+    int cpb = 1;
+    while (cpb < 64 && cpb < cols) cpb *= 2;      // power of two <= 64 so that it divides 256
     ProfScope ps("bn_stats", 0, 4.0 * M * C, stream);
     if (hipMemsetAsync(sums_scratch, 0, 2 * C * sizeof(float), s) != hipSuccess) return eoe_set_error(EOE_ERR_LAUNCH, "bn_stats: memset failed");
-    const int cpb = C < 256 ? C : 256, rpb = 256 / cpb;
-    int gy = cdiv(M, rpb * 64);
-    if (gy > 512) gy = 512;
+    const int rpb = 256 / cpb;
+    int gy = cdiv(M, rpb * 16);
+    const int gx = cdiv(cols, cpb);
+    if (gy * gx > 1024) gy = 1024 / gx;
     if (gy < 1) gy = 1;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(cdiv(C, cpb), gy), dim3(256), 0, s, y, sums_scratch, M, C);
+    if (vec == 4) hipLaunchKernelGGL(bn_stats_kernel<4>, dim3(gx, gy), dim3(256), 0, s, y, sums_scratch, M, C, cpb);
+    else hipLaunchKernelGGL(bn_stats_kernel<1>, dim3(gx, gy), dim3(256), 0, s, y, sums_scratch, M, C, cpb);
     EOE_CHECK_LAUNCH("bn_stats");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, sums_scratch, stats, running_mean, running_var,
                        num_batches_tracked, M, C, eps, momentum);
@@ -436,7 +481,14 @@ extern "C" int eoe_bn_act_pool_bwd(const float* y, const float* stats, const flo
     ProfScope ps("bn_act_pool_bwd", 0, 2 * 4.0 * n * H * W * C + 2.0 * n * H * W * C, stream);
     if (hipMemsetAsync(red_scratch, 0, 2 * C * sizeof(float), s) != hipSuccess) return eoe_set_error(EOE_ERR_LAUNCH, "bn_act_pool_bwd: memset failed");
     const int grid = grid_for((size_t)n * (H / pool) * (W / pool) * C / 4);
-    const int g0 = grid > 512 ? 512 : grid;
+    int g0 = grid > 1024 ? 1024 : grid;
+    {   // reduce pass: gridDim.x * 256 must be a multiple of C/4 (one channel quad per thread)
+        int cc = C / 4, a = cc, b = 256;
+        while (b) { const int t = a % b; a = b; b = t; }
+        const int q = cc / a;                     // cc / gcd(cc, 256)
+        g0 = g0 / q * q;
+        if (g0 < q) g0 = q;
+    }
 #define EOE_BNB(MODE, PP, GRID, LDS)                                                                                  \
     DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_pool_bwd_kernel<T, MODE, PP>), dim3(GRID), dim3(256), LDS, s, y, stats, gamma, \
                                          beta, dout, red_scratch, dy, dy_f32, n, H, W, C, nchw_flat, training, slope))

@@ -34,6 +34,9 @@ struct GemmP {
     float alpha;
     unsigned bytesA, bytesB;
     unsigned long long* stamp;     // diagnostics (EOE_GEMM_STAMP=1): per-workgroup s_memtime stamps, else NULL
+    // implicit patch matrix (GATHER kernels): A = 16-bit NHWC tensor [n, gH, gW, gC]; row m = output pixel (img, ho, wo) of
+    // a gHo x gWo grid, column k = (ky*gkw + kx)*gC + c -> element (img, ho*gstride - gpad + ky, wo*gstride - gpad + kx, c)
+    int gH, gW, gC, gWo, gHoWo, gkw, gstride, gpad;
 };
 
 // General (slow) epilogue: straight from the MFMA accumulator layout (lane = output row within a 16-row band, 4
@@ -287,7 +290,10 @@ __device__ __forceinline__ void load_epilogue_args(GemmP& ep, const GemmP& p) {
 // -> 2 rounds of 3/4-size tiles).  The LDS image keeps the 128-row B slot; rows >= 32*NI are never fetched.
 // FLAGS (tuning switches, A/B-able in one binary when built with -DEOE_AB): bit 0 = LDS-transposed fast epilogue,
 // bit 1 = sched_group_barrier interleave of fragment reads with MFMAs (2:1)
-template <typename T, int EPI, int NI, int FLAGS>
+// GATHER: the A operand is a convolution's patch matrix that is never materialised -- every 16-B LDS-DMA piece (8
+// channels of one tap of one output pixel) is fetched from the NHWC activation with its own address; taps that fall into
+// the zero padding get the out-of-range offset and arrive as zeros.  gC % 64 == 0, so a 64-deep k-tile is one tap.
+template <typename T, int EPI, int NI, int FLAGS, bool GATHER = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -307,6 +313,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
     // a wave-load (1 KiB) covers 8 tile rows of 128 B; lane -> (row, 16-B slot); the slot holds logical chunk
     // slot ^ ((row>>1)&7).  A image: 256 rows = 32 wave-loads (4 per wave); B image: 128 rows = 16 (2 per wave)
     unsigned offA[4], offB[2];
+    int gh[4], gw[4];                              // GATHER: top-left input coordinate of each staged row's window
+    int g_ky = 0, g_kx = 0, g_c0 = 0;              // GATHER: tap / channel offset of the k-tile being staged (uniform)
     int st_tile = 0, st_kt = 0, st_slot = 0;       // st_tile / c_tile count this workgroup's tiles (0 .. my_tiles)
     // (tried and rejected, measured interleaved on one device: giving each XCD a band of whole tile rows swept
     //  column-major to keep A panels L2-resident -- 587 vs 551 us per layer stand-alone, 10.6 vs 8.2 ms in the step)
@@ -323,7 +331,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
             const int row = (wave * 4 + j) * 8 + (lane >> 3);
             const int c = (lane & 7) ^ ((row >> 1) & 7);
             const int ga = m0 + row;
-            offA[j] = (ga < p.M) ? (unsigned)(((size_t)ga * p.lda + c * 8) * 2) : EOE_OOB;
+            if (GATHER) {
+                if (ga < p.M) {
+                    const int img = ga / p.gHoWo, rem = ga - img * p.gHoWo;
+                    const int ho = rem / p.gWo, wo = rem - ho * p.gWo;
+                    gh[j] = ho * p.gstride - p.gpad;
+                    gw[j] = wo * p.gstride - p.gpad;
+                    offA[j] = (unsigned)((((img * p.gH + gh[j]) * p.gW + gw[j]) * p.gC + c * 8) * 2);   // wraps for h < 0: only used when valid
+                } else {
+                    gh[j] = -(1 << 24);
+                    gw[j] = 0;
+                    offA[j] = 0;
+                }
+            } else {
+                offA[j] = (ga < p.M) ? (unsigned)(((size_t)ga * p.lda + c * 8) * 2) : EOE_OOB;
+            }
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -337,15 +359,31 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
         char* sa = smem + st_slot * STAGE_BYTES;
         char* sb = sa + A_BYTES;
         const unsigned k0 = (unsigned)st_kt * (BK * 2u);
+        if (GATHER) {
+            const unsigned delta = (unsigned)(((g_ky * p.gW + g_kx) * p.gC + g_c0) * 2);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(sa + (wave * 4 + j) * 1024), 16, offA[j] + k0, 0, 0, 0);
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = (unsigned)(gh[j] + g_ky) < (unsigned)p.gH && (unsigned)(gw[j] + g_kx) < (unsigned)p.gW;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(sa + (wave * 4 + j) * 1024), 16,
+                                                         ok ? offA[j] + delta : EOE_OOB, 0, 0, 0);
+            }
+            g_c0 += BK;
+            if (g_c0 == p.gC) {
+                g_c0 = 0;
+                if (++g_kx == p.gkw) { g_kx = 0; ++g_ky; }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(sa + (wave * 4 + j) * 1024), 16, offA[j] + k0, 0, 0, 0);
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(sb + (wave * 2 + j) * 1024), 16, offB[j] + k0, 0, 0, 0);
         st_slot = (st_slot == NSTAGE - 1) ? 0 : st_slot + 1;
         if (++st_kt == nk) {
             st_kt = 0;
+            g_ky = 0; g_kx = 0; g_c0 = 0;
             st_tile += 1;
             if (st_tile < my_tiles) set_offsets(st_tile);
         }
@@ -477,6 +515,17 @@ int launch_nt_f(const GemmP& p, int epi, int grid, hipStream_t s) {
     return 0;
 }
 
+// convolution variants (plain epilogue only): implicit patch matrix and / or the 256x64 tile for cout = 64
+template <typename T, int NI, bool GATHER>
+int launch_nt_conv(const GemmP& p, int grid, hipStream_t s) {
+    static bool once = (hipFuncSetAttribute((const void*)gemm_nt_kernel<T, EOE_EPI_NONE, NI, EOE_NT_DEFAULT_FLAGS, GATHER>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES), true);
+    (void)once;
+    hipLaunchKernelGGL((gemm_nt_kernel<T, EOE_EPI_NONE, NI, EOE_NT_DEFAULT_FLAGS, GATHER>), dim3(grid), dim3(512), SMEM_BYTES, s, p);
+    EOE_CHECK_LAUNCH("gemm_nt");
+    return 0;
+}
+
 template <typename T, int NI>
 int launch_nt_ni(const GemmP& p, int epi, int grid, hipStream_t s) {
 #ifdef EOE_AB
@@ -492,8 +541,15 @@ int launch_nt_ni(const GemmP& p, int epi, int grid, hipStream_t s) {
 }
 
 template <typename T>
-int launch_nt(const GemmP& p, int epi, hipStream_t s) {
+int launch_nt(const GemmP& p, int epi, bool gather, hipStream_t s) {
     static const int ncu = [] { int d = 0, n = 256; hipDeviceProp_t pr; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) n = pr.multiProcessorCount; return n; }();
+    if (gather || (epi == EOE_EPI_NONE && p.N <= 64)) {
+        const bool narrow = p.N <= 64;               // 256x64 tiles: no MFMA / LDS work on columns that do not exist
+        const int tiles = cdiv(p.M, BM) * cdiv(p.N, narrow ? 64 : 128);
+        const int grid = tiles < ncu ? tiles : ncu;
+        if (gather) return narrow ? launch_nt_conv<T, 2, true>(p, grid, s) : launch_nt_conv<T, 4, true>(p, grid, s);
+        return launch_nt_conv<T, 2, false>(p, grid, s);
+    }
     // tile width: 256x128 unless 256x96 needs >= 10 % fewer (rounds x width) units over the CUs
     const int t4 = cdiv(p.M, BM) * cdiv(p.N, 128), t3 = cdiv(p.M, BM) * cdiv(p.N, 96);
     const int c4 = cdiv(t4, ncu) * 4, c3 = cdiv(t3, ncu) * 3;
@@ -516,9 +572,22 @@ int fill_params(const eoe_gemm_args* a, GemmP& p) {
     p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ldaux = a->ldaux;
     p.out_f32 = a->out_f32; p.accumulate = a->accumulate; p.alpha = a->alpha;
     EOE_CHECK_ARG((a->K % BK) == 0, "gemm_nt: K=%d must be a multiple of %d", a->K, BK);
-    EOE_CHECK_ARG(a->lda >= a->K && a->ldb >= a->K, "gemm_nt: leading dims smaller than K");
-    const size_t ba = ((size_t)(a->M - 1) * a->lda + a->K) * 2;
+    EOE_CHECK_ARG(a->ldb >= a->K, "gemm_nt: leading dims smaller than K");
+    size_t ba = ((size_t)(a->M - 1) * a->lda + a->K) * 2;
     const size_t bb = ((size_t)(a->N - 1) * a->ldb + a->K) * 2;
+    p.gH = p.gW = p.gC = p.gWo = p.gHoWo = p.gkw = p.gstride = p.gpad = 0;
+    if (a->gather) {
+        const eoe_conv_geometry& g = a->geo;
+        EOE_CHECK_ARG(a->epilogue == EOE_EPI_NONE, "gemm_nt: an implicit patch matrix supports the plain epilogue only");
+        EOE_CHECK_ARG(g.n > 0 && g.H > 0 && g.W > 0 && g.C > 0 && g.C % BK == 0 && g.kh > 0 && g.kw > 0 && g.stride > 0 && g.pad >= 0 &&
+                      g.Ho > 0 && g.Wo > 0, "gemm_nt: bad conv geometry (C = %d must be a multiple of %d)", g.C, BK);
+        EOE_CHECK_ARG((g.Ho - 1) * g.stride - g.pad + g.kh - 1 < g.H + g.pad + g.kh && a->M == g.n * g.Ho * g.Wo &&
+                      a->K == g.kh * g.kw * g.C, "gemm_nt: conv geometry does not match M = %d, K = %d", a->M, a->K);
+        ba = (size_t)g.n * g.H * g.W * g.C * 2;
+        p.gH = g.H; p.gW = g.W; p.gC = g.C; p.gWo = g.Wo; p.gHoWo = g.Ho * g.Wo; p.gkw = g.kw; p.gstride = g.stride; p.gpad = g.pad;
+    } else {
+        EOE_CHECK_ARG(a->lda >= a->K, "gemm_nt: leading dims smaller than K");
+    }
     EOE_CHECK_ARG(ba < 0x7fffffffull && bb < 0x7fffffffull, "gemm: operand larger than 2 GiB");
     p.bytesA = (unsigned)ba; p.bytesB = (unsigned)bb;
     // diagnostics only: EOE_GEMM_DEBUG=1 makes every operand load out of range (zero-filled, nothing fetched), which
@@ -546,11 +615,12 @@ extern "C" int eoe_gemm_nt(const eoe_gemm_args* a, void* stream) {
     EOE_TRY(fill_params(a, p));
     const int osz = a->out_f32 ? 4 : 2;
     ProfScope ps("gemm_nt", 2.0 * a->M * a->N * a->K,
-                 2.0 * ((double)a->M * a->K + (double)a->N * a->K) + (double)osz * a->M * a->N *
+                 2.0 * ((a->gather ? (double)a->geo.n * a->geo.H * a->geo.W * a->geo.C : (double)a->M * a->K) + (double)a->N * a->K) +
+                     (double)osz * a->M * a->N *
                      (a->epilogue == EOE_EPI_GELU ? 2 : 1) + (a->epilogue == EOE_EPI_RESIDUAL ? 4.0 * a->M * a->N : 0.0) +
                      (a->epilogue == EOE_EPI_GELU_BWD ? 2.0 * a->M * a->N : 0.0), stream);
-    return a->dtype == EOE_F16 ? launch_nt<f16_t>(p, a->epilogue, (hipStream_t)stream)
-                               : launch_nt<bf16_t>(p, a->epilogue, (hipStream_t)stream);
+    return a->dtype == EOE_F16 ? launch_nt<f16_t>(p, a->epilogue, a->gather != 0, (hipStream_t)stream)
+                               : launch_nt<bf16_t>(p, a->epilogue, a->gather != 0, (hipStream_t)stream);
 }
 
 

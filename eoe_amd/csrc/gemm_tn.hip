@@ -17,7 +17,7 @@
 #include "common.h"
 #include <stdlib.h>
 
-int g_tn_flags = 0;     // bit 0: L2 prefetcher wave (option "tn_flags")
+int g_tn_flags = 0;     // option "tn_flags": reserved for A/B experiments (none active)
 
 namespace {
 
@@ -38,6 +38,9 @@ struct TnGroup {
     TnProblem p[EOE_TN_MAX_GROUP];
     int count, T, total_tiles, splits, t_per_split, accumulate;
     float alpha;
+    // GATHER (single-problem groups): geometry of the implicit patch matrix, multiply-shift constants for / (Ho*Wo), / Wo
+    int gH, gW, gC, gWo, gHoWo, gkw, gstride, gpad;
+    unsigned long long mHoWo, mWo;
 };
 
 __device__ __forceinline__ int swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
@@ -52,12 +55,15 @@ __device__ __forceinline__ typename T16<T>::v8 tr_frag(const char* base, int off
     return __builtin_bit_cast(typename T16<T>::v8, r);
 }
 
-// PF: a ninth wavefront per workgroup does nothing but touch the operand lines of k-tile kt+PFD (one dword per 128-B
-// line, results discarded), PFD-2 barrier intervals before the LDS-DMA of that tile is issued: the DMA then hits L2
-// instead of waiting ~an HBM-miss latency behind a one-iteration lead.  It joins every barrier, so it stays in step.
-constexpr int PFD = 6;
-template <typename T, bool PF>
-__global__ __launch_bounds__(PF ? 576 : 512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
+// (An L2-prefetcher ninth wavefront touching the operand lines of k-tile kt+6 was measured and rejected: 356 vs 304 us
+//  stand-alone, 4.58 vs 3.9 ms in the step.)
+// GATHER: the A operand is a convolution's patch matrix [T = n*Ho*Wo pixels, M = kh*kw*C] that is never materialised:
+// each lane's column (tap, channel) is fixed for the whole kernel, its row (pixel) changes every k-tile and is decoded
+// with two multiply-shift divisions; pieces in the zero padding get the out-of-range offset (zero fill).
+__device__ __forceinline__ int div_magic(int x, unsigned long long m) { return (int)(((unsigned long long)(unsigned)x * m) >> 40); }
+
+template <typename T, bool GATHER>
+__global__ __launch_bounds__(512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int split = blockIdx.x / g.total_tiles;
@@ -76,47 +82,11 @@ __global__ __launch_bounds__(PF ? 576 : 512, 2) void gemm_tn_grouped_kernel(TnGr
     __amdgpu_buffer_rsrc_t rb = make_rsrc(P.B, P.bytesB);
     const int lda = P.lda, ldb = P.ldb;
 
-    if (PF && wave == NWAVES) {
-        // ---- L2 prefetcher wave: lane = row of the k-tile; 4 lines of the A slice (512 B) + 2 of the B slice (256 B)
-        const int nkp = (t_end - t_begin + BK - 1) / BK;
-        unsigned sink = 0;
-        const char* pa = (const char*)P.A;
-        const char* pb = (const char*)P.B;
-        const int ca = min(m0, P.M - 1), cb = min(n0, P.N - 1);
-        auto touch = [&](int kt) {
-            int t = t_begin + kt * BK + lane;
-            if (t > t_end - 1) t = t_end - 1;                       // clamp: touching a valid line twice is harmless
-            const char* ra_ = pa + ((size_t)t * lda + ca) * 2;
-            const char* rb_ = pb + ((size_t)t * ldb + cb) * 2;
-            const size_t la = (size_t)(min(256, P.M - ca) * 2 - 4), lb = (size_t)(min(128, P.N - cb) * 2 - 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const char* q = ra_ + min((size_t)j * 128, la);
-                asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(q) : "memory");
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const char* q = rb_ + min((size_t)j * 128, lb);
-                asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(q) : "memory");
-            }
-        };
-        if (nkp > 0) {
-            for (int kt = 2; kt < PFD && kt < nkp; ++kt) touch(kt);
-            __builtin_amdgcn_s_barrier();                            // prologue barrier of the compute waves
-            for (int kt = 0; kt < nkp; ++kt) {
-                if (kt + PFD < nkp) touch(kt + PFD);
-                __builtin_amdgcn_s_barrier();                        // one per k-tile
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("" :: "v"(sink));
-        return;
-    }
-
     // staging.  A image: 64 rows x 512 B -> 32 wave-loads (2 rows each), 4 per wave;
     //           B image: 64 rows x 256 B -> 16 wave-loads (4 rows each), 2 per wave.
     int rowA[4], rowB[2];
     unsigned colA[4], colB[2];
+    int gky[4], gkx[4];                                              // GATHER: tap offset (ky - pad, kx - pad) of the lane's column
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int wl = wave * 4 + j;
@@ -124,7 +94,15 @@ __global__ __launch_bounds__(PF ? 576 : 512, 2) void gemm_tn_grouped_kernel(TnGr
         const int c16 = (((s >> 1) ^ swz(row)) << 1) | (s & 1);      // swz touches the low 3 granule bits only
         rowA[j] = row;
         const int c = m0 + c16 * 8;
-        colA[j] = (c < P.M) ? (unsigned)(c * 2) : EOE_OOB;
+        if (GATHER) {
+            const int tap = c / g.gC, ch = c - tap * g.gC;
+            const int ky = tap / g.gkw;
+            gky[j] = ky - g.gpad;
+            gkx[j] = tap - ky * g.gkw - g.gpad;
+            colA[j] = (c < P.M) ? (unsigned)(ch * 2) : EOE_OOB;
+        } else {
+            colA[j] = (c < P.M) ? (unsigned)(c * 2) : EOE_OOB;
+        }
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -141,7 +119,18 @@ __global__ __launch_bounds__(PF ? 576 : 512, 2) void gemm_tn_grouped_kernel(TnGr
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int t = t0 + rowA[j];
-            const unsigned o = (t < t_end && colA[j] != EOE_OOB) ? (unsigned)((size_t)t * lda * 2) + colA[j] : EOE_OOB;
+            unsigned o = EOE_OOB;
+            if (GATHER) {
+                if (t < t_end && colA[j] != EOE_OOB) {
+                    const int img = div_magic(t, g.mHoWo), rem = t - img * g.gHoWo;
+                    const int ho = div_magic(rem, g.mWo), wo = rem - ho * g.gWo;
+                    const int hh = ho * g.gstride + gky[j], ww = wo * g.gstride + gkx[j];
+                    if ((unsigned)hh < (unsigned)g.gH && (unsigned)ww < (unsigned)g.gW)
+                        o = (unsigned)(((img * g.gH + hh) * g.gW + ww) * g.gC * 2) + colA[j];
+                }
+            } else {
+                o = (t < t_end && colA[j] != EOE_OOB) ? (unsigned)((size_t)t * lda * 2) + colA[j] : EOE_OOB;
+            }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(sa + (wave * 4 + j) * 1024), 16, o, 0, 0, 0);
         }
 #pragma unroll
@@ -252,7 +241,7 @@ int check_problem(const eoe_gemm_args* a, int T, int dtype) {
     EOE_CHECK_ARG((a->lda % 8) == 0 && (a->ldb % 8) == 0, "gemm_tn: lda/ldb must be multiples of 8 (16-B rows)");
     EOE_CHECK_ARG((((uintptr_t)a->A | (uintptr_t)a->B) & 15) == 0, "gemm_tn: A/B must be 16-B aligned");
     EOE_CHECK_ARG((a->M % 8) == 0 && (a->N % 8) == 0, "gemm_tn: M, N must be multiples of 8");
-    EOE_CHECK_ARG(a->lda >= a->M && a->ldb >= a->N && a->ldc >= a->N, "gemm_tn: leading dims too small");
+    EOE_CHECK_ARG((a->gather || a->lda >= a->M) && a->ldb >= a->N && a->ldc >= a->N, "gemm_tn: leading dims too small");
     EOE_CHECK_ARG(a->epilogue == EOE_EPI_NONE && a->out_f32 && !a->bias, "gemm_tn: only plain fp32 output is supported");
     return 0;
 }
@@ -279,7 +268,20 @@ extern "C" int eoe_gemm_tn_grouped(const eoe_gemm_args* args, int count, void* s
         p.tiles_n = cdiv(a->N, BN);
         p.tile_start = tiles;
         tiles += cdiv(a->M, BM) * p.tiles_n;
-        const size_t ba = ((size_t)(T - 1) * a->lda + a->M) * 2, bb = ((size_t)(T - 1) * a->ldb + a->N) * 2;
+        size_t ba = ((size_t)(T - 1) * a->lda + a->M) * 2;
+        const size_t bb = ((size_t)(T - 1) * a->ldb + a->N) * 2;
+        if (a->gather) {
+            const eoe_conv_geometry& q = a->geo;
+            EOE_CHECK_ARG(count == 1, "gemm_tn: an implicit patch matrix cannot be grouped");
+            EOE_CHECK_ARG(q.n > 0 && q.H > 0 && q.W > 0 && q.C > 0 && q.C % 8 == 0 && q.kh > 0 && q.kw > 0 && q.stride > 0 && q.pad >= 0 &&
+                          q.Ho > 0 && q.Wo > 0 && q.Ho * q.Wo < 65536, "gemm_tn: bad conv geometry");
+            EOE_CHECK_ARG(T == q.n * q.Ho * q.Wo && a->M == q.kh * q.kw * q.C && T < (1 << 24),
+                          "gemm_tn: conv geometry does not match T = %d, M = %d", T, a->M);
+            ba = (size_t)q.n * q.H * q.W * q.C * 2;
+            g.gH = q.H; g.gW = q.W; g.gC = q.C; g.gWo = q.Wo; g.gHoWo = q.Ho * q.Wo; g.gkw = q.kw; g.gstride = q.stride; g.gpad = q.pad;
+            g.mHoWo = (1ull << 40) / (unsigned)g.gHoWo + 1;      // exact for x * d < 2^40 (x < 2^24, d < 2^16)
+            g.mWo = (1ull << 40) / (unsigned)g.gWo + 1;
+        }
         EOE_CHECK_ARG(ba < 0x7fffffffull && bb < 0x7fffffffull, "gemm_tn: operand larger than 2 GiB");
         p.bytesA = (unsigned)ba; p.bytesB = (unsigned)bb;
         flops += 2.0 * a->M * a->N * T;
@@ -290,7 +292,7 @@ extern "C" int eoe_gemm_tn_grouped(const eoe_gemm_args* args, int count, void* s
     g.count = count; g.T = T; g.total_tiles = tiles; g.accumulate = args[0].accumulate; g.alpha = args[0].alpha;
     // split the reduction only when the whole group leaves most of the chip idle
     int splits = 1;
-    while (tiles * splits < 128 && splits < 32 && T / (splits * 2) >= 256) splits *= 2;
+    while (tiles * splits < 160 && splits < 128 && T / (splits * 2) >= 512) splits *= 2;
     int t_per = cdiv(cdiv(T, splits), BK) * BK;
     splits = cdiv(T, t_per);
     g.splits = splits; g.t_per_split = t_per;
@@ -303,27 +305,20 @@ extern "C" int eoe_gemm_tn_grouped(const eoe_gemm_args* args, int count, void* s
                 return eoe_set_error(EOE_ERR_LAUNCH, "gemm_tn: memset failed");
         }
     }
+    const bool gather = args[0].gather != 0;
+#define EOE_TN_LAUNCH(TT, GG)                                                                                              \
+    do {                                                                                                                   \
+        static bool once = (hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel<TT, GG>,                               \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES), true);            \
+        (void)once;                                                                                                        \
+        hipLaunchKernelGGL((gemm_tn_grouped_kernel<TT, GG>), dim3(tiles * splits), dim3(512), SMEM_BYTES, s, g);           \
+    } while (0)
     if (dtype == EOE_F16) {
-        if (g_tn_flags & 1) {
-            static bool once = (hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel<f16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES), true);
-            (void)once;
-            hipLaunchKernelGGL((gemm_tn_grouped_kernel<f16_t, true>), dim3(tiles * splits), dim3(576), SMEM_BYTES, s, g);
-        } else {
-            static bool once = (hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel<f16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES), true);
-            (void)once;
-            hipLaunchKernelGGL((gemm_tn_grouped_kernel<f16_t, false>), dim3(tiles * splits), dim3(512), SMEM_BYTES, s, g);
-        }
+        if (gather) EOE_TN_LAUNCH(f16_t, true); else EOE_TN_LAUNCH(f16_t, false);
     } else {
-        if (g_tn_flags & 1) {
-            static bool once = (hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel<bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES), true);
-            (void)once;
-            hipLaunchKernelGGL((gemm_tn_grouped_kernel<bf16_t, true>), dim3(tiles * splits), dim3(576), SMEM_BYTES, s, g);
-        } else {
-            static bool once = (hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel<bf16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES), true);
-            (void)once;
-            hipLaunchKernelGGL((gemm_tn_grouped_kernel<bf16_t, false>), dim3(tiles * splits), dim3(512), SMEM_BYTES, s, g);
-        }
+        if (gather) EOE_TN_LAUNCH(bf16_t, true); else EOE_TN_LAUNCH(bf16_t, false);
     }
+#undef EOE_TN_LAUNCH
     EOE_CHECK_LAUNCH("gemm_tn_grouped");
     return 0;
 }

@@ -15,7 +15,7 @@ namespace {
 
 eoe_gemm_args gemm(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, int lda, int ldb,
                    int ldc, int dtype) {
-    eoe_gemm_args g;
+    eoe_gemm_args g = {};
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = nullptr; g.aux_out = nullptr; g.colsum = nullptr;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = 0;
     g.dtype = dtype; g.epilogue = EOE_EPI_NONE; g.out_f32 = 0; g.accumulate = 0; g.alpha = 1.0f;

@@ -549,28 +549,65 @@ def _conv_kp(cin: int, taps: int = 25) -> int:
 
 
 def _conv_weight_copies(w: torch.Tensor):
-    """16-bit [cout, Kp] / [Kp, cout] copies of a conv weight in patch-column order, cached like `shadow`"""
+    """16-bit copies of a conv weight, cached like `shadow`: [cout, Kp] in patch-column order, its transpose [Kp, cout]
+    (materialised dgrad) and [cin, (taps reversed) x cout] (implicit stride-1 dgrad)"""
     key = ("conv", id(w))
     tag = (w._version, w.data_ptr(), _compute_dtype)
     hit = shadow.cache.get(key)
     if hit is not None and hit[0]() is w and hit[1] == tag:
-        return hit[2], hit[3]
+        return hit[2], hit[3], hit[4]
     cout, cin, kh, kw = w.shape
     kp = _conv_kp(cin, kh * kw)
     w16 = torch.empty((cout, kp), dtype=_compute_dtype, device=w.device)
     w16t = torch.empty((kp, cout), dtype=_compute_dtype, device=w.device)
-    check(lib.eoe_conv_pack_weight(_p(w.detach().contiguous()), _p(w16), _p(w16t), cout, cin, kh, kw, kp,
+    w16d = torch.empty((cin, kh * kw * cout), dtype=_compute_dtype, device=w.device)
+    check(lib.eoe_conv_pack_weight(_p(w.detach().contiguous()), _p(w16), _p(w16t), _p(w16d), cout, cin, kh, kw, kp,
                                    dtype_code(_compute_dtype), _stream()), "eoe_conv_pack_weight")
-    shadow.cache[key] = (weakref.ref(w, lambda _r, k=key, c=shadow.cache: c.pop(k, None)), tag, w16, w16t)
-    return w16, w16t
+    shadow.cache[key] = (weakref.ref(w, lambda _r, k=key, c=shadow.cache: c.pop(k, None)), tag, w16, w16t, w16d)
+    return w16, w16t, w16d
+
+
+_implicit_conv = True
+
+
+def set_implicit_conv(on: bool):
+    """A/B switch: True (default) = convolutions with cin % 64 == 0 fetch their patches inside the GEMM's LDS stage
+    (implicit GEMM); False = every convolution materialises its patch matrix with eoe_im2col"""
+    global _implicit_conv
+    _implicit_conv = bool(on)
+
+
+def conv_gemm_fwd(x16, w16, y, geo, bias=None):
+    """y[n*Ho*Wo, cout] (fp32) = patches(x16) @ w16^T without materialising the patches; x16 16-bit NHWC [n,H,W,C]"""
+    n, H, W, Cc, kh, kw, stride, pad, Ho, Wo = geo
+    M, K, N = n * Ho * Wo, kh * kw * Cc, w16.shape[0]
+    assert x16.is_contiguous() and w16.shape[1] == K and w16.stride(1) == 1 and y.shape == (M, N) and y.stride(1) == 1
+    g = GemmArgs(_p(x16), _p(w16), _p(y), _p(bias), None, None, None, M, N, K, 0, w16.stride(0), y.stride(0), 0,
+                 dtype_code(x16.dtype), EPI_NONE, 1 if y.dtype == torch.float32 else 0, 0, 1.0, 1, _lib.ConvGeometry(*geo))
+    check(lib.eoe_gemm_nt(C.byref(g), _stream()), "eoe_gemm_nt")
+    return y
+
+
+def conv_gemm_wgrad(x16, dy16, gT, geo):
+    """gT[kh*kw*C, cout] (fp32) = patches(x16)^T @ dy16 without materialising the patches"""
+    n, H, W, Cc, kh, kw, stride, pad, Ho, Wo = geo
+    T, M, N = n * Ho * Wo, kh * kw * Cc, dy16.shape[1]
+    assert x16.is_contiguous() and dy16.shape[0] == T and dy16.stride(1) == 1 and gT.shape == (M, N) and gT.is_contiguous()
+    g = GemmArgs(_p(x16), _p(dy16), _p(gT), None, None, None, None, M, N, T, 0, dy16.stride(0), N, 0, dtype_code(x16.dtype),
+                 EPI_NONE, 1, 0, 1.0, 1, _lib.ConvGeometry(*geo))
+    check(lib.eoe_gemm_tn(C.byref(g), _stream()), "eoe_gemm_tn")
+    return gT
 
 
 class ConvBnActPoolFunction(torch.autograd.Function):
     """conv (+ bias) -> BatchNorm2d -> act -> MaxPool(pool), one layer per call: conv5x5(pad 2) + LeakyReLU(0.01) + pool 2
     for `cnn.py:73-82` (the default when cfg has 8 entries); cfg[8] = (kh, kw, stride, pad) and cfg[9] = the activation's
     negative slope (0 = ReLU, 1 = none) give the conv->bn(->relu) units of `resnet.py:93-95,133-141`.
-    Input: the fp32 NCHW image batch (first layer; optional fused Normalize) or an fp32 NHWC activation; output:
-    fp32 NHWC [n, Ho/p, Wo/p, cout], or the reference's NCHW-flattened [n, cout*(Ho/p)*(Wo/p)] (`cnn.py:83`) if flat_out."""
+    Input: the fp32 NCHW image batch (first layer; optional fused Normalize) or an fp32 NHWC activation (a 16-bit copy
+    attached to it as `._eoe16` by the producing op is used instead of casting); output: fp32 NHWC [n, Ho/p, Wo/p, cout], or
+    the reference's NCHW-flattened [n, cout*(Ho/p)*(Wo/p)] (`cnn.py:83`) if flat_out.
+    With cin % 64 == 0 the patch matrix is never built (implicit GEMM: forward, wgrad, and the dgrad of stride-1 convs);
+    otherwise (the 3-channel first layers, CNN32's 32-channel layer) eoe_im2col materialises it once for forward + wgrad."""
 
     @staticmethod
     def forward(ctx, x, conv_w, conv_b, bn_w, bn_b, rm, rv, nbt, cfg):
@@ -578,6 +615,7 @@ class ConvBnActPoolFunction(torch.autograd.Function):
         training, eps, momentum, pool, is_image, mean, std, flat_out = cfg[:8]
         kh, kw, stride, pad = cfg[8] if len(cfg) > 8 else (5, 5, 1, 2)
         slope = float(cfg[9]) if len(cfg) > 9 else 0.01
+        x16 = getattr(x, "_eoe16", None)
         x = x.contiguous().float()
         cout, cin = conv_w.shape[0], conv_w.shape[1]
         if is_image:
@@ -587,12 +625,19 @@ class ConvBnActPoolFunction(torch.autograd.Function):
         H, W = (Hi + 2 * pad - kh) // stride + 1, (Wi + 2 * pad - kw) // stride + 1       # conv output grid
         M, kp, dev, dt = n * H * W, _conv_kp(cin, kh * kw), x.device, _compute_dtype
         code = dtype_code(dt)
-        patches = torch.empty((M, kp), dtype=dt, device=dev)
-        check(lib.eoe_im2col(_p(x), 1 if is_image else 2, _p(mean), _p(std), _p(patches), n, cin, Hi, Wi, kh, kw, stride, pad, kp,
-                             code, _stream()), "eoe_im2col")
-        w16, _ = _conv_weight_copies(conv_w)
+        implicit = _implicit_conv and (not is_image) and cin % 64 == 0
+        w16, _, _ = _conv_weight_copies(conv_w)
         y = torch.empty((M, cout), dtype=torch.float32, device=dev)
-        gemm_nt(patches, w16, y, bias=conv_b)
+        if implicit:
+            if x16 is None or x16.dtype != dt or x16.shape != x.shape:
+                x16 = cast16(x.view(-1, cin)).view(n, Hi, Wi, cin)
+            operand = x16
+            conv_gemm_fwd(x16, w16, y, (n, Hi, Wi, cin, kh, kw, stride, pad, H, W), bias=conv_b)
+        else:
+            operand = torch.empty((M, kp), dtype=dt, device=dev)
+            check(lib.eoe_im2col(_p(x), 1 if is_image else 2, _p(mean), _p(std), _p(operand), n, cin, Hi, Wi, kh, kw, stride, pad,
+                                 kp, code, _stream()), "eoe_im2col")
+            gemm_nt(operand, w16, y, bias=conv_b)
         stats = torch.empty(2 * cout, dtype=torch.float32, device=dev)
         sums = scratch("bn_sums", (2 * cout,), torch.float32, dev)
         check(lib.eoe_bn_stats(_p(y), _p(sums), _p(stats), _p(rm), _p(rv), _p(nbt), M, cout, float(eps), float(momentum),
@@ -601,15 +646,15 @@ class ConvBnActPoolFunction(torch.autograd.Function):
         out = torch.empty((n, cout * Ho * Wo) if flat_out else (n, Ho, Wo, cout), dtype=torch.float32, device=dev)
         check(lib.eoe_bn_act_pool_fwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(out), n, H, W, cout, pool, 1 if flat_out else 0,
                                       1, slope, code, _stream()), "eoe_bn_act_pool_fwd")
-        ctx.save_for_backward(patches, y, stats, conv_w, conv_b, bn_w, bn_b)
-        ctx.cfg = (n, H, W, cin, cout, kp, pool, flat_out, training, is_image, Hi, Wi, kh, kw, stride, pad, slope)
+        ctx.save_for_backward(operand, y, stats, conv_w, conv_b, bn_w, bn_b)
+        ctx.cfg = (n, H, W, cin, cout, kp, pool, flat_out, training, is_image, Hi, Wi, kh, kw, stride, pad, slope, implicit)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        patches, y, stats, conv_w, conv_b, bn_w, bn_b = ctx.saved_tensors
-        n, H, W, cin, cout, kp, pool, flat_out, training, is_image, Hi, Wi, kh, kw, stride, pad, slope = ctx.cfg
-        dev, dt = y.device, patches.dtype
+        operand, y, stats, conv_w, conv_b, bn_w, bn_b = ctx.saved_tensors
+        n, H, W, cin, cout, kp, pool, flat_out, training, is_image, Hi, Wi, kh, kw, stride, pad, slope, implicit = ctx.cfg
+        dev, dt = y.device, operand.dtype
         code = dtype_code(dt)
         M = n * H * W
         dout = dout.contiguous().float()
@@ -620,21 +665,31 @@ class ConvBnActPoolFunction(torch.autograd.Function):
         check(lib.eoe_bn_act_pool_bwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(dout), _p(red), _p(dy16), 0, _p(dg), _p(db), n, H,
                                       W, cout, pool, 1 if flat_out else 0, 1 if training else 0, 0, slope, code, _stream()),
               "eoe_bn_act_pool_bwd")
-        g = torch.empty((cout, kp), dtype=torch.float32, device=dev)
-        gemm_tn(dy16, patches, g)
         dw = _grad_target(conv_w)
-        check(lib.eoe_conv_unpack_wgrad(_p(g), _p(dw), cout, cin, kh, kw, kp, 0, _stream()), "eoe_conv_unpack_wgrad")
+        if implicit:
+            gT = torch.empty((kh * kw * cin, cout), dtype=torch.float32, device=dev)
+            conv_gemm_wgrad(operand, dy16, gT, (n, Hi, Wi, cin, kh, kw, stride, pad, H, W))
+            check(lib.eoe_conv_unpack_wgrad(_p(gT), _p(dw), cout, cin, kh, kw, kp, 1, 0, _stream()), "eoe_conv_unpack_wgrad")
+        else:
+            g = torch.empty((cout, kp), dtype=torch.float32, device=dev)
+            gemm_tn(dy16, operand, g)
+            check(lib.eoe_conv_unpack_wgrad(_p(g), _p(dw), cout, cin, kh, kw, kp, 0, 0, _stream()), "eoe_conv_unpack_wgrad")
         dcb = None
         if conv_b is not None:
             dcb = _grad_target(conv_b)
             colsum(dy16, dcb)
         dx = None
         if ctx.needs_input_grad[0] and not is_image:
-            _, w16t = _conv_weight_copies(conv_w)
-            dpatches = torch.empty((M, kp), dtype=dt, device=dev)
-            gemm_nt(dy16, w16t, dpatches)
+            _, w16t, w16d = _conv_weight_copies(conv_w)
             dx = torch.empty((n, Hi, Wi, cin), dtype=torch.float32, device=dev)
-            check(lib.eoe_col2im(_p(dpatches), _p(dx), n, cin, Hi, Wi, kh, kw, stride, pad, kp, code, _stream()), "eoe_col2im")
+            if _implicit_conv and stride == 1 and kh == kw and cout % 64 == 0:
+                # dx = conv of dy with the flipped kernel: the same implicit GEMM, gathering from dy16 [n, H, W, cout]
+                conv_gemm_fwd(dy16.view(n, H, W, cout), w16d, dx.view(-1, cin),
+                              (n, H, W, cout, kh, kw, 1, kh - 1 - pad, Hi, Wi))
+            else:
+                dpatches = torch.empty((M, kp), dtype=dt, device=dev)
+                gemm_nt(dy16, w16t, dpatches)
+                check(lib.eoe_col2im(_p(dpatches), _p(dx), n, cin, Hi, Wi, kh, kw, stride, pad, kp, code, _stream()), "eoe_col2im")
         return dx, dw, dcb, dg, db, None, None, None, None
 
 

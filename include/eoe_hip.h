@@ -45,6 +45,16 @@ enum {
     EOE_EPI_GELU_BWD = 3   /* C = acc * d/dpre[pre sigmoid(1.702 pre)],  pre = aux (16-bit [M,N])      */
 };
 
+/* geometry of a convolution whose patch matrix is never materialised ("implicit GEMM": the GEMM kernel fetches every
+ * 16-byte piece -- 8 channels of one tap of one output pixel -- from the 16-bit NHWC activation [n, H, W, C] straight into
+ * its LDS stage; taps in the zero padding arrive as zeros).  Patch row = output pixel (img, ho, wo) of the Ho x Wo grid,
+ * patch column = (ky*kw + kx)*C + c  ->  element (img, ho*stride - pad + ky, wo*stride - pad + kx, c). */
+typedef struct {
+    int32_t n, H, W, C;           /* gathered tensor */
+    int32_t kh, kw, stride, pad;
+    int32_t Ho, Wo;               /* grid of patch rows */
+} eoe_conv_geometry;
+
 typedef struct {
     const void* A;      /* 16-bit */
     const void* B;      /* 16-bit */
@@ -60,6 +70,10 @@ typedef struct {
     int32_t out_f32;    /* C is fp32 */
     int32_t accumulate; /* C += result (C must be fp32) */
     float alpha;        /* result scale applied to acc before bias/epilogue (1.0 = none) */
+    int32_t gather;     /* 1: A is the NHWC tensor of `geo` and stands for its patch matrix (lda ignored).
+                         *    NT: [M = n*Ho*Wo, K = kh*kw*C], C % 64 == 0, plain epilogue (conv forward; stride-1 dgrad)
+                         *    TN: [T = n*Ho*Wo, M = kh*kw*C], C % 8 == 0 (conv wgrad, transposed: C[kh*kw*C, cout]) */
+    eoe_conv_geometry geo;
 } eoe_gemm_args;
 
 int eoe_gemm_nt(const eoe_gemm_args* args, void* stream);
@@ -238,11 +252,13 @@ int eoe_im2col(const void* x, int x_kind, const float* mean, const float* std, v
 /* dx fp32 NHWC [n,H,W,C] = transpose of im2col applied to dpatches 16-bit [n*Ho*Wo, Kp] */
 int eoe_col2im(const void* dpatches, float* dx, int n, int C, int H, int W, int kh, int kw, int stride, int pad, int Kp,
                int dtype, void* stream);
-/* conv weight fp32 [cout,cin,kh,kw] -> 16-bit [cout,Kp] (patch column order) and transposed [Kp,cout]; and the inverse
- * reorder of the fp32 weight gradient [cout,Kp] -> [cout,cin,kh,kw] */
-int eoe_conv_pack_weight(const float* w, void* w16, void* w16t, int cout, int cin, int kh, int kw, int Kp, int dtype,
-                         void* stream);
-int eoe_conv_unpack_wgrad(const float* g, float* dw, int cout, int cin, int kh, int kw, int Kp, int accumulate, void* stream);
+/* conv weight fp32 [cout,cin,kh,kw] -> 16-bit [cout,Kp] (patch column order), optionally its transpose [Kp,cout] and the
+ * operand of the implicit stride-1 dgrad [cin, (kh*kw reversed) x cout] (dx = conv of dy with the flipped kernel);
+ * and the inverse reorder of the fp32 weight gradient [cout,Kp] (or, transposed, [kh*kw*cin, cout]) -> [cout,cin,kh,kw] */
+int eoe_conv_pack_weight(const float* w, void* w16, void* w16t, void* w16d, int cout, int cin, int kh, int kw, int Kp,
+                         int dtype, void* stream);
+int eoe_conv_unpack_wgrad(const float* g, float* dw, int cout, int cin, int kh, int kw, int Kp, int transposed,
+                          int accumulate, void* stream);
 /* batch statistics of y fp32 [M,C]: stats[0..C) = mean, stats[C..2C) = 1/sqrt(var+eps) (biased var); training updates
  * running_mean/var (momentum, unbiased var) and num_batches_tracked as nn.BatchNorm does (cnn.py:57-66); eval reads
  * the running buffers.  sums_scratch: 2*C floats. */

@@ -132,7 +132,7 @@ def test_cnn32_trajectory_vs_golden(golden, clf, obj):
     # implementations already differ by 2e-4 after 5 steps, tests/test_oracle_golden.py; fp16 GEMM operands start from
     # 5e-4, and fp32 atomics make the run-to-run noise differ): the stated 1e-3 bar holds for the forward pass and
     # the first update; later steps are held to 1e-2 (measured 2e-3 .. 5e-3)
-    assert dl[0] < 1e-4 and dl[1] < 2e-3 and dl.max() < 1e-2, (losses, g["losses"])
+    assert dl[0] < 3e-4 and dl[1] < 2e-3 and dl.max() < 1e-2, (losses, g["losses"])
     assert np.abs(scores[0] - g["scores"][0]).max() < 1e-3 and ds < 2e-2
     for k, v in bufs0.items():
         np.testing.assert_allclose(v.cpu().numpy(), g[f"buf0/{k}"], rtol=2e-3, atol=2e-3)

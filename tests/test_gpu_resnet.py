@@ -73,6 +73,36 @@ def test_conv_bn_general_vs_oracle(dtype, n, cin, cout, H, k, s, p, slope, is_im
         assert r < tol, ("dx", r)
 
 
+@pytest.mark.parametrize("n,cin,cout,H,k,s,p", [(5, 64, 64, 13, 3, 1, 1), (3, 128, 256, 14, 3, 2, 1), (2, 64, 128, 9, 1, 2, 0),
+                                               (2, 256, 64, 7, 3, 1, 1), (1, 64, 192, 30, 5, 1, 2)])
+def test_implicit_conv_equals_materialised(n, cin, cout, H, k, s, p):
+    """the implicit-GEMM path (patches fetched inside the GEMM's LDS stage: forward, wgrad, stride-1 dgrad) against the
+    materialised im2col / col2im path on the same 16-bit operands: same products, different summation order only"""
+    import eoe_amd.ops as ops
+    x, _ = f32("ic/x", (n, H, H, cin), 1.0)
+    w, _ = f32("ic/w", (cout, cin, k, k), (1.0 / (k * k * cin)) ** 0.5)
+    g, _ = f32("ic/g", (cout,), 0.1, mean=1.0)
+    b, _ = f32("ic/b", (cout,), 0.1)
+    res = {}
+    for mode in (True, False):
+        ops.set_implicit_conv(mode)
+        try:
+            xin = x.clone().requires_grad_(True)
+            wg, gg, bg = (t.clone().requires_grad_(True) for t in (w, g, b))
+            rm, rv = torch.zeros(cout, device="cuda"), torch.ones(cout, device="cuda")
+            nbt = torch.zeros((), dtype=torch.long, device="cuda")
+            cfg = (True, 1e-5, 0.1, 1, False, None, None, False, (k, k, s, p), 0.0)
+            out = ops.ConvBnActPoolFunction.apply(xin, wg, None, gg, bg, rm, rv, nbt, cfg)
+            dout, _ = f32("ic/dout", tuple(out.shape), 1.0)
+            (out * dout).sum().backward()
+            res[mode] = (out.detach(), xin.grad, wg.grad, gg.grad, bg.grad)
+        finally:
+            ops.set_implicit_conv(True)
+    for name, a, bb in zip(("out", "dx", "dw", "dgamma", "dbeta"), res[True], res[False]):
+        r = rel_rms(a, bb.cpu())
+        assert r < 2e-3, (name, r)        # dy16 is rounded to 16 bit after slightly different fp32 sums: a few flipped roundings
+
+
 @pytest.mark.parametrize("n,C,H,W", [(2, 64, 16, 16), (3, 16, 9, 7), (1, 64, 112, 112)])
 def test_maxpool_3x3_s2(n, C, H, W):
     """nn.MaxPool2d(3, 2, 1) incl. ties after a ReLU (the first maximum takes the gradient) -- exact"""
