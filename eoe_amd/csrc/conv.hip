@@ -119,12 +119,56 @@ __global__ __launch_bounds__(256) void conv_unpack_kernel(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------- packed 3-channel first layer
+// image fp32 NCHW [n,3,H,W] (+ per-channel normalise) -> 16-bit [n, Hp, Wp, 4] with the conv's zero padding made physical
+// (pixel (h, w) lands at (h + pad, w + pad); channel 3 and the border are 0): the operand of the GATHER == 2 GEMMs
+template <typename T>
+__global__ __launch_bounds__(256) void stem_pack_image_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                              const float* __restrict__ stdv, T* __restrict__ out, int n, int H, int W,
+                                                              int Hp, int Wp, int pad) {
+    const size_t total = (size_t)n * Hp * Wp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int wp = (int)(i % Wp), hp = (int)((i / Wp) % Hp), img = (int)(i / ((size_t)Wp * Hp));
+        const int h = hp - pad, w = wp - pad;
+        float v[3] = {0.f, 0.f, 0.f};
+        if (h >= 0 && h < H && w >= 0 && w < W) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                v[c] = x[(((size_t)img * 3 + c) * H + h) * W + w];
+                if (mean) v[c] = (v[c] - mean[c]) / stdv[c];
+            }
+        }
+        *(u32x2*)(out + i * 4) = pack4<T>(v[0], v[1], v[2], 0.f);
+    }
+}
+// w fp32 [cout,3,kh,kw] -> 16-bit [cout, K], K = ceil(kh/2)*64, column = ky*32 + kx*4 + c (zero where ky >= kh, kx >= kw, c = 3)
+template <typename T>
+__global__ __launch_bounds__(256) void stem_pack_weight_kernel(const float* __restrict__ w, T* __restrict__ w16, int cout, int kh, int kw, int K) {
+    const int total = cout * K;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int o = i / K, col = i % K;
+        const int ky = col >> 5, kx = (col >> 2) & 7, c = col & 3;
+        float v = 0.f;
+        if (ky < kh && kx < kw && c < 3) v = w[(((size_t)o * 3 + c) * kh + ky) * kw + kx];
+        w16[i] = (T)v;
+    }
+}
+// gT fp32 [K, cout] -> dw fp32 [cout,3,kh,kw]
+__global__ __launch_bounds__(256) void stem_unpack_kernel(const float* __restrict__ g, float* __restrict__ dw, int cout, int kh, int kw) {
+    const int total = cout * 3 * kh * kw;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int kx = i % kw, ky = (i / kw) % kh, c = (i / (kw * kh)) % 3, o = i / (3 * kh * kw);
+        dw[i] = g[(size_t)(ky * 32 + kx * 4 + c) * cout + o];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- BatchNorm
-// column sums of y and y^2 over M rows, y fp32 [M, C]; sums[0..C) += sum, sums[C..2C) += sumsq (fp32 atomics of
-// per-workgroup partial sums accumulated in double).  VEC = 4: a thread owns 4 adjacent channels (16-B loads), cpb
+// column sums of y and y^2 over M rows, y fp32 [M, C]: workgroup (bx, by) writes its partial sums (accumulated in double)
+// to row by of part[gridDim.y][2C] -- no atomics (device-scope float atomics from 8 XCDs cost ~80 us per call here,
+// more than the streaming pass itself), no zero-init; bn_finalize_kernel adds the rows up.  VEC = 4: a thread owns 4 adjacent channels (16-B loads), cpb
 // thread-columns x rpb row lanes per workgroup; VEC = 1 for C not a multiple of 4 (the 1-channel gate BatchNorm).
 template <int VEC>
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ y, float* __restrict__ sums, int M, int C, int cpb) {
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ y, float* __restrict__ part, int M, int C, int cpb) {
     __shared__ double red[2][256][VEC];
     const int rpb = 256 / cpb;
     const int c = (blockIdx.x * cpb + threadIdx.x % cpb) * VEC;
@@ -167,24 +211,51 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
         for (int k = 1; k < rpb; ++k)
 #pragma unroll
             for (int r = 0; r < VEC; ++r) { s[r] += red[0][threadIdx.x + k * cpb][r]; q[r] += red[1][threadIdx.x + k * cpb][r]; }
+        float* row = part + (size_t)blockIdx.y * 2 * C;
 #pragma unroll
         for (int r = 0; r < VEC; ++r) {
-            atomicAdd(sums + c + r, (float)s[r]);
-            atomicAdd(sums + C + c + r, (float)q[r]);
+            row[c + r] = (float)s[r];
+            row[C + c + r] = (float)q[r];
         }
+    }
+}
+
+// out[i] = sum_p part[p][i], i < n: 64 columns x 16 row lanes per workgroup (P <= 1024 rows: <= 64 independent loads each)
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int P, int n) {
+    __shared__ float l[1024];
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+    float s = 0.f;
+    if (i < n)
+        for (int p = lane; p < P; p += 16) s += part[(size_t)p * n + i];
+    l[threadIdx.x] = s;
+    __syncthreads();
+    if (lane == 0 && i < n) {
+        for (int k = 1; k < 16; ++k) s += l[threadIdx.x + 64 * k];
+        out[i] = s;
     }
 }
 
 // sums -> stats[0..C) = mean, stats[C..2C) = rstd; running buffers updated as nn.BatchNorm does (momentum 0.1,
 // unbiased variance for the running estimate)
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ sums, float* __restrict__ stats,
-                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                          int64_t* __restrict__ nbt, int M, int C, float eps, float momentum) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && nbt) nbt[0] += 1;
-    if (c >= C) return;
-    const double mean = (double)sums[c] / M;
-    double var = (double)sums[C + c] / M - mean * mean;
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int P, float* __restrict__ stats,
+                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                           int64_t* __restrict__ nbt, int M, int C, float eps, float momentum) {
+    __shared__ double l[2][1024];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int p = lane; p < P; p += 16) {
+            s += part[(size_t)p * 2 * C + c];
+            q += part[(size_t)p * 2 * C + C + c];
+        }
+    l[0][threadIdx.x] = s;
+    l[1][threadIdx.x] = q;
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
+    if (lane != 0 || c >= C) return;
+    for (int k = 1; k < 16; ++k) { s += l[0][threadIdx.x + 64 * k]; q += l[1][threadIdx.x + 64 * k]; }
+    const double mean = s / M;
+    double var = q / M - mean * mean;
     if (var < 0) var = 0;
     stats[c] = (float)mean;
     stats[C + c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -333,7 +404,8 @@ __global__ __launch_bounds__(256) void bn_act_pool_bwd_kernel(const float* __res
             }
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(red + i, lds[i]);
+        float* row = red + (size_t)(1 + blockIdx.x) * 2 * C;          // partial row of this workgroup (row 0 = the total)
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) row[i] = lds[i];
     }
 }
 
@@ -424,6 +496,34 @@ extern "C" int eoe_conv_unpack_wgrad(const float* g, float* dw, int cout, int ci
     return 0;
 }
 
+extern "C" int eoe_stem_pack_image(const float* x, const float* mean, const float* stdv, void* out, int n, int H, int W, int Hp,
+                                   int Wp, int pad, int dtype, void* stream) {
+    EOE_CHECK_ARG(x && out && n > 0 && H > 0 && W > 0 && pad >= 0 && Hp >= H + pad && Wp >= W + pad, "stem_pack_image: bad args");
+    EOE_CHECK_ARG((mean == nullptr) == (stdv == nullptr), "stem_pack_image: mean/std must both be given or both NULL");
+    ProfScope ps("stem_pack", 0, 12.0 * n * H * W + 8.0 * n * Hp * Wp, stream);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((stem_pack_image_kernel<T>), dim3(grid_for((size_t)n * Hp * Wp)), dim3(256), 0,
+                                         (hipStream_t)stream, x, mean, stdv, (T*)out, n, H, W, Hp, Wp, pad));
+    EOE_CHECK_LAUNCH("stem_pack_image");
+    return 0;
+}
+
+extern "C" int eoe_stem_pack_weight(const float* w, void* w16, int cout, int kh, int kw, int dtype, void* stream) {
+    EOE_CHECK_ARG(w && w16 && cout > 0 && kh > 0 && kw > 0 && kw <= 8, "stem_pack_weight: bad args");
+    const int K = (kh + 1) / 2 * 64;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((stem_pack_weight_kernel<T>), dim3(grid_for((size_t)cout * K)), dim3(256), 0,
+                                         (hipStream_t)stream, w, (T*)w16, cout, kh, kw, K));
+    EOE_CHECK_LAUNCH("stem_pack_weight");
+    return 0;
+}
+
+extern "C" int eoe_stem_unpack_wgrad(const float* g, float* dw, int cout, int kh, int kw, void* stream) {
+    EOE_CHECK_ARG(g && dw && cout > 0 && kh > 0 && kw > 0 && kw <= 8, "stem_unpack_wgrad: bad args");
+    hipLaunchKernelGGL(stem_unpack_kernel, dim3(grid_for((size_t)cout * 3 * kh * kw)), dim3(256), 0, (hipStream_t)stream, g, dw, cout,
+                       kh, kw);
+    EOE_CHECK_LAUNCH("stem_unpack_wgrad");
+    return 0;
+}
+
 extern "C" int eoe_bn_stats(const float* y, float* sums_scratch, float* stats, float* running_mean, float* running_var,
                             int64_t* num_batches_tracked, int M, int C, float eps, float momentum, int training, void* stream) {
     EOE_CHECK_ARG(stats && M > 0 && C > 0, "bn_stats: bad args");
@@ -440,17 +540,17 @@ extern "C" int eoe_bn_stats(const float* y, float* sums_scratch, float* stats, f
     int cpb = 1;
     while (cpb < 64 && cpb < cols) cpb *= 2;      // power of two <= 64 so that it divides 256
     ProfScope ps("bn_stats", 0, 4.0 * M * C, stream);
-    if (hipMemsetAsync(sums_scratch, 0, 2 * C * sizeof(float), s) != hipSuccess) return eoe_set_error(EOE_ERR_LAUNCH, "bn_stats: memset failed");
     const int rpb = 256 / cpb;
     int gy = cdiv(M, rpb * 16);
     const int gx = cdiv(cols, cpb);
     if (gy * gx > 1024) gy = 1024 / gx;
+    if (gy > 512) gy = 512;
     if (gy < 1) gy = 1;
     if (vec == 4) hipLaunchKernelGGL(bn_stats_kernel<4>, dim3(gx, gy), dim3(256), 0, s, y, sums_scratch, M, C, cpb);
     else hipLaunchKernelGGL(bn_stats_kernel<1>, dim3(gx, gy), dim3(256), 0, s, y, sums_scratch, M, C, cpb);
     EOE_CHECK_LAUNCH("bn_stats");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, sums_scratch, stats, running_mean, running_var,
-                       num_batches_tracked, M, C, eps, momentum);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, s, (const float*)sums_scratch, gy, stats, running_mean,
+                       running_var, num_batches_tracked, M, C, eps, momentum);
     EOE_CHECK_LAUNCH("bn_finalize");
     return 0;
 }
@@ -479,13 +579,13 @@ extern "C" int eoe_bn_act_pool_bwd(const float* y, const float* stats, const flo
     EOE_CHECK_ARG(C <= 4096, "bn_act_pool_bwd: C too large");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps("bn_act_pool_bwd", 0, 2 * 4.0 * n * H * W * C + 2.0 * n * H * W * C, stream);
-    if (hipMemsetAsync(red_scratch, 0, 2 * C * sizeof(float), s) != hipSuccess) return eoe_set_error(EOE_ERR_LAUNCH, "bn_act_pool_bwd: memset failed");
     const int grid = grid_for((size_t)n * (H / pool) * (W / pool) * C / 4);
-    int g0 = grid > 1024 ? 1024 : grid;
+    int g0 = grid > EOE_BN_PARTIALS ? EOE_BN_PARTIALS : grid;
     {   // reduce pass: gridDim.x * 256 must be a multiple of C/4 (one channel quad per thread)
         int cc = C / 4, a = cc, b = 256;
         while (b) { const int t = a % b; a = b; b = t; }
         const int q = cc / a;                     // cc / gcd(cc, 256)
+        EOE_CHECK_ARG(q <= EOE_BN_PARTIALS, "bn_act_pool_bwd: C = %d not supported", C);
         g0 = g0 / q * q;
         if (g0 < q) g0 = q;
     }
@@ -494,6 +594,9 @@ extern "C" int eoe_bn_act_pool_bwd(const float* y, const float* stats, const flo
                                          beta, dout, red_scratch, dy, dy_f32, n, H, W, C, nchw_flat, training, slope))
     if (pool == 1) { EOE_BNB(0, 1, g0, 2 * C * sizeof(float)); } else { EOE_BNB(0, 2, g0, 2 * C * sizeof(float)); }
     EOE_CHECK_LAUNCH("bn_act_pool_bwd_reduce");
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * C, 64)), dim3(1024), 0, s, (const float*)(red_scratch + 2 * C), red_scratch, g0,
+                       2 * C);
+    EOE_CHECK_LAUNCH("bn_act_pool_bwd_reduce2");
     if (pool == 1) { EOE_BNB(1, 1, grid, 0); } else { EOE_BNB(1, 2, grid, 0); }
     EOE_CHECK_LAUNCH("bn_act_pool_bwd_apply");
 #undef EOE_BNB

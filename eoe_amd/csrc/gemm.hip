@@ -37,6 +37,9 @@ struct GemmP {
     // implicit patch matrix (GATHER kernels): A = 16-bit NHWC tensor [n, gH, gW, gC]; row m = output pixel (img, ho, wo) of
     // a gHo x gWo grid, column k = (ky*gkw + kx)*gC + c -> element (img, ho*gstride - gpad + ky, wo*gstride - gpad + kx, c)
     int gH, gW, gC, gWo, gHoWo, gkw, gstride, gpad;
+    // GATHER == 2 (3-channel first layer): A = physically zero-padded 16-bit [n, gH, gW, 4] image; a 128-B k-tile = 2 kernel
+    // rows x 8 pixels x 4 channels, i.e. 16-B piece q of k-tile kt = pixels (2*(q&3), +1) of kernel row 2*kt + (q>>2)
+    int gkstep;       // bytes between consecutive k-tiles = 2 * gW * 8
 };
 
 // General (slow) epilogue: straight from the MFMA accumulator layout (lane = output row within a 16-row band, 4
@@ -293,7 +296,7 @@ __device__ __forceinline__ void load_epilogue_args(GemmP& ep, const GemmP& p) {
 // GATHER: the A operand is a convolution's patch matrix that is never materialised -- every 16-B LDS-DMA piece (8
 // channels of one tap of one output pixel) is fetched from the NHWC activation with its own address; taps that fall into
 // the zero padding get the out-of-range offset and arrive as zeros.  gC % 64 == 0, so a 64-deep k-tile is one tap.
-template <typename T, int EPI, int NI, int FLAGS, bool GATHER = false>
+template <typename T, int EPI, int NI, int FLAGS, int GATHER = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -331,7 +334,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
             const int row = (wave * 4 + j) * 8 + (lane >> 3);
             const int c = (lane & 7) ^ ((row >> 1) & 7);
             const int ga = m0 + row;
-            if (GATHER) {
+            if (GATHER == 2) {
+                if (ga < p.M) {
+                    const int img = ga / p.gHoWo, rem = ga - img * p.gHoWo;
+                    const int ho = rem / p.gWo, wo = rem - ho * p.gWo;
+                    offA[j] = (unsigned)((((img * p.gH + ho * p.gstride + (c >> 2)) * p.gW + wo * p.gstride + 2 * (c & 3)) * 4) * 2);
+                } else {
+                    offA[j] = EOE_OOB;
+                }
+            } else if (GATHER == 1) {
                 if (ga < p.M) {
                     const int img = ga / p.gHoWo, rem = ga - img * p.gHoWo;
                     const int ho = rem / p.gWo, wo = rem - ho * p.gWo;
@@ -359,7 +370,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
         char* sa = smem + st_slot * STAGE_BYTES;
         char* sb = sa + A_BYTES;
         const unsigned k0 = (unsigned)st_kt * (BK * 2u);
-        if (GATHER) {
+        const unsigned kA = (GATHER == 2) ? (unsigned)(st_kt * p.gkstep) : k0;
+        if (GATHER == 1) {
             const unsigned delta = (unsigned)(((g_ky * p.gW + g_kx) * p.gC + g_c0) * 2);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -375,7 +387,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(sa + (wave * 4 + j) * 1024), 16, offA[j] + k0, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(sa + (wave * 4 + j) * 1024), 16, offA[j] + kA, 0, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -516,7 +528,7 @@ int launch_nt_f(const GemmP& p, int epi, int grid, hipStream_t s) {
 }
 
 // convolution variants (plain epilogue only): implicit patch matrix and / or the 256x64 tile for cout = 64
-template <typename T, int NI, bool GATHER>
+template <typename T, int NI, int GATHER>
 int launch_nt_conv(const GemmP& p, int grid, hipStream_t s) {
     static bool once = (hipFuncSetAttribute((const void*)gemm_nt_kernel<T, EOE_EPI_NONE, NI, EOE_NT_DEFAULT_FLAGS, GATHER>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES), true);
@@ -541,14 +553,15 @@ int launch_nt_ni(const GemmP& p, int epi, int grid, hipStream_t s) {
 }
 
 template <typename T>
-int launch_nt(const GemmP& p, int epi, bool gather, hipStream_t s) {
+int launch_nt(const GemmP& p, int epi, int gather, hipStream_t s) {
     static const int ncu = [] { int d = 0, n = 256; hipDeviceProp_t pr; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) n = pr.multiProcessorCount; return n; }();
     if (gather || (epi == EOE_EPI_NONE && p.N <= 64)) {
         const bool narrow = p.N <= 64;               // 256x64 tiles: no MFMA / LDS work on columns that do not exist
         const int tiles = cdiv(p.M, BM) * cdiv(p.N, narrow ? 64 : 128);
         const int grid = tiles < ncu ? tiles : ncu;
-        if (gather) return narrow ? launch_nt_conv<T, 2, true>(p, grid, s) : launch_nt_conv<T, 4, true>(p, grid, s);
-        return launch_nt_conv<T, 2, false>(p, grid, s);
+        if (gather == 2) return narrow ? launch_nt_conv<T, 2, 2>(p, grid, s) : launch_nt_conv<T, 4, 2>(p, grid, s);
+        if (gather) return narrow ? launch_nt_conv<T, 2, 1>(p, grid, s) : launch_nt_conv<T, 4, 1>(p, grid, s);
+        return launch_nt_conv<T, 2, 0>(p, grid, s);
     }
     // tile width: 256x128 unless 256x96 needs >= 10 % fewer (rounds x width) units over the CUs
     const int t4 = cdiv(p.M, BM) * cdiv(p.N, 128), t3 = cdiv(p.M, BM) * cdiv(p.N, 96);
@@ -575,8 +588,18 @@ int fill_params(const eoe_gemm_args* a, GemmP& p) {
     EOE_CHECK_ARG(a->ldb >= a->K, "gemm_nt: leading dims smaller than K");
     size_t ba = ((size_t)(a->M - 1) * a->lda + a->K) * 2;
     const size_t bb = ((size_t)(a->N - 1) * a->ldb + a->K) * 2;
-    p.gH = p.gW = p.gC = p.gWo = p.gHoWo = p.gkw = p.gstride = p.gpad = 0;
-    if (a->gather) {
+    p.gH = p.gW = p.gC = p.gWo = p.gHoWo = p.gkw = p.gstride = p.gpad = p.gkstep = 0;
+    if (a->gather == 2) {
+        const eoe_conv_geometry& g = a->geo;
+        EOE_CHECK_ARG(a->epilogue == EOE_EPI_NONE, "gemm_nt: an implicit patch matrix supports the plain epilogue only");
+        EOE_CHECK_ARG(g.n > 0 && g.C == 4 && g.kh > 0 && g.kw > 0 && g.kw <= 8 && g.stride > 0 && g.stride % 2 == 0 && g.pad == 0 && g.Ho > 0 &&
+                      g.Wo > 0 && g.W % 2 == 0, "gemm_nt: bad packed first-layer geometry");
+        EOE_CHECK_ARG((g.Ho - 1) * g.stride + g.kh <= g.H && (g.Wo - 1) * g.stride + 8 <= g.W && a->M == g.n * g.Ho * g.Wo &&
+                      a->K == (g.kh + 1) / 2 * BK, "gemm_nt: packed geometry does not match M = %d, K = %d (image must be padded)", a->M, a->K);
+        ba = (size_t)g.n * g.H * g.W * 4 * 2;
+        p.gH = g.H; p.gW = g.W; p.gC = 4; p.gWo = g.Wo; p.gHoWo = g.Ho * g.Wo; p.gkw = g.kw; p.gstride = g.stride;
+        p.gkstep = 2 * g.W * 8;
+    } else if (a->gather) {
         const eoe_conv_geometry& g = a->geo;
         EOE_CHECK_ARG(a->epilogue == EOE_EPI_NONE, "gemm_nt: an implicit patch matrix supports the plain epilogue only");
         EOE_CHECK_ARG(g.n > 0 && g.H > 0 && g.W > 0 && g.C > 0 && g.C % BK == 0 && g.kh > 0 && g.kw > 0 && g.stride > 0 && g.pad >= 0 &&
@@ -619,8 +642,8 @@ extern "C" int eoe_gemm_nt(const eoe_gemm_args* a, void* stream) {
                      (double)osz * a->M * a->N *
                      (a->epilogue == EOE_EPI_GELU ? 2 : 1) + (a->epilogue == EOE_EPI_RESIDUAL ? 4.0 * a->M * a->N : 0.0) +
                      (a->epilogue == EOE_EPI_GELU_BWD ? 2.0 * a->M * a->N : 0.0), stream);
-    return a->dtype == EOE_F16 ? launch_nt<f16_t>(p, a->epilogue, a->gather != 0, (hipStream_t)stream)
-                               : launch_nt<bf16_t>(p, a->epilogue, a->gather != 0, (hipStream_t)stream);
+    return a->dtype == EOE_F16 ? launch_nt<f16_t>(p, a->epilogue, a->gather, (hipStream_t)stream)
+                               : launch_nt<bf16_t>(p, a->epilogue, a->gather, (hipStream_t)stream);
 }
 
 

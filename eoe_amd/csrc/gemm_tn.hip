@@ -41,6 +41,8 @@ struct TnGroup {
     // GATHER (single-problem groups): geometry of the implicit patch matrix, multiply-shift constants for / (Ho*Wo), / Wo
     int gH, gW, gC, gWo, gHoWo, gkw, gstride, gpad;
     unsigned long long mHoWo, mWo;
+    float* part;      // split reduction without atomics (optional workspace): split s of problem i writes a dense [M][N] block
+    long long part_stride[EOE_TN_MAX_GROUP];   // element offset of problem i's partial block in `part`
 };
 
 __device__ __forceinline__ int swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
@@ -62,7 +64,7 @@ __device__ __forceinline__ typename T16<T>::v8 tr_frag(const char* base, int off
 // with two multiply-shift divisions; pieces in the zero padding get the out-of-range offset (zero fill).
 __device__ __forceinline__ int div_magic(int x, unsigned long long m) { return (int)(((unsigned long long)(unsigned)x * m) >> 40); }
 
-template <typename T, bool GATHER>
+template <typename T, int GATHER>
 __global__ __launch_bounds__(512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -94,7 +96,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
         const int c16 = (((s >> 1) ^ swz(row)) << 1) | (s & 1);      // swz touches the low 3 granule bits only
         rowA[j] = row;
         const int c = m0 + c16 * 8;
-        if (GATHER) {
+        if (GATHER == 2) {
+            // packed 3-channel first layer: column = ky*32 + px*4 + ch over a zero-padded [n, gH, gW, 4] image
+            const int q8 = c >> 3;                                   // 16-B piece: kernel row q8 >> 2, pixels 2*(q8 & 3), +1
+            colA[j] = (c < P.M) ? (unsigned)((((q8 >> 2) * g.gW + 2 * (q8 & 3)) * 4) * 2) : EOE_OOB;
+        } else if (GATHER == 1) {
             const int tap = c / g.gC, ch = c - tap * g.gC;
             const int ky = tap / g.gkw;
             gky[j] = ky - g.gpad;
@@ -120,7 +126,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
         for (int j = 0; j < 4; ++j) {
             const int t = t0 + rowA[j];
             unsigned o = EOE_OOB;
-            if (GATHER) {
+            if (GATHER == 2) {
+                if (t < t_end && colA[j] != EOE_OOB) {
+                    const int img = div_magic(t, g.mHoWo), rem = t - img * g.gHoWo;
+                    const int ho = div_magic(rem, g.mWo), wo = rem - ho * g.gWo;
+                    o = (unsigned)((((img * g.gH + ho * g.gstride) * g.gW + wo * g.gstride) * 4) * 2) + colA[j];
+                }
+            } else if (GATHER == 1) {
                 if (t < t_end && colA[j] != EOE_OOB) {
                     const int img = div_magic(t, g.mHoWo), rem = t - img * g.gHoWo;
                     const int ho = div_magic(rem, g.mWo), wo = rem - ho * g.gWo;
@@ -207,6 +219,22 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
 #undef EOE_READ
 #undef EOE_MFMA
 
+    if (g.splits > 1 && g.part) {
+        // per-split partial result [M][N] (dense), summed by tn_reduce_kernel
+        float* base = g.part + g.part_stride[pi] + (size_t)split * P.M * P.N;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int m = m0 + wm0 + mi * 16 + lr;
+            if (m >= P.M) continue;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = n0 + wn0 + ni * 16 + lg * 4;
+                if (n >= P.N) continue;            // N % 8 == 0: a 4-column piece is entirely in or out
+                *(f32x4*)(base + (size_t)m * P.N + n) = acc[mi][ni];
+            }
+        }
+        return;
+    }
     const bool atomic = g.splits > 1;
     const bool vec = ((P.ldc & 3) == 0) && ((P.N & 3) == 0) && !atomic;
 #pragma unroll
@@ -231,6 +259,26 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
                 }
             }
         }
+    }
+}
+
+// C[m][n] = alpha * sum_s part[s][m][n] (+ C if accumulate); 4 columns per thread
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, int M, int N, int ldc,
+                                                        int splits, float alpha, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n4 = N / 4;
+    if (i >= M * n4) return;
+    const int m = i / n4, n = (i - m * n4) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < splits; ++k) s += *(const f32x4*)(part + ((size_t)k * M + m) * N + n);
+    s *= alpha;
+    float* c = C + (size_t)m * ldc + n;
+    if ((ldc & 3) == 0) {
+        if (accumulate) s += *(const f32x4*)c;
+        *(f32x4*)c = s;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[r] = accumulate ? c[r] + s[r] : s[r];
     }
 }
 
@@ -273,10 +321,14 @@ extern "C" int eoe_gemm_tn_grouped(const eoe_gemm_args* args, int count, void* s
         if (a->gather) {
             const eoe_conv_geometry& q = a->geo;
             EOE_CHECK_ARG(count == 1, "gemm_tn: an implicit patch matrix cannot be grouped");
-            EOE_CHECK_ARG(q.n > 0 && q.H > 0 && q.W > 0 && q.C > 0 && q.C % 8 == 0 && q.kh > 0 && q.kw > 0 && q.stride > 0 && q.pad >= 0 &&
-                          q.Ho > 0 && q.Wo > 0 && q.Ho * q.Wo < 65536, "gemm_tn: bad conv geometry");
-            EOE_CHECK_ARG(T == q.n * q.Ho * q.Wo && a->M == q.kh * q.kw * q.C && T < (1 << 24),
-                          "gemm_tn: conv geometry does not match T = %d, M = %d", T, a->M);
+            EOE_CHECK_ARG(q.n > 0 && q.H > 0 && q.W > 0 && q.C > 0 && q.kh > 0 && q.kw > 0 && q.stride > 0 && q.pad >= 0 &&
+                          q.Ho > 0 && q.Wo > 0 && q.Ho * q.Wo < 65536 && T == q.n * q.Ho * q.Wo && T < (1 << 24), "gemm_tn: bad conv geometry");
+            if (a->gather == 2) {
+                EOE_CHECK_ARG(q.C == 4 && q.kw <= 8 && q.stride % 2 == 0 && q.pad == 0 && q.W % 2 == 0 && (q.Ho - 1) * q.stride + q.kh <= q.H &&
+                              (q.Wo - 1) * q.stride + 8 <= q.W && a->M == (q.kh + 1) / 2 * 64, "gemm_tn: bad packed first-layer geometry");
+            } else {
+                EOE_CHECK_ARG(q.C % 8 == 0 && a->M == q.kh * q.kw * q.C, "gemm_tn: conv geometry does not match M = %d", a->M);
+            }
             ba = (size_t)q.n * q.H * q.W * q.C * 2;
             g.gH = q.H; g.gW = q.W; g.gC = q.C; g.gWo = q.Wo; g.gHoWo = q.Ho * q.Wo; g.gkw = q.kw; g.gstride = q.stride; g.gpad = q.pad;
             g.mHoWo = (1ull << 40) / (unsigned)g.gHoWo + 1;      // exact for x * d < 2^40 (x < 2^24, d < 2^16)
@@ -291,21 +343,39 @@ extern "C" int eoe_gemm_tn_grouped(const eoe_gemm_args* args, int count, void* s
     if (dbg & 1) for (int i = 0; i < count; ++i) { g.p[i].bytesA = 0; g.p[i].bytesB = 0; }
     g.count = count; g.T = T; g.total_tiles = tiles; g.accumulate = args[0].accumulate; g.alpha = args[0].alpha;
     // split the reduction only when the whole group leaves most of the chip idle
+    // (as many splits as fill the CUs exactly once: tiles * splits <= #CUs -- a power-of-two rule left e.g. 18 tiles x 16
+    //  splits = 288 workgroups on 256 CUs, i.e. a second, nearly empty round)
+    static const int ncu = [] { int d = 0, n = 256; hipDeviceProp_t pr; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) n = pr.multiProcessorCount; return n; }();
     int splits = 1;
-    while (tiles * splits < 160 && splits < 128 && T / (splits * 2) >= 512) splits *= 2;
+    if (tiles * 8 < ncu * 5) {
+        splits = ncu / tiles;
+        if (splits > T / 512) splits = T / 512;
+        if (splits > 256) splits = 256;
+        if (splits < 1) splits = 1;
+    }
     int t_per = cdiv(cdiv(T, splits), BK) * BK;
     splits = cdiv(T, t_per);
     g.splits = splits; g.t_per_split = t_per;
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps("gemm_tn", flops, bytes, stream);
-    if (splits > 1 && !g.accumulate) {
+    g.part = nullptr;
+    if (splits > 1 && args[0].workspace) {
+        size_t need = 0;
+        for (int i = 0; i < count; ++i) {
+            g.part_stride[i] = (long long)need;
+            need += (size_t)splits * args[i].M * args[i].N;
+        }
+        if (need * sizeof(float) <= (size_t)args[0].workspace_bytes && (((uintptr_t)args[0].workspace) & 15) == 0)
+            g.part = (float*)args[0].workspace;
+    }
+    if (splits > 1 && !g.accumulate && !g.part) {
         for (int i = 0; i < count; ++i) {
             EOE_CHECK_ARG(args[i].ldc == args[i].N, "gemm_tn: split reduction needs a dense C");
             if (hipMemsetAsync(args[i].C, 0, (size_t)args[i].M * args[i].N * sizeof(float), s) != hipSuccess)
                 return eoe_set_error(EOE_ERR_LAUNCH, "gemm_tn: memset failed");
         }
     }
-    const bool gather = args[0].gather != 0;
+    const int gather = args[0].gather;
 #define EOE_TN_LAUNCH(TT, GG)                                                                                              \
     do {                                                                                                                   \
         static bool once = (hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel<TT, GG>,                               \
@@ -314,12 +384,20 @@ extern "C" int eoe_gemm_tn_grouped(const eoe_gemm_args* args, int count, void* s
         hipLaunchKernelGGL((gemm_tn_grouped_kernel<TT, GG>), dim3(tiles * splits), dim3(512), SMEM_BYTES, s, g);           \
     } while (0)
     if (dtype == EOE_F16) {
-        if (gather) EOE_TN_LAUNCH(f16_t, true); else EOE_TN_LAUNCH(f16_t, false);
+        if (gather == 2) EOE_TN_LAUNCH(f16_t, 2); else if (gather) EOE_TN_LAUNCH(f16_t, 1); else EOE_TN_LAUNCH(f16_t, 0);
     } else {
-        if (gather) EOE_TN_LAUNCH(bf16_t, true); else EOE_TN_LAUNCH(bf16_t, false);
+        if (gather == 2) EOE_TN_LAUNCH(bf16_t, 2); else if (gather) EOE_TN_LAUNCH(bf16_t, 1); else EOE_TN_LAUNCH(bf16_t, 0);
     }
 #undef EOE_TN_LAUNCH
     EOE_CHECK_LAUNCH("gemm_tn_grouped");
+    if (g.part) {
+        for (int i = 0; i < count; ++i) {
+            hipLaunchKernelGGL(tn_reduce_kernel, dim3(cdiv(args[i].M * (args[i].N / 4), 256)), dim3(256), 0, s,
+                               (const float*)(g.part + g.part_stride[i]), (float*)args[i].C, args[i].M, args[i].N, args[i].ldc, splits,
+                               g.alpha, g.accumulate);
+        }
+        EOE_CHECK_LAUNCH("gemm_tn_reduce");
+    }
     return 0;
 }
 

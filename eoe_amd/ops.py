@@ -74,6 +74,9 @@ def gemm_nt(a, b, out, bias=None, epilogue=EPI_NONE, aux=None, aux_out=None, acc
     return out
 
 
+TN_WORKSPACE_BYTES = 512 * 256 * 128 * 4      # EOE_TN_WORKSPACE_BYTES of include/eoe_hip.h
+
+
 def gemm_tn(a, b, out, accumulate=False, alpha=1.0):
     """out[M,N] (fp32) = a[T,M]^T @ b[T,N]; a, b 16-bit row-major"""
     _chk(a, b, out)
@@ -81,8 +84,9 @@ def gemm_tn(a, b, out, accumulate=False, alpha=1.0):
     N = b.shape[1]
     assert b.shape[0] == T and out.shape == (M, N) and out.dtype == torch.float32
     assert a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1 and a.dtype == b.dtype
+    ws = scratch("tn_ws", (TN_WORKSPACE_BYTES,), torch.uint8, a.device)
     g = GemmArgs(_p(a), _p(b), _p(out), None, None, None, None, M, N, T, a.stride(0), b.stride(0), out.stride(0), 0,
-                 dtype_code(a.dtype), EPI_NONE, 1, 1 if accumulate else 0, float(alpha))
+                 dtype_code(a.dtype), EPI_NONE, 1, 1 if accumulate else 0, float(alpha), _p(ws), TN_WORKSPACE_BYTES)
     check(lib.eoe_gemm_tn(C.byref(g), _stream()), "eoe_gemm_tn")
     return out
 
@@ -544,6 +548,9 @@ def bce_score(feats, nominal_label=0):
 
 
 # ------------------------------------------------------------------------------------------------ autograd: CNN backbone
+BN_SCRATCH = (1024 + 1) * 2         # EOE_BN_SCRATCH(C) / C of include/eoe_hip.h: per-workgroup partial sums + the total
+
+
 def _conv_kp(cin: int, taps: int = 25) -> int:
     return (taps * cin + 63) // 64 * 64
 
@@ -567,6 +574,21 @@ def _conv_weight_copies(w: torch.Tensor):
     return w16, w16t, w16d
 
 
+def _stem_weight_copy(w: torch.Tensor):
+    """16-bit [cout, ceil(kh/2)*64] copy of a 3-channel first-layer weight in the packed (ky, kx, c4) column order"""
+    key = ("stem", id(w))
+    tag = (w._version, w.data_ptr(), _compute_dtype)
+    hit = shadow.cache.get(key)
+    if hit is not None and hit[0]() is w and hit[1] == tag:
+        return hit[2]
+    cout, _, kh, kw = w.shape
+    w16 = torch.empty((cout, (kh + 1) // 2 * 64), dtype=_compute_dtype, device=w.device)
+    check(lib.eoe_stem_pack_weight(_p(w.detach().contiguous()), _p(w16), cout, kh, kw, dtype_code(_compute_dtype), _stream()),
+          "eoe_stem_pack_weight")
+    shadow.cache[key] = (weakref.ref(w, lambda _r, k=key, c=shadow.cache: c.pop(k, None)), tag, w16)
+    return w16
+
+
 _implicit_conv = True
 
 
@@ -577,24 +599,27 @@ def set_implicit_conv(on: bool):
     _implicit_conv = bool(on)
 
 
-def conv_gemm_fwd(x16, w16, y, geo, bias=None):
-    """y[n*Ho*Wo, cout] (fp32) = patches(x16) @ w16^T without materialising the patches; x16 16-bit NHWC [n,H,W,C]"""
+def conv_gemm_fwd(x16, w16, y, geo, bias=None, mode=1):
+    """y[n*Ho*Wo, cout] (fp32) = patches(x16) @ w16^T without materialising the patches; x16 16-bit NHWC [n,H,W,C]
+    (mode 2: the zero-padded NHWC4 image of eoe_stem_pack_image, packed k axis)"""
     n, H, W, Cc, kh, kw, stride, pad, Ho, Wo = geo
-    M, K, N = n * Ho * Wo, kh * kw * Cc, w16.shape[0]
+    M, K, N = n * Ho * Wo, (kh * kw * Cc if mode == 1 else (kh + 1) // 2 * 64), w16.shape[0]
     assert x16.is_contiguous() and w16.shape[1] == K and w16.stride(1) == 1 and y.shape == (M, N) and y.stride(1) == 1
     g = GemmArgs(_p(x16), _p(w16), _p(y), _p(bias), None, None, None, M, N, K, 0, w16.stride(0), y.stride(0), 0,
-                 dtype_code(x16.dtype), EPI_NONE, 1 if y.dtype == torch.float32 else 0, 0, 1.0, 1, _lib.ConvGeometry(*geo))
+                 dtype_code(x16.dtype), EPI_NONE, 1 if y.dtype == torch.float32 else 0, 0, 1.0, None, 0, mode,
+                 _lib.ConvGeometry(*geo))
     check(lib.eoe_gemm_nt(C.byref(g), _stream()), "eoe_gemm_nt")
     return y
 
 
-def conv_gemm_wgrad(x16, dy16, gT, geo):
+def conv_gemm_wgrad(x16, dy16, gT, geo, mode=1):
     """gT[kh*kw*C, cout] (fp32) = patches(x16)^T @ dy16 without materialising the patches"""
     n, H, W, Cc, kh, kw, stride, pad, Ho, Wo = geo
-    T, M, N = n * Ho * Wo, kh * kw * Cc, dy16.shape[1]
+    T, M, N = n * Ho * Wo, (kh * kw * Cc if mode == 1 else (kh + 1) // 2 * 64), dy16.shape[1]
     assert x16.is_contiguous() and dy16.shape[0] == T and dy16.stride(1) == 1 and gT.shape == (M, N) and gT.is_contiguous()
+    ws = scratch("tn_ws", (TN_WORKSPACE_BYTES,), torch.uint8, x16.device)
     g = GemmArgs(_p(x16), _p(dy16), _p(gT), None, None, None, None, M, N, T, 0, dy16.stride(0), N, 0, dtype_code(x16.dtype),
-                 EPI_NONE, 1, 0, 1.0, 1, _lib.ConvGeometry(*geo))
+                 EPI_NONE, 1, 0, 1.0, _p(ws), TN_WORKSPACE_BYTES, mode, _lib.ConvGeometry(*geo))
     check(lib.eoe_gemm_tn(C.byref(g), _stream()), "eoe_gemm_tn")
     return gT
 
@@ -626,20 +651,31 @@ class ConvBnActPoolFunction(torch.autograd.Function):
         M, kp, dev, dt = n * H * W, _conv_kp(cin, kh * kw), x.device, _compute_dtype
         code = dtype_code(dt)
         implicit = _implicit_conv and (not is_image) and cin % 64 == 0
-        w16, _, _ = _conv_weight_copies(conv_w)
+        stem = _implicit_conv and is_image and cin == 3 and kw <= 8 and stride % 2 == 0
         y = torch.empty((M, cout), dtype=torch.float32, device=dev)
-        if implicit:
+        if stem:
+            # packed first layer: normalised 16-bit NHWC4 image with physical zero padding, gathered inside the GEMM
+            Hp, Wp = (H - 1) * stride + (kh + 1) // 2 * 2, ((W - 1) * stride + 8 + 1) // 2 * 2
+            Hp, Wp = max(Hp, Hi + pad), max(Wp, Wi + pad + (Wi + pad) % 2)
+            operand = torch.empty((n, Hp, Wp, 4), dtype=dt, device=dev)
+            check(lib.eoe_stem_pack_image(_p(x), _p(mean), _p(std), _p(operand), n, Hi, Wi, Hp, Wp, pad, code, _stream()),
+                  "eoe_stem_pack_image")
+            implicit = 2
+            conv_gemm_fwd(operand, _stem_weight_copy(conv_w), y, (n, Hp, Wp, 4, kh, kw, stride, 0, H, W), bias=conv_b, mode=2)
+        elif implicit:
+            w16, _, _ = _conv_weight_copies(conv_w)
             if x16 is None or x16.dtype != dt or x16.shape != x.shape:
                 x16 = cast16(x.view(-1, cin)).view(n, Hi, Wi, cin)
             operand = x16
             conv_gemm_fwd(x16, w16, y, (n, Hi, Wi, cin, kh, kw, stride, pad, H, W), bias=conv_b)
         else:
+            w16, _, _ = _conv_weight_copies(conv_w)
             operand = torch.empty((M, kp), dtype=dt, device=dev)
             check(lib.eoe_im2col(_p(x), 1 if is_image else 2, _p(mean), _p(std), _p(operand), n, cin, Hi, Wi, kh, kw, stride, pad,
                                  kp, code, _stream()), "eoe_im2col")
             gemm_nt(operand, w16, y, bias=conv_b)
         stats = torch.empty(2 * cout, dtype=torch.float32, device=dev)
-        sums = scratch("bn_sums", (2 * cout,), torch.float32, dev)
+        sums = scratch("bn_sums", (BN_SCRATCH * cout,), torch.float32, dev)
         check(lib.eoe_bn_stats(_p(y), _p(sums), _p(stats), _p(rm), _p(rv), _p(nbt), M, cout, float(eps), float(momentum),
                                1 if training else 0, _stream()), "eoe_bn_stats")
         Ho, Wo = H // pool, W // pool
@@ -661,12 +697,17 @@ class ConvBnActPoolFunction(torch.autograd.Function):
         dy16 = torch.empty((M, cout), dtype=dt, device=dev)
         dg = _grad_target(bn_w) if bn_w is not None else None
         db = _grad_target(bn_b) if bn_b is not None else None
-        red = scratch("bn_red", (2 * cout,), torch.float32, dev)
+        red = scratch("bn_red", (BN_SCRATCH * cout,), torch.float32, dev)
         check(lib.eoe_bn_act_pool_bwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(dout), _p(red), _p(dy16), 0, _p(dg), _p(db), n, H,
                                       W, cout, pool, 1 if flat_out else 0, 1 if training else 0, 0, slope, code, _stream()),
               "eoe_bn_act_pool_bwd")
         dw = _grad_target(conv_w)
-        if implicit:
+        if implicit == 2:
+            _, Hp, Wp, _ = operand.shape
+            gT = torch.empty(((kh + 1) // 2 * 64, cout), dtype=torch.float32, device=dev)
+            conv_gemm_wgrad(operand, dy16, gT, (n, Hp, Wp, 4, kh, kw, stride, 0, H, W), mode=2)
+            check(lib.eoe_stem_unpack_wgrad(_p(gT), _p(dw), cout, kh, kw, _stream()), "eoe_stem_unpack_wgrad")
+        elif implicit:
             gT = torch.empty((kh * kw * cin, cout), dtype=torch.float32, device=dev)
             conv_gemm_wgrad(operand, dy16, gT, (n, Hi, Wi, cin, kh, kw, stride, pad, H, W))
             check(lib.eoe_conv_unpack_wgrad(_p(gT), _p(dw), cout, cin, kh, kw, kp, 1, 0, _stream()), "eoe_conv_unpack_wgrad")
@@ -704,7 +745,7 @@ class BnActFunction(torch.autograd.Function):
         n, C = y.shape
         dev = y.device
         stats = torch.empty(2 * C, dtype=torch.float32, device=dev)
-        sums = scratch("bn_sums", (2 * C,), torch.float32, dev)
+        sums = scratch("bn_sums", (BN_SCRATCH * C,), torch.float32, dev)
         check(lib.eoe_bn_stats(_p(y), _p(sums), _p(stats), _p(rm), _p(rv), _p(nbt), n, C, float(eps), float(momentum),
                                1 if training else 0, _stream()), "eoe_bn_stats")
         out = torch.empty_like(y)
@@ -723,7 +764,7 @@ class BnActFunction(torch.autograd.Function):
         dy = torch.empty_like(y)
         dg = _grad_target(bn_w) if bn_w is not None else None
         db = _grad_target(bn_b) if bn_b is not None else None
-        red = scratch("bn_red", (2 * C,), torch.float32, dev)
+        red = scratch("bn_red", (BN_SCRATCH * C,), torch.float32, dev)
         check(lib.eoe_bn_act_pool_bwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(dout), _p(red), _p(dy), 1, _p(dg), _p(db), n, 1, 1,
                                       C, 1, 0, 1 if ctx.training else 0, 0, 0.01, dtype_code(_compute_dtype), _stream()),
               "eoe_bn_act_pool_bwd")

@@ -8,7 +8,7 @@ import torch
 
 from . import _lib
 from ._lib import check, lib
-from .ops import _chk, _grad_target, _p, _stream, scratch
+from .ops import BN_SCRATCH, _chk, _grad_target, _p, _stream, scratch
 
 
 class MaxPoolFunction(torch.autograd.Function):
@@ -95,7 +95,7 @@ class SpatialGateFunction(torch.autograd.Function):
         z = torch.empty((n, H, W), dtype=torch.float32, device=dev)
         stats = torch.empty(2, dtype=torch.float32, device=dev)
         scale = torch.empty((n, H, W), dtype=torch.float32, device=dev)
-        sums = scratch("sg_sums", (2,), torch.float32, dev)
+        sums = scratch("sg_sums", (BN_SCRATCH,), torch.float32, dev)
         wc = w.detach().contiguous()
         a = _lib.SGateArgs(_p(x), _p(out), _p(wc), _p(bn_w), _p(bn_b), _p(rm), _p(rv), _p(nbt), _p(comp), _p(argmax), _p(z),
                            _p(stats), _p(scale), _p(sums), n, H, W, Cc, float(eps), float(momentum), 1 if training else 0)
@@ -115,7 +115,7 @@ class SpatialGateFunction(torch.autograd.Function):
         dscale = scratch("sg_dscale", (n, H, W), torch.float32, dev)
         dcomp = scratch("sg_dcomp", (n, H, W, 2), torch.float32, dev)
         red = scratch("sg_red", (2,), torch.float32, dev)
-        sums = scratch("sg_sums", (2,), torch.float32, dev)
+        sums = scratch("sg_sums", (BN_SCRATCH,), torch.float32, dev)
         dw = _grad_target(w)
         dg = _grad_target(bn_w) if bn_w is not None else None
         db = _grad_target(bn_b) if bn_b is not None else None

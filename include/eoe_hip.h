@@ -70,9 +70,15 @@ typedef struct {
     int32_t out_f32;    /* C is fp32 */
     int32_t accumulate; /* C += result (C must be fp32) */
     float alpha;        /* result scale applied to acc before bias/epilogue (1.0 = none) */
+    void* workspace;    /* optional (TN): scratch for the per-split partial results of a split reduction; with
+                         * workspace_bytes >= EOE_TN_WORKSPACE_BYTES the splits are summed by a second kernel instead of fp32
+                         * atomics (faster, and bitwise reproducible) */
+    int64_t workspace_bytes;
     int32_t gather;     /* 1: A is the NHWC tensor of `geo` and stands for its patch matrix (lda ignored).
                          *    NT: [M = n*Ho*Wo, K = kh*kw*C], C % 64 == 0, plain epilogue (conv forward; stride-1 dgrad)
-                         *    TN: [T = n*Ho*Wo, M = kh*kw*C], C % 8 == 0 (conv wgrad, transposed: C[kh*kw*C, cout]) */
+                         *    TN: [T = n*Ho*Wo, M = kh*kw*C], C % 8 == 0 (conv wgrad, transposed: C[kh*kw*C, cout])
+                         * 2: A is the zero-padded NHWC4 image of eoe_stem_pack_image (geo.C = 4, geo.pad = 0, geo.H/W = Hp/Wp),
+                         *    K (NT) / M (TN) = ceil(kh/2)*64 */
     eoe_conv_geometry geo;
 } eoe_gemm_args;
 
@@ -81,6 +87,7 @@ int eoe_gemm_tn(const eoe_gemm_args* args, void* stream);
 /* up to EOE_TN_MAX_GROUP independent TN problems with the same reduction length T, dtype, accumulate and alpha in
  * ONE launch (the four weight gradients of a transformer block fill the chip together: no split-K, no atomics) */
 #define EOE_TN_MAX_GROUP 4
+#define EOE_TN_WORKSPACE_BYTES (512ll * 256 * 128 * 4)   /* (#CUs rounded up) x one 256x128 fp32 tile */
 int eoe_gemm_tn_grouped(const eoe_gemm_args* args, int count, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
@@ -259,9 +266,21 @@ int eoe_conv_pack_weight(const float* w, void* w16, void* w16t, void* w16d, int 
                          int dtype, void* stream);
 int eoe_conv_unpack_wgrad(const float* g, float* dw, int cout, int cin, int kh, int kw, int Kp, int transposed,
                           int accumulate, void* stream);
+/* 3-channel first layer without a materialised patch matrix (gather = 2 of eoe_gemm_args): the image batch fp32 NCHW
+ * [n,3,H,W] (optional per-channel normalise, ad_trainer.py:413-425) becomes a 16-bit NHWC4 tensor [n,Hp,Wp,4] with the
+ * convolution's zero padding made physical (pixel (h,w) at (h+pad, w+pad)); the GEMM's k axis is ky*32 + kx*4 + c with
+ * K = ceil(kh/2)*64 (kw <= 8, even stride), weights packed to match, wgrad [K, cout] unpacked to [cout,3,kh,kw].
+ * Needs Hp >= (Ho-1)*stride + 2*ceil(kh/2), Wp >= (Wo-1)*stride + 8, Wp even. */
+int eoe_stem_pack_image(const float* x, const float* mean, const float* std, void* out, int n, int H, int W, int Hp, int Wp,
+                        int pad, int dtype, void* stream);
+int eoe_stem_pack_weight(const float* w, void* w16, int cout, int kh, int kw, int dtype, void* stream);
+int eoe_stem_unpack_wgrad(const float* g, float* dw, int cout, int kh, int kw, void* stream);
+
 /* batch statistics of y fp32 [M,C]: stats[0..C) = mean, stats[C..2C) = 1/sqrt(var+eps) (biased var); training updates
  * running_mean/var (momentum, unbiased var) and num_batches_tracked as nn.BatchNorm does (cnn.py:57-66); eval reads
- * the running buffers.  sums_scratch: 2*C floats. */
+ * the running buffers.  sums_scratch: EOE_BN_SCRATCH(C) floats (per-workgroup partial sums: no atomics). */
+#define EOE_BN_PARTIALS 1024
+#define EOE_BN_SCRATCH(C) ((EOE_BN_PARTIALS + 1) * 2 * (C))
 int eoe_bn_stats(const float* y, float* sums_scratch, float* stats, float* running_mean, float* running_var,
                  int64_t* num_batches_tracked, int M, int C, float eps, float momentum, int training, void* stream);
 /* out = maxpool_{pool}(act(bn(y))), act(z) = z > 0 ? z : slope*z (slope 0.01 = LeakyReLU of cnn.py, 0 = ReLU of
@@ -270,7 +289,7 @@ int eoe_bn_stats(const float* y, float* sums_scratch, float* stats, float* runni
 int eoe_bn_act_pool_fwd(const float* y, const float* stats, const float* gamma, const float* beta, void* out, int n, int H,
                         int W, int C, int pool, int nchw_flat, int out_f32, float slope, int dtype, void* stream);
 /* backward of the above: dout fp32 (layout of `out`) -> dy [n*H*W, C] 16-bit (dY operand of the conv wgrad/dgrad), or
- * fp32 if dy_f32; dgamma, dbeta */
+ * fp32 if dy_f32; dgamma, dbeta.  red_scratch: EOE_BN_SCRATCH(C) floats. */
 int eoe_bn_act_pool_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* dout,
                         float* red_scratch, void* dy, int dy_f32, float* dgamma, float* dbeta, int n, int H, int W, int C,
                         int pool, int nchw_flat, int training, int accumulate, float slope, int dtype, void* stream);
@@ -329,7 +348,7 @@ typedef struct {
     float* z;             /* [n, H, W]    conv output               (saved) */
     float* stats;         /* [2]          mean, rstd used           (saved) */
     float* scale;         /* [n, H, W]    sigmoid output            (saved) */
-    float* sums;          /* [2] scratch */
+    float* sums;          /* EOE_BN_SCRATCH(1) floats scratch */
     int n, H, W, C;
     float eps, momentum;
     int training;         /* 1: batch statistics (+ running update), 0: running statistics */
