@@ -330,3 +330,54 @@ def test_wideresnet_eval_mode_and_clf():
         want = ref(x)
     assert out.shape == (2, 1)
     assert rel_rms(out, want) < 2e-2
+
+
+def test_wideresnet_full_batch_properties():
+    """at the benchmark's full step batch (128 + 128 images of 224x224): fp16 and bf16 paths agree per tensor (no fp16
+    gradient underflow; BatchNorm over 256 images is well conditioned), the implicit-GEMM path equals the materialised one at
+    the full size, the loss equals the mean of the per-sample losses recomputed from the returned features, and one
+    optimiser step moves every parameter that has a non-zero gradient."""
+    import eoe_amd
+    import eoe_amd.ops as ops
+    from eoe_amd.models import WideResNet
+    torch.manual_seed(0)
+    n = 256
+    x = torch.randn(n, 3, 224, 224, device="cuda")
+    x[n // 2:] += 0.5 * torch.randn(1, 3, 224, 224, device="cuda")
+    y = torch.cat([torch.zeros(n // 2, dtype=torch.long), torch.ones(n // 2, dtype=torch.long)]).cuda()
+    m = WideResNet().cuda().train()
+    with torch.no_grad():                        # the reference's zero init of the gate BN weight hides the spatial gate
+        for k, p in m.named_parameters():
+            if k.endswith("SpatialGate.spatial.bn.weight"):
+                p.fill_(0.5)
+    res = {}
+    for tag, dt, implicit in (("fp16", "fp16", True), ("bf16", "bf16", True), ("fp16m", "fp16", False)):
+        eoe_amd.set_compute_dtype(dt)
+        ops.set_implicit_conv(implicit)
+        try:
+            for p in m.parameters():
+                p.grad = None
+            f = m(x)
+            loss = eoe_amd.hsc_loss(f, y, 0)
+            loss.backward()
+            res[tag] = (loss.item(), f.detach().clone(), {k: p.grad.double().norm().item() for k, p in m.named_parameters()})
+        finally:
+            ops.set_implicit_conv(True)
+    l16, f16, g16 = res["fp16"]
+    lb, fb, gb = res["bf16"]
+    lm, fm, gm = res["fp16m"]
+    assert np.isfinite(l16) and abs(l16 - lb) < 1e-2 * max(1, abs(l16)), (l16, lb)
+    d_b = sorted(abs(g16[k] - gb[k]) / max(gb[k], 1e-12) for k in g16)
+    d_m = sorted(abs(g16[k] - gm[k]) / max(gm[k], 1e-12) for k in g16)
+    print(f"[wrn full batch] loss fp16 {l16:.6f} bf16 {lb:.6f} materialised {lm:.6f}; grad-norm rel diff fp16 vs bf16 median "
+          f"{d_b[len(d_b) // 2]:.2e} max {d_b[-1]:.2e}; implicit vs materialised median {d_m[len(d_m) // 2]:.2e} max {d_m[-1]:.2e}")
+    assert d_b[len(d_b) // 2] < 2e-2 and d_b[int(0.9 * len(d_b))] < 1e-1
+    assert abs(l16 - lm) < 1e-3 * max(1, abs(l16)) and rel_rms(f16, fm.cpu()) < 5e-3
+    assert d_m[len(d_m) // 2] < 5e-3 and d_m[int(0.9 * len(d_m))] < 5e-2
+    want = objectives.hsc_loss(f16.double().cpu(), y.cpu()).item()
+    assert abs(l16 - want) < 1e-5 * max(1, abs(want))
+    before = {k: p.detach().clone() for k, p in m.named_parameters()}
+    opt = eoe_amd.FusedAdam(m.parameters(), lr=1e-3, weight_decay=0.0)
+    opt.step()
+    still = [k for k, p in m.named_parameters() if gm[k] > 0 and torch.equal(before[k], p.detach())]
+    assert not still, still
