@@ -69,6 +69,28 @@ def cpu_baseline(args):
             "sample": f"{args.cpu_steps} steps of {2 * nh} images (ViT-B/32 {args.layers} layers, {args.mode}, fp32 oracle)"}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC summary of this same command (rocprofv3 --pmc FETCH_SIZE and
+    WRITE_SIZE in separate passes, tools/pmc_summary.py; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
+    PMC counters cannot be collected from inside the timed process, so this is the last profiled run, not this one."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*", "bench_pmc_hbm_bytes.csv")))
+    if not paths:
+        return None, None
+    tot = {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]}
+    with open(paths[-1]) as f:
+        for line in f:
+            parts = line.strip().split(",")
+            if len(parts) != 4 or parts[0] not in tot or kernel not in parts[1]:
+                continue
+            tot[parts[0]][0] += float(parts[3]) * 1024.0 * int(parts[2])
+            tot[parts[0]][1] += int(parts[2])
+    if not tot["FETCH_SIZE"][1] or not tot["WRITE_SIZE"][1]:
+        return None, None
+    per = 2.0 * tot["FETCH_SIZE"][0] / tot["FETCH_SIZE"][1] + tot["WRITE_SIZE"][0] / tot["WRITE_SIZE"][1]
+    return round(per), os.path.relpath(paths[-1], os.path.dirname(os.path.abspath(__file__)))
+
+
 def main():
     args = parse()
     import torch
@@ -161,8 +183,11 @@ def main():
         dom = max(gemm, key=lambda k: gemm[k]["total_ms"])
         d = gemm[dom]
         achieved = d["flops"] / (d["total_ms"] * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic(dom) if (args.model == "vit" and args.mode == "full" and args.dtype == "fp16") else (None, None)
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
                 "avg_launch_us": round(d["total_ms"] * 1e3 / d["launches"], 2), "launches_per_step": d["launches"] // 3,
                 "kernels_ms_per_step": {k: round(v["total_ms"] / 3, 3) for k, v in sorted(prof.items())},
                 "profiled_ms_per_step": round(tot_ms / 3, 3)}

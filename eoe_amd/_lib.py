@@ -121,17 +121,17 @@ SIGNATURES = {
     "eoe_stem_pack_weight": [_vp, _vp] + [C.c_int] * 4 + [_vp],
     "eoe_stem_unpack_wgrad": [_vp, _vp] + [C.c_int] * 3 + [_vp],
     "eoe_bn_stats": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _f32, C.c_int, _vp],
-    "eoe_bn_act_pool_fwd": [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32,
+    "eoe_bn_act_pool_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32,
                             C.c_int, _vp],
     "eoe_bn_act_pool_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                             C.c_int, C.c_int, _f32, C.c_int, _vp],
-    "eoe_maxpool_fwd": [_vp, _vp, _vp] + [C.c_int] * 7 + [_vp],
+    "eoe_maxpool_fwd": [_vp, _vp, _vp, _vp] + [C.c_int] * 8 + [_vp],
     "eoe_maxpool_bwd": [_vp, _vp, _vp] + [C.c_int] * 7 + [_vp],
     "eoe_cgate_fwd": [C.POINTER(CGateArgs), _vp],
     "eoe_cgate_bwd": [C.POINTER(CGateBwdArgs), _vp],
     "eoe_sgate_fwd": [C.POINTER(SGateArgs), _vp],
     "eoe_sgate_bwd": [C.POINTER(SGateBwdArgs), _vp],
-    "eoe_add_relu_fwd": [_vp, _vp, _vp, _i64, _vp],
+    "eoe_add_relu_fwd": [_vp, _vp, _vp, _vp, C.c_int, _i64, _vp],
     "eoe_relu_bwd": [_vp, _vp, _vp, _i64, _vp],
     "eoe_avgpool_fwd": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
     "eoe_avgpool_bwd": [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp],

@@ -18,7 +18,8 @@ __device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + __exp
 
 // ---------------------------------------------------------------------------------------------- MaxPool2d(k, stride, pad)
 // out[n,Ho,Wo,C] = max over the window (padding never wins); idx = winning tap ky*k+kx (first maximum, as max_pool2d)
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, T* __restrict__ out16,
                                                           uint8_t* __restrict__ idx, int n, int H, int W, int C, int k, int stride,
                                                           int pad, int Ho, int Wo) {
     const int cc = C / 4;
@@ -38,6 +39,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
                 if (v[r] > best[r]) { best[r] = v[r]; arg[r] = tap; }
         }
         *(f32x4*)(out + op * C + c) = (f32x4){best[0], best[1], best[2], best[3]};
+        if (out16) *(u32x2*)(out16 + op * C + c) = pack4<T>(best[0], best[1], best[2], best[3]);
         *(uint32_t*)(idx + op * C + c) = (uint32_t)arg[0] | ((uint32_t)arg[1] << 8) | ((uint32_t)arg[2] << 16) | ((uint32_t)arg[3] << 24);
     }
 }
@@ -443,13 +445,15 @@ __global__ __launch_bounds__(256) void sgate_bwd_apply_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------------------------------------- residual add + ReLU, avg pool
+template <typename T>
 __global__ __launch_bounds__(256) void add_relu_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                           float* __restrict__ out, size_t n4) {
+                                                           float* __restrict__ out, T* __restrict__ out16, size_t n4) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         f32x4 v = ((const f32x4*)a)[i] + ((const f32x4*)b)[i];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         ((f32x4*)out)[i] = v;
+        if (out16) ((u32x2*)out16)[i] = pack4<T>(v[0], v[1], v[2], v[3]);
     }
 }
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
@@ -478,15 +482,22 @@ int chan_cpb(int C) { return C / 4 < 64 ? C / 4 : 64; }
 
 }  // namespace
 
-extern "C" int eoe_maxpool_fwd(const float* x, float* out, uint8_t* idx, int n, int H, int W, int C, int k, int stride, int pad,
-                               void* stream) {
+#define DISPATCH_T(dtype, ...)                                  \
+    do {                                                        \
+        if ((dtype) == EOE_F16) { typedef f16_t T; __VA_ARGS__; } \
+        else if ((dtype) == EOE_BF16) { typedef bf16_t T; __VA_ARGS__; } \
+        else return eoe_set_error(EOE_ERR_ARG, "bad dtype %d", (int)(dtype)); \
+    } while (0)
+
+extern "C" int eoe_maxpool_fwd(const float* x, float* out, void* out16, uint8_t* idx, int n, int H, int W, int C, int k, int stride,
+                               int pad, int dtype, void* stream) {
     EOE_CHECK_ARG(x && out && idx && n > 0 && C % 4 == 0 && k >= 1 && k * k <= 255 && stride >= 1 && pad >= 0 && 2 * pad <= k,
                   "maxpool_fwd: bad args");
     const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
     EOE_CHECK_ARG(Ho >= 1 && Wo >= 1, "maxpool_fwd: empty output");
     ProfScope ps("maxpool_fwd", 0, 4.0 * n * H * W * C + 5.0 * n * Ho * Wo * C, stream);
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((size_t)n * Ho * Wo * C / 4)), dim3(256), 0, (hipStream_t)stream, x, out,
-                       idx, n, H, W, C, k, stride, pad, Ho, Wo);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(grid_for((size_t)n * Ho * Wo * C / 4)), dim3(256), 0,
+                                         (hipStream_t)stream, x, out, (T*)out16, idx, n, H, W, C, k, stride, pad, Ho, Wo));
     EOE_CHECK_LAUNCH("maxpool_fwd");
     return 0;
 }
@@ -616,11 +627,11 @@ extern "C" int eoe_sgate_bwd(const eoe_sgate_bwd_args* b, void* stream) {
     return 0;
 }
 
-extern "C" int eoe_add_relu_fwd(const float* a, const float* b, float* out, int64_t count, void* stream) {
+extern "C" int eoe_add_relu_fwd(const float* a, const float* b, float* out, void* out16, int dtype, int64_t count, void* stream) {
     EOE_CHECK_ARG(a && b && out && count > 0 && count % 4 == 0, "add_relu_fwd: bad args");
     ProfScope ps("add_relu_fwd", 0, 12.0 * count, stream);
-    hipLaunchKernelGGL(add_relu_fwd_kernel, dim3(grid_for((size_t)count / 4)), dim3(256), 0, (hipStream_t)stream, a, b, out,
-                       (size_t)count / 4);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((add_relu_fwd_kernel<T>), dim3(grid_for((size_t)count / 4)), dim3(256), 0, (hipStream_t)stream,
+                                         a, b, out, (T*)out16, (size_t)count / 4));
     EOE_CHECK_LAUNCH("add_relu_fwd");
     return 0;
 }

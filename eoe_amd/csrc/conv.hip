@@ -280,8 +280,8 @@ __device__ __forceinline__ float lrelu(float z, float slope) { return z > 0.f ? 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ stats,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              void* __restrict__ out, int n, int H, int W, int C, int P,
-                                                              int nchw_flat, int out_f32, float slope) {
+                                                              void* __restrict__ out, T* __restrict__ out16, int n, int H, int W,
+                                                              int C, int P, int nchw_flat, int out_f32, float slope) {
     const int Ho = H / P, Wo = W / P, cc = C / 4;
     const size_t total = (size_t)n * Ho * Wo * cc;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -307,6 +307,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __res
             }
         } else if (out_f32) {
             *(f32x4*)((float*)out + op * C + c) = (f32x4){best[0], best[1], best[2], best[3]};
+            if (out16) *(u32x2*)(out16 + op * C + c) = pack4<T>(best[0], best[1], best[2], best[3]);
         } else {
             *(u32x2*)((T*)out + op * C + c) = pack4<T>(best[0], best[1], best[2], best[3]);
         }
@@ -555,16 +556,17 @@ extern "C" int eoe_bn_stats(const float* y, float* sums_scratch, float* stats, f
     return 0;
 }
 
-extern "C" int eoe_bn_act_pool_fwd(const float* y, const float* stats, const float* gamma, const float* beta, void* out, int n,
-                                   int H, int W, int C, int pool, int nchw_flat, int out_f32, float slope, int dtype,
-                                   void* stream) {
+extern "C" int eoe_bn_act_pool_fwd(const float* y, const float* stats, const float* gamma, const float* beta, void* out,
+                                   void* out16, int n, int H, int W, int C, int pool, int nchw_flat, int out_f32, float slope,
+                                   int dtype, void* stream) {
+    EOE_CHECK_ARG(!out16 || (out_f32 && !nchw_flat), "bn_act_pool_fwd: the extra 16-bit copy goes with an fp32 NHWC output");
     EOE_CHECK_ARG(y && stats && out && n > 0 && C % 4 == 0, "bn_act_pool_fwd: bad args");
     EOE_CHECK_ARG((pool == 1 || pool == 2) && H % pool == 0 && W % pool == 0, "bn_act_pool: pool must be 1 or 2 and divide H, W");
     EOE_CHECK_ARG((gamma == nullptr) == (beta == nullptr), "bn_act_pool: gamma/beta must both be given or both NULL");
     ProfScope ps("bn_act_pool_fwd", 0, 4.0 * n * H * W * C + 2.0 * n * H * W * C / (pool * pool), stream);
     DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_pool_fwd_kernel<T>), dim3(grid_for((size_t)n * (H / pool) * (W / pool) * C / 4)),
-                                         dim3(256), 0, (hipStream_t)stream, y, stats, gamma, beta, out, n, H, W, C, pool,
-                                         nchw_flat, out_f32, slope));
+                                         dim3(256), 0, (hipStream_t)stream, y, stats, gamma, beta, out, (T*)out16, n, H, W, C,
+                                         pool, nchw_flat, out_f32, slope));
     EOE_CHECK_LAUNCH("bn_act_pool_fwd");
     return 0;
 }

@@ -48,8 +48,8 @@ class CNN32(nn.Module):
     def _layer(self, x, conv, bn, is_image, flat_out):
         mean, std = self.normalize if (is_image and self.normalize is not None) else (None, None)
         cfg = (self.training, bn.eps, bn.momentum, 2, is_image, mean, std, flat_out)
-        return ops.ConvBnActPoolFunction.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                               bn.num_batches_tracked, cfg)
+        return ops.conv_bn_act_pool(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                    bn.num_batches_tracked, cfg)
 
     def forward(self, x):
         if not x.is_cuda:

@@ -16,13 +16,13 @@ def conv3x3(in_planes, out_planes, stride=1):
     return nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)
 
 
-def _conv_bn(x, conv, bn, training, slope, is_image=False, normalize=None):
+def _conv_bn(x, conv, bn, training, slope, is_image=False, normalize=None, want16=False):
     """conv (no bias) -> BatchNorm2d -> ReLU (slope 0) or nothing (slope 1); fp32 NHWC in/out"""
     mean, std = normalize if (is_image and normalize is not None) else (None, None)
     k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
-    cfg = (training, bn.eps, bn.momentum, 1, is_image, mean, std, False, (k, k, s, p), slope)
-    return ops.ConvBnActPoolFunction.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                           bn.num_batches_tracked, cfg)
+    cfg = (training, bn.eps, bn.momentum, 1, is_image, mean, std, False, (k, k, s, p), slope, want16)
+    return ops.conv_bn_act_pool(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                bn.num_batches_tracked, cfg)
 
 
 class BasicBlock(nn.Module):
@@ -40,14 +40,14 @@ class BasicBlock(nn.Module):
         self.cbam = CBAM(planes, 16) if use_cbam else None
 
     def forward(self, x):      # x: fp32 NHWC (resnet.py:130-149)
-        out = _conv_bn(x, self.conv1, self.bn1, self.training, 0.0)
+        out = _conv_bn(x, self.conv1, self.bn1, self.training, 0.0, want16=True)       # feeds conv2 only
         out = _conv_bn(out, self.conv2, self.bn2, self.training, 1.0)
         residual = x
         if self.downsample is not None:
             residual = _conv_bn(x, self.downsample[0], self.downsample[1], self.training, 1.0)
         if self.cbam is not None:
             out = self.cbam(out)
-        return ops_resnet.AddReluFunction.apply(out, residual)
+        return ops_resnet.add_relu(out, residual)
 
 
 class WideResNet(nn.Module):
@@ -114,7 +114,7 @@ class WideResNet(nn.Module):
             raise RuntimeError("eoe_amd.WideResNet runs on the GPU only (no CPU fallback)")
         x = x.view(-1, 3, 224, 224)
         x = _conv_bn(x, self.conv1, self.bn1, self.training, 0.0, is_image=True, normalize=self.normalize)   # NHWC from here
-        x = ops_resnet.MaxPoolFunction.apply(x, 3, 2, 1)
+        x = ops_resnet.max_pool(x, 3, 2, 1)
         x = self.layer1(x)
         x = self.layer2(x)
         x = self.layer3(x)

@@ -627,7 +627,8 @@ def conv_gemm_wgrad(x16, dy16, gT, geo, mode=1):
 class ConvBnActPoolFunction(torch.autograd.Function):
     """conv (+ bias) -> BatchNorm2d -> act -> MaxPool(pool), one layer per call: conv5x5(pad 2) + LeakyReLU(0.01) + pool 2
     for `cnn.py:73-82` (the default when cfg has 8 entries); cfg[8] = (kh, kw, stride, pad) and cfg[9] = the activation's
-    negative slope (0 = ReLU, 1 = none) give the conv->bn(->relu) units of `resnet.py:93-95,133-141`.
+    negative slope (0 = ReLU, 1 = none) give the conv->bn(->relu) units of `resnet.py:93-95,133-141`; cfg[10] = also emit a
+    16-bit copy of the output (returned second, non-differentiable) for a following convolution.
     Input: the fp32 NCHW image batch (first layer; optional fused Normalize) or an fp32 NHWC activation (a 16-bit copy
     attached to it as `._eoe16` by the producing op is used instead of casting); output: fp32 NHWC [n, Ho/p, Wo/p, cout], or
     the reference's NCHW-flattened [n, cout*(Ho/p)*(Wo/p)] (`cnn.py:83`) if flat_out.
@@ -680,14 +681,20 @@ class ConvBnActPoolFunction(torch.autograd.Function):
                                1 if training else 0, _stream()), "eoe_bn_stats")
         Ho, Wo = H // pool, W // pool
         out = torch.empty((n, cout * Ho * Wo) if flat_out else (n, Ho, Wo, cout), dtype=torch.float32, device=dev)
-        check(lib.eoe_bn_act_pool_fwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(out), n, H, W, cout, pool, 1 if flat_out else 0,
-                                      1, slope, code, _stream()), "eoe_bn_act_pool_fwd")
+        # a 16-bit copy of the output for the next convolution's implicit GEMM (saves that layer a cast pass)
+        want16 = bool(cfg[10]) if len(cfg) > 10 else False
+        out16 = torch.empty((n, Ho, Wo, cout), dtype=dt, device=dev) if (want16 and _implicit_conv and not flat_out) else None
+        check(lib.eoe_bn_act_pool_fwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(out), _p(out16), n, H, W, cout, pool,
+                                      1 if flat_out else 0, 1, slope, code, _stream()), "eoe_bn_act_pool_fwd")
         ctx.save_for_backward(operand, y, stats, conv_w, conv_b, bn_w, bn_b)
         ctx.cfg = (n, H, W, cin, cout, kp, pool, flat_out, training, is_image, Hi, Wi, kh, kw, stride, pad, slope, implicit)
-        return out
+        if out16 is None:
+            return out
+        ctx.mark_non_differentiable(out16)
+        return out, out16
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _d16=None):
         operand, y, stats, conv_w, conv_b, bn_w, bn_b = ctx.saved_tensors
         n, H, W, cin, cout, kp, pool, flat_out, training, is_image, Hi, Wi, kh, kw, stride, pad, slope, implicit = ctx.cfg
         dev, dt = y.device, operand.dtype
@@ -734,6 +741,16 @@ class ConvBnActPoolFunction(torch.autograd.Function):
         return dx, dw, dcb, dg, db, None, None, None, None
 
 
+def conv_bn_act_pool(x, conv_w, conv_b, bn_w, bn_b, rm, rv, nbt, cfg):
+    """ConvBnActPoolFunction + the 16-bit copy of its output attached as `._eoe16` (consumed by the next convolution)"""
+    r = ConvBnActPoolFunction.apply(x, conv_w, conv_b, bn_w, bn_b, rm, rv, nbt, cfg)
+    if isinstance(r, tuple):
+        out, out16 = r
+        out._eoe16 = out16
+        return out
+    return r
+
+
 class BnActFunction(torch.autograd.Function):
     """BatchNorm1d -> LeakyReLU(0.01) on an fp32 [n, C] matrix (`cnn.py:84-85`)"""
 
@@ -749,7 +766,7 @@ class BnActFunction(torch.autograd.Function):
         check(lib.eoe_bn_stats(_p(y), _p(sums), _p(stats), _p(rm), _p(rv), _p(nbt), n, C, float(eps), float(momentum),
                                1 if training else 0, _stream()), "eoe_bn_stats")
         out = torch.empty_like(y)
-        check(lib.eoe_bn_act_pool_fwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(out), n, 1, 1, C, 1, 0, 1, 0.01,
+        check(lib.eoe_bn_act_pool_fwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(out), None, n, 1, 1, C, 1, 0, 1, 0.01,
                                       dtype_code(_compute_dtype), _stream()), "eoe_bn_act_pool_fwd")
         ctx.save_for_backward(y, stats, bn_w, bn_b)
         ctx.training = training

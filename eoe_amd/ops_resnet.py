@@ -8,7 +8,8 @@ import torch
 
 from . import _lib
 from ._lib import check, lib
-from .ops import BN_SCRATCH, _chk, _grad_target, _p, _stream, scratch
+from . import ops
+from .ops import BN_SCRATCH, _chk, _grad_target, _p, _stream, scratch, dtype_code
 
 
 class MaxPoolFunction(torch.autograd.Function):
@@ -21,14 +22,17 @@ class MaxPoolFunction(torch.autograd.Function):
         n, H, W, Cc = x.shape
         Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
         out = torch.empty((n, Ho, Wo, Cc), dtype=torch.float32, device=x.device)
+        out16 = torch.empty((n, Ho, Wo, Cc), dtype=ops.compute_dtype(), device=x.device)     # operand of the next conv
         idx = torch.empty((n, Ho, Wo, Cc), dtype=torch.uint8, device=x.device)
-        check(lib.eoe_maxpool_fwd(_p(x), _p(out), _p(idx), n, H, W, Cc, k, stride, pad, _stream()), "eoe_maxpool_fwd")
+        check(lib.eoe_maxpool_fwd(_p(x), _p(out), _p(out16), _p(idx), n, H, W, Cc, k, stride, pad, dtype_code(out16.dtype),
+                                  _stream()), "eoe_maxpool_fwd")
         ctx.save_for_backward(idx)
         ctx.geo = (n, H, W, Cc, k, stride, pad)
-        return out
+        ctx.mark_non_differentiable(out16)
+        return out, out16
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _d16=None):
         (idx,) = ctx.saved_tensors
         n, H, W, Cc, k, stride, pad = ctx.geo
         dout = dout.contiguous().float()
@@ -135,12 +139,15 @@ class AddReluFunction(torch.autograd.Function):
         _chk(a, b)
         a, b = a.contiguous().float(), b.contiguous().float()
         out = torch.empty_like(a)
-        check(lib.eoe_add_relu_fwd(_p(a), _p(b), _p(out), a.numel(), _stream()), "eoe_add_relu_fwd")
+        out16 = torch.empty(a.shape, dtype=ops.compute_dtype(), device=a.device)              # operand of the next conv
+        check(lib.eoe_add_relu_fwd(_p(a), _p(b), _p(out), _p(out16), dtype_code(out16.dtype), a.numel(), _stream()),
+              "eoe_add_relu_fwd")
         ctx.save_for_backward(out)
-        return out
+        ctx.mark_non_differentiable(out16)
+        return out, out16
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _d16=None):
         (out,) = ctx.saved_tensors
         dout = dout.contiguous().float()
         g = torch.empty_like(out)
@@ -169,3 +176,15 @@ class GlobalAvgPoolFunction(torch.autograd.Function):
         dx = torch.empty((n, H, W, Cc), dtype=torch.float32, device=dout.device)
         check(lib.eoe_avgpool_bwd(_p(dout), _p(dx), n, H * W, Cc, _stream()), "eoe_avgpool_bwd")
         return dx
+
+
+def max_pool(x, k, stride, pad):
+    out, out16 = MaxPoolFunction.apply(x, k, stride, pad)
+    out._eoe16 = out16
+    return out
+
+
+def add_relu(a, b):
+    out, out16 = AddReluFunction.apply(a, b)
+    out._eoe16 = out16
+    return out

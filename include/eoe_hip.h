@@ -285,9 +285,10 @@ int eoe_bn_stats(const float* y, float* sums_scratch, float* stats, float* runni
                  int64_t* num_batches_tracked, int M, int C, float eps, float momentum, int training, void* stream);
 /* out = maxpool_{pool}(act(bn(y))), act(z) = z > 0 ? z : slope*z (slope 0.01 = LeakyReLU of cnn.py, 0 = ReLU of
  * resnet.py, 1 = identity); y fp32 [n,H,W,C]; out 16-bit NHWC (or fp32 if out_f32; or the reference's NCHW flatten
- * order [n, C*(H/p)*(W/p)] if nchw_flat, cnn.py:83) */
-int eoe_bn_act_pool_fwd(const float* y, const float* stats, const float* gamma, const float* beta, void* out, int n, int H,
-                        int W, int C, int pool, int nchw_flat, int out_f32, float slope, int dtype, void* stream);
+ * order [n, C*(H/p)*(W/p)] if nchw_flat, cnn.py:83); out16 (optional, with an fp32 NHWC out): a 16-bit copy of out, the
+ * operand of the next convolution's implicit GEMM */
+int eoe_bn_act_pool_fwd(const float* y, const float* stats, const float* gamma, const float* beta, void* out, void* out16,
+                        int n, int H, int W, int C, int pool, int nchw_flat, int out_f32, float slope, int dtype, void* stream);
 /* backward of the above: dout fp32 (layout of `out`) -> dy [n*H*W, C] 16-bit (dY operand of the conv wgrad/dgrad), or
  * fp32 if dy_f32; dgamma, dbeta.  red_scratch: EOE_BN_SCRATCH(C) floats. */
 int eoe_bn_act_pool_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* dout,
@@ -300,8 +301,8 @@ int eoe_bn_act_pool_bwd(const float* y, const float* stats, const float* gamma, 
  * with slope 0 = ReLU or 1 = none); the pieces below are the HBM-bound rest of a BasicBlock.
  * ---------------------------------------------------------------------------------------------------- */
 /* nn.MaxPool2d(k, stride, pad) (resnet.py:96): out [n,Ho,Wo,C]; idx [n,Ho,Wo,C] = winning tap ky*k+kx (first maximum) */
-int eoe_maxpool_fwd(const float* x, float* out, uint8_t* idx, int n, int H, int W, int C, int k, int stride, int pad,
-                    void* stream);
+int eoe_maxpool_fwd(const float* x, float* out, void* out16 /* optional 16-bit copy */, uint8_t* idx, int n, int H, int W, int C,
+                    int k, int stride, int pad, int dtype, void* stream);
 int eoe_maxpool_bwd(const float* dout, const uint8_t* idx, float* dx, int n, int H, int W, int C, int k, int stride, int pad,
                     void* stream);
 
@@ -368,7 +369,8 @@ int eoe_sgate_fwd(const eoe_sgate_args* a, void* stream);
 int eoe_sgate_bwd(const eoe_sgate_bwd_args* a, void* stream);
 
 /* out = relu(a + b) (resnet.py:146-147); g = dout * [out > 0] (the gradient of both summands) */
-int eoe_add_relu_fwd(const float* a, const float* b, float* out, int64_t count, void* stream);
+int eoe_add_relu_fwd(const float* a, const float* b, float* out, void* out16 /* optional 16-bit copy */, int dtype,
+                     int64_t count, void* stream);
 int eoe_relu_bwd(const float* dout, const float* out, float* g, int64_t count, void* stream);
 /* nn.AvgPool2d over the whole HW grid (resnet.py:38,104): pooled_scratch [n,2,C] receives (mean, max), the mean is
  * pooled_scratch[:,0,:]; backward dx[n,hw,c] = dout[n,c] / HW */

@@ -38,7 +38,7 @@ def test_conv_layer_vs_oracle(dtype, n, cin, cout, H, is_image, flat):
     std = torch.tensor([0.9, 1.1, 1.3], device="cuda") if is_image else None
     xin = (x if is_image else x.permute(0, 2, 3, 1).contiguous()).requires_grad_(not is_image)
     wg, cbg, gg, bg = (t.clone().requires_grad_(True) for t in (w, cb, g, b))
-    out = ops.ConvBnActPoolFunction.apply(xin, wg, cbg, gg, bg, rm, rv, nbt, (True, 1e-4, 0.1, 2, is_image, mean, std, flat))
+    out = ops.conv_bn_act_pool(xin, wg, cbg, gg, bg, rm, rv, nbt, (True, 1e-4, 0.1, 2, is_image, mean, std, flat))
     # reference in fp64 on the CPU (operands rounded to 16 bit exactly as the kernel sees them)
     xd = xr.double()
     if is_image:

@@ -48,7 +48,7 @@ def test_conv_bn_general_vs_oracle(dtype, n, cin, cout, H, k, s, p, slope, is_im
     xin = (x if is_image else _nhwc(x)).requires_grad_(not is_image)
     wg, gg, bg = (t.clone().requires_grad_(True) for t in (w, g, b))
     cfg = (True, 1e-5, 0.1, 1, is_image, mean, std, False, (k, k, s, p), slope)
-    out = ops.ConvBnActPoolFunction.apply(xin, wg, None, gg, bg, rm, rv, nbt, cfg)
+    out = ops.conv_bn_act_pool(xin, wg, None, gg, bg, rm, rv, nbt, cfg)
     xd = xr.double()
     if is_image:
         xd = (xd - mean.cpu().double().view(1, 3, 1, 1)) / std.cpu().double().view(1, 3, 1, 1)
@@ -92,7 +92,7 @@ def test_implicit_conv_equals_materialised(n, cin, cout, H, k, s, p):
             rm, rv = torch.zeros(cout, device="cuda"), torch.ones(cout, device="cuda")
             nbt = torch.zeros((), dtype=torch.long, device="cuda")
             cfg = (True, 1e-5, 0.1, 1, False, None, None, False, (k, k, s, p), 0.0)
-            out = ops.ConvBnActPoolFunction.apply(xin, wg, None, gg, bg, rm, rv, nbt, cfg)
+            out = ops.conv_bn_act_pool(xin, wg, None, gg, bg, rm, rv, nbt, cfg)
             dout, _ = f32("ic/dout", tuple(out.shape), 1.0)
             (out * dout).sum().backward()
             res[mode] = (out.detach(), xin.grad, wg.grad, gg.grad, bg.grad)
@@ -110,7 +110,7 @@ def test_maxpool_3x3_s2(n, C, H, W):
     x, xr = f32("mp/x", (n, C, H, W), 1.0)
     x, xr = torch.relu(x), torch.relu(xr)                       # about half the entries tie at 0
     xin = _nhwc(x).requires_grad_(True)
-    out = R.MaxPoolFunction.apply(xin, 3, 2, 1)
+    out = R.max_pool(xin, 3, 2, 1)
     xd = xr.clone().requires_grad_(True)
     want = F.max_pool2d(xd, 3, 2, 1)
     assert torch.equal(out.detach().cpu(), want.detach().permute(0, 2, 3, 1))
@@ -185,7 +185,7 @@ def test_add_relu_and_avgpool():
     b, br = f32("ar/b", (2, 7, 7, 512), 1.0)
     a.requires_grad_(True), b.requires_grad_(True)
     ad, bd = ar.clone().requires_grad_(True), br.clone().requires_grad_(True)
-    out = R.GlobalAvgPoolFunction.apply(R.AddReluFunction.apply(a, b))
+    out = R.GlobalAvgPoolFunction.apply(R.add_relu(a, b))
     want = torch.relu(ad + bd).mean(dim=(1, 2))
     assert_close(out, want, 1e-6, 1e-6, "avgpool(relu(a+b))")
     dout, doutr = f32("ar/d", (2, 512), 1.0)

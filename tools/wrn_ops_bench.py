@@ -60,7 +60,7 @@ for cin, H, cout, k, s, p, cnt in SHAPES:
                                                 ops._stream()), "bn_stats"))
     g = torch.ones(cout, device=dev); b = torch.zeros(cout, device=dev)
     out = torch.empty((N, Ho, Ho, cout), device=dev)
-    t_bf = timeit(lambda: check(lib.eoe_bn_act_pool_fwd(y.data_ptr(), stats.data_ptr(), g.data_ptr(), b.data_ptr(), out.data_ptr(), N, Ho, Ho,
+    t_bf = timeit(lambda: check(lib.eoe_bn_act_pool_fwd(y.data_ptr(), stats.data_ptr(), g.data_ptr(), b.data_ptr(), out.data_ptr(), None, N, Ho, Ho,
                                                         cout, 1, 0, 1, 0.0, 1, ops._stream()), "bn_fwd"))
     red = ops.scratch("bn_red", (ops.BN_SCRATCH * cout,), torch.float32, dev)
     dg_, db_ = torch.empty(cout, device=dev), torch.empty(cout, device=dev)
