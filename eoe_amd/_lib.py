@@ -125,6 +125,8 @@ SIGNATURES = {
                             C.c_int, _vp],
     "eoe_bn_act_pool_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                             C.c_int, C.c_int, _f32, C.c_int, _vp],
+    "eoe_bn_act_maxpool_fwd": [_vp] * 7 + [C.c_int] * 7 + [_f32, C.c_int, _vp],
+    "eoe_bn_act_maxpool_bwd": [_vp] * 10 + [C.c_int] * 8 + [_f32, C.c_int, _vp],
     "eoe_maxpool_fwd": [_vp, _vp, _vp, _vp] + [C.c_int] * 8 + [_vp],
     "eoe_maxpool_bwd": [_vp, _vp, _vp] + [C.c_int] * 7 + [_vp],
     "eoe_cgate_fwd": [C.POINTER(CGateArgs), _vp],

@@ -410,6 +410,118 @@ __global__ __launch_bounds__(256) void bn_act_pool_bwd_kernel(const float* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------- BN + act + overlapping MaxPool
+// out = maxpool_{k,stride,pad}(act(bn(y))) in one pass over y (the stem of resnet.py:93-96: the 112x112x64 activation is
+// never written); idx = winning tap (first maximum), out16 = optional 16-bit copy
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_maxpool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ stats,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float* __restrict__ out, T* __restrict__ out16,
+                                                                 uint8_t* __restrict__ idx, int n, int H, int W, int C, int k,
+                                                                 int stride, int pad, int Ho, int Wo, float slope) {
+    const int cc = C / 4;
+    const size_t total = (size_t)n * Ho * Wo * cc;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cc) * 4;
+        const size_t op = i / cc;
+        const int wo = (int)(op % Wo), ho = (int)((op / Wo) % Ho), img = (int)(op / ((size_t)Wo * Ho));
+        const f32x4 mu = *(const f32x4*)(stats + c), rs = *(const f32x4*)(stats + C + c);
+        f32x4 g = {1.f, 1.f, 1.f, 1.f}, b = {0.f, 0.f, 0.f, 0.f};
+        if (gamma) { g = *(const f32x4*)(gamma + c); b = *(const f32x4*)(beta + c); }
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int arg[4] = {0, 0, 0, 0};
+        for (int tap = 0; tap < k * k; ++tap) {
+            const int h = ho * stride + tap / k - pad, w = wo * stride + tap % k - pad;
+            if (h < 0 || h >= H || w < 0 || w >= W) continue;
+            const f32x4 v = *(const f32x4*)(y + (((size_t)img * H + h) * W + w) * C + c);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = lrelu((v[r] - mu[r]) * rs[r] * g[r] + b[r], slope);
+                if (a > best[r]) { best[r] = a; arg[r] = tap; }
+            }
+        }
+        *(f32x4*)(out + op * C + c) = (f32x4){best[0], best[1], best[2], best[3]};
+        if (out16) *(u32x2*)(out16 + op * C + c) = pack4<T>(best[0], best[1], best[2], best[3]);
+        *(uint32_t*)(idx + op * C + c) = (uint32_t)arg[0] | ((uint32_t)arg[1] << 8) | ((uint32_t)arg[2] << 16) | ((uint32_t)arg[3] << 24);
+    }
+}
+// backward, one thread per (pixel of y, 4 channels): gradient at the BN output = sum of the windows this pixel won (gather
+// form, as maxpool_bwd_kernel) times act'.  MODE 0 = per-channel sums of g and g*xhat into this workgroup's partial row;
+// MODE 1 = dy (16-bit) from those sums.
+// S = the pooling stride as a compile-time constant (1 or 2; 0 = use the run-time value): the window enumeration below
+// divides by it twice per pixel
+template <typename T, int MODE, int S>
+__global__ __launch_bounds__(256) void bn_act_maxpool_bwd_kernel(const float* __restrict__ y, const float* __restrict__ stats,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 const float* __restrict__ dout, const uint8_t* __restrict__ idx,
+                                                                 float* __restrict__ red, T* __restrict__ dy, int n, int H, int W,
+                                                                 int C, int k, int stride, int pad, int Ho, int Wo,
+                                                                 int use_batch_stats, float slope) {
+    extern __shared__ float lds[];
+    const int cc = C / 4;
+    const size_t total = (size_t)n * H * W * cc;
+    const float invM = 1.0f / ((float)n * H * W);
+    if (MODE == 0) {
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lds[i] = 0.f;
+        __syncthreads();
+    }
+    float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cc) * 4;
+        const size_t ip = i / cc;
+        const int w = (int)(ip % W), h = (int)((ip / W) % H), img = (int)(ip / ((size_t)W * H));
+        const f32x4 mu = *(const f32x4*)(stats + c), rs = *(const f32x4*)(stats + C + c);
+        f32x4 g = {1.f, 1.f, 1.f, 1.f}, b = {0.f, 0.f, 0.f, 0.f};
+        if (gamma) { g = *(const f32x4*)(gamma + c); b = *(const f32x4*)(beta + c); }
+        const f32x4 v = *(const f32x4*)(y + ip * C + c);
+        float gs[4] = {0.f, 0.f, 0.f, 0.f};
+        {   // the windows (ho, wo) that contain this pixel: ho*st <= h+pad <= ho*st + k-1
+            const int st = S ? S : stride;
+            const int hp = h + pad, wp = w + pad;
+            const int ho_hi = min(hp / st, Ho - 1), ho_lo = max(0, (hp - k + st) / st);
+            const int wo_hi = min(wp / st, Wo - 1), wo_lo = max(0, (wp - k + st) / st);
+            for (int ho = ho_lo; ho <= ho_hi; ++ho)
+                for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                    const int tap = (hp - ho * st) * k + (wp - wo * st);
+                    const size_t o = (((size_t)img * Ho + ho) * Wo + wo) * C + c;
+                    const uint32_t a = *(const uint32_t*)(idx + o);
+                    const f32x4 d = *(const f32x4*)(dout + o);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if ((int)((a >> (8 * r)) & 255u) == tap) gs[r] += d[r];
+                }
+        }
+        float o4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float xh = (v[r] - mu[r]) * rs[r];
+            const float gz = gs[r] * (xh * g[r] + b[r] > 0.f ? 1.f : slope);
+            if (MODE == 0) {
+                acc0[r] += gz;
+                acc1[r] += gz * xh;
+            } else {
+                const float s1 = red[c + r], s2 = red[C + c + r];
+                o4[r] = use_batch_stats ? g[r] * rs[r] * (gz - s1 * invM - xh * s2 * invM) : g[r] * rs[r] * gz;
+            }
+        }
+        if (MODE == 1) *(u32x2*)(dy + ip * C + c) = pack4<T>(o4[0], o4[1], o4[2], o4[3]);
+    }
+    if (MODE == 0) {
+        const size_t first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (first < total) {
+            const int c = (int)(first % cc) * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                atomicAdd(&lds[c + r], acc0[r]);
+                atomicAdd(&lds[C + c + r], acc1[r]);
+            }
+        }
+        __syncthreads();
+        float* row = red + (size_t)(1 + blockIdx.x) * 2 * C;
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) row[i] = lds[i];
+    }
+}
+
 __global__ __launch_bounds__(256) void add_copy_kernel(float* __restrict__ dst, const float* __restrict__ src, int n, int accumulate) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = accumulate ? dst[i] + src[i] : src[i];
@@ -606,6 +718,61 @@ extern "C" int eoe_bn_act_pool_bwd(const float* y, const float* stats, const flo
         hipLaunchKernelGGL(add_copy_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, dbeta, (const float*)red_scratch, C, accumulate);
         hipLaunchKernelGGL(add_copy_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, dgamma, (const float*)(red_scratch + C), C, accumulate);
         EOE_CHECK_LAUNCH("bn_act_pool_bwd_params");
+    }
+    return 0;
+}
+
+extern "C" int eoe_bn_act_maxpool_fwd(const float* y, const float* stats, const float* gamma, const float* beta, float* out,
+                                      void* out16, uint8_t* idx, int n, int H, int W, int C, int k, int stride, int pad, float slope,
+                                      int dtype, void* stream) {
+    EOE_CHECK_ARG(y && stats && out && idx && n > 0 && C % 4 == 0 && k >= 1 && k * k <= 255 && stride >= 1 && pad >= 0 && 2 * pad <= k,
+                  "bn_act_maxpool_fwd: bad args");
+    EOE_CHECK_ARG((gamma == nullptr) == (beta == nullptr), "bn_act_maxpool: gamma/beta must both be given or both NULL");
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    EOE_CHECK_ARG(Ho >= 1 && Wo >= 1, "bn_act_maxpool_fwd: empty output");
+    ProfScope ps("bn_act_maxpool_fwd", 0, 4.0 * n * H * W * C + 7.0 * n * Ho * Wo * C, stream);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_maxpool_fwd_kernel<T>), dim3(grid_for((size_t)n * Ho * Wo * C / 4)), dim3(256), 0,
+                                         (hipStream_t)stream, y, stats, gamma, beta, out, (T*)out16, idx, n, H, W, C, k, stride, pad, Ho,
+                                         Wo, slope));
+    EOE_CHECK_LAUNCH("bn_act_maxpool_fwd");
+    return 0;
+}
+
+extern "C" int eoe_bn_act_maxpool_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* dout,
+                                      const uint8_t* idx, float* red_scratch, void* dy, float* dgamma, float* dbeta, int n, int H,
+                                      int W, int C, int k, int stride, int pad, int training, float slope, int dtype, void* stream) {
+    EOE_CHECK_ARG(y && stats && dout && idx && red_scratch && dy && n > 0 && C % 4 == 0 && C <= 4096 && k >= 1 && stride >= 1 && pad >= 0,
+                  "bn_act_maxpool_bwd: bad args");
+    EOE_CHECK_ARG((gamma == nullptr) == (beta == nullptr) && (dgamma == nullptr) == (dbeta == nullptr), "bn_act_maxpool_bwd: gamma/beta pairs");
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("bn_act_maxpool_bwd", 0, 2 * 4.0 * n * H * W * C + 2.0 * n * H * W * C + 2 * 5.0 * n * Ho * Wo * C, stream);
+    const int grid = grid_for((size_t)n * H * W * C / 4);
+    int g0 = grid > EOE_BN_PARTIALS ? EOE_BN_PARTIALS : grid;
+    {
+        int cc = C / 4, a = cc, b = 256;
+        while (b) { const int t = a % b; a = b; b = t; }
+        const int q = cc / a;
+        EOE_CHECK_ARG(q <= EOE_BN_PARTIALS, "bn_act_maxpool_bwd: C = %d not supported", C);
+        g0 = g0 / q * q;
+        if (g0 < q) g0 = q;
+    }
+#define EOE_BMP(MODE, SS, GRID, LDS)                                                                                             \
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_maxpool_bwd_kernel<T, MODE, SS>), dim3(GRID), dim3(256), LDS, s, y, stats, gamma, beta, \
+                                         dout, idx, red_scratch, (T*)dy, n, H, W, C, k, stride, pad, Ho, Wo, training, slope))
+    if (stride == 2) { EOE_BMP(0, 2, g0, 2 * C * sizeof(float)); } else if (stride == 1) { EOE_BMP(0, 1, g0, 2 * C * sizeof(float)); }
+    else { EOE_BMP(0, 0, g0, 2 * C * sizeof(float)); }
+    EOE_CHECK_LAUNCH("bn_act_maxpool_bwd_reduce");
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * C, 64)), dim3(1024), 0, s, (const float*)(red_scratch + 2 * C), red_scratch, g0,
+                       2 * C);
+    EOE_CHECK_LAUNCH("bn_act_maxpool_bwd_reduce2");
+    if (stride == 2) { EOE_BMP(1, 2, grid, 0); } else if (stride == 1) { EOE_BMP(1, 1, grid, 0); } else { EOE_BMP(1, 0, grid, 0); }
+#undef EOE_BMP
+    EOE_CHECK_LAUNCH("bn_act_maxpool_bwd_apply");
+    if (dgamma) {
+        hipLaunchKernelGGL(add_copy_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, dbeta, (const float*)red_scratch, C, 0);
+        hipLaunchKernelGGL(add_copy_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, dgamma, (const float*)(red_scratch + C), C, 0);
+        EOE_CHECK_LAUNCH("bn_act_maxpool_bwd_params");
     }
     return 0;
 }

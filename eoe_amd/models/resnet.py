@@ -16,11 +16,11 @@ def conv3x3(in_planes, out_planes, stride=1):
     return nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)
 
 
-def _conv_bn(x, conv, bn, training, slope, is_image=False, normalize=None, want16=False):
+def _conv_bn(x, conv, bn, training, slope, is_image=False, normalize=None, want16=False, pool=1):
     """conv (no bias) -> BatchNorm2d -> ReLU (slope 0) or nothing (slope 1); fp32 NHWC in/out"""
     mean, std = normalize if (is_image and normalize is not None) else (None, None)
     k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
-    cfg = (training, bn.eps, bn.momentum, 1, is_image, mean, std, False, (k, k, s, p), slope, want16)
+    cfg = (training, bn.eps, bn.momentum, pool, is_image, mean, std, False, (k, k, s, p), slope, want16)
     return ops.conv_bn_act_pool(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                 bn.num_batches_tracked, cfg)
 
@@ -113,8 +113,10 @@ class WideResNet(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("eoe_amd.WideResNet runs on the GPU only (no CPU fallback)")
         x = x.view(-1, 3, 224, 224)
-        x = _conv_bn(x, self.conv1, self.bn1, self.training, 0.0, is_image=True, normalize=self.normalize)   # NHWC from here
-        x = ops_resnet.max_pool(x, 3, 2, 1)
+        mp = self.maxpool
+        # conv1 -> bn1 -> relu -> maxpool in one unit: the 112x112x64 activation is never written; fp32 NHWC from here
+        x = _conv_bn(x, self.conv1, self.bn1, self.training, 0.0, is_image=True, normalize=self.normalize, want16=True,
+                     pool=(mp.kernel_size, mp.stride, mp.padding))
         x = self.layer1(x)
         x = self.layer2(x)
         x = self.layer3(x)

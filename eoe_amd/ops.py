@@ -679,14 +679,25 @@ class ConvBnActPoolFunction(torch.autograd.Function):
         sums = scratch("bn_sums", (BN_SCRATCH * cout,), torch.float32, dev)
         check(lib.eoe_bn_stats(_p(y), _p(sums), _p(stats), _p(rm), _p(rv), _p(nbt), M, cout, float(eps), float(momentum),
                                1 if training else 0, _stream()), "eoe_bn_stats")
-        Ho, Wo = H // pool, W // pool
-        out = torch.empty((n, cout * Ho * Wo) if flat_out else (n, Ho, Wo, cout), dtype=torch.float32, device=dev)
-        # a 16-bit copy of the output for the next convolution's implicit GEMM (saves that layer a cast pass)
         want16 = bool(cfg[10]) if len(cfg) > 10 else False
-        out16 = torch.empty((n, Ho, Wo, cout), dtype=dt, device=dev) if (want16 and _implicit_conv and not flat_out) else None
-        check(lib.eoe_bn_act_pool_fwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(out), _p(out16), n, H, W, cout, pool,
-                                      1 if flat_out else 0, 1, slope, code, _stream()), "eoe_bn_act_pool_fwd")
-        ctx.save_for_backward(operand, y, stats, conv_w, conv_b, bn_w, bn_b)
+        idx = None
+        if isinstance(pool, tuple):
+            # overlapping MaxPool2d(k, s, p) fused behind BN + act: the pre-pool activation is never written (resnet.py:93-96)
+            pk, pstride, ppad = pool
+            Ho, Wo = (H + 2 * ppad - pk) // pstride + 1, (W + 2 * ppad - pk) // pstride + 1
+            out = torch.empty((n, Ho, Wo, cout), dtype=torch.float32, device=dev)
+            out16 = torch.empty((n, Ho, Wo, cout), dtype=dt, device=dev) if (want16 and _implicit_conv) else None
+            idx = torch.empty((n, Ho, Wo, cout), dtype=torch.uint8, device=dev)
+            check(lib.eoe_bn_act_maxpool_fwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(out), _p(out16), _p(idx), n, H, W, cout, pk,
+                                             pstride, ppad, slope, code, _stream()), "eoe_bn_act_maxpool_fwd")
+        else:
+            Ho, Wo = H // pool, W // pool
+            out = torch.empty((n, cout * Ho * Wo) if flat_out else (n, Ho, Wo, cout), dtype=torch.float32, device=dev)
+            # a 16-bit copy of the output for the next convolution's implicit GEMM (saves that layer a cast pass)
+            out16 = torch.empty((n, Ho, Wo, cout), dtype=dt, device=dev) if (want16 and _implicit_conv and not flat_out) else None
+            check(lib.eoe_bn_act_pool_fwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(out), _p(out16), n, H, W, cout, pool,
+                                          1 if flat_out else 0, 1, slope, code, _stream()), "eoe_bn_act_pool_fwd")
+        ctx.save_for_backward(operand, y, stats, conv_w, conv_b, bn_w, bn_b, idx)
         ctx.cfg = (n, H, W, cin, cout, kp, pool, flat_out, training, is_image, Hi, Wi, kh, kw, stride, pad, slope, implicit)
         if out16 is None:
             return out
@@ -695,7 +706,7 @@ class ConvBnActPoolFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, _d16=None):
-        operand, y, stats, conv_w, conv_b, bn_w, bn_b = ctx.saved_tensors
+        operand, y, stats, conv_w, conv_b, bn_w, bn_b, idx = ctx.saved_tensors
         n, H, W, cin, cout, kp, pool, flat_out, training, is_image, Hi, Wi, kh, kw, stride, pad, slope, implicit = ctx.cfg
         dev, dt = y.device, operand.dtype
         code = dtype_code(dt)
@@ -705,9 +716,14 @@ class ConvBnActPoolFunction(torch.autograd.Function):
         dg = _grad_target(bn_w) if bn_w is not None else None
         db = _grad_target(bn_b) if bn_b is not None else None
         red = scratch("bn_red", (BN_SCRATCH * cout,), torch.float32, dev)
-        check(lib.eoe_bn_act_pool_bwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(dout), _p(red), _p(dy16), 0, _p(dg), _p(db), n, H,
-                                      W, cout, pool, 1 if flat_out else 0, 1 if training else 0, 0, slope, code, _stream()),
-              "eoe_bn_act_pool_bwd")
+        if isinstance(pool, tuple):
+            check(lib.eoe_bn_act_maxpool_bwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(dout), _p(idx), _p(red), _p(dy16), _p(dg), _p(db),
+                                             n, H, W, cout, pool[0], pool[1], pool[2], 1 if training else 0, slope, code, _stream()),
+                  "eoe_bn_act_maxpool_bwd")
+        else:
+            check(lib.eoe_bn_act_pool_bwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(dout), _p(red), _p(dy16), 0, _p(dg), _p(db), n, H,
+                                          W, cout, pool, 1 if flat_out else 0, 1 if training else 0, 0, slope, code, _stream()),
+                  "eoe_bn_act_pool_bwd")
         dw = _grad_target(conv_w)
         if implicit == 2:
             _, Hp, Wp, _ = operand.shape

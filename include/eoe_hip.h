@@ -295,6 +295,16 @@ int eoe_bn_act_pool_bwd(const float* y, const float* stats, const float* gamma, 
                         float* red_scratch, void* dy, int dy_f32, float* dgamma, float* dbeta, int n, int H, int W, int C,
                         int pool, int nchw_flat, int training, int accumulate, float slope, int dtype, void* stream);
 
+/* BatchNorm + activation + OVERLAPPING MaxPool2d(k, stride, pad) in one pass (the stem of resnet.py:93-96: the
+ * 112x112x64 post-ReLU activation is never written): out fp32 [n,Ho,Wo,C], optional 16-bit copy, idx = winning tap;
+ * backward: dout fp32 [n,Ho,Wo,C] -> dy 16-bit [n*H*W, C] (gather form), dgamma, dbeta; red_scratch EOE_BN_SCRATCH(C). */
+int eoe_bn_act_maxpool_fwd(const float* y, const float* stats, const float* gamma, const float* beta, float* out, void* out16,
+                           uint8_t* idx, int n, int H, int W, int C, int k, int stride, int pad, float slope, int dtype,
+                           void* stream);
+int eoe_bn_act_maxpool_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* dout,
+                           const uint8_t* idx, float* red_scratch, void* dy, float* dgamma, float* dbeta, int n, int H, int W,
+                           int C, int k, int stride, int pad, int training, float slope, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * WideResNet + CBAM (resnet.py:85-109,130-149; cbam.py:31-107).  All activations fp32 NHWC.  The 7x7/2 stem,
  * the 3x3 and the 1x1/2 downsample convolutions are eoe_im2col + eoe_gemm_nt (+ eoe_bn_stats / eoe_bn_act_pool_*

@@ -381,3 +381,39 @@ def test_wideresnet_full_batch_properties():
     opt.step()
     still = [k for k, p in m.named_parameters() if gm[k] > 0 and torch.equal(before[k], p.detach())]
     assert not still, still
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_stem_conv_bn_relu_maxpool_fused(dtype):
+    """conv7x7/2 -> BN -> ReLU -> MaxPool(3,2,1) as ONE unit (packed first layer + fused BN/ReLU/overlapping max-pool kernels)
+    against torch-CPU fp64, forward and every gradient"""
+    import eoe_amd
+    import eoe_amd.ops as ops
+    eoe_amd.set_compute_dtype(dtype)
+    n, cout, H = 3, 64, 36
+    x, xr = f32("st/x", (n, 3, H, H), 1.0)
+    w, wr = f32("st/w", (cout, 3, 7, 7), (1.0 / 147) ** 0.5)
+    g, gr = f32("st/g", (cout,), 0.1, mean=1.0)
+    b, br = f32("st/b", (cout,), 0.1)
+    rm, rv = torch.zeros(cout, device="cuda"), torch.ones(cout, device="cuda")
+    nbt = torch.zeros((), dtype=torch.long, device="cuda")
+    mean = torch.tensor([0.1, -0.2, 0.05], device="cuda")
+    std = torch.tensor([0.9, 1.1, 1.3], device="cuda")
+    wg, gg, bg = (t.clone().requires_grad_(True) for t in (w, g, b))
+    cfg = (True, 1e-5, 0.1, (3, 2, 1), True, mean, std, False, (7, 7, 2, 3), 0.0, True)
+    out = ops.conv_bn_act_pool(x, wg, None, gg, bg, rm, rv, nbt, cfg)
+    assert out._eoe16.dtype == dtype and rel_rms(out._eoe16.float(), out.detach().cpu()) < 2 * EPS16[dtype]
+    xd = ((xr.double() - mean.cpu().double().view(1, 3, 1, 1)) / std.cpu().double().view(1, 3, 1, 1)).to(dtype).double()
+    wd = wr.to(dtype).double().requires_grad_(True)
+    gd, bd = (t.double().requires_grad_(True) for t in (gr, br))
+    rmr, rvr = torch.zeros(cout, dtype=torch.float64), torch.ones(cout, dtype=torch.float64)
+    zr = torch.relu(omodels.batch_norm(F.conv2d(xd, wd, None, stride=2, padding=3), gd, bd, rmr, rvr, True, 0.1, 1e-5))
+    want = F.max_pool2d(zr, 3, 2, 1).permute(0, 2, 3, 1)
+    assert_close(out, want, 1e-3, 2e-3, "stem forward")
+    dout, doutr = f32("st/dout", tuple(out.shape), 1.0)
+    (out * dout).sum().backward()
+    (want * doutr.double()).sum().backward()
+    tol = 30 * EPS16[dtype]
+    for name, got, ref in (("dw", wg.grad, wd.grad), ("dgamma", gg.grad, gd.grad), ("dbeta", bg.grad, bd.grad)):
+        r = rel_rms(got, ref)
+        assert r < tol, (name, r)
