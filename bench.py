@@ -168,6 +168,11 @@ def main():
         elapsed = t.item()
     final_loss = loss.item()
     assert final_loss == final_loss, "NaN loss"
+    # epoch-tail metric of the reference (ad_trainer.py:456-471: ROC-AUC of the scores collected during training), on the
+    # last timed step's scores of this rank (outside the timed region)
+    from eoe_amd import metrics
+    last = score_buf[(args.warmup + args.steps - 1) % score_buf.shape[0]].float().cpu().numpy()
+    auc = float(metrics.roc_auc(lbls.cpu().numpy(), last))
 
     roof = None
     if not args.no_roofline:
@@ -217,7 +222,7 @@ def main():
             "config": {"workload": workload, "global_batch": n_global, "parallelism": f"dp{world}"},
             "model_tflops": round(value * flop_per_img / 1e3, 1),
             "mfma_roofline_frac_end_to_end": round(value * flop_per_img / 1e3 / (MFMA_PEAK_TFLOPS * world), 4),
-            "final_loss": round(final_loss, 5),
+            "final_loss": round(final_loss, 5), "auc_last_step": round(auc, 4),
         }
         if roof is not None:
             out["roofline"] = roof

@@ -96,25 +96,27 @@ __global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dp, f
 // w fp32 [cout, cin, 5, 5] -> w16 [cout, Kp] (column = tap*cin + c) and w16t [Kp, cout]
 template <typename T>
 __global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict__ w, T* __restrict__ w16, T* __restrict__ w16t,
-                                                        T* __restrict__ w16d, int cout, int cin, int Kp, int taps) {
+                                                        T* __restrict__ w16d, int cout, int cin, int cpad, int Kp, int taps) {
+    // cpad >= cin: channels per tap in the column order (the channel-padded NHWC image of a 3-channel first layer)
     const int total = cout * Kp;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int o = i / Kp, col = i % Kp;
+        const int tap = col / cpad, c = col % cpad;
         float v = 0.f;
-        if (col < taps * cin) v = w[((size_t)o * cin + col % cin) * taps + col / cin];
+        if (tap < taps && c < cin) v = w[((size_t)o * cin + c) * taps + tap];
         w16[i] = (T)v;
         if (w16t) w16t[(size_t)col * cout + o] = (T)v;
         // dgrad operand of a stride-1 convolution: [cin, (taps reversed) x cout] (dx = conv of dy with the flipped kernel)
-        if (w16d && col < taps * cin) w16d[((size_t)(col % cin) * taps + (taps - 1 - col / cin)) * cout + o] = (T)v;
+        if (w16d && tap < taps && c < cin) w16d[((size_t)c * taps + (taps - 1 - tap)) * cout + o] = (T)v;
     }
 }
 // g fp32 [cout, Kp] (or transposed: [taps*cin, cout]) -> dw fp32 [cout, cin, kh, kw] (+= if accumulate)
 __global__ __launch_bounds__(256) void conv_unpack_kernel(const float* __restrict__ g, float* __restrict__ dw, int cout, int cin,
-                                                          int Kp, int taps, int transposed, int accumulate) {
+                                                          int cpad, int Kp, int taps, int transposed, int accumulate) {
     const int total = cout * cin * taps;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int tap = i % taps, c = (i / taps) % cin, o = i / (taps * cin);
-        const float v = transposed ? g[(size_t)(tap * cin + c) * cout + o] : g[(size_t)o * Kp + tap * cin + c];
+        const float v = transposed ? g[(size_t)(tap * cpad + c) * cout + o] : g[(size_t)o * Kp + tap * cpad + c];
         dw[i] = accumulate ? dw[i] + v : v;
     }
 }
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256) void conv_unpack_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------- packed 3-channel first layer
 // image fp32 NCHW [n,3,H,W] (+ per-channel normalise) -> 16-bit [n, Hp, Wp, 4] with the conv's zero padding made physical
 // (pixel (h, w) lands at (h + pad, w + pad); channel 3 and the border are 0): the operand of the GATHER == 2 GEMMs
-template <typename T>
+template <typename T, int CP>
 __global__ __launch_bounds__(256) void stem_pack_image_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                               const float* __restrict__ stdv, T* __restrict__ out, int n, int H, int W,
                                                               int Hp, int Wp, int pad) {
@@ -138,7 +140,8 @@ __global__ __launch_bounds__(256) void stem_pack_image_kernel(const float* __res
                 if (mean) v[c] = (v[c] - mean[c]) / stdv[c];
             }
         }
-        *(u32x2*)(out + i * 4) = pack4<T>(v[0], v[1], v[2], 0.f);
+        *(u32x2*)(out + i * CP) = pack4<T>(v[0], v[1], v[2], 0.f);
+        if (CP == 8) *(u32x2*)(out + i * CP + 4) = (u32x2){0u, 0u};
     }
 }
 // w fp32 [cout,3,kh,kw] -> 16-bit [cout, K], K = ceil(kh/2)*64, column = ky*32 + kx*4 + c (zero where ky >= kh, kx >= kw, c = 3)
@@ -591,31 +594,37 @@ extern "C" int eoe_col2im(const void* dpatches, float* dx, int n, int C, int H, 
     return 0;
 }
 
-extern "C" int eoe_conv_pack_weight(const float* w, void* w16, void* w16t, void* w16d, int cout, int cin, int kh, int kw, int Kp,
-                                    int dtype, void* stream) {
-    EOE_CHECK_ARG(w && w16 && cout > 0 && cin > 0 && Kp >= kh * kw * cin, "conv_pack_weight: bad args");
+extern "C" int eoe_conv_pack_weight(const float* w, void* w16, void* w16t, void* w16d, int cout, int cin, int cpad, int kh, int kw,
+                                    int Kp, int dtype, void* stream) {
+    EOE_CHECK_ARG(w && w16 && cout > 0 && cin > 0 && cpad >= cin && Kp >= kh * kw * cpad, "conv_pack_weight: bad args");
     DISPATCH_T(dtype, hipLaunchKernelGGL((conv_pack_kernel<T>), dim3(grid_for((size_t)cout * Kp)), dim3(256), 0,
-                                         (hipStream_t)stream, w, (T*)w16, (T*)w16t, (T*)w16d, cout, cin, Kp, kh * kw));
+                                         (hipStream_t)stream, w, (T*)w16, (T*)w16t, (T*)w16d, cout, cin, cpad, Kp, kh * kw));
     EOE_CHECK_LAUNCH("conv_pack_weight");
     return 0;
 }
 
-extern "C" int eoe_conv_unpack_wgrad(const float* g, float* dw, int cout, int cin, int kh, int kw, int Kp, int transposed,
+extern "C" int eoe_conv_unpack_wgrad(const float* g, float* dw, int cout, int cin, int cpad, int kh, int kw, int Kp, int transposed,
                                      int accumulate, void* stream) {
-    EOE_CHECK_ARG(g && dw && cout > 0 && cin > 0 && Kp >= kh * kw * cin, "conv_unpack_wgrad: bad args");
+    EOE_CHECK_ARG(g && dw && cout > 0 && cin > 0 && cpad >= cin && Kp >= kh * kw * cpad, "conv_unpack_wgrad: bad args");
     hipLaunchKernelGGL(conv_unpack_kernel, dim3(grid_for((size_t)cout * cin * kh * kw)), dim3(256), 0, (hipStream_t)stream, g, dw,
-                       cout, cin, Kp, kh * kw, transposed, accumulate);
+                       cout, cin, cpad, Kp, kh * kw, transposed, accumulate);
     EOE_CHECK_LAUNCH("conv_unpack_wgrad");
     return 0;
 }
 
 extern "C" int eoe_stem_pack_image(const float* x, const float* mean, const float* stdv, void* out, int n, int H, int W, int Hp,
-                                   int Wp, int pad, int dtype, void* stream) {
-    EOE_CHECK_ARG(x && out && n > 0 && H > 0 && W > 0 && pad >= 0 && Hp >= H + pad && Wp >= W + pad, "stem_pack_image: bad args");
+                                   int Wp, int pad, int cpad, int dtype, void* stream) {
+    EOE_CHECK_ARG(x && out && n > 0 && H > 0 && W > 0 && pad >= 0 && Hp >= H + pad && Wp >= W + pad && (cpad == 4 || cpad == 8),
+                  "stem_pack_image: bad args");
     EOE_CHECK_ARG((mean == nullptr) == (stdv == nullptr), "stem_pack_image: mean/std must both be given or both NULL");
     ProfScope ps("stem_pack", 0, 12.0 * n * H * W + 8.0 * n * Hp * Wp, stream);
-    DISPATCH_T(dtype, hipLaunchKernelGGL((stem_pack_image_kernel<T>), dim3(grid_for((size_t)n * Hp * Wp)), dim3(256), 0,
-                                         (hipStream_t)stream, x, mean, stdv, (T*)out, n, H, W, Hp, Wp, pad));
+    if (cpad == 4) {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((stem_pack_image_kernel<T, 4>), dim3(grid_for((size_t)n * Hp * Wp)), dim3(256), 0,
+                                             (hipStream_t)stream, x, mean, stdv, (T*)out, n, H, W, Hp, Wp, pad));
+    } else {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((stem_pack_image_kernel<T, 8>), dim3(grid_for((size_t)n * Hp * Wp)), dim3(256), 0,
+                                             (hipStream_t)stream, x, mean, stdv, (T*)out, n, H, W, Hp, Wp, pad));
+    }
     EOE_CHECK_LAUNCH("stem_pack_image");
     return 0;
 }

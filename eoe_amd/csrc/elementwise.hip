@@ -405,27 +405,31 @@ __global__ __launch_bounds__(256) void embed_lnpre_bwd_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------ column sums
-// block = 256 threads = 64 column-groups(4 cols = 8 B) x 4 row lanes; grid.x over column groups of 256 cols,
-// grid.y strides rows; combine through LDS then one atomic per column per block.
+// block = 256 threads = cpb column-groups (4 cols = 8 B each; cpb = min(64, cols/4) rounded up to a power of two, so narrow
+// matrices -- the conv-bias gradients of CNN32, 32..128 columns -- still use every thread) x 256/cpb row lanes; grid.x over
+// column groups, grid.y strides rows; combine through LDS then one atomic per column per block.
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int ldx, float* __restrict__ out, int rows, int cols) {
-    __shared__ float red[4][256];
-    const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 256 + cg * 4;
-    float a[4] = {0.f, 0.f, 0.f, 0.f};
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int ldx, float* __restrict__ out, int rows, int cols,
+                                                     int cpb) {
+    __shared__ f32x4 red[256];
+    const int rpb = 256 / cpb;
+    const int tc = threadIdx.x % cpb, rl = threadIdx.x / cpb;
+    const int c = (blockIdx.x * cpb + tc) * 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
     if (c < cols) {
-        for (int r = blockIdx.y * 4 + rl; r < rows; r += gridDim.y * 4) {
+        for (int r = blockIdx.y * rpb + rl; r < rows; r += gridDim.y * rpb) {
             float t[4];
             unpack4<T>(*(const u32x2*)(x + (size_t)r * ldx + c), t);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) a[k] += t[k];
+            a += (f32x4){t[0], t[1], t[2], t[3]};
         }
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) red[rl][cg * 4 + k] = a[k];
+    red[threadIdx.x] = a;
     __syncthreads();
-    const int cc = blockIdx.x * 256 + threadIdx.x;
-    if (cc < cols) atomicAdd(out + cc, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (rl == 0 && c < cols) {
+        for (int k = 1; k < rpb; ++k) a += red[threadIdx.x + k * cpb];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(out + c + k, a[k]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ objectives
@@ -762,11 +766,15 @@ extern "C" int eoe_colsum(const void* x, int ldx, float* out, int rows, int cols
         if (hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), (hipStream_t)stream) != hipSuccess)
             return eoe_set_error(EOE_ERR_LAUNCH, "colsum: memset failed");
     }
-    int gy = cdiv(rows, 4 * 16);
+    int cpb = 1;
+    while (cpb < 64 && cpb < cols / 4) cpb *= 2;
+    const int rpb = 256 / cpb, gx = cdiv(cols / 4, cpb);
+    int gy = cdiv(rows, rpb * 16);
     if (gy > 128) gy = 128;
+    if (gx * gy > 1024) gy = 1024 / gx;
     if (gy < 1) gy = 1;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), dim3(cdiv(cols, 256), gy), dim3(256), 0,
-                                         (hipStream_t)stream, (const T*)x, ldx, out, rows, cols));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), dim3(gx, gy), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)x, ldx, out, rows, cols, cpb));
     EOE_CHECK_LAUNCH("colsum");
     return 0;
 }

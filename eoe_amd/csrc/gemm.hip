@@ -40,6 +40,11 @@ struct GemmP {
     // GATHER == 2 (3-channel first layer): A = physically zero-padded 16-bit [n, gH, gW, 4] image; a 128-B k-tile = 2 kernel
     // rows x 8 pixels x 4 channels, i.e. 16-B piece q of k-tile kt = pixels (2*(q&3), +1) of kernel row 2*kt + (q>>2)
     int gkstep;       // bytes between consecutive k-tiles = 2 * gW * 8
+    // GATHER == 3 (narrow layers, gC in {8, 16, 32}): a 64-deep k-tile spans 64/gC taps, so every 16-B piece decodes its
+    // own tap: k = kt*64 + 8*piece, tap = k >> glog2c, (ky, kx) = divmod(tap, gkw) by multiply-shift; taps >= gkh*gkw (the
+    // zero padding of K up to a multiple of 64) and taps in the image's zero padding read as zeros
+    int gkh, glog2c;
+    unsigned gmagic;  // ceil(65536 / gkw)
 };
 
 // General (slow) epilogue: straight from the MFMA accumulator layout (lane = output row within a 16-row band, 4
@@ -317,6 +322,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
     // slot ^ ((row>>1)&7).  A image: 256 rows = 32 wave-loads (4 per wave); B image: 128 rows = 16 (2 per wave)
     unsigned offA[4], offB[2];
     int gh[4], gw[4];                              // GATHER: top-left input coordinate of each staged row's window
+    int gw3[4];                                    // GATHER == 3: element offset of the lane's 16-B piece within a k-tile
     int g_ky = 0, g_kx = 0, g_c0 = 0;              // GATHER: tap / channel offset of the k-tile being staged (uniform)
     int st_tile = 0, st_kt = 0, st_slot = 0;       // st_tile / c_tile count this workgroup's tiles (0 .. my_tiles)
     // (tried and rejected, measured interleaved on one device: giving each XCD a band of whole tile rows swept
@@ -342,13 +348,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
                 } else {
                     offA[j] = EOE_OOB;
                 }
-            } else if (GATHER == 1) {
+            } else if (GATHER == 1 || GATHER == 3) {
+                if (GATHER == 3) gw3[j] = c * 8;
                 if (ga < p.M) {
                     const int img = ga / p.gHoWo, rem = ga - img * p.gHoWo;
                     const int ho = rem / p.gWo, wo = rem - ho * p.gWo;
                     gh[j] = ho * p.gstride - p.gpad;
                     gw[j] = wo * p.gstride - p.gpad;
-                    offA[j] = (unsigned)((((img * p.gH + gh[j]) * p.gW + gw[j]) * p.gC + c * 8) * 2);   // wraps for h < 0: only used when valid
+                    offA[j] = (unsigned)((((img * p.gH + gh[j]) * p.gW + gw[j]) * p.gC + (GATHER == 3 ? 0 : c * 8)) * 2);   // wraps for h < 0: only used when valid
                 } else {
                     gh[j] = -(1 << 24);
                     gw[j] = 0;
@@ -383,6 +390,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
             if (g_c0 == p.gC) {
                 g_c0 = 0;
                 if (++g_kx == p.gkw) { g_kx = 0; ++g_ky; }
+            }
+        } else if (GATHER == 3) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kg = st_kt * BK + gw3[j];
+                const int tap = kg >> p.glog2c, ch = kg & (p.gC - 1);
+                const int ky = (int)(((unsigned)tap * p.gmagic) >> 16), kx = tap - ky * p.gkw;
+                const bool ok = ky < p.gkh && (unsigned)(gh[j] + ky) < (unsigned)p.gH && (unsigned)(gw[j] + kx) < (unsigned)p.gW;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(sa + (wave * 4 + j) * 1024), 16,
+                                                         ok ? offA[j] + (unsigned)(((ky * p.gW + kx) * p.gC + ch) * 2) : EOE_OOB, 0, 0, 0);
             }
         } else {
 #pragma unroll
@@ -560,6 +577,7 @@ int launch_nt(const GemmP& p, int epi, int gather, hipStream_t s) {
         const int tiles = cdiv(p.M, BM) * cdiv(p.N, narrow ? 64 : 128);
         const int grid = tiles < ncu ? tiles : ncu;
         if (gather == 2) return narrow ? launch_nt_conv<T, 2, 2>(p, grid, s) : launch_nt_conv<T, 4, 2>(p, grid, s);
+        if (gather == 3) return narrow ? launch_nt_conv<T, 2, 3>(p, grid, s) : launch_nt_conv<T, 4, 3>(p, grid, s);
         if (gather) return narrow ? launch_nt_conv<T, 2, 1>(p, grid, s) : launch_nt_conv<T, 4, 1>(p, grid, s);
         return launch_nt_conv<T, 2, 0>(p, grid, s);
     }
@@ -588,7 +606,8 @@ int fill_params(const eoe_gemm_args* a, GemmP& p) {
     EOE_CHECK_ARG(a->ldb >= a->K, "gemm_nt: leading dims smaller than K");
     size_t ba = ((size_t)(a->M - 1) * a->lda + a->K) * 2;
     const size_t bb = ((size_t)(a->N - 1) * a->ldb + a->K) * 2;
-    p.gH = p.gW = p.gC = p.gWo = p.gHoWo = p.gkw = p.gstride = p.gpad = p.gkstep = 0;
+    p.gH = p.gW = p.gC = p.gWo = p.gHoWo = p.gkw = p.gstride = p.gpad = p.gkstep = p.gkh = p.glog2c = 0;
+    p.gmagic = 0;
     if (a->gather == 2) {
         const eoe_conv_geometry& g = a->geo;
         EOE_CHECK_ARG(a->epilogue == EOE_EPI_NONE, "gemm_nt: an implicit patch matrix supports the plain epilogue only");
@@ -602,10 +621,17 @@ int fill_params(const eoe_gemm_args* a, GemmP& p) {
     } else if (a->gather) {
         const eoe_conv_geometry& g = a->geo;
         EOE_CHECK_ARG(a->epilogue == EOE_EPI_NONE, "gemm_nt: an implicit patch matrix supports the plain epilogue only");
-        EOE_CHECK_ARG(g.n > 0 && g.H > 0 && g.W > 0 && g.C > 0 && g.C % BK == 0 && g.kh > 0 && g.kw > 0 && g.stride > 0 && g.pad >= 0 &&
-                      g.Ho > 0 && g.Wo > 0, "gemm_nt: bad conv geometry (C = %d must be a multiple of %d)", g.C, BK);
-        EOE_CHECK_ARG((g.Ho - 1) * g.stride - g.pad + g.kh - 1 < g.H + g.pad + g.kh && a->M == g.n * g.Ho * g.Wo &&
-                      a->K == g.kh * g.kw * g.C, "gemm_nt: conv geometry does not match M = %d, K = %d", a->M, a->K);
+        const bool narrowc = g.C == 8 || g.C == 16 || g.C == 32;
+        EOE_CHECK_ARG(g.n > 0 && g.H > 0 && g.W > 0 && g.C > 0 && (g.C % BK == 0 || narrowc) && g.kh > 0 && g.kw > 0 && g.stride > 0 &&
+                      g.pad >= 0 && g.Ho > 0 && g.Wo > 0, "gemm_nt: bad conv geometry (C = %d must be 8, 16, 32 or a multiple of %d)", g.C, BK);
+        EOE_CHECK_ARG(a->M == g.n * g.Ho * g.Wo && (narrowc ? a->K >= g.kh * g.kw * g.C : a->K == g.kh * g.kw * g.C),
+                      "gemm_nt: conv geometry does not match M = %d, K = %d", a->M, a->K);
+        if (narrowc) {
+            p.gkh = g.kh;
+            p.glog2c = g.C == 8 ? 3 : (g.C == 16 ? 4 : 5);
+            p.gmagic = (65536u + (unsigned)g.kw - 1) / (unsigned)g.kw;
+            EOE_CHECK_ARG((a->K >> p.glog2c) < 4096, "gemm_nt: too many taps");
+        }
         ba = (size_t)g.n * g.H * g.W * g.C * 2;
         p.gH = g.H; p.gW = g.W; p.gC = g.C; p.gWo = g.Wo; p.gHoWo = g.Ho * g.Wo; p.gkw = g.kw; p.gstride = g.stride; p.gpad = g.pad;
     } else {
@@ -642,8 +668,9 @@ extern "C" int eoe_gemm_nt(const eoe_gemm_args* a, void* stream) {
                      (double)osz * a->M * a->N *
                      (a->epilogue == EOE_EPI_GELU ? 2 : 1) + (a->epilogue == EOE_EPI_RESIDUAL ? 4.0 * a->M * a->N : 0.0) +
                      (a->epilogue == EOE_EPI_GELU_BWD ? 2.0 * a->M * a->N : 0.0), stream);
-    return a->dtype == EOE_F16 ? launch_nt<f16_t>(p, a->epilogue, a->gather, (hipStream_t)stream)
-                               : launch_nt<bf16_t>(p, a->epilogue, a->gather, (hipStream_t)stream);
+    const int mode = (a->gather == 1 && p.gkh) ? 3 : a->gather;      // narrow-channel geometry -> per-piece tap decoding
+    return a->dtype == EOE_F16 ? launch_nt<f16_t>(p, a->epilogue, mode, (hipStream_t)stream)
+                               : launch_nt<bf16_t>(p, a->epilogue, mode, (hipStream_t)stream);
 }
 
 

@@ -47,7 +47,8 @@ class CNN32(nn.Module):
 
     def _layer(self, x, conv, bn, is_image, flat_out):
         mean, std = self.normalize if (is_image and self.normalize is not None) else (None, None)
-        cfg = (self.training, bn.eps, bn.momentum, 2, is_image, mean, std, flat_out)
+        # 5x5 stride 1 pad 2, LeakyReLU(0.01), MaxPool 2; a 16-bit copy of the output feeds the next conv's implicit GEMM
+        cfg = (self.training, bn.eps, bn.momentum, 2, is_image, mean, std, flat_out, (5, 5, 1, 2), 0.01, not flat_out)
         return ops.conv_bn_act_pool(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                     bn.num_batches_tracked, cfg)
 

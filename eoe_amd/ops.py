@@ -555,20 +555,22 @@ def _conv_kp(cin: int, taps: int = 25) -> int:
     return (taps * cin + 63) // 64 * 64
 
 
-def _conv_weight_copies(w: torch.Tensor):
+def _conv_weight_copies(w: torch.Tensor, cpad=None):
     """16-bit copies of a conv weight, cached like `shadow`: [cout, Kp] in patch-column order, its transpose [Kp, cout]
-    (materialised dgrad) and [cin, (taps reversed) x cout] (implicit stride-1 dgrad)"""
-    key = ("conv", id(w))
+    (materialised dgrad) and [cin, (taps reversed) x cout] (implicit stride-1 dgrad).  cpad: channels per tap in the column
+    order when the gathered tensor is channel-padded (NHWC8 image of a 3-channel first layer)"""
+    cpad = int(cpad or w.shape[1])
+    key = ("conv", id(w), cpad)
     tag = (w._version, w.data_ptr(), _compute_dtype)
     hit = shadow.cache.get(key)
     if hit is not None and hit[0]() is w and hit[1] == tag:
         return hit[2], hit[3], hit[4]
     cout, cin, kh, kw = w.shape
-    kp = _conv_kp(cin, kh * kw)
+    kp = _conv_kp(cpad, kh * kw)
     w16 = torch.empty((cout, kp), dtype=_compute_dtype, device=w.device)
     w16t = torch.empty((kp, cout), dtype=_compute_dtype, device=w.device)
     w16d = torch.empty((cin, kh * kw * cout), dtype=_compute_dtype, device=w.device)
-    check(lib.eoe_conv_pack_weight(_p(w.detach().contiguous()), _p(w16), _p(w16t), _p(w16d), cout, cin, kh, kw, kp,
+    check(lib.eoe_conv_pack_weight(_p(w.detach().contiguous()), _p(w16), _p(w16t), _p(w16d), cout, cin, cpad, kh, kw, kp,
                                    dtype_code(_compute_dtype), _stream()), "eoe_conv_pack_weight")
     shadow.cache[key] = (weakref.ref(w, lambda _r, k=key, c=shadow.cache: c.pop(k, None)), tag, w16, w16t, w16d)
     return w16, w16t, w16d
@@ -603,7 +605,7 @@ def conv_gemm_fwd(x16, w16, y, geo, bias=None, mode=1):
     """y[n*Ho*Wo, cout] (fp32) = patches(x16) @ w16^T without materialising the patches; x16 16-bit NHWC [n,H,W,C]
     (mode 2: the zero-padded NHWC4 image of eoe_stem_pack_image, packed k axis)"""
     n, H, W, Cc, kh, kw, stride, pad, Ho, Wo = geo
-    M, K, N = n * Ho * Wo, (kh * kw * Cc if mode == 1 else (kh + 1) // 2 * 64), w16.shape[0]
+    M, K, N = n * Ho * Wo, (_conv_kp(Cc, kh * kw) if mode == 1 else (kh + 1) // 2 * 64), w16.shape[0]
     assert x16.is_contiguous() and w16.shape[1] == K and w16.stride(1) == 1 and y.shape == (M, N) and y.stride(1) == 1
     g = GemmArgs(_p(x16), _p(w16), _p(y), _p(bias), None, None, None, M, N, K, 0, w16.stride(0), y.stride(0), 0,
                  dtype_code(x16.dtype), EPI_NONE, 1 if y.dtype == torch.float32 else 0, 0, 1.0, None, 0, mode,
@@ -651,18 +653,26 @@ class ConvBnActPoolFunction(torch.autograd.Function):
         H, W = (Hi + 2 * pad - kh) // stride + 1, (Wi + 2 * pad - kw) // stride + 1       # conv output grid
         M, kp, dev, dt = n * H * W, _conv_kp(cin, kh * kw), x.device, _compute_dtype
         code = dtype_code(dt)
-        implicit = _implicit_conv and (not is_image) and cin % 64 == 0
+        implicit = _implicit_conv and (not is_image) and (cin % 64 == 0 or cin in (8, 16, 32))
         stem = _implicit_conv and is_image and cin == 3 and kw <= 8 and stride % 2 == 0
+        img8 = _implicit_conv and is_image and cin == 3 and not stem           # NHWC8 image, per-piece tap decoding
         y = torch.empty((M, cout), dtype=torch.float32, device=dev)
         if stem:
             # packed first layer: normalised 16-bit NHWC4 image with physical zero padding, gathered inside the GEMM
             Hp, Wp = (H - 1) * stride + (kh + 1) // 2 * 2, ((W - 1) * stride + 8 + 1) // 2 * 2
             Hp, Wp = max(Hp, Hi + pad), max(Wp, Wi + pad + (Wi + pad) % 2)
             operand = torch.empty((n, Hp, Wp, 4), dtype=dt, device=dev)
-            check(lib.eoe_stem_pack_image(_p(x), _p(mean), _p(std), _p(operand), n, Hi, Wi, Hp, Wp, pad, code, _stream()),
+            check(lib.eoe_stem_pack_image(_p(x), _p(mean), _p(std), _p(operand), n, Hi, Wi, Hp, Wp, pad, 4, code, _stream()),
                   "eoe_stem_pack_image")
             implicit = 2
             conv_gemm_fwd(operand, _stem_weight_copy(conv_w), y, (n, Hp, Wp, 4, kh, kw, stride, 0, H, W), bias=conv_b, mode=2)
+        elif img8:
+            operand = torch.empty((n, Hi, Wi, 8), dtype=dt, device=dev)
+            check(lib.eoe_stem_pack_image(_p(x), _p(mean), _p(std), _p(operand), n, Hi, Wi, Hi, Wi, 0, 8, code, _stream()),
+                  "eoe_stem_pack_image")
+            implicit = 3
+            w16, _, _ = _conv_weight_copies(conv_w, 8)
+            conv_gemm_fwd(operand, w16, y, (n, Hi, Wi, 8, kh, kw, stride, pad, H, W), bias=conv_b)
         elif implicit:
             w16, _, _ = _conv_weight_copies(conv_w)
             if x16 is None or x16.dtype != dt or x16.shape != x.shape:
@@ -731,13 +741,15 @@ class ConvBnActPoolFunction(torch.autograd.Function):
             conv_gemm_wgrad(operand, dy16, gT, (n, Hp, Wp, 4, kh, kw, stride, 0, H, W), mode=2)
             check(lib.eoe_stem_unpack_wgrad(_p(gT), _p(dw), cout, kh, kw, _stream()), "eoe_stem_unpack_wgrad")
         elif implicit:
-            gT = torch.empty((kh * kw * cin, cout), dtype=torch.float32, device=dev)
-            conv_gemm_wgrad(operand, dy16, gT, (n, Hi, Wi, cin, kh, kw, stride, pad, H, W))
-            check(lib.eoe_conv_unpack_wgrad(_p(gT), _p(dw), cout, cin, kh, kw, kp, 1, 0, _stream()), "eoe_conv_unpack_wgrad")
+            cg = 8 if implicit == 3 else cin          # channels per tap of the gathered tensor (NHWC8 image: 8)
+            gT = torch.empty((kh * kw * cg, cout), dtype=torch.float32, device=dev)
+            conv_gemm_wgrad(operand, dy16, gT, (n, Hi, Wi, cg, kh, kw, stride, pad, H, W))
+            check(lib.eoe_conv_unpack_wgrad(_p(gT), _p(dw), cout, cin, cg, kh, kw, kh * kw * cg, 1, 0, _stream()),
+                  "eoe_conv_unpack_wgrad")
         else:
             g = torch.empty((cout, kp), dtype=torch.float32, device=dev)
             gemm_tn(dy16, operand, g)
-            check(lib.eoe_conv_unpack_wgrad(_p(g), _p(dw), cout, cin, kh, kw, kp, 0, 0, _stream()), "eoe_conv_unpack_wgrad")
+            check(lib.eoe_conv_unpack_wgrad(_p(g), _p(dw), cout, cin, cin, kh, kw, kp, 0, 0, _stream()), "eoe_conv_unpack_wgrad")
         dcb = None
         if conv_b is not None:
             dcb = _grad_target(conv_b)

@@ -75,7 +75,9 @@ typedef struct {
                          * atomics (faster, and bitwise reproducible) */
     int64_t workspace_bytes;
     int32_t gather;     /* 1: A is the NHWC tensor of `geo` and stands for its patch matrix (lda ignored).
-                         *    NT: [M = n*Ho*Wo, K = kh*kw*C], C % 64 == 0, plain epilogue (conv forward; stride-1 dgrad)
+                         *    NT: [M = n*Ho*Wo, K = kh*kw*C], C % 64 == 0 (one tap per 64-deep k-tile), or C in {8,16,32} with K
+                         *        = kh*kw*C rounded up to a multiple of 64 (every 16-byte piece decodes its own tap); plain epilogue
+                         *        (conv forward; stride-1 dgrad)
                          *    TN: [T = n*Ho*Wo, M = kh*kw*C], C % 8 == 0 (conv wgrad, transposed: C[kh*kw*C, cout])
                          * 2: A is the zero-padded NHWC4 image of eoe_stem_pack_image (geo.C = 4, geo.pad = 0, geo.H/W = Hp/Wp),
                          *    K (NT) / M (TN) = ceil(kh/2)*64 */
@@ -261,10 +263,11 @@ int eoe_col2im(const void* dpatches, float* dx, int n, int C, int H, int W, int 
                int dtype, void* stream);
 /* conv weight fp32 [cout,cin,kh,kw] -> 16-bit [cout,Kp] (patch column order), optionally its transpose [Kp,cout] and the
  * operand of the implicit stride-1 dgrad [cin, (kh*kw reversed) x cout] (dx = conv of dy with the flipped kernel);
- * and the inverse reorder of the fp32 weight gradient [cout,Kp] (or, transposed, [kh*kw*cin, cout]) -> [cout,cin,kh,kw] */
-int eoe_conv_pack_weight(const float* w, void* w16, void* w16t, void* w16d, int cout, int cin, int kh, int kw, int Kp,
-                         int dtype, void* stream);
-int eoe_conv_unpack_wgrad(const float* g, float* dw, int cout, int cin, int kh, int kw, int Kp, int transposed,
+ * and the inverse reorder of the fp32 weight gradient [cout,Kp] (or, transposed, [kh*kw*cpad, cout]) -> [cout,cin,kh,kw].
+ * cpad >= cin = channels per tap in the column order (8 for the channel-padded NHWC8 image of a 3-channel first layer). */
+int eoe_conv_pack_weight(const float* w, void* w16, void* w16t, void* w16d, int cout, int cin, int cpad, int kh, int kw,
+                         int Kp, int dtype, void* stream);
+int eoe_conv_unpack_wgrad(const float* g, float* dw, int cout, int cin, int cpad, int kh, int kw, int Kp, int transposed,
                           int accumulate, void* stream);
 /* 3-channel first layer without a materialised patch matrix (gather = 2 of eoe_gemm_args): the image batch fp32 NCHW
  * [n,3,H,W] (optional per-channel normalise, ad_trainer.py:413-425) becomes a 16-bit NHWC4 tensor [n,Hp,Wp,4] with the
@@ -272,7 +275,8 @@ int eoe_conv_unpack_wgrad(const float* g, float* dw, int cout, int cin, int kh, 
  * K = ceil(kh/2)*64 (kw <= 8, even stride), weights packed to match, wgrad [K, cout] unpacked to [cout,3,kh,kw].
  * Needs Hp >= (Ho-1)*stride + 2*ceil(kh/2), Wp >= (Wo-1)*stride + 8, Wp even. */
 int eoe_stem_pack_image(const float* x, const float* mean, const float* std, void* out, int n, int H, int W, int Hp, int Wp,
-                        int pad, int dtype, void* stream);
+                        int pad, int cpad /* 4, or 8 = NHWC8 for gather 1 with C = 8 (any stride; pad 0: no physical border) */,
+                        int dtype, void* stream);
 int eoe_stem_pack_weight(const float* w, void* w16, int cout, int kh, int kw, int dtype, void* stream);
 int eoe_stem_unpack_wgrad(const float* g, float* dw, int cout, int kh, int kw, void* stream);
 

@@ -84,7 +84,7 @@ y = torch.empty((M, 64), device=dev)
 dy16 = torch.randn((M, 64), device=dev).to(dt)
 gT = torch.empty((256, 64), device=dev)
 geo = (N, 230, 230, 4, 7, 7, 2, 0, 112, 112)
-t_i = timeit(lambda: check(lib.eoe_stem_pack_image(x.data_ptr(), None, None, img.data_ptr(), N, 224, 224, 230, 230, 3, 1, ops._stream()), "pack"))
+t_i = timeit(lambda: check(lib.eoe_stem_pack_image(x.data_ptr(), None, None, img.data_ptr(), N, 224, 224, 230, 230, 3, 4, 1, ops._stream()), "pack"))
 t_f = timeit(lambda: ops.conv_gemm_fwd(img, w16s, y, geo, mode=2))
 t_w = timeit(lambda: ops.conv_gemm_wgrad(img, dy16, gT, geo, mode=2))
 stats = torch.empty(128, device=dev); sums = ops.scratch("bn_sums", (ops.BN_SCRATCH * 64,), torch.float32, dev)
