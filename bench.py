@@ -44,6 +44,10 @@ def parse():
                          "wrn = secondary (WideResNet+CBAM, 224x224, config 3 backbone)")
     ap.add_argument("--nt-flags", type=int, default=None, help="tuning switch of the NT GEMM (A/B builds only)")
     ap.add_argument("--tn-flags", type=int, default=None, help="tuning switch of the wgrad GEMM")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="capture forward + loss + backward + scores of one step in a HIP graph and replay it (1 GPU only; "
+                         "the optimiser step stays outside the graph).  auto = on for the launch-bound cnn32 configuration; "
+                         "the ViT / WideResNet steps are GPU-bound and measure the same either way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32)
@@ -154,6 +158,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    use_graph = args.graph == "on" or (args.graph == "auto" and args.model == "cnn32" and world == 1)
+    eager_step = step
+    if use_graph:
+        assert world == 1, "--graph on is a single-GPU option"
+        graphed = eoe_amd.GraphedStep(model, lambda f, y: eoe_amd.hsc_loss(f, y, 0, 1.0 / n_global), eoe_amd.hsc_score, imgs, lbls)
+
+        def step(i):                                       # noqa: F811  (replaces the eager step)
+            opt.zero_grad()
+            loss, scores = graphed(imgs, lbls)
+            opt.step()
+            score_buf[i % score_buf.shape[0]] = scores
+            return loss
+
     for i in range(args.warmup):
         loss = step(i)
     sync()
@@ -175,6 +192,8 @@ def main():
     auc = float(metrics.roc_auc(lbls.cpu().numpy(), last))
 
     roof = None
+    if use_graph:
+        step = eager_step                                  # the per-kernel profile runs the eager launches
     if not args.no_roofline:
         # separate profiled pass: hipEvents around every kernel launch (inside the library, on the launch stream)
         _lib.prof_enable(True)
@@ -219,7 +238,8 @@ def main():
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": workload, "global_batch": n_global, "parallelism": f"dp{world}"},
+            "config": {"workload": workload, "global_batch": n_global, "parallelism": f"dp{world}",
+                       "launch": "hip graph replay" if use_graph else "eager"},
             "model_tflops": round(value * flop_per_img / 1e3, 1),
             "mfma_roofline_frac_end_to_end": round(value * flop_per_img / 1e3 / (MFMA_PEAK_TFLOPS * world), 4),
             "final_loss": round(final_loss, 5), "auc_last_step": round(auc, 4),

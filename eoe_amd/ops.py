@@ -187,14 +187,18 @@ class _Shadow:
     def get(self, p: torch.Tensor, want=True, want_t=True, view2d=None):
         key = id(p)
         tag = (p._version, p.data_ptr(), _compute_dtype, want, want_t)
+        # while a HIP graph is being captured (eoe_amd.GraphedStep) the cast must be part of the graph -- every replay
+        # sees new weights -- and its output is not real until a replay ran: neither read nor fill the cache
+        capturing = torch.cuda.is_current_stream_capturing()
         hit = self.cache.get(key)
-        if hit is not None and hit[0]() is p and hit[1] == tag:
+        if not capturing and hit is not None and hit[0]() is p and hit[1] == tag:
             return hit[2], hit[3]
         src = p.detach()
         if view2d is not None:
             src = src.reshape(view2d)
         d, dt = cast_transpose(src, _compute_dtype, want, want_t)
-        self.cache[key] = (weakref.ref(p, lambda _r, k=key, c=self.cache: c.pop(k, None)), tag, d, dt)
+        if not capturing:
+            self.cache[key] = (weakref.ref(p, lambda _r, k=key, c=self.cache: c.pop(k, None)), tag, d, dt)
         return d, dt
 
 
@@ -209,7 +213,8 @@ def scratch(name, shape, dtype, device):
     t = _scratch.get(key)
     if t is None:
         t = torch.empty(shape, dtype=dtype, device=device)
-        _scratch[key] = t
+        if not torch.cuda.is_current_stream_capturing():     # a buffer from a graph's private pool dies with the graph
+            _scratch[key] = t
     return t
 
 
@@ -562,8 +567,9 @@ def _conv_weight_copies(w: torch.Tensor, cpad=None):
     cpad = int(cpad or w.shape[1])
     key = ("conv", id(w), cpad)
     tag = (w._version, w.data_ptr(), _compute_dtype)
+    capturing = torch.cuda.is_current_stream_capturing()           # see _Shadow.get
     hit = shadow.cache.get(key)
-    if hit is not None and hit[0]() is w and hit[1] == tag:
+    if not capturing and hit is not None and hit[0]() is w and hit[1] == tag:
         return hit[2], hit[3], hit[4]
     cout, cin, kh, kw = w.shape
     kp = _conv_kp(cpad, kh * kw)
@@ -572,7 +578,8 @@ def _conv_weight_copies(w: torch.Tensor, cpad=None):
     w16d = torch.empty((cin, kh * kw * cout), dtype=_compute_dtype, device=w.device)
     check(lib.eoe_conv_pack_weight(_p(w.detach().contiguous()), _p(w16), _p(w16t), _p(w16d), cout, cin, cpad, kh, kw, kp,
                                    dtype_code(_compute_dtype), _stream()), "eoe_conv_pack_weight")
-    shadow.cache[key] = (weakref.ref(w, lambda _r, k=key, c=shadow.cache: c.pop(k, None)), tag, w16, w16t, w16d)
+    if not capturing:
+        shadow.cache[key] = (weakref.ref(w, lambda _r, k=key, c=shadow.cache: c.pop(k, None)), tag, w16, w16t, w16d)
     return w16, w16t, w16d
 
 
@@ -580,14 +587,16 @@ def _stem_weight_copy(w: torch.Tensor):
     """16-bit [cout, ceil(kh/2)*64] copy of a 3-channel first-layer weight in the packed (ky, kx, c4) column order"""
     key = ("stem", id(w))
     tag = (w._version, w.data_ptr(), _compute_dtype)
+    capturing = torch.cuda.is_current_stream_capturing()           # see _Shadow.get
     hit = shadow.cache.get(key)
-    if hit is not None and hit[0]() is w and hit[1] == tag:
+    if not capturing and hit is not None and hit[0]() is w and hit[1] == tag:
         return hit[2]
     cout, _, kh, kw = w.shape
     w16 = torch.empty((cout, (kh + 1) // 2 * 64), dtype=_compute_dtype, device=w.device)
     check(lib.eoe_stem_pack_weight(_p(w.detach().contiguous()), _p(w16), cout, kh, kw, dtype_code(_compute_dtype), _stream()),
           "eoe_stem_pack_weight")
-    shadow.cache[key] = (weakref.ref(w, lambda _r, k=key, c=shadow.cache: c.pop(k, None)), tag, w16)
+    if not capturing:
+        shadow.cache[key] = (weakref.ref(w, lambda _r, k=key, c=shadow.cache: c.pop(k, None)), tag, w16)
     return w16
 
 
