@@ -85,6 +85,7 @@ class VitBlockBwdArgs(C.Structure):
 # name -> argtypes (restype is int unless listed in _RESTYPES); must match include/eoe_hip.h
 SIGNATURES = {
     "eoe_abi_version": [],
+    "eoe_struct_size": [C.c_int],
     "eoe_last_error": [],
     "eoe_gemm_nt": [C.POINTER(GemmArgs), _vp],
     "eoe_gemm_tn": [C.POINTER(GemmArgs), _vp],

@@ -20,6 +20,23 @@ int eoe_set_error(int code, const char* fmt, ...) {
 }
 
 extern "C" int eoe_abi_version(void) { return EOE_ABI_VERSION; }
+
+// sizeof of the argument structs as this library was compiled: a binding checks its own mirror of the layout against it
+extern "C" int eoe_struct_size(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(eoe_gemm_args);
+        case 1: return (int)sizeof(eoe_conv_geometry);
+        case 2: return (int)sizeof(eoe_adam_chunk);
+        case 3: return (int)sizeof(eoe_adam_scalars);
+        case 4: return (int)sizeof(eoe_vit_block_fwd_args);
+        case 5: return (int)sizeof(eoe_vit_block_bwd_args);
+        case 6: return (int)sizeof(eoe_cgate_args);
+        case 7: return (int)sizeof(eoe_cgate_bwd_args);
+        case 8: return (int)sizeof(eoe_sgate_args);
+        case 9: return (int)sizeof(eoe_sgate_bwd_args);
+        default: return -1;
+    }
+}
 extern "C" const char* eoe_last_error(void) { return g_eoe_err; }
 
 namespace {

@@ -28,6 +28,9 @@ enum { EOE_OK = 0, EOE_ERR_ARG = 1, EOE_ERR_LAUNCH = 2, EOE_ERR_UNSUPPORTED = 3 
 enum { EOE_F16 = 1, EOE_BF16 = 2 };
 
 int eoe_abi_version(void);
+/* sizeof of an argument struct as compiled into the library: 0 eoe_gemm_args, 1 eoe_conv_geometry, 2 eoe_adam_chunk,
+ * 3 eoe_adam_scalars, 4/5 eoe_vit_block_fwd/bwd_args, 6/7 eoe_cgate(_bwd)_args, 8/9 eoe_sgate(_bwd)_args; -1 otherwise */
+int eoe_struct_size(int which);
 const char* eoe_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------------

@@ -20,7 +20,11 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib.eoe_abi_version() == _lib.ABI_VERSION
     # struct layouts the Python side mirrors
     assert C.sizeof(_lib.AdamChunk) == 40 and C.sizeof(_lib.AdamScalars) == 32
-    assert C.sizeof(_lib.GemmArgs) == 7 * 8 + 12 * 4
+    mirrors = [_lib.GemmArgs, _lib.ConvGeometry, _lib.AdamChunk, _lib.AdamScalars, _lib.VitBlockFwdArgs, _lib.VitBlockBwdArgs,
+               _lib.CGateArgs, _lib.CGateBwdArgs, _lib.SGateArgs, _lib.SGateBwdArgs]
+    for which, cls in enumerate(mirrors):
+        assert _lib.lib.eoe_struct_size(which) == C.sizeof(cls), (cls.__name__, _lib.lib.eoe_struct_size(which), C.sizeof(cls))
+    assert _lib.lib.eoe_struct_size(len(mirrors)) == -1
 
 
 def test_argument_errors_are_reported_not_fatal():
