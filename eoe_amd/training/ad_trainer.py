@@ -80,11 +80,15 @@ class ADTrainer(ABC):
                  oe_dataset=None, datapath: str = None, logger: JsonLogger = None, epochs: int = 1, lr: float = 1e-3,
                  wdk: float = 0.0, milestones: List[int] = (), batch_size: int = 128, ad_mode: str = "one_vs_rest",
                  device: Union[str, torch.device] = "cuda", oe_limit_samples=np.inf, oe_limit_classes=np.inf,
-                 msms=(), workers: int = 2, classes: List[str] = None, data_parallel: bool = False):
+                 msms=(), workers: int = 2, classes: List[str] = None, data_parallel: bool = False,
+                 graph_steps: bool = False):
         """same parameters as the reference (`ad_trainer.py:98-164`).  `dataset` is either a step-batch source
         (eoe_amd.data: an object with `.loaders(batch_size)`, `.nominal_label`, `.normalize`) or a callable
         `(cls, seed) -> source`; `classes` names the classes to iterate (default: one class "0")."""
         self.model = model.cpu() if model is not None else model
+        # replay forward + loss + backward + scores of the full-size step batch from a HIP graph (eoe_amd.GraphedStep): for the
+        # launch-bound small encoders (CNN32 at 32x32); single GPU only, ragged batches run eagerly
+        self.graph_steps = graph_steps
         self.train_transform, self.test_transform = train_transform, test_transform
         self.dsstr, self.oe_dsstr, self.datapath = dataset, oe_dataset, datapath
         self.logger = logger if logger is not None else JsonLogger(None)
@@ -225,6 +229,7 @@ class ADTrainer(ABC):
             arena.install_hooks()
         nominal = getattr(ds, "nominal_label", 0)
         self.last_losses = []
+        graphed = None                                      # (batch shape, GraphedStep) of the full-size step batch
         try:
             for ep in range(ep, epochs):
                 ep_labels, ep_scores, ep_losses = [], [], []
@@ -238,15 +243,25 @@ class ADTrainer(ABC):
                     imgs = imgs.to(self.device, non_blocking=True)                                      # :411
                     lbls = lbls.to(self.device, non_blocking=True)                                      # :412
                     opt.zero_grad()                                                                     # :428
-                    feats = model(imgs)                                                                 # :429
-                    loss = self.loss(feats, lbls, center, inputs=imgs, nominal_label=nominal,
-                                     inv_count=(1.0 / n_glob))                                          # :430
-                    loss.backward()                                                                     # :431
-                    if arena is not None:
-                        arena.finish()
-                    opt.step()                                                                          # :432
-                    opt.zero_grad()                                                                     # :433
-                    scores = self.compute_anomaly_score(feats, center, inputs=imgs, nominal_label=nominal)   # :434
+                    if self.graph_steps and world == 1 and graphed is None:
+                        from ..graph import GraphedStep
+                        graphed = (tuple(imgs.shape), GraphedStep(
+                            model, lambda f, y: self.loss(f, y, center, inputs=None, nominal_label=nominal, inv_count=(1.0 / n_glob)),
+                            lambda f: self.compute_anomaly_score(f, center, inputs=None, nominal_label=nominal), imgs, lbls))
+                    if graphed is not None and graphed[0] == tuple(imgs.shape):
+                        loss, scores = graphed[1](imgs, lbls)                                           # :429-431,434 replayed
+                        opt.step()                                                                      # :432
+                        loss, scores = loss.detach().clone(), scores.detach().clone()                   # static graph outputs
+                    else:
+                        feats = model(imgs)                                                             # :429
+                        loss = self.loss(feats, lbls, center, inputs=imgs, nominal_label=nominal,
+                                         inv_count=(1.0 / n_glob))                                      # :430
+                        loss.backward()                                                                 # :431
+                        if arena is not None:
+                            arena.finish()
+                        opt.step()                                                                      # :432
+                        opt.zero_grad()                                                                 # :433
+                        scores = self.compute_anomaly_score(feats, center, inputs=imgs, nominal_label=nominal)   # :434
                     ep_labels.append(lbls)
                     ep_scores.append(scores.detach())
                     ep_losses.append(loss.detach())
