@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libeoe_hip.so")
-SOURCES = ["api.cpp", "gemm.hip", "gemm_tn.hip", "elementwise.hip", "attention.hip", "conv.hip", "cbam.hip", "vit.cpp"]
+SOURCES = ["api.cpp", "gemm.hip", "gemm_tn.hip", "elementwise.hip", "attention.hip", "conv.hip", "cbam.hip", "augment.hip", "vit.cpp"]
 
 
 def hipcc_path():

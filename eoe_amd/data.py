@@ -97,3 +97,95 @@ class SyntheticAD:
         test = [(self.test_x[s:s + batch_size], self.test_y[s:s + batch_size],
                  torch.arange(s, min(s + batch_size, len(self.test_y)))) for s in range(0, len(self.test_y), batch_size)]
         return _Train(self), test
+
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# on-device input pipeline
+# ---------------------------------------------------------------------------------------------------------------------
+def augment_batch(src_u8, params, out_hw, mean=None, std=None, flip_first=True, noise_std=0.001, seed=0):
+    """gather + RandomCrop(zero padding) + RandomHorizontalFlip + ToTensor + noise + Normalize in ONE kernel over a uint8
+    NHWC image set resident in HBM (`eoe_augment_batch`, include/eoe_hip.h): replaces the PIL transform chain of
+    `main/train_cifar.py:31-38` / `main/train_clip_imagenet.py:27-36` and the Normalize of `ad_trainer.py:413-425`.
+    src_u8 uint8 [n_src,Hs,Ws,3] (GPU); params int32 [n,4] = (index, top, left, flip) (GPU) -> fp32 NCHW [n,3,Ho,Wo]"""
+    import ctypes as C                                  # noqa: F401
+    from ._lib import check, lib
+    if not (src_u8.is_cuda and params.is_cuda):
+        raise RuntimeError("augment_batch needs GPU tensors (there is no CPU fallback)")
+    assert src_u8.dtype == torch.uint8 and src_u8.dim() == 4 and src_u8.shape[3] == 3 and src_u8.is_contiguous()
+    assert params.dtype == torch.int32 and params.dim() == 2 and params.shape[1] == 4 and params.is_contiguous()
+    n, (Ho, Wo) = params.shape[0], out_hw
+    dev = src_u8.device
+    m = torch.as_tensor(mean, dtype=torch.float32, device=dev).contiguous() if mean is not None else None
+    s = torch.as_tensor(std, dtype=torch.float32, device=dev).contiguous() if std is not None else None
+    out = torch.empty((n, 3, Ho, Wo), dtype=torch.float32, device=dev)
+    check(lib.eoe_augment_batch(src_u8.data_ptr(), src_u8.shape[0], src_u8.shape[1], src_u8.shape[2], params.data_ptr(),
+                                None if m is None else m.data_ptr(), None if s is None else s.data_ptr(), out.data_ptr(), n, Ho, Wo,
+                                1 if flip_first else 0, float(noise_std), int(seed), torch.cuda.current_stream().cuda_stream),
+          "eoe_augment_batch")
+    return out
+
+
+class ResidentImageSource:
+    """one-vs-rest step-batch source whose uint8 images live in HBM: every step batch ([normal half | OE half], the
+    BalancedConcatLoader contract of `datasets/bases.py:570-600`) is gathered, cropped, flipped, noised and normalised by one
+    kernel; the host only draws (index, crop origin, flip) per sample.  Batches come out already normalised, so
+    `.normalize` is None (the trainer then installs no second Normalize)."""
+
+    nominal_label, anomalous_label = 0, 1
+
+    def __init__(self, normal_u8, oe_u8, test_u8, test_labels, crop, padding=0, mean=None, std=None, flip_first=True,
+                 noise_std=0.001, seed=0, device="cuda"):
+        dev = torch.device(device)
+        self.normal, self.oe, self.test = (t.to(dev).contiguous() for t in (normal_u8, oe_u8, test_u8))
+        self.test_y = test_labels.clone()
+        self.crop, self.padding, self.mean, self.std = int(crop), int(padding), mean, std
+        self.flip_first, self.noise_std, self.seed = flip_first, noise_std, int(seed)
+        self.normalize = None
+        self._g = torch.Generator().manual_seed(seed)
+        self._step = 0
+
+    def _params(self, idx, Hs, Ws):
+        n = len(idx)
+        top = torch.randint(-self.padding, Hs + self.padding - self.crop + 1, (n,), generator=self._g)
+        left = torch.randint(-self.padding, Ws + self.padding - self.crop + 1, (n,), generator=self._g)
+        flip = torch.randint(0, 2, (n,), generator=self._g)
+        return torch.stack([idx.to(torch.int64), top, left, flip], dim=1).to(torch.int32)
+
+    def _epoch(self, batch_size):
+        n, m = self.normal.shape[0], self.oe.shape[0]
+        perm = torch.randperm(n, generator=self._g)
+        oe_idx = tile_oe_indices(torch.arange(m), n)
+        oe_order = oe_idx[torch.randperm(len(oe_idx), generator=self._g)]
+        dev = self.normal.device
+        for s in range(0, n, batch_size):
+            ni, oi = perm[s:s + batch_size], oe_order[s:s + batch_size]
+            self._step += 1
+            # two launches (normal half from its image set, OE half from the other), written into one batch tensor
+            pn = self._params(ni, self.normal.shape[1], self.normal.shape[2]).to(dev)
+            po = self._params(oi, self.oe.shape[1], self.oe.shape[2]).to(dev)
+            seed = (self.seed * 65521 + self._step) % (1 << 23)
+            xn = augment_batch(self.normal, pn, (self.crop, self.crop), self.mean, self.std, self.flip_first, self.noise_std, 2 * seed)
+            xo = augment_batch(self.oe, po, (self.crop, self.crop), self.mean, self.std, self.flip_first, self.noise_std, 2 * seed + 1)
+            lbls = torch.cat([torch.zeros(len(ni), dtype=torch.int64), torch.ones(len(oi), dtype=torch.int64)])
+            yield torch.cat([xn, xo]), lbls, torch.cat([ni, oi + n])          # OE indices offset by the normal set size (bases.py:597)
+
+    def loaders(self, batch_size, **kw):
+        outer = self
+
+        class _Train:
+            def __iter__(s):
+                return outer._epoch(batch_size)
+
+            def __len__(s):
+                return math.ceil(outer.normal.shape[0] / batch_size)
+
+        # test split: centre crop, no flip, no noise (val_transform: ToTensor + normalize, train_cifar.py:39-42)
+        Hs, Ws = self.test.shape[1], self.test.shape[2]
+        test = []
+        for s in range(0, len(self.test_y), batch_size):
+            idx = torch.arange(s, min(s + batch_size, len(self.test_y)))
+            p = torch.stack([idx, torch.full_like(idx, (Hs - self.crop) // 2), torch.full_like(idx, (Ws - self.crop) // 2),
+                             torch.zeros_like(idx)], dim=1).to(torch.int32).to(self.test.device)
+            test.append((augment_batch(self.test, p, (self.crop, self.crop), self.mean, self.std, True, 0.0, 0), self.test_y[idx], idx))
+        return _Train(), test

@@ -395,6 +395,20 @@ int eoe_avgpool_fwd(const float* x, float* pooled_scratch, int* argmax_scratch, 
 int eoe_avgpool_bwd(const float* dout, float* dx, int n, int HW, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
+ * on-device input pipeline: gather + RandomCrop (zero padding) + RandomHorizontalFlip +
+ * ToTensor + Gaussian noise + per-channel Normalize in one pass over a uint8 NHWC image set resident in HBM
+ * (main/train_cifar.py:31-38, main/train_clip_imagenet.py:27-36, training/ad_trainer.py:413-425).
+ *   src    uint8 [n_src, Hs, Ws, 3];   params int32 [n, 4] = (source index, crop top, crop left, flip) per batch slot
+ *          (top / left may be negative or reach past the image: RandomCrop(padding) with fill 0)
+ *   out    fp32 NCHW [n, 3, Ho, Wo] = ((src / 255 + noise_std * N(0,1)) - mean[c]) / std[c]   (mean/std NULL: none)
+ *   flip_first 1: flip the source then crop (CIFAR order), 0: crop then flip (CLIP order)
+ *   noise  element e = (c*Ho + y)*Wo + x of slot b draws Box-Muller from splitmix64(seed*2^40 + b*2^18 + e)
+ * ---------------------------------------------------------------------------------------------------- */
+int eoe_augment_batch(const uint8_t* src, int64_t n_src, int Hs, int Ws, const int32_t* params, const float* mean,
+                      const float* std, float* out, int n, int Ho, int Wo, int flip_first, float noise_std, uint64_t seed,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
  * in-library kernel timing (used by bench.py for the roofline line): while enabled, every entry point brackets
  * its kernel launches with hipEvents on the stream it launches on and records the algorithmic flops / bytes.
  * eoe_prof_collect synchronises the recorded events and aggregates them per kernel name.
