@@ -2,6 +2,8 @@
 
   python tools/pmc_summary.py hbm  <fetch counter_collection.csv> <write counter_collection.csv>  > profiles/rN/bench_pmc_hbm_bytes.csv
   python tools/pmc_summary.py sq   <sq counter_collection.csv>                                   > profiles/rN/bench_pmc_sq.csv
+  python tools/pmc_summary.py stats <results.db>                                                 > profiles/rN/bench_kernel_stats.csv
+Inputs may be rocprofv3 CSVs (--output-format csv) or its default rocpd sqlite database (*_results.db).
 
 FETCH_SIZE / WRITE_SIZE are reported in KiB per launch, RAW: on gfx950 FETCH_SIZE under-reports wide coalesced
 reads by 2x (MI355X_MICROARCH.md, HBM/rocprofv3 section) -- bench.py doubles it when it quotes `roofline.traffic`.
@@ -14,6 +16,13 @@ import sys
 def per_kernel(path):
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     launches = collections.defaultdict(set)
+    if path.endswith(".db"):                      # rocprofv3's default rocpd (sqlite) output
+        import sqlite3
+        con = sqlite3.connect(path)
+        for k, cname, v, d in con.execute("select kernel_name, counter_name, value, dispatch_id from counters_collection"):
+            acc[k][cname] += float(v)
+            launches[k].add(d)
+        return acc, {k: len(v) for k, v in launches.items()}
     with open(path) as f:
         for row in csv.DictReader(f):
             k = row["Kernel_Name"]
@@ -22,8 +31,25 @@ def per_kernel(path):
     return acc, {k: len(v) for k, v in launches.items()}
 
 
+def kernel_stats(path):
+    """the --stats table (per kernel: calls, total / average / min / max duration in ns) from a rocpd database"""
+    import sqlite3
+    import statistics
+    con = sqlite3.connect(path)
+    d = collections.defaultdict(list)
+    for name, dur in con.execute("select name, duration from kernels"):
+        d[name].append(int(dur))
+    tot = sum(sum(v) for v in d.values())
+    print('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"')
+    for name, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
+        sd = statistics.pstdev(v) if len(v) > 1 else 0.0
+        print(f'"{name}",{len(v)},{sum(v)},{sum(v) / len(v):.6f},{100.0 * sum(v) / tot:.2f},{min(v)},{max(v)},{sd:.6f}')
+
+
 def main():
     mode = sys.argv[1]
+    if mode == "stats":
+        return kernel_stats(sys.argv[2])
     if mode == "hbm":
         print("counter,kernel,launches,kib_per_launch_raw   (FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950: double it)")
         for path in sys.argv[2:]:
