@@ -138,6 +138,12 @@ SIGNATURES = {
     "eoe_relu_bwd": [_vp, _vp, _vp, _i64, _vp],
     "eoe_avgpool_fwd": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
     "eoe_avgpool_bwd": [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
+    "eoe_dsad_fwd": [_vp, _vp, _i64, _vp, _vp, C.c_int, C.c_int, _f32, _vp],
+    "eoe_dsad_bwd": [_vp, _vp, _i64, _vp, _vp, C.c_int, C.c_int, _f32, _vp],
+    "eoe_dsvdd_fwd": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _vp],
+    "eoe_dsvdd_bwd": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _vp],
+    "eoe_focal_fwd": [_vp, _vp, _i64, _vp, _vp, _vp, C.c_int, _f32, _f32, _f32, _vp],
+    "eoe_focal_bwd": [_vp, _vp, _vp, _vp, C.c_int, _f32, _f32, _f32, _vp],
     "eoe_augment_batch": [_vp, _i64, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f32, C.c_uint64, _vp],
     "eoe_prof_enable": [C.c_int],
     "eoe_set_option": [C.c_char_p, C.c_int],

@@ -496,6 +496,82 @@ __global__ __launch_bounds__(256) void hsc_bwd_kernel(const float* __restrict__ 
     }
 }
 
+// the other row objectives of the TRAINER registry, one wavefront per sample:
+//   KIND 1 = DSAD  (dsad.py:17-21):  d = |f|^2,        loss = d if nominal else 1 / (d + 1e-9)
+//   KIND 2 = DSVDD (dsvdd.py:24-27): d = |f - c|^2,    loss = score = d for every sample
+template <int KIND>
+__global__ __launch_bounds__(256) void rowobj_fwd_kernel(const float* __restrict__ f, const float* __restrict__ center,
+                                                         const int64_t* __restrict__ labels, int64_t nominal,
+                                                         float* __restrict__ losses, int n, int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    float ss = 0.f;
+    for (int c = lane; c < d; c += 64) {
+        float v = f[(size_t)row * d + c];
+        if (KIND == 2) v -= center[c];
+        ss += v * v;
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) losses[row] = (KIND == 2 || labels[row] == nominal) ? ss : 1.0f / (ss + 1e-9f);
+}
+template <int KIND>
+__global__ __launch_bounds__(256) void rowobj_bwd_kernel(const float* __restrict__ f, const float* __restrict__ center,
+                                                         const int64_t* __restrict__ labels, int64_t nominal,
+                                                         const float* __restrict__ gscale, float* __restrict__ df, int n, int d,
+                                                         float inv_count) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    float coef = 2.0f;
+    if (KIND == 1 && labels[row] != nominal) {
+        float ss = 0.f;
+        for (int c = lane; c < d; c += 64) {
+            const float v = f[(size_t)row * d + c];
+            ss += v * v;
+        }
+        ss = wave_sum(ss);
+        const float t = ss + 1e-9f;
+        coef = -2.0f / (t * t);
+    }
+    coef *= inv_count * (gscale ? gscale[0] : 1.0f);
+    for (int c = lane; c < d; c += 64) {
+        float v = f[(size_t)row * d + c];
+        if (KIND == 2) v -= center[c];
+        df[(size_t)row * d + c] = v * coef;
+    }
+}
+
+// focal loss on logits (focal.py:11-24): b = bce(x, y), pt = clamp(exp(-b), eps, 1 - eps), loss = (1 - pt)^gamma * b
+__global__ __launch_bounds__(256) void focal_rows_kernel(const float* __restrict__ x, const int64_t* __restrict__ labels, int64_t nominal,
+                                                         float* __restrict__ scores, float* __restrict__ losses, int n, float gamma,
+                                                         float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i], y = (float)labels[i];
+    const float s = 1.0f / (1.0f + expf(-v));
+    if (scores) scores[i] = (nominal == 0) ? s : 1.0f - s;
+    if (losses) {
+        const float b = fmaxf(v, 0.f) - v * y + log1pf(expf(-fabsf(v)));
+        const float pt = fminf(fmaxf(expf(-b), eps), 1.0f - eps);
+        losses[i] = powf(1.0f - pt, gamma) * b;
+    }
+}
+__global__ __launch_bounds__(256) void focal_bwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ labels,
+                                                        const float* __restrict__ gscale, float* __restrict__ dx, int n,
+                                                        float inv_count, float gamma, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i], y = (float)labels[i];
+    const float b = fmaxf(v, 0.f) - v * y + log1pf(expf(-fabsf(v)));
+    const float db = 1.0f / (1.0f + expf(-v)) - y;
+    const float raw = expf(-b);
+    const float pt = fminf(fmaxf(raw, eps), 1.0f - eps);
+    float g = powf(1.0f - pt, gamma) * db;
+    if (raw >= eps && raw <= 1.0f - eps) g += gamma * powf(1.0f - pt, gamma - 1.0f) * pt * db * b;   // the clamp's derivative is 0 outside
+    dx[i] = g * inv_count * (gscale ? gscale[0] : 1.0f);
+}
+
 __global__ __launch_bounds__(256) void bce_rows_kernel(const float* __restrict__ x, const int64_t* __restrict__ labels, int64_t nominal,
                                 float* __restrict__ scores, float* __restrict__ losses, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -897,6 +973,73 @@ extern "C" int eoe_bce_bwd(const float* x, const int64_t* labels, const float* g
     hipLaunchKernelGGL(bce_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, labels, gscale, dx, n,
                        inv_count);
     EOE_CHECK_LAUNCH("bce_bwd");
+    return 0;
+}
+
+extern "C" int eoe_dsad_fwd(const float* f, const int64_t* labels, int64_t nominal_label, float* loss, float* losses, int n, int d,
+                            float inv_count, void* stream) {
+    EOE_CHECK_ARG(f && labels && losses && n > 0 && d > 0, "dsad_fwd: bad args");
+    hipLaunchKernelGGL(rowobj_fwd_kernel<1>, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, f, (const float*)nullptr, labels,
+                       nominal_label, losses, n, d);
+    EOE_CHECK_LAUNCH("dsad_rows");
+    if (loss) {
+        hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, losses, loss, n, inv_count);
+        EOE_CHECK_LAUNCH("dsad_sum");
+    }
+    return 0;
+}
+
+extern "C" int eoe_dsad_bwd(const float* f, const int64_t* labels, int64_t nominal_label, const float* gscale, float* df, int n,
+                            int d, float inv_count, void* stream) {
+    EOE_CHECK_ARG(f && labels && df && n > 0 && d > 0, "dsad_bwd: bad args");
+    hipLaunchKernelGGL(rowobj_bwd_kernel<1>, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, f, (const float*)nullptr, labels,
+                       nominal_label, gscale, df, n, d, inv_count);
+    EOE_CHECK_LAUNCH("dsad_bwd");
+    return 0;
+}
+
+extern "C" int eoe_dsvdd_fwd(const float* f, const float* center, float* loss, float* dists, int n, int d, float inv_count,
+                             void* stream) {
+    EOE_CHECK_ARG(f && center && dists && n > 0 && d > 0, "dsvdd_fwd: bad args");
+    hipLaunchKernelGGL(rowobj_fwd_kernel<2>, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, f, center, (const int64_t*)nullptr,
+                       (int64_t)0, dists, n, d);
+    EOE_CHECK_LAUNCH("dsvdd_rows");
+    if (loss) {
+        hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, dists, loss, n, inv_count);
+        EOE_CHECK_LAUNCH("dsvdd_sum");
+    }
+    return 0;
+}
+
+extern "C" int eoe_dsvdd_bwd(const float* f, const float* center, const float* gscale, float* df, int n, int d, float inv_count,
+                             void* stream) {
+    EOE_CHECK_ARG(f && center && df && n > 0 && d > 0, "dsvdd_bwd: bad args");
+    hipLaunchKernelGGL(rowobj_bwd_kernel<2>, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, f, center, (const int64_t*)nullptr,
+                       (int64_t)0, gscale, df, n, d, inv_count);
+    EOE_CHECK_LAUNCH("dsvdd_bwd");
+    return 0;
+}
+
+extern "C" int eoe_focal_fwd(const float* x, const int64_t* labels, int64_t nominal_label, float* loss, float* scores,
+                             float* losses, int n, float inv_count, float gamma, float eps, void* stream) {
+    EOE_CHECK_ARG(x && labels && n > 0 && gamma >= 1.0f && eps > 0.f && eps < 0.5f, "focal_fwd: bad args");
+    EOE_CHECK_ARG(!loss || losses, "focal_fwd: the loss needs the per-sample `losses` buffer");
+    hipLaunchKernelGGL(focal_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, labels, nominal_label, scores,
+                       losses, n, gamma, eps);
+    EOE_CHECK_LAUNCH("focal_rows");
+    if (loss) {
+        hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, losses, loss, n, inv_count);
+        EOE_CHECK_LAUNCH("focal_sum");
+    }
+    return 0;
+}
+
+extern "C" int eoe_focal_bwd(const float* x, const int64_t* labels, const float* gscale, float* dx, int n, float inv_count,
+                             float gamma, float eps, void* stream) {
+    EOE_CHECK_ARG(x && labels && dx && n > 0 && gamma >= 1.0f && eps > 0.f && eps < 0.5f, "focal_bwd: bad args");
+    hipLaunchKernelGGL(focal_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, labels, gscale, dx, n, inv_count,
+                       gamma, eps);
+    EOE_CHECK_LAUNCH("focal_bwd");
     return 0;
 }
 

@@ -552,6 +552,111 @@ def bce_score(feats, nominal_label=0):
     return out
 
 
+# ------------------------------------------------------------------------------------------------ autograd: other objectives
+class DsadLossFunction(torch.autograd.Function):
+    """DSADTrainer.loss (dsad.py:17-21)"""
+
+    @staticmethod
+    def forward(ctx, feats, labels, nominal_label, inv_count):
+        _chk(feats, labels)
+        f = feats.contiguous().float()
+        n, d = f.shape
+        labels = labels.contiguous().to(torch.int64)
+        loss = torch.empty(1, dtype=torch.float32, device=f.device)
+        losses = torch.empty(n, dtype=torch.float32, device=f.device)
+        inv = float(inv_count) if inv_count is not None else 1.0 / n
+        check(lib.eoe_dsad_fwd(_p(f), _p(labels), int(nominal_label), _p(loss), _p(losses), n, d, inv, _stream()), "eoe_dsad_fwd")
+        ctx.save_for_backward(f, labels)
+        ctx.cfg = (int(nominal_label), inv)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        f, labels = ctx.saved_tensors
+        nominal, inv = ctx.cfg
+        df = torch.empty_like(f)
+        gs = gout.contiguous().float().reshape(1)
+        check(lib.eoe_dsad_bwd(_p(f), _p(labels), nominal, _p(gs), _p(df), f.shape[0], f.shape[1], inv, _stream()), "eoe_dsad_bwd")
+        return df, None, None, None
+
+
+def dsad_loss(feats, labels, nominal_label=0, inv_count=None):
+    return DsadLossFunction.apply(feats, labels, nominal_label, inv_count)
+
+
+class DsvddLossFunction(torch.autograd.Function):
+    """DSVDDTrainer.loss (dsvdd.py:26-27): mean squared distance to the fixed centre"""
+
+    @staticmethod
+    def forward(ctx, feats, center, inv_count):
+        _chk(feats, center)
+        f = feats.contiguous().float()
+        n, d = f.shape
+        c = center.detach().contiguous().float().reshape(-1)
+        assert c.shape[0] == d
+        loss = torch.empty(1, dtype=torch.float32, device=f.device)
+        dists = torch.empty(n, dtype=torch.float32, device=f.device)
+        inv = float(inv_count) if inv_count is not None else 1.0 / n
+        check(lib.eoe_dsvdd_fwd(_p(f), _p(c), _p(loss), _p(dists), n, d, inv, _stream()), "eoe_dsvdd_fwd")
+        ctx.save_for_backward(f, c)
+        ctx.inv = inv
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        f, c = ctx.saved_tensors
+        df = torch.empty_like(f)
+        gs = gout.contiguous().float().reshape(1)
+        check(lib.eoe_dsvdd_bwd(_p(f), _p(c), _p(gs), _p(df), f.shape[0], f.shape[1], ctx.inv, _stream()), "eoe_dsvdd_bwd")
+        return df, None, None
+
+
+def dsvdd_loss(feats, center, inv_count=None):
+    return DsvddLossFunction.apply(feats, center, inv_count)
+
+
+def dsvdd_score(feats, center):
+    """DSVDDTrainer.compute_anomaly_score (dsvdd.py:24-25)"""
+    _chk(feats, center)
+    f = feats.detach().contiguous().float()
+    c = center.detach().contiguous().float().reshape(-1)
+    out = torch.empty(f.shape[0], dtype=torch.float32, device=f.device)
+    check(lib.eoe_dsvdd_fwd(_p(f), _p(c), None, _p(out), f.shape[0], f.shape[1], 1.0, _stream()), "eoe_dsvdd_fwd")
+    return out
+
+
+class FocalLossFunction(torch.autograd.Function):
+    """FocalTrainer.loss (focal.py:11-24,34-36), gamma = 2, eps = 1e-7"""
+
+    @staticmethod
+    def forward(ctx, feats, labels, inv_count, gamma, eps):
+        _chk(feats, labels)
+        x = feats.contiguous().float().reshape(-1)
+        n = x.shape[0]
+        labels = labels.contiguous().to(torch.int64)
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        losses = torch.empty(n, dtype=torch.float32, device=x.device)
+        inv = float(inv_count) if inv_count is not None else 1.0 / n
+        check(lib.eoe_focal_fwd(_p(x), _p(labels), 0, _p(loss), None, _p(losses), n, inv, float(gamma), float(eps), _stream()),
+              "eoe_focal_fwd")
+        ctx.save_for_backward(x, labels)
+        ctx.cfg = (inv, float(gamma), float(eps), feats.shape)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, labels = ctx.saved_tensors
+        inv, gamma, eps, shape = ctx.cfg
+        dx = torch.empty_like(x)
+        gs = gout.contiguous().float().reshape(1)
+        check(lib.eoe_focal_bwd(_p(x), _p(labels), _p(gs), _p(dx), x.shape[0], inv, gamma, eps, _stream()), "eoe_focal_bwd")
+        return dx.reshape(shape), None, None, None, None
+
+
+def focal_loss(feats, labels, inv_count=None, gamma=2.0, eps=1e-7):
+    return FocalLossFunction.apply(feats, labels, inv_count, gamma, eps)
+
+
 # ------------------------------------------------------------------------------------------------ autograd: CNN backbone
 BN_SCRATCH = (1024 + 1) * 2         # EOE_BN_SCRATCH(C) / C of include/eoe_hip.h: per-workgroup partial sums + the total
 

@@ -394,6 +394,24 @@ int eoe_relu_bwd(const float* dout, const float* out, float* g, int64_t count, v
 int eoe_avgpool_fwd(const float* x, float* pooled_scratch, int* argmax_scratch, int n, int HW, int C, void* stream);
 int eoe_avgpool_bwd(const float* dout, float* dx, int n, int HW, int C, void* stream);
 
+/* the other objectives of the reference's TRAINER registry (training/__init__.py:8-11), same
+ * conventions as eoe_hsc_* / eoe_bce_* (loss[0] = inv_count * sum of the per-sample losses; gscale = upstream gradient):
+ *   DSAD  (dsad.py:17-21):  loss_i = |f|^2 if label == nominal else 1 / (|f|^2 + 1e-9);  score = the HSC score (eoe_hsc_score)
+ *   DSVDD (dsvdd.py:24-27): loss_i = score_i = |f - center|^2 (center fp32 [d], from prepare_metric dsvdd.py:10-22)
+ *   focal (focal.py:11-36): b = bce_with_logits(x, y), pt = clamp(exp(-b), eps, 1 - eps), loss_i = (1 - pt)^gamma * b;
+ *                           scores = sigmoid(x) (1 - sigmoid if nominal_label != 0) */
+int eoe_dsad_fwd(const float* f, const int64_t* labels, int64_t nominal_label, float* loss, float* losses, int n, int d,
+                 float inv_count, void* stream);
+int eoe_dsad_bwd(const float* f, const int64_t* labels, int64_t nominal_label, const float* gscale, float* df, int n, int d,
+                 float inv_count, void* stream);
+int eoe_dsvdd_fwd(const float* f, const float* center, float* loss, float* dists, int n, int d, float inv_count, void* stream);
+int eoe_dsvdd_bwd(const float* f, const float* center, const float* gscale, float* df, int n, int d, float inv_count,
+                  void* stream);
+int eoe_focal_fwd(const float* x, const int64_t* labels, int64_t nominal_label, float* loss, float* scores, float* losses,
+                  int n, float inv_count, float gamma, float eps, void* stream);
+int eoe_focal_bwd(const float* x, const int64_t* labels, const float* gscale, float* dx, int n, float inv_count, float gamma,
+                  float eps, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * on-device input pipeline: gather + RandomCrop (zero padding) + RandomHorizontalFlip +
  * ToTensor + Gaussian noise + per-channel Normalize in one pass over a uint8 NHWC image set resident in HBM

@@ -68,3 +68,77 @@ def bce_loss_grad(features: torch.Tensor, labels: torch.Tensor, inv_count: float
     inv = (1.0 / n) if inv_count is None else inv_count
     x = features.reshape(n)
     return ((torch.sigmoid(x) - labels.to(x.dtype)) * inv).reshape(features.shape)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the other objectives of the TRAINER registry
+# ---------------------------------------------------------------------------------------------------------
+def dsad_losses(features: torch.Tensor, labels: torch.Tensor, nominal_label: int = 0) -> torch.Tensor:
+    """`src/eoe/training/dsad.py:17-21`: |f|^2 for nominal samples, 1 / (|f|^2 + 1e-9) for the others"""
+    d = (features * features).sum(dim=1)
+    return torch.where(labels == nominal_label, d, 1.0 / (d + 1e-9))
+
+
+def dsad_loss(features, labels, nominal_label: int = 0):
+    return dsad_losses(features, labels, nominal_label).mean()
+
+
+def dsad_loss_grad(features, labels, nominal_label: int = 0, inv_count: float = None):
+    """closed form of d(mean loss)/df: 2 f for nominal rows, -2 f / (|f|^2 + 1e-9)^2 for the others"""
+    n = features.shape[0]
+    inv = (1.0 / n) if inv_count is None else inv_count
+    d = (features * features).sum(dim=1, keepdim=True)
+    coef = torch.where((labels == nominal_label).unsqueeze(1), torch.full_like(d, 2.0), -2.0 / (d + 1e-9) ** 2)
+    return features * coef * inv
+
+
+def dsvdd_center(batch_features, eps: float = 1e-1) -> torch.Tensor:
+    """`src/eoe/training/dsvdd.py:10-22`: mean over the batches of the per-batch mean feature of the nominal samples, entries
+    closer to zero than eps pushed to +-eps (zero stays zero)"""
+    center = torch.stack([bf.mean(dim=0) for bf in batch_features]).mean(dim=0, keepdim=True).clone()
+    neg = (center.abs() < eps) & (center < 0)
+    pos = (center.abs() < eps) & (center > 0)
+    center[neg] = -eps
+    center[pos] = eps
+    return center
+
+
+def dsvdd_score(features, center):
+    """`dsvdd.py:24-25` (also the per-sample loss, `:26-27`)"""
+    return ((features - center) ** 2).sum(dim=-1)
+
+
+def dsvdd_loss(features, center):
+    return dsvdd_score(features, center).mean()
+
+
+def dsvdd_loss_grad(features, center, inv_count: float = None):
+    inv = (1.0 / features.shape[0]) if inv_count is None else inv_count
+    return 2.0 * (features - center) * inv
+
+
+def focal_losses(logits: torch.Tensor, labels: torch.Tensor, gamma: float = 2.0, eps: float = 1e-7) -> torch.Tensor:
+    """`src/eoe/training/focal.py:11-24`: (1 - pt)^gamma * bce with pt = clamp(exp(-bce), eps, 1 - eps)"""
+    bce = bce_losses(logits, labels)
+    pt = torch.exp(-bce).clamp(eps, 1.0 - eps)
+    return (1.0 - pt) ** gamma * bce
+
+
+def focal_loss(logits, labels, gamma: float = 2.0, eps: float = 1e-7):
+    return focal_losses(logits, labels, gamma, eps).mean()
+
+
+def focal_loss_grad(logits, labels, gamma: float = 2.0, eps: float = 1e-7, inv_count: float = None):
+    """closed form: with b = bce, b' = sigmoid(x) - y, pt = exp(-b): dF/dx = (1-pt)^g b' + g (1-pt)^(g-1) pt b' b inside the
+    clamp, (1-pt)^g b' where the clamp is active (its derivative is zero there)"""
+    x = logits.reshape(-1)
+    y = labels.reshape(-1).to(x.dtype)
+    n = x.shape[0]
+    inv = (1.0 / n) if inv_count is None else inv_count
+    b = bce_losses(logits, labels).reshape(-1)
+    db = torch.sigmoid(x) - y
+    raw = torch.exp(-b)
+    pt = raw.clamp(eps, 1.0 - eps)
+    inside = (raw >= eps) & (raw <= 1.0 - eps)
+    g = (1.0 - pt) ** gamma * db + torch.where(inside, gamma * (1.0 - pt) ** (gamma - 1.0) * pt * db * b, torch.zeros_like(b))
+    return (g * inv).reshape(logits.shape)

@@ -130,6 +130,57 @@ def g1():
     save("g1_objectives", **out)
 
 
+# ----------------------------------------------------------------------------------------------- G9 other objectives (N4)
+def dsad_loss_ref(f, y, nominal=0):                     # training/dsad.py:17-21
+    dists = torch.norm(f, p=2, dim=1) ** 2
+    return torch.where(y == nominal, dists, ((dists + 1e-9) ** (-1))).mean()
+
+
+def dsvdd_loss_ref(f, c):                               # training/dsvdd.py:24-27
+    return (f - c).pow(2).sum(-1).mean()
+
+
+def dsvdd_center_ref(batch_feats, eps=1e-1):            # training/dsvdd.py:10-22 on already-computed nominal features
+    center = torch.cat([bf.mean(0).unsqueeze(0) for bf in batch_feats]).mean(0).unsqueeze(0)
+    center[(abs(center) < eps) & (center < 0)] = -eps
+    center[(abs(center) < eps) & (center > 0)] = eps
+    return center
+
+
+def focal_loss_ref(x, y, gamma=2.0, eps=1e-7):          # training/focal.py:11-24,34-36
+    bce = torch.nn.functional.binary_cross_entropy_with_logits(x.squeeze(), y.float(), reduction='none')
+    pt = torch.exp(-bce).clamp(eps, 1. - eps)
+    return ((1 - pt).pow(gamma) * bce).mean()
+
+
+def g9():
+    f = torch.from_numpy(fill.fill("g9/features", (16, 256), std=0.08))
+    y = torch.from_numpy(fill.fill_int("g9/labels", (16,), 0, 2))
+    out = {}
+    ff = f.clone().requires_grad_(True)
+    loss = dsad_loss_ref(ff, y)
+    loss.backward()
+    out["dsad_loss"], out["dsad_grad"] = loss.item(), ff.grad.numpy()
+    out["dsad_scores"] = hsc_score_ref(f).numpy()                                   # dsad.py:12-15 = the HSC score
+    feats = [torch.from_numpy(fill.fill(f"g9/cb{i}", (5 + i, 256), std=0.3, mean=0.02)) for i in range(3)]
+    c = dsvdd_center_ref(feats)
+    out["dsvdd_center"] = c.numpy()
+    ff = f.clone().requires_grad_(True)
+    loss = dsvdd_loss_ref(ff, c)
+    loss.backward()
+    out["dsvdd_loss"], out["dsvdd_grad"] = loss.item(), ff.grad.numpy()
+    out["dsvdd_scores"] = (f - c).pow(2).sum(-1).numpy()
+    x = torch.cat([f[:, :1] * 20, torch.tensor([[40.0], [-40.0], [0.0], [18.0]])])     # incl. saturated logits (pt clamp)
+    yy = torch.cat([y, torch.tensor([1, 0, 1, 0])])
+    xx = x.clone().requires_grad_(True)
+    loss = focal_loss_ref(xx, yy)
+    loss.backward()
+    out["focal_x"], out["focal_y"] = x.numpy(), yy.numpy()
+    out["focal_loss"], out["focal_grad"] = loss.item(), xx.grad.numpy()
+    out["focal_scores"] = torch.sigmoid(x).squeeze().numpy()
+    save("g9_objectives", **out)
+
+
 # ----------------------------------------------------------------------------------------------- G2 CNN32
 def g2():
     for clf, obj in ((False, "hsc"), (True, "bce")):
@@ -249,6 +300,6 @@ def g8():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g7", "g8", "g9"]
     for w in which:
         globals()[w]()

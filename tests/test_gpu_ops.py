@@ -301,3 +301,51 @@ def test_fused_adam(golden, wd):
         ooptim.adam_step(ref, gs, st, lr=3e-3, weight_decay=wd)
     for p, r in zip(big, ref):
         assert_close(p, r, 3e-6, 1e-6, "fused adam vs oracle")
+
+
+def test_other_objectives_n4_vs_golden(golden):
+    """DSAD / DSVDD / focal heads against the vectors made with the stock torch calls of the reference's
+    dsad.py / dsvdd.py / focal.py, plus the data-parallel inv_count convention"""
+    import eoe_amd
+    g = golden("g9_objectives")
+    f = torch.from_numpy(fill.fill("g9/features", (16, 256), std=0.08)).cuda()
+    y = torch.from_numpy(fill.fill_int("g9/labels", (16,), 0, 2)).cuda()
+    ff = f.clone().requires_grad_(True)
+    loss = eoe_amd.dsad_loss(ff, y, 0)
+    loss.backward()
+    assert abs(loss.item() - float(g["dsad_loss"])) <= 2e-5 * abs(float(g["dsad_loss"]))
+    np.testing.assert_allclose(ff.grad.cpu().numpy(), g["dsad_grad"], rtol=2e-4, atol=1e-6)
+    c = torch.from_numpy(g["dsvdd_center"]).cuda()
+    ff = f.clone().requires_grad_(True)
+    loss = eoe_amd.dsvdd_loss(ff, c)
+    loss.backward()
+    assert abs(loss.item() - float(g["dsvdd_loss"])) <= 2e-5 * abs(float(g["dsvdd_loss"]))
+    np.testing.assert_allclose(ff.grad.cpu().numpy(), g["dsvdd_grad"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(eoe_amd.dsvdd_score(f, c).cpu().numpy(), g["dsvdd_scores"], rtol=1e-5)
+    x = torch.from_numpy(g["focal_x"]).cuda()
+    yy = torch.from_numpy(g["focal_y"]).cuda()
+    xx = x.clone().requires_grad_(True)
+    loss = eoe_amd.focal_loss(xx, yy)
+    loss.backward()
+    assert abs(loss.item() - float(g["focal_loss"])) <= 2e-5 * abs(float(g["focal_loss"]))
+    np.testing.assert_allclose(xx.grad.cpu().numpy(), g["focal_grad"], rtol=5e-4, atol=1e-7)
+    np.testing.assert_allclose(eoe_amd.bce_score(x).cpu().numpy(), g["focal_scores"], rtol=1e-5)
+    # inv_count (1 / global batch): a half batch with inv_count 1/16 gives its share of the full-batch loss
+    l_half = eoe_amd.dsad_loss(f[:8], y[:8], 0, 1.0 / 16).item() + eoe_amd.dsad_loss(f[8:], y[8:], 0, 1.0 / 16).item()
+    assert abs(l_half - float(g["dsad_loss"])) <= 2e-5 * abs(float(g["dsad_loss"]))
+
+
+@pytest.mark.parametrize("objective", ["dsad", "dsvdd", "focal"])
+def test_other_objective_trainers_run(objective):
+    """the three extra TRAINER entries run end to end on a small CNN32 task and learn (DSVDD: the loss falls)"""
+    from eoe_amd.data import SyntheticAD
+    from eoe_amd.models import CNN32
+    from eoe_amd.training import TRAINER
+    torch.manual_seed(0)
+    ds = SyntheticAD(n_train_normal=48, n_oe=16, n_test=32, res=32, shift=1.5, seed=3)
+    tr = TRAINER[objective](CNN32(bias=True, clf=(objective == "focal")), dataset=ds, epochs=4, lr=1e-3, wdk=0.0, milestones=[],
+                            batch_size=16, classes=["only"])
+    _, res = tr.run(run_seeds=1)
+    assert np.isfinite(tr.last_losses).all() and tr.last_losses[-1] < tr.last_losses[0]
+    if objective != "dsvdd":
+        assert res["mean_auc"] > 0.8, res

@@ -215,3 +215,25 @@ def test_cbam(golden):
     _grad_check(cb, g, rtol=1e-3)
     for n, b in cb.named_buffers():
         np.testing.assert_allclose(b.numpy(), g[f"buf/{n}"], rtol=1e-4, atol=1e-6)
+
+
+def test_other_objectives_n4(golden):
+    """DSAD / DSVDD (incl. the centre rule) / focal restatements against the vectors produced with the stock torch calls of
+    `training/dsad.py`, `dsvdd.py`, `focal.py` (tests/golden/make_golden.py::g9)"""
+    g = golden("g9_objectives")
+    f = torch.from_numpy(fill.fill("g9/features", (16, 256), std=0.08))
+    y = torch.from_numpy(fill.fill_int("g9/labels", (16,), 0, 2))
+    assert abs(objectives.dsad_loss(f, y).item() - float(g["dsad_loss"])) <= 1e-5 * abs(float(g["dsad_loss"]))
+    np.testing.assert_allclose(objectives.dsad_loss_grad(f, y).numpy(), g["dsad_grad"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(objectives.hsc_score(f).numpy(), g["dsad_scores"], rtol=1e-5, atol=1e-7)
+    feats = [torch.from_numpy(fill.fill(f"g9/cb{i}", (5 + i, 256), std=0.3, mean=0.02)) for i in range(3)]
+    c = objectives.dsvdd_center(feats)
+    np.testing.assert_allclose(c.numpy(), g["dsvdd_center"], rtol=1e-6, atol=1e-7)
+    assert (c.abs() >= 0.1 - 1e-7).all()
+    assert abs(objectives.dsvdd_loss(f, c).item() - float(g["dsvdd_loss"])) <= 1e-5 * abs(float(g["dsvdd_loss"]))
+    np.testing.assert_allclose(objectives.dsvdd_loss_grad(f, c).numpy(), g["dsvdd_grad"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(objectives.dsvdd_score(f, c).numpy(), g["dsvdd_scores"], rtol=1e-5)
+    x, yy = torch.from_numpy(g["focal_x"]), torch.from_numpy(g["focal_y"])
+    assert abs(objectives.focal_loss(x, yy).item() - float(g["focal_loss"])) <= 1e-5 * abs(float(g["focal_loss"]))
+    np.testing.assert_allclose(objectives.focal_loss_grad(x, yy).numpy(), g["focal_grad"], rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(objectives.bce_score(x).numpy(), g["focal_scores"], rtol=1e-6)
