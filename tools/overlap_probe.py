@@ -1,0 +1,75 @@
+#!/usr/bin/env python
+"""can the grouped wgrad GEMM of a ViT block run UNDER the HBM-bound kernels of the next block's backward (LayerNorm
+backward x2, attention backward, column sums) when it is launched on a second stream?  sequential vs two-stream time.
+Also: wgrad GEMM under a dgrad NT GEMM (both MFMA-bound; only tail effects can overlap)."""
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import eoe_amd.ops as ops
+from eoe_amd import _lib
+
+dt = torch.float16
+M, D, n, L, H = 12800, 768, 256, 50, 12
+dev = "cuda"
+args = (_lib.GemmArgs * 4)()
+keep = []
+for i, (m, nn, t) in enumerate([(3072, 768, M), (768, 3072, M), (2304, 768, M), (768, 768, M)]):
+    a = torch.randn(t, m, device=dev).to(dt); b = torch.randn(t, nn, device=dev).to(dt)
+    out = torch.empty(m, nn, device=dev)
+    keep += [a, b, out]
+    args[i] = _lib.GemmArgs(a.data_ptr(), b.data_ptr(), out.data_ptr(), None, None, None, None, m, nn, t, m, nn, nn, 0,
+                            ops.dtype_code(dt), 0, 1, 0, 1.0)
+
+
+def tn(stream):
+    _lib.check(_lib.lib.eoe_gemm_tn_grouped(args, 4, stream.cuda_stream), "tn")
+
+
+x = torch.randn(M, D, device=dev); dy = torch.randn(M, D, device=dev)
+stats = torch.stack([x.mean(1), 1.0 / x.std(1)], 1).contiguous()
+g = torch.ones(D, device=dev)
+dx = torch.empty(M, D, device=dev); dx16 = torch.empty(M, D, device=dev, dtype=dt)
+dg = torch.zeros(D, device=dev); db = torch.zeros(D, device=dev)
+qkv = torch.randn(M, 3 * D, device=dev).to(dt); datt = torch.randn(M, D, device=dev).to(dt); dqkv = torch.empty_like(qkv)
+cs = torch.zeros(3 * D, device=dev)
+a16 = torch.randn(M, D, device=dev).to(dt); w16 = torch.randn(3072, D, device=dev).to(dt); c16 = torch.empty(M, 3072, device=dev, dtype=dt)
+
+
+def membound():
+    ops.layernorm_bwd(dy, x, stats, g, M, D, D, dx, D, dx16=dx16, dgamma=dg, dbeta=db)
+    ops.attn_bwd(qkv, datt, dqkv, n, L, H)
+    ops.colsum(dqkv, cs)
+    ops.layernorm_bwd(dy, x, stats, g, M, D, D, dx, D, dx16=dx16, dgamma=dg, dbeta=db)
+
+
+def nt():
+    ops.gemm_nt(a16, w16, c16)
+
+
+main, side = torch.cuda.current_stream(), torch.cuda.Stream()
+
+
+def timed(fn, reps=20):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+def both(work):
+    def f():
+        side.wait_stream(main)
+        tn(side)
+        work()
+        main.wait_stream(side)
+    return f
+
+
+for name, work in (("HBM-bound chain (LN bwd x2, attn bwd, colsum)", membound), ("dgrad-like NT GEMM 12800x3072x768", nt)):
+    t_w = timed(work); t_t = timed(lambda: tn(main)); t_seq = timed(lambda: (tn(main), work())); t_par = timed(both(work))
+    print(f"{name}: alone {t_w:.0f} us, wgrad alone {t_t:.0f} us, sequential {t_seq:.0f} us, two streams {t_par:.0f} us "
+          f"(hidden {t_seq - t_par:.0f} us = {100 * (t_seq - t_par) / min(t_w, t_t):.0f} % of the shorter)")
