@@ -425,11 +425,14 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
     }
     red[threadIdx.x] = a;
     __syncthreads();
-    if (rl == 0 && c < cols) {
+    if (rl == 0) {
         for (int k = 1; k < rpb; ++k) a += red[threadIdx.x + k * cpb];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) atomicAdd(out + c + k, a[k]);
+        red[tc] = a;                              // row 0 of the LDS image: only this thread read / writes slot tc
     }
+    __syncthreads();
+    // one atomic per column, consecutive lanes on consecutive addresses (a 4-atomics-per-lane epilogue measured 50 % slower)
+    const int cc = blockIdx.x * cpb * 4 + threadIdx.x;
+    if ((int)threadIdx.x < cpb * 4 && cc < cols) atomicAdd(out + cc, ((const float*)red)[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------ objectives
