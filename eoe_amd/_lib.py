@@ -49,7 +49,7 @@ class SGateArgs(C.Structure):
     _fields_ = [("x", _vp), ("out", _vp), ("w", _vp), ("gamma", _vp), ("beta", _vp), ("running_mean", _vp), ("running_var", _vp),
                 ("num_batches_tracked", _vp), ("comp", _vp), ("argmax", _vp), ("z", _vp), ("stats", _vp), ("scale", _vp),
                 ("sums", _vp), ("n", _i32), ("H", _i32), ("W", _i32), ("C", _i32), ("eps", _f32), ("momentum", _f32),
-                ("training", _i32)]
+                ("training", _i32), ("res", _vp), ("out16", _vp), ("dtype", _i32)]
 
 
 class SGateBwdArgs(C.Structure):

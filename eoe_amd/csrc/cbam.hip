@@ -241,6 +241,23 @@ __global__ __launch_bounds__(256) void gate_scale_kernel(const float* __restrict
         *(f32x4*)(out + p * C + c) = v;
     }
 }
+// spatial gate + residual junction in one pass (resnet.py:143-147): out = relu(x * sp[img, hw] + res), optional 16-bit copy
+template <typename T>
+__global__ __launch_bounds__(256) void gate_scale_add_relu_kernel(const float* __restrict__ x, const float* __restrict__ sp,
+                                                                  const float* __restrict__ res, float* __restrict__ out,
+                                                                  T* __restrict__ out16, size_t P, int C) {
+    const int cc = C / 4;
+    const size_t total = P * cc;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cc) * 4;
+        const size_t p = i / cc;
+        f32x4 v = *(const f32x4*)(x + p * C + c) * sp[p] + *(const f32x4*)(res + p * C + c);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        *(f32x4*)(out + p * C + c) = v;
+        if (out16) *(u32x2*)(out16 + p * C + c) = pack4<T>(v[0], v[1], v[2], v[3]);
+    }
+}
 // channel gate: dx = dout * s[img,c] + dpooled_avg[img,c] / HW + [hw == argmax[img,c]] * dpooled_max[img,c]
 __global__ __launch_bounds__(256) void cgate_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ scale,
                                                               const float* __restrict__ dpooled, const int* __restrict__ argmax,
@@ -590,6 +607,17 @@ extern "C" int eoe_sgate_fwd(const eoe_sgate_args* a, void* stream) {
     ProfScope ps("sgate_fwd", 0, 2 * 4.0 * P * a->C, stream);
     hipLaunchKernelGGL(sgate_sigmoid_kernel, dim3(grid_for(P)), dim3(256), 0, s, a->z, a->stats, a->gamma, a->beta, a->scale, P);
     EOE_CHECK_LAUNCH("sgate_sigmoid");
+    if (a->res) {      // fused residual junction: out = relu(x * scale + res) (+ 16-bit copy)
+        EOE_CHECK_ARG(!a->out16 || a->dtype == EOE_F16 || a->dtype == EOE_BF16, "sgate_fwd: bad dtype %d", a->dtype);
+        if (a->out16 && a->dtype == EOE_BF16)
+            hipLaunchKernelGGL((gate_scale_add_relu_kernel<bf16_t>), dim3(grid_for(P * a->C / 4)), dim3(256), 0, s, a->x,
+                               (const float*)a->scale, a->res, a->out, (bf16_t*)a->out16, P, a->C);
+        else
+            hipLaunchKernelGGL((gate_scale_add_relu_kernel<f16_t>), dim3(grid_for(P * a->C / 4)), dim3(256), 0, s, a->x,
+                               (const float*)a->scale, a->res, a->out, (f16_t*)a->out16, P, a->C);
+        EOE_CHECK_LAUNCH("sgate_scale_add_relu");
+        return 0;
+    }
     hipLaunchKernelGGL(gate_scale_kernel, dim3(grid_for(P * a->C / 4)), dim3(256), 0, s, a->x, (const float*)nullptr, a->scale, a->out,
                        a->n, a->H * a->W, a->C);
     EOE_CHECK_LAUNCH("sgate_scale");

@@ -45,6 +45,11 @@ class BasicBlock(nn.Module):
         residual = x
         if self.downsample is not None:
             residual = _conv_bn(x, self.downsample[0], self.downsample[1], self.training, 1.0)
+        if self.cbam is not None and not self.cbam.no_spatial:
+            # channel gate, then the spatial gate fused with the residual junction (the gated tensor is never written)
+            out = self.cbam.ChannelGate(out)
+            sg = self.cbam.SpatialGate.spatial
+            return ops_resnet.spatial_gate_add_relu(out, residual, sg.conv.weight, sg.bn, self.training)
         if self.cbam is not None:
             out = self.cbam(out)
         return ops_resnet.add_relu(out, residual)

@@ -102,7 +102,8 @@ class SpatialGateFunction(torch.autograd.Function):
         sums = scratch("sg_sums", (BN_SCRATCH,), torch.float32, dev)
         wc = w.detach().contiguous()
         a = _lib.SGateArgs(_p(x), _p(out), _p(wc), _p(bn_w), _p(bn_b), _p(rm), _p(rv), _p(nbt), _p(comp), _p(argmax), _p(z),
-                           _p(stats), _p(scale), _p(sums), n, H, W, Cc, float(eps), float(momentum), 1 if training else 0)
+                           _p(stats), _p(scale), _p(sums), n, H, W, Cc, float(eps), float(momentum), 1 if training else 0,
+                           None, None, 0)
         check(lib.eoe_sgate_fwd(C.byref(a), _stream()), "eoe_sgate_fwd")
         ctx.save_for_backward(x, w, bn_w, bn_b, comp, argmax, z, stats, scale)
         ctx.cfg = (training, float(eps), float(momentum))
@@ -125,10 +126,71 @@ class SpatialGateFunction(torch.autograd.Function):
         db = _grad_target(bn_b) if bn_b is not None else None
         wc = w.detach().contiguous()
         f = _lib.SGateArgs(_p(x), None, _p(wc), _p(bn_w), _p(bn_b), None, None, None, _p(comp), _p(argmax), _p(z), _p(stats),
-                           _p(scale), _p(sums), n, H, W, Cc, eps, momentum, 1 if training else 0)
+                           _p(scale), _p(sums), n, H, W, Cc, eps, momentum, 1 if training else 0, None, None, 0)
         b = _lib.SGateBwdArgs(f, _p(dout), _p(dx), _p(dscale), _p(dcomp), _p(red), _p(dw), _p(dg), _p(db))
         check(lib.eoe_sgate_bwd(C.byref(b), _stream()), "eoe_sgate_bwd")
         return dx, dw, dg, db, None, None, None, None
+
+
+class SpatialGateAddReluFunction(torch.autograd.Function):
+    """relu(x * sigmoid(bn(conv7x7([max_c x, mean_c x]))) + res): the spatial gate (`cbam.py:76-92`) and the residual junction
+    of the BasicBlock (`resnet.py:143-147`) in one unit -- the gated tensor is never written.  Returns (out, 16-bit copy)."""
+
+    @staticmethod
+    def forward(ctx, x, res, w, bn_w, bn_b, rm, rv, nbt, cfg):
+        _chk(x, res, w, bn_w, bn_b, rm, rv)
+        training, eps, momentum = cfg
+        x, res = x.contiguous().float(), res.contiguous().float()
+        n, H, W, Cc = x.shape
+        dev = x.device
+        out = torch.empty_like(x)
+        out16 = torch.empty(x.shape, dtype=ops.compute_dtype(), device=dev)
+        comp = torch.empty((n, H, W, 2), dtype=torch.float32, device=dev)
+        argmax = torch.empty((n, H, W), dtype=torch.int32, device=dev)
+        z = torch.empty((n, H, W), dtype=torch.float32, device=dev)
+        stats = torch.empty(2, dtype=torch.float32, device=dev)
+        scale = torch.empty((n, H, W), dtype=torch.float32, device=dev)
+        sums = scratch("sg_sums", (BN_SCRATCH,), torch.float32, dev)
+        wc = w.detach().contiguous()
+        a = _lib.SGateArgs(_p(x), _p(out), _p(wc), _p(bn_w), _p(bn_b), _p(rm), _p(rv), _p(nbt), _p(comp), _p(argmax), _p(z),
+                           _p(stats), _p(scale), _p(sums), n, H, W, Cc, float(eps), float(momentum), 1 if training else 0,
+                           _p(res), _p(out16), dtype_code(out16.dtype))
+        check(lib.eoe_sgate_fwd(C.byref(a), _stream()), "eoe_sgate_fwd")
+        ctx.save_for_backward(x, w, bn_w, bn_b, comp, argmax, z, stats, scale, out)
+        ctx.cfg = (training, float(eps), float(momentum))
+        ctx.mark_non_differentiable(out16)
+        return out, out16
+
+    @staticmethod
+    def backward(ctx, dout, _d16=None):
+        x, w, bn_w, bn_b, comp, argmax, z, stats, scale, out = ctx.saved_tensors
+        training, eps, momentum = ctx.cfg
+        n, H, W, Cc = x.shape
+        dev = x.device
+        dout = dout.contiguous().float()
+        g = torch.empty_like(out)                      # gradient at the junction = gradient of the residual branch
+        check(lib.eoe_relu_bwd(_p(dout), _p(out), _p(g), out.numel(), _stream()), "eoe_relu_bwd")
+        dx = torch.empty_like(x)
+        dscale = scratch("sg_dscale", (n, H, W), torch.float32, dev)
+        dcomp = scratch("sg_dcomp", (n, H, W, 2), torch.float32, dev)
+        red = scratch("sg_red", (2,), torch.float32, dev)
+        sums = scratch("sg_sums", (BN_SCRATCH,), torch.float32, dev)
+        dw = _grad_target(w)
+        dg = _grad_target(bn_w) if bn_w is not None else None
+        db = _grad_target(bn_b) if bn_b is not None else None
+        wc = w.detach().contiguous()
+        f = _lib.SGateArgs(_p(x), None, _p(wc), _p(bn_w), _p(bn_b), None, None, None, _p(comp), _p(argmax), _p(z), _p(stats),
+                           _p(scale), _p(sums), n, H, W, Cc, eps, momentum, 1 if training else 0, None, None, 0)
+        b = _lib.SGateBwdArgs(f, _p(g), _p(dx), _p(dscale), _p(dcomp), _p(red), _p(dw), _p(dg), _p(db))
+        check(lib.eoe_sgate_bwd(C.byref(b), _stream()), "eoe_sgate_bwd")
+        return dx, g, dw, dg, db, None, None, None, None
+
+
+def spatial_gate_add_relu(x, res, conv_w, bn, training):
+    out, out16 = SpatialGateAddReluFunction.apply(x, res, conv_w, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                                  bn.num_batches_tracked, (training, bn.eps, bn.momentum))
+    out._eoe16 = out16
+    return out
 
 
 class AddReluFunction(torch.autograd.Function):

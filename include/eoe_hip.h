@@ -370,6 +370,10 @@ typedef struct {
     int n, H, W, C;
     float eps, momentum;
     int training;         /* 1: batch statistics (+ running update), 0: running statistics */
+    const float* res;     /* optional (forward): residual [n, H, W, C]; then out = relu(x * scale + res), the block's junction
+                           * (resnet.py:143-147) fused into the gate's last pass */
+    void* out16;          /* optional with res: 16-bit copy of out (operand of the next convolution) */
+    int dtype;            /* EOE_F16 | EOE_BF16 of out16 */
 } eoe_sgate_args;
 typedef struct {
     eoe_sgate_args f;
