@@ -57,6 +57,23 @@ __device__ __forceinline__ typename T16<T>::v8 tr_frag(const char* base, int off
     return __builtin_bit_cast(typename T16<T>::v8, r);
 }
 
+// Fragment read without the compiler's LDS-DMA bookkeeping.  With the ds_read_tr intrinsic the waitcnt pass cannot tell the
+// transposed LDS reads from the ring slots the in-flight LDS-DMA is filling and puts `s_waitcnt vmcnt(0)` in front of them:
+// the k-tile that was just requested (two tiles ahead) must land before this iteration may read the current one -- the
+// whole HBM/L2 latency is exposed every k-tile (the NT kernel's plain ds_read_b128 do not get that wait).  As inline asm
+// the reads are opaque; the kernel's own counted vmcnt + barrier protocol already orders them against the DMA, and their
+// completion is awaited with explicit lgkmcnt(0) before the MFMAs that consume them.
+template <typename T, int HI_OFF>
+__device__ __forceinline__ typename T16<T>::v8 tr_frag_asm(unsigned lds_addr) {
+    i16x4v lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(lds_addr) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(lds_addr), "n"(HI_OFF) : "memory");
+    i16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return __builtin_bit_cast(typename T16<T>::v8, r);
+}
+
 // (An L2-prefetcher ninth wavefront touching the operand lines of k-tile kt+6 was measured and rejected: 356 vs 304 us
 //  stand-alone, 4.58 vs 3.9 ms in the step.)
 // GATHER: the A operand is a convolution's patch matrix [T = n*Ho*Wo pixels, M = kh*kw*C] that is never materialised:
@@ -64,7 +81,7 @@ __device__ __forceinline__ typename T16<T>::v8 tr_frag(const char* base, int off
 // with two multiply-shift divisions; pieces in the zero padding get the out-of-range offset (zero fill).
 __device__ __forceinline__ int div_magic(int x, unsigned long long m) { return (int)(((unsigned long long)(unsigned)x * m) >> 40); }
 
-template <typename T, int GATHER>
+template <typename T, int GATHER, int RD = 1>
 __global__ __launch_bounds__(512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -176,11 +193,27 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
     // fragments double-buffered in registers (same schedule and hazard argument as gemm_nt_kernel in gemm.hip)
     typedef typename T16<T>::v8 V8;
 #define EOE_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+    // RD = 1: asm reads (see tr_frag_asm); the ring starts at LDS address 0 (the kernel's only LDS object)
 #define EOE_READ(XA, WB, base, ks)                                                         \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                        \
-        XA[i] = tr_frag<T>((base), (ks) * 32 * (BM * 2) + offA[i], BM * 2);                \
-        WB[i] = tr_frag<T>((base) + A_BYTES, (ks) * 32 * (BN * 2) + offB[i], BN * 2);      \
+        if (RD) {                                                                          \
+            const unsigned b_ = (unsigned)((base) - smem);                                 \
+            XA[i] = tr_frag_asm<T, 4 * BM * 2>(b_ + (ks) * 32 * (BM * 2) + offA[i]);       \
+            WB[i] = tr_frag_asm<T, 4 * BN * 2>(b_ + A_BYTES + (ks) * 32 * (BN * 2) + offB[i]); \
+        } else {                                                                           \
+            XA[i] = tr_frag<T>((base), (ks) * 32 * (BM * 2) + offA[i], BM * 2);            \
+            WB[i] = tr_frag<T>((base) + A_BYTES, (ks) * 32 * (BN * 2) + offB[i], BN * 2);  \
+        }                                                                                  \
     }
+    // the asm reads complete asynchronously and the compiler does not know: wait for them IN an asm statement that also
+    // "rewrites" the fragment registers, so that no MFMA consuming them can be scheduled above the wait
+#define EOE_LANDED(XA, WB)                                                                                       \
+    do {                                                                                                         \
+        if (RD) asm volatile("s_waitcnt lgkmcnt(0)"                                                              \
+                             : "+v"(XA[0]), "+v"(XA[1]), "+v"(XA[2]), "+v"(XA[3]), "+v"(WB[0]), "+v"(WB[1]), "+v"(WB[2]), \
+                               "+v"(WB[3])                                                                       \
+                             :: "memory");                                                                       \
+    } while (0)
     // D = (B-tile fragment as the A operand) x (A-tile fragment as the B operand): the lane holds 4 consecutive n
     // (output columns) of one output row m
 #define EOE_MFMA(XA, WB)                                                                   \
@@ -205,10 +238,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
             const int nx2 = (nxt == NSTAGE - 1) ? 0 : nxt + 1;
             const char* sc = smem + cur * STAGE_BYTES;
             if (kt + 2 < nk) stage(nx2, t_begin + (kt + 2) * BK);
+            EOE_LANDED(xa0, wb0);               // F0 (read during the previous MFMA half) has landed
             EOE_READ(xa1, wb1, sc, 1);
             EOE_MFMA(xa0, wb0);
             if (kt + 2 < nk) { EOE_WAIT_VM(6); } else { EOE_WAIT_VM(0); }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (RD) { EOE_LANDED(xa1, wb1); } else { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
             __builtin_amdgcn_s_barrier();
             const char* sn = smem + nxt * STAGE_BYTES;
             EOE_READ(xa0, wb0, sn, 0);          // unconditional: the last one reads a stale slot and is discarded
@@ -218,6 +252,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
     }
 #undef EOE_READ
 #undef EOE_MFMA
+#undef EOE_LANDED
 
     if (g.splits > 1 && g.part) {
         // per-split partial result [M][N] (dense), summed by tn_reduce_kernel
@@ -376,12 +411,17 @@ extern "C" int eoe_gemm_tn_grouped(const eoe_gemm_args* args, int count, void* s
         }
     }
     const int gather = args[0].gather;
-#define EOE_TN_LAUNCH(TT, GG)                                                                                              \
+#define EOE_TN_LAUNCH_RD(TT, GG, RR)                                                                                       \
     do {                                                                                                                   \
-        static bool once = (hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel<TT, GG>,                               \
+        static bool once = (hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel<TT, GG, RR>,                           \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES), true);            \
         (void)once;                                                                                                        \
-        hipLaunchKernelGGL((gemm_tn_grouped_kernel<TT, GG>), dim3(tiles * splits), dim3(512), SMEM_BYTES, s, g);           \
+        hipLaunchKernelGGL((gemm_tn_grouped_kernel<TT, GG, RR>), dim3(tiles * splits), dim3(512), SMEM_BYTES, s, g);       \
+    } while (0)
+    // option "tn_flags" bit 0 = 1 selects the intrinsic fragment reads (A/B of tr_frag_asm, plain kernel only)
+#define EOE_TN_LAUNCH(TT, GG)                                                                                              \
+    do {                                                                                                                   \
+        if (GG == 0 && (g_tn_flags & 1)) EOE_TN_LAUNCH_RD(TT, GG, 0); else EOE_TN_LAUNCH_RD(TT, GG, 1);                    \
     } while (0)
     if (dtype == EOE_F16) {
         if (gather == 2) EOE_TN_LAUNCH(f16_t, 2); else if (gather) EOE_TN_LAUNCH(f16_t, 1); else EOE_TN_LAUNCH(f16_t, 0);
@@ -389,6 +429,7 @@ extern "C" int eoe_gemm_tn_grouped(const eoe_gemm_args* args, int count, void* s
         if (gather == 2) EOE_TN_LAUNCH(bf16_t, 2); else if (gather) EOE_TN_LAUNCH(bf16_t, 1); else EOE_TN_LAUNCH(bf16_t, 0);
     }
 #undef EOE_TN_LAUNCH
+#undef EOE_TN_LAUNCH_RD
     EOE_CHECK_LAUNCH("gemm_tn_grouped");
     if (g.part) {
         for (int i = 0; i < count; ++i) {
