@@ -297,7 +297,7 @@ __device__ __forceinline__ void load_epilogue_args(GemmP& ep, const GemmP& p) {
 // NI = 3 (256x96) is chosen when it quantises better over the CUs (e.g. N = 768, M = 12800: 400 tiles instead of 300
 // -> 2 rounds of 3/4-size tiles).  The LDS image keeps the 128-row B slot; rows >= 32*NI are never fetched.
 // FLAGS (tuning switches, A/B-able in one binary when built with -DEOE_AB): bit 0 = LDS-transposed fast epilogue,
-// bit 1 = sched_group_barrier interleave of fragment reads with MFMAs (2:1)
+// bit 1 = fragment reads as inline asm with explicit waits
 // GATHER: the A operand is a convolution's patch matrix that is never materialised -- every 16-B LDS-DMA piece (8
 // channels of one tap of one output pixel) is fetched from the NHWC activation with its own address; taps that fall into
 // the zero padding get the out-of-range offset and arrive as zeros.  gC % 64 == 0, so a 64-deep k-tile is one tap.
@@ -433,22 +433,40 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // FLAGS bit 1: fragment reads as inline asm (opaque to the compiler's waitcnt bookkeeping; completion awaited by
+    // EOE_LANDED, an lgkmcnt(0) that also "rewrites" the fragment registers so no MFMA can be scheduled above it) -- the
+    // A/B of what fixed the wgrad kernel (gemm_tn.hip, tr_frag_asm)
 #define EOE_READ(XA, WB, base, ks)                                                        \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                         \
-        XA[i] = *(const V8*)((base) + fragA + i * 2048 + ((ks) ? chA1 : chA0));           \
-    _Pragma("unroll") for (int i = 0; i < NI; ++i)                                        \
-        WB[i] = *(const V8*)((base) + fragB + i * 2048 + ((ks) ? chB1 : chB0));
+    if (FLAGS & 2) {                                                                      \
+        const unsigned a_ = (unsigned)((base) - smem) + fragA + ((ks) ? chA1 : chA0);     \
+        const unsigned b_ = (unsigned)((base) - smem) + fragB + ((ks) ? chB1 : chB0);     \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(XA[0]) : "v"(a_) : "memory");           \
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(XA[1]) : "v"(a_) : "memory"); \
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(XA[2]) : "v"(a_) : "memory"); \
+        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(XA[3]) : "v"(a_) : "memory"); \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(WB[0]) : "v"(b_) : "memory");           \
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(WB[1]) : "v"(b_) : "memory"); \
+        if (NI > 2) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(WB[2]) : "v"(b_) : "memory"); \
+        if (NI > 3) asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(WB[3 < NI ? 3 : 0]) : "v"(b_) : "memory"); \
+    } else {                                                                              \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                     \
+            XA[i] = *(const V8*)((base) + fragA + i * 2048 + ((ks) ? chA1 : chA0));       \
+        _Pragma("unroll") for (int i = 0; i < NI; ++i)                                    \
+            WB[i] = *(const V8*)((base) + fragB + i * 2048 + ((ks) ? chB1 : chB0));       \
+    }
+#define EOE_LANDED(XA, WB)                                                                \
+    do {                                                                                  \
+        if (NI == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(XA[0]), "+v"(XA[1]), "+v"(XA[2]), "+v"(XA[3]), "+v"(WB[0]), \
+                                  "+v"(WB[1]), "+v"(WB[2 < NI ? 2 : 0]), "+v"(WB[3 < NI ? 3 : 0]) :: "memory");           \
+        else if (NI == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(XA[0]), "+v"(XA[1]), "+v"(XA[2]), "+v"(XA[3]),        \
+                                       "+v"(WB[0]), "+v"(WB[1]), "+v"(WB[2 < NI ? 2 : 0]) :: "memory");                    \
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(XA[0]), "+v"(XA[1]), "+v"(XA[2]), "+v"(XA[3]), "+v"(WB[0]),        \
+                          "+v"(WB[1]) :: "memory");                                                                         \
+    } while (0)
 #define EOE_MFMA(XA, WB)                                                  \
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                      \
         _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T16<T>::mfma16(WB[ni], XA[mi], acc[mi][ni]);
 
-    // FLAGS bit 1: spread the 8 fragment reads of the NEXT half iteration between the 16 MFMAs of this one (2 MFMA : 1
-    // ds_read), instead of a read burst of all 8 waves at once (64 KiB = 256 LDS cycles during which no MFMA issues)
-#define EOE_INTERLEAVE()                                                   \
-    _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                     \
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                 \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                 \
-    }
     if (iters <= 0) return;
     unsigned long long* stp = p.stamp ? p.stamp + (size_t)blockIdx.x * 16 : nullptr;
     int sti = 0;
@@ -473,13 +491,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
         const int nxt = (cur == NSTAGE - 1) ? 0 : cur + 1;
         const char* sc = smem + cur * STAGE_BYTES;
         if (it + 2 < iters) stage_next();
+        if (FLAGS & 2) { EOE_LANDED(xa0, wb0); }
         EOE_READ(xa1, wb1, sc, 1);
         EOE_MFMA(xa0, wb0);
-        if (FLAGS & 2) { EOE_INTERLEAVE(); }
         unsigned long long tq0 = 0, tq1 = 0;
         if (stp) tq0 = __builtin_amdgcn_s_memtime();
         if (it + 2 < iters) { EOE_WAIT_VM(6); } else { EOE_WAIT_VM(0); }
-        EOE_WAIT_LGKM0();
+        if (FLAGS & 2) { EOE_LANDED(xa1, wb1); } else { EOE_WAIT_LGKM0(); }
         if (stp) tq1 = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_barrier();
         if (stp) { const unsigned long long tq2 = __builtin_amdgcn_s_memtime(); acc_vm += tq1 - tq0; acc_bar += tq2 - tq1; }
@@ -489,12 +507,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
             EOE_READ(xa0, wb0, sn, 0);
         }
         EOE_MFMA(xa1, wb1);
-        if (FLAGS & 2) { EOE_INTERLEAVE(); }
         cur = nxt;
         if (++c_kt == nk) {                        // tile finished: epilogue while the next tile's DMA is in flight
             int m0, n0;
             tile_origin(c_tile, m0, n0);
             EOE_STAMP();                           // [2+2i] main loop of tile i done
+            if (FLAGS & 2) { EOE_LANDED(xa0, wb0); }   // asm reads in flight are invisible to the compiler: none may be
+                                                       // outstanding when the epilogue starts reusing registers
             GemmP ep;
             load_epilogue_args(ep, p);
             if (FLAGS & 1) epilogue<T, EPI, NI>(ep, acc, m0 + wm0, n0 + wn0, lane, (char*)sc + wave * 4096);
@@ -511,6 +530,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
     }
 #undef EOE_READ
 #undef EOE_MFMA
+#undef EOE_LANDED
     if (stp && lane == 0 && wave < 2) { stp[12 + wave * 2 - 0] = acc_vm; stp[13 + wave * 2 - 0] = acc_bar; }
 }
 

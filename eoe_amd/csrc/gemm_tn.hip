@@ -249,6 +249,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
             EOE_MFMA(xa1, wb1);
             cur = nxt;
         }
+        // the last (stale, discarded) asm read is still in flight and the compiler does not know: without this wait it may
+        // hand those registers to the epilogue while the LDS unit is about to write them
+        EOE_LANDED(xa0, wb0);
     }
 #undef EOE_READ
 #undef EOE_MFMA
