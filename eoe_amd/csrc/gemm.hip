@@ -534,6 +534,119 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
     if (stp && lane == 0 && wave < 2) { stp[12 + wave * 2 - 0] = acc_vm; stp[13 + wave * 2 - 0] = acc_bar; }
 }
 
+// ------------------------------------------------------------------------------------------------ NT, 128x128 tiles
+// Second tile shape: 128x128x64 tiles, FOUR wavefronts (2x2, 64x64 each), a 2-stage 64
+// KiB ring -> TWO workgroups per CU.  The 256x128 kernel leaves the MFMA pipe idle while its one workgroup per CU is in a
+// prologue, at the per-k-tile barrier (~25 % of a wave's time) or in the epilogue (6-18 k cycles per tile, HBM-saturating
+// for the fp32 residual outputs while every workgroup is in that phase together); with two independent workgroups per CU
+// each SIMD holds one wave of each, so one workgroup's stalls are the other's issue slots.  Non-persistent: one tile per
+// workgroup, tiles XCD-remapped.  Same LDS image / swizzle / fragment layout / epilogues as gemm_nt_kernel.
+constexpr int A128_BYTES = 128 * BK * 2;            // 16 KiB
+constexpr int STAGE128_BYTES = 2 * A128_BYTES;      // A + B: 32 KiB
+constexpr int SMEM128_BYTES = 2 * STAGE128_BYTES;   // 64 KiB: two workgroups per CU
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NI = 4;
+    const int tiles_n = (p.N + 127) / 128;
+    const int total_tiles = tiles_n * ((p.M + 127) / 128);
+    const int r = xcd_remap((int)blockIdx.x, total_tiles);
+    const int m0 = (r / tiles_n) * 128, n0 = (r % tiles_n) * 128;
+    const int nk = p.K / BK;
+
+    __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.bytesA);
+    __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.bytesB);
+    // 128 rows = 16 wave-loads per operand, 4 per wave; lane -> (row, 16-B slot holding chunk slot ^ ((row>>1)&7))
+    unsigned offA[4], offB[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wave * 4 + j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        offA[j] = (m0 + row < p.M) ? (unsigned)(((size_t)(m0 + row) * p.lda + c * 8) * 2) : EOE_OOB;
+        offB[j] = (n0 + row < p.N) ? (unsigned)(((size_t)(n0 + row) * p.ldb + c * 8) * 2) : EOE_OOB;
+    }
+    auto stage = [&](int slot, int kt) {                 // 8 LDS-DMA instructions per wave per k-tile
+        char* sa = smem + slot * STAGE128_BYTES;
+        char* sb = sa + A128_BYTES;
+        const unsigned k0 = (unsigned)kt * (BK * 2u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(sa + (wave * 4 + j) * 1024), 16, offA[j] + k0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(sb + (wave * 4 + j) * 1024), 16, offB[j] + k0, 0, 0, 0);
+    };
+
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int sw = (lr >> 1) & 7;                        // wm0, wn0 are multiples of 16: (row>>1)&7 depends on lr only
+    const int fragA = (wm0 + lr) * 128, fragB = A128_BYTES + (wn0 + lr) * 128;
+    const int ch0 = ((0 + lg) ^ sw) * 16, ch1 = ((4 + lg) ^ sw) * 16;
+    typedef typename T16<T>::v8 V8;
+
+    f32x4 acc[4][NI];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#define EOE_READ128(XA, WB, base, ks)                                                     \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
+        XA[i] = *(const V8*)((base) + fragA + i * 2048 + ((ks) ? ch1 : ch0));             \
+        WB[i] = *(const V8*)((base) + fragB + i * 2048 + ((ks) ? ch1 : ch0));             \
+    }
+#define EOE_MFMA128(XA, WB)                                               \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                      \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T16<T>::mfma16(WB[ni], XA[mi], acc[mi][ni]);
+
+    // 2-stage ring: iteration kt multiplies slot kt&1 while the LDS-DMA fills the other slot with k-tile kt+1.
+    //   WAR: the DMA into slot (kt+1)&1 is issued after the barrier that ended iteration kt-1, whose reads of that slot are done.
+    //   RAW: every wave waits for its own DMA pieces (vmcnt(0)) before the barrier that ends iteration kt.
+    V8 xa0[4], wb0[4], xa1[4], wb1[4];
+    stage(0, 0);
+    EOE_WAIT_VM(0);
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* sc = smem + (kt & 1) * STAGE128_BYTES;
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        EOE_READ128(xa0, wb0, sc, 0);
+        EOE_READ128(xa1, wb1, sc, 1);
+        EOE_MFMA128(xa0, wb0);
+        EOE_MFMA128(xa1, wb1);
+        EOE_WAIT_VM(0);
+        EOE_WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
+    }
+#undef EOE_READ128
+#undef EOE_MFMA128
+    GemmP ep;
+    load_epilogue_args(ep, p);
+    // scratch: this wave's own 4 KiB of slot 0 (all reads of the ring are behind the final barrier)
+    epilogue<T, EPI, NI>(ep, acc, m0 + wm0, n0 + wn0, lane, smem + wave * 4096);
+}
+
+template <typename T>
+int launch_nt128(const GemmP& p, int epi, hipStream_t s) {
+    const int tiles = cdiv(p.M, 128) * cdiv(p.N, 128);
+#define EOE_NT128_CASE(E)                                                                   \
+    case E:                                                                                 \
+        { static bool once = (hipFuncSetAttribute((const void*)gemm_nt128_kernel<T, E>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM128_BYTES), true); (void)once; } \
+        hipLaunchKernelGGL((gemm_nt128_kernel<T, E>), dim3(tiles), dim3(256), SMEM128_BYTES, s, p); \
+        break;
+    switch (epi) {
+        EOE_NT128_CASE(EOE_EPI_NONE)
+        EOE_NT128_CASE(EOE_EPI_GELU)
+        EOE_NT128_CASE(EOE_EPI_RESIDUAL)
+        EOE_NT128_CASE(EOE_EPI_GELU_BWD)
+        default: return eoe_set_error(EOE_ERR_ARG, "gemm_nt: unknown epilogue %d", epi);
+    }
+#undef EOE_NT128_CASE
+    EOE_CHECK_LAUNCH("gemm_nt128");
+    return 0;
+}
+
 // Variants measured and rejected (interleaved A/B on one device with tools/gemm_ab.py, layer total of the 8 forward +
 // dgrad GEMMs of a ViT-B/32 block at M = 12800; the kept kernel = 546 us stand-alone, 8.1 ms/step in the full step):
 //   * sched_barrier pinning "8 fragment reads, then 16 MFMAs" per half iteration ........ 613 us (-11 %)
@@ -601,6 +714,11 @@ int launch_nt(const GemmP& p, int epi, int gather, hipStream_t s) {
         if (gather) return narrow ? launch_nt_conv<T, 2, 1>(p, grid, s) : launch_nt_conv<T, 4, 1>(p, grid, s);
         return launch_nt_conv<T, 2, 0>(p, grid, s);
     }
+    // 128x128 tiles with two workgroups per CU win where the epilogue is heavy against a short K loop (measured interleaved,
+    // tools/gemm_ab.py 1 9, M = 12800: GELU' x dY epilogue N=3072 K=768 114 -> 96 us; fp32 residual N=768 K=768 42 -> 38.5 us;
+    // plain / GELU / long-K shapes are 0-4 % faster on the 256-row persistent kernel).  nt_flags bit 3 forces it, bit 2 forbids it.
+    const bool heavy = epi == EOE_EPI_GELU_BWD || (epi == EOE_EPI_RESIDUAL && p.K <= 1024);
+    if ((g_nt_flags & 8) || (heavy && !(g_nt_flags & 4))) return launch_nt128<T>(p, epi, s);
     // tile width: 256x128 unless 256x96 needs >= 10 % fewer (rounds x width) units over the CUs
     const int t4 = cdiv(p.M, BM) * cdiv(p.N, 128), t3 = cdiv(p.M, BM) * cdiv(p.N, 96);
     const int c4 = cdiv(t4, ncu) * 4, c3 = cdiv(t3, ncu) * 3;

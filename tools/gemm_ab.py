@@ -44,7 +44,17 @@ for name, m, n, k, epi in shapes:
             e1.record()
             torch.cuda.synchronize()
             times[v].append(e0.elapsed_time(e1) / 5 * 1e3)
-    line = f"{name:9s} {m:6d}x{n:5d}x{k:5d} {epi:6s}"
+    ref = None
+    worst = 0.0
+    for v in variants:                       # the variants must compute the same thing
+        _lib.check(_lib.lib.eoe_set_option(b"nt_flags", v), "opt")
+        out.zero_(); fn(); torch.cuda.synchronize()
+        cur = out.float().clone()
+        if ref is None:
+            ref = cur
+        else:
+            worst = max(worst, ((cur - ref).abs().max() / ref.abs().max().clamp_min(1e-9)).item())
+    line = f"{name:9s} {m:6d}x{n:5d}x{k:5d} {epi:6s} maxdiff {worst:.1e}"
     for v in variants:
         med = float(np.median(times[v]))
         if name != "4096^3":
