@@ -539,8 +539,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
 // KiB ring -> TWO workgroups per CU.  The 256x128 kernel leaves the MFMA pipe idle while its one workgroup per CU is in a
 // prologue, at the per-k-tile barrier (~25 % of a wave's time) or in the epilogue (6-18 k cycles per tile, HBM-saturating
 // for the fp32 residual outputs while every workgroup is in that phase together); with two independent workgroups per CU
-// each SIMD holds one wave of each, so one workgroup's stalls are the other's issue slots.  Non-persistent: one tile per
-// workgroup, tiles XCD-remapped.  Same LDS image / swizzle / fragment layout / epilogues as gemm_nt_kernel.
+// each SIMD holds one wave of each, so one workgroup's stalls are the other's issue slots.  Non-persistent on purpose: one tile
+// per workgroup, dispatched as slots free up, which de-synchronises the two workgroups of a CU (a persistent tile loop with
+// cross-tile prefetch kept them in lockstep and measured 5-13 % slower on the heavy-epilogue shapes).  Tiles XCD-remapped.  Same LDS image / swizzle / fragment layout / epilogues as gemm_nt_kernel.
 constexpr int A128_BYTES = 128 * BK * 2;            // 16 KiB
 constexpr int STAGE128_BYTES = 2 * A128_BYTES;      // A + B: 32 KiB
 constexpr int SMEM128_BYTES = 2 * STAGE128_BYTES;   // 64 KiB: two workgroups per CU
