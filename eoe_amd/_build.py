@@ -49,12 +49,18 @@ def build(force: bool = False, verbose: bool = True) -> str:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    # link next to the target and rename over it: a process that has the old library mapped keeps a valid image (writing
+    # into the mapped file in place leaves it with a torn code object -- every launch then fails with "no ROCm-capable device")
+    tmp = LIB + f".tmp{os.getpid()}"
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError(f"link failed:\n{r.stdout}")
+    os.replace(tmp, LIB)
     return LIB
 
 

@@ -4,6 +4,12 @@ import ctypes as C
 import os
 import re
 
+# PyTorch ships its own libamdhip64.so; libeoe_hip.so is linked against the system one (same SONAME).  Whichever is loaded
+# first serves both -- and with the system runtime loaded first the process ends up with TWO HIP runtimes, torch on its own
+# and this library on one that reports "no ROCm-capable device".  Import torch first so that its runtime is the one in the
+# process (the tensors, streams and events handed to the C ABI belong to it).
+import torch  # noqa: F401  (must precede the CDLL below)
+
 from . import _build
 
 ABI_VERSION = 1
