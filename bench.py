@@ -184,6 +184,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     final_loss = loss.item()
+    if final_loss != final_loss:                         # diagnose before failing: which tensors went non-finite
+        import sys as _sys
+        bad_p = [n for n, p in model.named_parameters() if not torch.isfinite(p).all()]
+        bad_g = [n for n, p in model.named_parameters() if p.grad is not None and not torch.isfinite(p.grad).all()]
+        bad_b = [n for n, b in model.named_buffers() if b.dtype.is_floating_point and not torch.isfinite(b).all()]
+        first = [i for i in range(score_buf.shape[0]) if not torch.isfinite(score_buf[i]).all()][:3]
+        print(f"NaN loss: non-finite params {bad_p[:6]} grads {bad_g[:6]} buffers {bad_b[:6]}; score rows non-finite from {first}",
+              file=_sys.stderr, flush=True)
     assert final_loss == final_loss, "NaN loss"
     # epoch-tail metric of the reference (ad_trainer.py:456-471: ROC-AUC of the scores collected during training), on the
     # last timed step's scores of this rank (outside the timed region)

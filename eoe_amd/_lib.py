@@ -108,6 +108,7 @@ SIGNATURES = {
     "eoe_zero_multi": [C.POINTER(_vp), C.POINTER(C.c_int), C.c_int, _vp],
     "eoe_cast_colsum": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "eoe_colsum": [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "eoe_colsum_det": [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
     "eoe_cast": [_vp, _vp, _sz, C.c_int, _vp],
     "eoe_attn_fwd": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "eoe_attn_bwd": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],

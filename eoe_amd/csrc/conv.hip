@@ -323,6 +323,34 @@ __device__ __forceinline__ float load_dout(const float* dout, int nchw_flat, int
                      : dout[(((size_t)img * Ho + ho) * Wo + wo) * C + c];
 }
 
+// Workgroup-level, FIXED-ORDER sum of the per-thread channel-quad accumulators of the BatchNorm backward reduce passes
+// (a thread keeps one channel quad for its whole grid-stride loop): thread t holds quad ((blockIdx.x*256 + t) % cc); every
+// output value adds its contributors t0, t0 + cc, t0 + 2cc, ... in that order -- no atomics, so the training step is bitwise
+// reproducible.  stage: 256 x 8 floats of LDS (the kernels' dynamic LDS, >= 2*C floats, is separate); row: this workgroup's
+// partial row [2*C] in global memory.
+__device__ __forceinline__ void block_channel_sums(const float (&acc0)[4], const float (&acc1)[4], float* /*unused dynamic lds*/,
+                                                   float* __restrict__ row, int C, size_t total) {
+    __shared__ float stage[256][8];
+    const int cc = C / 4;
+    const size_t first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = first < total;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        stage[threadIdx.x][r] = live ? acc0[r] : 0.f;
+        stage[threadIdx.x][4 + r] = live ? acc1[r] : 0.f;
+    }
+    __syncthreads();
+    const int base = (int)(((size_t)blockIdx.x * blockDim.x) % cc);          // quad of thread 0
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+        const int which = i / C, ch = i - which * C, quad = ch >> 2, r = ch & 3;
+        int t0 = quad - base;
+        if (t0 < 0) t0 += cc;
+        float s = 0.f;
+        for (int t = t0; t < 256; t += cc) s += stage[t][which * 4 + r];
+        row[i] = s;
+    }
+}
+
 // backward pass 1: per-channel sums of g and g*xhat, where g is the gradient at the BatchNorm OUTPUT (un-pooled through
 // the first maximum of each window, times LeakyReLU').  One thread per (pooled position, 4 channels); LDS + atomics.
 // mode 0 = reduce into red[0..C)=sum g, red[C..2C)=sum g*xhat;  mode 1 = write dy (16-bit [n*H*W, C]) using those sums.
@@ -397,20 +425,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_bwd_kernel(const float* __res
             }
         }
     }
-    if (MODE == 0) {
-        const size_t first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-        if (first < total) {
-            const int c = (int)(first % cc) * 4;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                atomicAdd(&lds[c + r], acc0[r]);
-                atomicAdd(&lds[C + c + r], acc1[r]);
-            }
-        }
-        __syncthreads();
-        float* row = red + (size_t)(1 + blockIdx.x) * 2 * C;          // partial row of this workgroup (row 0 = the total)
-        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) row[i] = lds[i];
-    }
+    if (MODE == 0) block_channel_sums(acc0, acc1, lds, red + (size_t)(1 + blockIdx.x) * 2 * C, C, total);
 }
 
 // ---------------------------------------------------------------------------------------------- BN + act + overlapping MaxPool
@@ -509,20 +524,7 @@ __global__ __launch_bounds__(256) void bn_act_maxpool_bwd_kernel(const float* __
         }
         if (MODE == 1) *(u32x2*)(dy + ip * C + c) = pack4<T>(o4[0], o4[1], o4[2], o4[3]);
     }
-    if (MODE == 0) {
-        const size_t first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-        if (first < total) {
-            const int c = (int)(first % cc) * 4;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                atomicAdd(&lds[c + r], acc0[r]);
-                atomicAdd(&lds[C + c + r], acc1[r]);
-            }
-        }
-        __syncthreads();
-        float* row = red + (size_t)(1 + blockIdx.x) * 2 * C;
-        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) row[i] = lds[i];
-    }
+    if (MODE == 0) block_channel_sums(acc0, acc1, lds, red + (size_t)(1 + blockIdx.x) * 2 * C, C, total);
 }
 
 __global__ __launch_bounds__(256) void add_copy_kernel(float* __restrict__ dst, const float* __restrict__ src, int n, int accumulate) {

@@ -435,6 +435,44 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
     if ((int)threadIdx.x < cpb * 4 && cc < cols) atomicAdd(out + cc, ((const float*)red)[threadIdx.x]);
 }
 
+// deterministic variant: workgroup (bx, by) writes its partial column sums to row by of part[gridDim.y][cols]; a second
+// kernel adds the rows (no atomics, no memset: bitwise reproducible bias gradients, and nothing but kernels in a captured graph)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, int ldx, float* __restrict__ part, int rows, int cols,
+                                                             int cpb) {
+    __shared__ f32x4 red[256];
+    const int rpb = 256 / cpb;
+    const int tc = threadIdx.x % cpb, rl = threadIdx.x / cpb;
+    const int c = (blockIdx.x * cpb + tc) * 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (c < cols) {
+        for (int r = blockIdx.y * rpb + rl; r < rows; r += gridDim.y * rpb) {
+            float t[4];
+            unpack4<T>(*(const u32x2*)(x + (size_t)r * ldx + c), t);
+            a += (f32x4){t[0], t[1], t[2], t[3]};
+        }
+    }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (rl == 0 && c < cols) {
+        for (int k = 1; k < rpb; ++k) a += red[threadIdx.x + k * cpb];
+        *(f32x4*)(part + (size_t)blockIdx.y * cols + c) = a;
+    }
+}
+__global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int P, int n) {
+    __shared__ float l[1024];
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+    float s = 0.f;
+    if (i < n)
+        for (int p = lane; p < P; p += 16) s += part[(size_t)p * n + i];
+    l[threadIdx.x] = s;
+    __syncthreads();
+    if (lane == 0 && i < n) {
+        for (int k = 1; k < 16; ++k) s += l[threadIdx.x + 64 * k];
+        out[i] = s;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ objectives
 // HSC rows: one wavefront per sample
 __global__ __launch_bounds__(256) void hsc_rows_kernel(const float* __restrict__ f, const int64_t* __restrict__ labels, int64_t nominal,
@@ -855,6 +893,25 @@ extern "C" int eoe_colsum(const void* x, int ldx, float* out, int rows, int cols
     DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), dim3(gx, gy), dim3(256), 0,
                                          (hipStream_t)stream, (const T*)x, ldx, out, rows, cols, cpb));
     EOE_CHECK_LAUNCH("colsum");
+    return 0;
+}
+
+extern "C" int eoe_colsum_det(const void* x, int ldx, float* out, float* scratch, int rows, int cols, int dtype, void* stream) {
+    EOE_CHECK_ARG(x && out && scratch && rows > 0 && cols > 0, "colsum_det: bad args");
+    EOE_CHECK_ARG(cols % 4 == 0 && ldx % 4 == 0, "colsum_det: cols and ldx must be multiples of 4");
+    ProfScope ps("colsum", 0, 2.0 * rows * cols, stream);
+    int cpb = 1;
+    while (cpb < 64 && cpb < cols / 4) cpb *= 2;
+    const int rpb = 256 / cpb, gx = cdiv(cols / 4, cpb);
+    int gy = cdiv(rows, rpb * 16);
+    if (gy > EOE_COLSUM_PARTIALS) gy = EOE_COLSUM_PARTIALS;
+    if (gx * gy > 1024) gy = 1024 / gx;
+    if (gy < 1) gy = 1;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_partial_kernel<T>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx,
+                                         scratch, rows, cols, cpb));
+    EOE_CHECK_LAUNCH("colsum_partial");
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(cols, 64)), dim3(1024), 0, (hipStream_t)stream, (const float*)scratch, out, gy, cols);
+    EOE_CHECK_LAUNCH("colsum_reduce");
     return 0;
 }
 

@@ -125,8 +125,12 @@ def cast_colsum(x: torch.Tensor, out16: torch.Tensor, colsum_out: torch.Tensor, 
 def colsum(x16: torch.Tensor, out: torch.Tensor, accumulate=False):
     _chk(x16, out)
     rows, cols = x16.shape
-    check(lib.eoe_colsum(_p(x16), x16.stride(0), _p(out), rows, cols, dtype_code(x16.dtype), 1 if accumulate else 0,
-                         _stream()), "eoe_colsum")
+    if not accumulate:      # partial rows + reduce: no atomics, no memset (reproducible; nothing but kernels under graph capture)
+        part = scratch("colsum_part", (256 * cols,), torch.float32, x16.device)
+        check(lib.eoe_colsum_det(_p(x16), x16.stride(0), _p(out), _p(part), rows, cols, dtype_code(x16.dtype), _stream()),
+              "eoe_colsum_det")
+        return out
+    check(lib.eoe_colsum(_p(x16), x16.stride(0), _p(out), rows, cols, dtype_code(x16.dtype), 1, _stream()), "eoe_colsum")
     return out
 
 

@@ -137,6 +137,10 @@ int eoe_layernorm_bwd(const void* dy, int dy_f32, const float* x, int ldx, const
 
 /* out[c] (+)= sum_r x[r, c]  -- bias gradients (x 16-bit [rows, cols], row stride ldx). */
 int eoe_colsum(const void* x, int ldx, float* out, int rows, int cols, int dtype, int accumulate, void* stream);
+/* the same sums without atomics or memset (out is overwritten): per-workgroup partial rows in `scratch`
+ * (EOE_COLSUM_PARTIALS * cols floats) + a reduce kernel -- bitwise reproducible, kernels only (graph capture) */
+#define EOE_COLSUM_PARTIALS 256
+int eoe_colsum_det(const void* x, int ldx, float* out, float* scratch, int rows, int cols, int dtype, void* stream);
 
 /* dst = 16-bit copy of x fp32 [rows, cols] and out[c] (+)= sum_r x[r, c] in one pass */
 int eoe_cast_colsum(const float* x, void* dst, float* out, int rows, int cols, int dtype, int accumulate, void* stream);
