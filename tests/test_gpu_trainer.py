@@ -139,6 +139,9 @@ def test_trainer_graph_steps_equals_eager(objective):
         out[graph] = (list(tr.last_losses), roc.auc)
     (le, ae), (lg, ag) = out[False], out[True]
     assert len(le) == len(lg) == 2 * 3                      # 2 full batches + 1 ragged batch per epoch
-    np.testing.assert_allclose(lg[:2], le[:2], rtol=5e-4)      # the replayed step computes what the eager step computes ...
-    np.testing.assert_allclose(lg, le, rtol=1e-2)              # ... later steps: atomics-order noise through Adam (eager vs eager too)
+    # the CNN32 step is free of atomics (bitwise reproducible): replayed and eager steps agree exactly for HSC; the BCE head's
+    # 1-wide linear uses fp32 atomics in its weight gradient, so that trajectory is only close
+    if objective == "hsc":
+        assert lg == le, (lg, le)
+    np.testing.assert_allclose(lg, le, rtol=1e-2)
     assert abs(ae - ag) < 2e-2

@@ -41,4 +41,7 @@ for rep in range(reps):
         mism += 1
         print(f"rep {rep}: {len(d)} of 60 losses differ from rep 0, first at step {int(d[0])}: {l[d[0]].item()} vs {ref[d[0]].item()}", flush=True)
     del model, opt, arena
-print(f"{'graph' if graph else 'eager'}: {mism}/{reps - 1} repetitions differ bitwise from the first; final loss {ref[-1].item():.6f}")
+import hashlib
+print(f"{'graph' if graph else 'eager'}: {mism}/{reps - 1} repetitions differ bitwise from the first; final loss {ref[-1].item():.6f}; "
+      f"trajectory sha1 {hashlib.sha1(ref.numpy().tobytes()).hexdigest()[:12]}")
+sys.exit(1 if mism else 0)
