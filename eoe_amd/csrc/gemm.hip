@@ -1,6 +1,9 @@
-// MFMA GEMM (NT) for gfx950: 256x128x64 tiles, 8 wavefronts (4x2, 64x64 each; two per SIMD), one workgroup per CU,
-// v_mfma_f32_16x16x32_{f16,bf16}, operands staged global -> LDS with bounds-checked LDS-DMA (buffer_load ... lds,
-// 16 B per lane; an out-of-range lane reads 0, which is the zero padding of ragged M / N tails), 3-stage LDS ring.
+// MFMA GEMM (NT) for gfx950.  Main shape: 256x128x64 tiles (256x96 / 256x64 where they quantise or fit better), 8 wavefronts
+// (4x2, 64x64 each; two per SIMD), one persistent workgroup per CU, 3-stage LDS ring.  Second shape (gemm_nt128_kernel): 128x128x64,
+// 4 wavefronts, 2-stage ring, two workgroups per CU -- for the GEMMs whose epilogue is heavy against a short K loop.
+// Both: v_mfma_f32_16x16x32_{f16,bf16}, operands staged global -> LDS with bounds-checked LDS-DMA (buffer_load ... lds,
+// 16 B per lane; an out-of-range lane reads 0, which is the zero padding of ragged M / N tails), and -- GATHER modes -- the A
+// operand of a convolution fetched piece by piece from the NHWC activation (implicit GEMM, no im2col).
 //
 //   NT:  C[M,N] = A[M,K] . B[N,K]^T   both operands K-contiguous; LDS image [128 rows][64 k] with the 16-B chunk
 //        index XOR-swizzled by (row>>1)&7 (applied on the SOURCE address, LDS-DMA writes linearly), fragments
@@ -21,7 +24,7 @@ namespace {
 
 constexpr int BM = 256, BN = 128, BK = 64, NSTAGE = 3;
 #ifndef EOE_NT_DEFAULT_FLAGS
-#define EOE_NT_DEFAULT_FLAGS 1     // measured (tools/gemm_ab.py, one device, interleaved): f0 669 us, f1 551 us, f2 795 us, f3 613 us per layer
+#define EOE_NT_DEFAULT_FLAGS 1     // bit 0 (fast epilogue): 551 vs 669 us per ViT layer; bit 1 (asm fragment reads): no gain here (574 vs 573 us)
 #endif
 constexpr int A_BYTES = BM * BK * 2;              // 32 KiB
 constexpr int B_BYTES = BN * BK * 2;              // 16 KiB
