@@ -1,6 +1,6 @@
 // MFMA GEMM (NT) for gfx950.  Main shape: 256x128x64 tiles (256x96 / 256x64 where they quantise or fit better), 8 wavefronts
 // (4x2, 64x64 each; two per SIMD), one persistent workgroup per CU, 3-stage LDS ring.  Second shape (gemm_nt128_kernel): 128x128x64,
-// 4 wavefronts, 2-stage ring, two workgroups per CU -- for the GEMMs whose epilogue is heavy against a short K loop.
+// 4 wavefronts, 2-stage ring, two workgroups per CU -- the default for everything but the GELU forward and large square problems.
 // Both: v_mfma_f32_16x16x32_{f16,bf16}, operands staged global -> LDS with bounds-checked LDS-DMA (buffer_load ... lds,
 // 16 B per lane; an out-of-range lane reads 0, which is the zero padding of ragged M / N tails), and -- GATHER modes -- the A
 // operand of a convolution fetched piece by piece from the NHWC activation (implicit GEMM, no im2col).
@@ -605,24 +605,32 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmP p) {
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                      \
         _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T16<T>::mfma16(WB[ni], XA[mi], acc[mi][ni]);
 
-    // 2-stage ring: iteration kt multiplies slot kt&1 while the LDS-DMA fills the other slot with k-tile kt+1.
-    //   WAR: the DMA into slot (kt+1)&1 is issued after the barrier that ended iteration kt-1, whose reads of that slot are done.
-    //   RAW: every wave waits for its own DMA pieces (vmcnt(0)) before the barrier that ends iteration kt.
+    // 2-stage ring with register double-buffered fragments (the schedule of gemm_nt_kernel with one stage less):
+    //   iteration kt:  F1 = frags(kt, ks1) | MFMA(F0) | vmcnt(0): tile kt+1 landed, lgkmcnt(0), barrier |
+    //                  stage(kt+2) into the slot just consumed | F0 = frags(kt+1, ks0) | MFMA(F1)
+    //   WAR: stage(kt+2) overwrites slot kt&1 after the barrier behind which every wave's reads of it (F0 in iteration kt-1,
+    //        F1 in this one) have completed.   RAW: the DMA of tile kt+1 was issued one iteration ago; each wave waits for its
+    //        own pieces before the barrier, the reads come after it.
     V8 xa0[4], wb0[4], xa1[4], wb1[4];
     stage(0, 0);
-    EOE_WAIT_VM(0);
+    if (nk > 1) stage(1, 1);
+    if (nk > 1) { EOE_WAIT_VM(8); } else { EOE_WAIT_VM(0); }
     __builtin_amdgcn_s_barrier();
+    EOE_READ128(xa0, wb0, smem, 0);
     for (int kt = 0; kt < nk; ++kt) {
         const char* sc = smem + (kt & 1) * STAGE128_BYTES;
-        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-        EOE_READ128(xa0, wb0, sc, 0);
+        const char* sn = smem + ((kt + 1) & 1) * STAGE128_BYTES;
         EOE_READ128(xa1, wb1, sc, 1);
         EOE_MFMA128(xa0, wb0);
-        EOE_MFMA128(xa1, wb1);
         EOE_WAIT_VM(0);
         EOE_WAIT_LGKM0();
         __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) stage(kt & 1, kt + 2);
+        EOE_READ128(xa0, wb0, sn, 0);          // unconditional (the last one reads a stale slot and is discarded)
+        EOE_MFMA128(xa1, wb1);
     }
+    EOE_WAIT_LGKM0();
+    __builtin_amdgcn_s_barrier();               // every wave is done reading the ring before the epilogue's scratch use
 #undef EOE_READ128
 #undef EOE_MFMA128
     GemmP ep;
@@ -718,11 +726,12 @@ int launch_nt(const GemmP& p, int epi, int gather, hipStream_t s) {
         if (gather) return narrow ? launch_nt_conv<T, 2, 1>(p, grid, s) : launch_nt_conv<T, 4, 1>(p, grid, s);
         return launch_nt_conv<T, 2, 0>(p, grid, s);
     }
-    // 128x128 tiles with two workgroups per CU win where the epilogue is heavy against a short K loop (measured interleaved,
-    // tools/gemm_ab.py 1 9, M = 12800: GELU' x dY epilogue N=3072 K=768 114 -> 96 us; fp32 residual N=768 K=768 42 -> 38.5 us;
-    // plain / GELU / long-K shapes are 0-4 % faster on the 256-row persistent kernel).  nt_flags bit 3 forces it, bit 2 forbids it.
-    const bool heavy = epi == EOE_EPI_GELU_BWD || (epi == EOE_EPI_RESIDUAL && p.K <= 1024);
-    if ((g_nt_flags & 8) || (heavy && !(g_nt_flags & 4))) return launch_nt128<T>(p, epi, s);
+    // Tile shape (measured interleaved, tools/gemm_ab.py 5 9, M = 12800): the two-workgroup 128x128 kernel wins on every ViT
+    // shape but the GELU forward (99.9 vs 102.2 us) -- most where the epilogue is heavy against a short K loop (GELU' x dY
+    // 116 -> 97 us, fp32 residual 42 -> 37 us), a few % on the plain ones -- 553 vs 588 us per layer; the persistent 256-row
+    // kernel keeps large square problems (4096^3: 1046 vs 984 TF).  nt_flags bit 3 forces the 128 kernel, bit 2 forbids it.
+    const bool big = p.K >= 4096 && p.N >= 2048;
+    if ((g_nt_flags & 8) || (epi != EOE_EPI_GELU && !big && !(g_nt_flags & 4))) return launch_nt128<T>(p, epi, s);
     // tile width: 256x128 unless 256x96 needs >= 10 % fewer (rounds x width) units over the CUs
     const int t4 = cdiv(p.M, BM) * cdiv(p.N, 128), t3 = cdiv(p.M, BM) * cdiv(p.N, 96);
     const int c4 = cdiv(t4, ncu) * 4, c3 = cdiv(t3, ncu) * 3;
