@@ -73,3 +73,36 @@ for name, work in (("HBM-bound chain (LN bwd x2, attn bwd, colsum)", membound), 
     t_w = timed(work); t_t = timed(lambda: tn(main)); t_seq = timed(lambda: (tn(main), work())); t_par = timed(both(work))
     print(f"{name}: alone {t_w:.0f} us, wgrad alone {t_t:.0f} us, sequential {t_seq:.0f} us, two streams {t_par:.0f} us "
           f"(hidden {t_seq - t_par:.0f} us = {100 * (t_seq - t_par) / min(t_w, t_t):.0f} % of the shorter)")
+
+# ---- second question: the optimiser (pure HBM streaming, no LDS, few registers) under the MFMA GEMMs
+import eoe_amd
+w = [torch.randn(3072, 768, device=dev, requires_grad=True) for _ in range(28)]       # ~66 M parameters
+for p in w:
+    p.grad = torch.randn_like(p)
+opt = eoe_amd.FusedAdam(w, lr=1e-4)
+opt.step()
+a2 = torch.randn(M, 3072, device=dev).to(dt); w2 = torch.randn(768, 3072, device=dev).to(dt); c2 = torch.empty(M, 768, device=dev, dtype=dt)
+
+
+def gemms():
+    for _ in range(3):
+        ops.gemm_nt(a16, w16, c16)          # 128x128 two-workgroup kernel (plain epilogue)
+        ops.gemm_nt(a2, w2, c2)
+    tn(main)
+
+
+def adam_side():
+    with torch.cuda.stream(side):
+        opt.step()
+
+
+def both2():
+    side.wait_stream(main)
+    adam_side()
+    gemms()
+    main.wait_stream(side)
+
+
+t_g = timed(gemms); t_a = timed(lambda: opt.step()); t_seq = timed(lambda: (opt.step(), gemms())); t_par = timed(both2)
+print(f"Adam over 66 M parameters under 6 NT GEMMs + the grouped wgrad: GEMMs alone {t_g:.0f} us, Adam alone {t_a:.0f} us, sequential {t_seq:.0f} us, "
+      f"two streams {t_par:.0f} us (hidden {t_seq - t_par:.0f} us = {100 * (t_seq - t_par) / min(t_g, t_a):.0f} % of the shorter)")
