@@ -60,7 +60,7 @@ class SGateArgs(C.Structure):
 
 class SGateBwdArgs(C.Structure):
     _fields_ = [("f", SGateArgs), ("dout", _vp), ("dx", _vp), ("dscale", _vp), ("dcomp", _vp), ("red", _vp), ("dw", _vp),
-                ("dgamma", _vp), ("dbeta", _vp)]
+                ("dgamma", _vp), ("dbeta", _vp), ("wpart", _vp)]
 
 
 class ProfEntry(C.Structure):

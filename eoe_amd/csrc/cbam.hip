@@ -201,29 +201,43 @@ __global__ __launch_bounds__(256) void cgate_mlp_bwd_kernel(const float* __restr
         dpooled[(size_t)img * 2 * C + i] = acc;
     }
 }
-// parameter gradients of the MLP, one thread per (c, j): sums over the images
+// parameter gradients of the MLP: sums over the images.  A workgroup owns 16 (c, j) pairs x 16 image slices (one thread per
+// (c, j) walking all n images serially was a 100-us chain of dependent L2 loads); the slices are added in a fixed order.
 __global__ __launch_bounds__(256) void cgate_mlp_wgrad_kernel(const float* __restrict__ pooled, const float* __restrict__ hidden,
                                                               const float* __restrict__ datt, const float* __restrict__ dhidden,
                                                               float* __restrict__ dw1, float* __restrict__ db1,
                                                               float* __restrict__ dw2, float* __restrict__ db2, int n, int C, int Ch) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= C * Ch) return;
-    const int j = i % Ch, c = i / Ch;
+    __shared__ float red[4][16][17];
+    const int pl = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + pl;
+    const bool ok = i < C * Ch;
+    const int j = ok ? i % Ch : 0, c = ok ? i / Ch : 0;
     float a1 = 0.f, a2 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (int img = 0; img < n; ++img) {
-        const float da = datt[(size_t)img * C + c];
-        const float* h = hidden + (size_t)img * 2 * Ch;
-        const float* dh = dhidden + (size_t)img * 2 * Ch;
-        const float* p = pooled + (size_t)img * 2 * C;
-        a2 += da * (h[j] + h[Ch + j]);
-        a1 += dh[j] * p[c] + dh[Ch + j] * p[C + c];
-        s2 += da;
-        s1 += dh[j] + dh[Ch + j];
-    }
-    dw2[(size_t)c * Ch + j] = a2;
-    dw1[(size_t)j * C + c] = a1;
-    if (j == 0) db2[c] = 2.f * s2;
-    if (c == 0) db1[j] = s1;
+    if (ok)
+        for (int img = slice; img < n; img += 16) {
+            const float da = datt[(size_t)img * C + c];
+            const float* h = hidden + (size_t)img * 2 * Ch;
+            const float* dh = dhidden + (size_t)img * 2 * Ch;
+            const float* p = pooled + (size_t)img * 2 * C;
+            a2 += da * (h[j] + h[Ch + j]);
+            a1 += dh[j] * p[c] + dh[Ch + j] * p[C + c];
+            s2 += da;
+            s1 += dh[j] + dh[Ch + j];
+        }
+    red[0][slice][pl] = a1;
+    red[1][slice][pl] = a2;
+    red[2][slice][pl] = s1;
+    red[3][slice][pl] = s2;
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    const int which = threadIdx.x >> 4;               // pl = threadIdx.x & 15 as above
+    if (!ok) return;
+    float s = 0.f;
+    for (int k = 0; k < 16; ++k) s += red[which][k][pl];
+    if (which == 0) dw1[(size_t)j * C + c] = s;
+    else if (which == 1) dw2[(size_t)c * Ch + j] = s;
+    else if (which == 2) { if (c == 0) db1[j] = s; }
+    else if (j == 0) db2[c] = 2.f * s;
 }
 
 // ---------------------------------------------------------------------------------------------- gate application
@@ -360,7 +374,8 @@ __global__ __launch_bounds__(256) void sgate_sigmoid_kernel(const float* __restr
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x)
         scale[p] = sigmoidf((z[p] - mu) * rs * g + b);
 }
-// g[p] = dscale[p] * s(1-s) (overwrites dscale); red[0] += sum g, red[1] += sum g*xhat
+// g[p] = dscale[p] * s(1-s) (overwrites dscale); workgroup b writes (sum g, sum g*xhat) over its pixels to red[2 + 2b ..]
+// (no atomics, no zero-init: sgate_bn_bwd_apply_kernel adds the pairs up in a fixed order)
 __global__ __launch_bounds__(256) void sgate_bn_bwd_reduce_kernel(const float* __restrict__ z, const float* __restrict__ stats,
                                                                   const float* __restrict__ scale, float* __restrict__ dscale,
                                                                   float* __restrict__ red, size_t P) {
@@ -379,18 +394,27 @@ __global__ __launch_bounds__(256) void sgate_bn_bwd_reduce_kernel(const float* _
     if ((threadIdx.x & 63) == 0) { l0[threadIdx.x >> 6] = s0; l1[threadIdx.x >> 6] = s1; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(red + 0, l0[0] + l0[1] + l0[2] + l0[3]);
-        atomicAdd(red + 1, l1[0] + l1[1] + l1[2] + l1[3]);
+        red[2 + 2 * blockIdx.x] = l0[0] + l0[1] + l0[2] + l0[3];
+        red[3 + 2 * blockIdx.x] = l1[0] + l1[1] + l1[2] + l1[3];
     }
 }
 // dz[p] = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)) (training) or gamma*rstd*g (running statistics); in place over g
 __global__ __launch_bounds__(256) void sgate_bn_bwd_apply_kernel(const float* __restrict__ z, const float* __restrict__ stats,
                                                                  const float* __restrict__ gamma, const float* __restrict__ red,
-                                                                 float* __restrict__ g, float* __restrict__ dgamma,
+                                                                 int nparts, float* __restrict__ g, float* __restrict__ dgamma,
                                                                  float* __restrict__ dbeta, size_t P, int training) {
+    __shared__ float l0[4], l1[4];
     const float mu = stats[0], rs = stats[1], ga = gamma ? gamma[0] : 1.f;
-    const float m0 = red[0] / (float)P, m1 = red[1] / (float)P;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && dgamma) { dgamma[0] = red[1]; dbeta[0] = red[0]; }
+    // every workgroup adds the nparts partial pairs in the same order (a few KB from L2)
+    float t0 = 0.f, t1 = 0.f;
+    for (int k = threadIdx.x; k < nparts; k += blockDim.x) { t0 += red[2 + 2 * k]; t1 += red[3 + 2 * k]; }
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) { t0 += __shfl_xor(t0, sft, 64); t1 += __shfl_xor(t1, sft, 64); }
+    if ((threadIdx.x & 63) == 0) { l0[threadIdx.x >> 6] = t0; l1[threadIdx.x >> 6] = t1; }
+    __syncthreads();
+    const float r0 = (l0[0] + l0[1]) + (l0[2] + l0[3]), r1 = (l1[0] + l1[1]) + (l1[2] + l1[3]);
+    const float m0 = r0 / (float)P, m1 = r1 / (float)P;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && dgamma) { dgamma[0] = r1; dbeta[0] = r0; }
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x) {
         const float xh = (z[p] - mu) * rs;
         g[p] = training ? ga * rs * (g[p] - m0 - xh * m1) : ga * rs * g[p];
@@ -421,24 +445,55 @@ __global__ __launch_bounds__(256) void sgate_conv_bwd_data_kernel(const float* _
         *(f32x2*)(dcomp + p * 2) = (f32x2){a0, a1};
     }
 }
-// dw[ch, ky, kx] += sum_p dz[p] * comp[(y+ky-3, x+kx-3), ch]; grid (98, chunks)
+// dw[ch, ky, kx] = sum_p dz[p] * comp[(y+ky-3, x+kx-3), ch].  One workgroup per image: the image's comp plane sits in LDS, a
+// thread walks its pixels with all 98 taps in registers (98 LDS reads + FMAs per pixel; the first version ran one workgroup
+// per (tap, pixel chunk) and re-read dz / comp 98 times through L2: 52 us average), the workgroup's sums go to
+// part[img][98]; sgate_wpart_sum_kernel adds the images up in a fixed order -- no atomics.
 __global__ __launch_bounds__(256) void sgate_conv_bwd_weight_kernel(const float* __restrict__ dz, const float* __restrict__ comp,
-                                                                    float* __restrict__ dw, int n, int H, int W) {
-    __shared__ float l0[4];
-    const int t = blockIdx.x, ch = t / 49, ky = (t % 49) / 7, kx = t % 7;
-    const size_t total = (size_t)n * H * W;
-    float acc = 0.f;
-    for (size_t p = (size_t)blockIdx.y * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.y * blockDim.x) {
-        const int x = (int)(p % W), y = (int)((p / W) % H);
-        const int yy = y + ky - 3, xx = x + kx - 3;
-        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-        acc += dz[p] * comp[(p + (size_t)(ky - 3) * W + (kx - 3)) * 2 + ch];
-    }
-#pragma unroll
-    for (int sft = 32; sft >= 1; sft >>= 1) acc += __shfl_xor(acc, sft, 64);
-    if ((threadIdx.x & 63) == 0) l0[threadIdx.x >> 6] = acc;
+                                                                    float* __restrict__ part, int H, int W) {
+    extern __shared__ float lc[];                  // [H*W][2], then reused as [4 waves][98]
+    const int img = blockIdx.x, HW = H * W;
+    for (int i = threadIdx.x; i < HW * 2; i += blockDim.x) lc[i] = comp[(size_t)img * HW * 2 + i];
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(dw + t, l0[0] + l0[1] + l0[2] + l0[3]);
+    float acc[98];
+#pragma unroll
+    for (int t = 0; t < 98; ++t) acc[t] = 0.f;
+    for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+        const int y = p / W, x = p - y * W;
+        const float d = dz[(size_t)img * HW + p];
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) {
+            const int yy = y + ky - 3;
+            if (yy < 0 || yy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) {
+                const int xx = x + kx - 3;
+                if (xx < 0 || xx >= W) continue;
+                const f32x2 c = *(const f32x2*)(lc + (yy * W + xx) * 2);
+                acc[ky * 7 + kx] += d * c[0];
+                acc[49 + ky * 7 + kx] += d * c[1];
+            }
+        }
+    }
+    __syncthreads();                               // everyone is done reading the comp plane
+#pragma unroll
+    for (int t = 0; t < 98; ++t) {
+        float v = acc[t];
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft, 64);
+        if ((threadIdx.x & 63) == 0) lc[(threadIdx.x >> 6) * 98 + t] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 98)
+        part[(size_t)img * 98 + threadIdx.x] = (lc[threadIdx.x] + lc[98 + threadIdx.x]) + (lc[196 + threadIdx.x] + lc[294 + threadIdx.x]);
+}
+// dw[t] = sum_img part[img][t]: one wavefront per tap
+__global__ __launch_bounds__(64) void sgate_wpart_sum_kernel(const float* __restrict__ part, float* __restrict__ dw, int n) {
+    float v = 0.f;
+    for (int img = threadIdx.x; img < n; img += 64) v += part[(size_t)img * 98 + blockIdx.x];
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft, 64);
+    if (threadIdx.x == 0) dw[blockIdx.x] = v;
 }
 // dx = dout * scale[p] + [c == argmax[p]] * dcomp[p,0] + dcomp[p,1] / C
 __global__ __launch_bounds__(256) void sgate_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ scale,
@@ -572,7 +627,7 @@ extern "C" int eoe_cgate_bwd(const eoe_cgate_bwd_args* b, void* stream) {
     hipLaunchKernelGGL(cgate_mlp_bwd_kernel, dim3(a->n), dim3(256), (a->C + 2 * a->Ch) * sizeof(float), s, a->scale, a->hidden, a->w1,
                        a->w2, b->dscale, b->dhidden, b->dpooled, a->C, a->Ch);
     EOE_CHECK_LAUNCH("cgate_mlp_bwd");
-    hipLaunchKernelGGL(cgate_mlp_wgrad_kernel, dim3(cdiv(a->C * a->Ch, 256)), dim3(256), 0, s, a->pooled, a->hidden, b->dscale,
+    hipLaunchKernelGGL(cgate_mlp_wgrad_kernel, dim3(cdiv(a->C * a->Ch, 16)), dim3(256), 0, s, a->pooled, a->hidden, b->dscale,
                        b->dhidden, b->dw1, b->db1, b->dw2, b->db2, a->n, a->C, a->Ch);
     EOE_CHECK_LAUNCH("cgate_mlp_wgrad");
     hipLaunchKernelGGL(cgate_bwd_apply_kernel, dim3(grid_for((size_t)a->n * a->HW * a->C / 4)), dim3(256), 0, s, b->dout, a->scale,
@@ -628,26 +683,30 @@ extern "C" int eoe_sgate_bwd(const eoe_sgate_bwd_args* b, void* stream) {
     EOE_CHECK_ARG(b != nullptr, "sgate_bwd: null args");
     const eoe_sgate_args* a = &b->f;
     EOE_TRY(check_sgate(a));
-    EOE_CHECK_ARG(b->dout && b->dx && b->dscale && b->dcomp && b->red && b->dw, "sgate_bwd: null args");
+    EOE_CHECK_ARG(b->dout && b->dx && b->dscale && b->dcomp && b->red && b->dw && b->wpart, "sgate_bwd: null args");
+    EOE_CHECK_ARG(a->H * a->W <= 8192, "sgate_bwd: feature map too large (%d x %d)", a->H, a->W);
     EOE_CHECK_ARG((b->dgamma == nullptr) == (b->dbeta == nullptr), "sgate_bwd: dgamma/dbeta must both be given or both NULL");
     hipStream_t s = (hipStream_t)stream;
     const size_t P = (size_t)a->n * a->H * a->W;
     ProfScope ps("sgate_bwd", 0, 5 * 4.0 * P * a->C, stream);
-    if (hipMemsetAsync(b->red, 0, 2 * sizeof(float), s) != hipSuccess || hipMemsetAsync(b->dw, 0, 98 * sizeof(float), s) != hipSuccess)
-        return eoe_set_error(EOE_ERR_LAUNCH, "sgate_bwd: memset failed");
     hipLaunchKernelGGL(pix_reduce_kernel<1>, dim3(grid_for(P * 16)), dim3(256), 0, s, b->dout, a->x, b->dscale, (int*)nullptr, P, a->C);
     EOE_CHECK_LAUNCH("sgate_bwd_reduce");
-    int g = grid_for(P, 512);
+    int g = grid_for(P, EOE_SGATE_PARTIALS);
     hipLaunchKernelGGL(sgate_bn_bwd_reduce_kernel, dim3(g), dim3(256), 0, s, a->z, a->stats, a->scale, b->dscale, b->red, P);
     EOE_CHECK_LAUNCH("sgate_bn_bwd_reduce");
-    hipLaunchKernelGGL(sgate_bn_bwd_apply_kernel, dim3(grid_for(P)), dim3(256), 0, s, a->z, a->stats, a->gamma, (const float*)b->red,
+    hipLaunchKernelGGL(sgate_bn_bwd_apply_kernel, dim3(grid_for(P)), dim3(256), 0, s, a->z, a->stats, a->gamma, (const float*)b->red, g,
                        b->dscale, b->dgamma, b->dbeta, P, a->training);
     EOE_CHECK_LAUNCH("sgate_bn_bwd_apply");
     hipLaunchKernelGGL(sgate_conv_bwd_data_kernel, dim3(grid_for(P)), dim3(256), 0, s, (const float*)b->dscale, a->w, b->dcomp, a->n,
                        a->H, a->W);
     EOE_CHECK_LAUNCH("sgate_conv_bwd_data");
-    hipLaunchKernelGGL(sgate_conv_bwd_weight_kernel, dim3(98, grid_for(P, 64)), dim3(256), 0, s, (const float*)b->dscale, a->comp, b->dw,
-                       a->n, a->H, a->W);
+    {
+        size_t lds = (size_t)a->H * a->W * 2 * sizeof(float);
+        if (lds < 4 * 98 * sizeof(float)) lds = 4 * 98 * sizeof(float);
+        hipLaunchKernelGGL(sgate_conv_bwd_weight_kernel, dim3(a->n), dim3(256), lds, s, (const float*)b->dscale, a->comp, b->wpart, a->H,
+                           a->W);
+        hipLaunchKernelGGL(sgate_wpart_sum_kernel, dim3(98), dim3(64), 0, s, (const float*)b->wpart, b->dw, a->n);
+    }
     EOE_CHECK_LAUNCH("sgate_conv_bwd_weight");
     hipLaunchKernelGGL(sgate_bwd_apply_kernel, dim3(grid_for(P * a->C / 4)), dim3(256), 0, s, b->dout, a->scale, (const float*)b->dcomp,
                        a->argmax, b->dx, P, a->C);

@@ -66,29 +66,35 @@ __global__ __launch_bounds__(256) void im2col_nhwc_kernel(const void* __restrict
     }
 }
 
-// gradient wrt the layer input: dx fp32 NHWC [n,H,W,C] = gather over the 25 taps of dpatches 16-bit [n*H*W, Kp]
-template <typename T>
+// gradient wrt the layer input: dx fp32 NHWC [n,H,W,C] = gather over the kh*kw taps of dpatches 16-bit [n*Ho*Wo, Kp].
+// S = the stride as a compile-time constant (1 or 2; 0 = run-time value): the tap loop tests divisibility by it.
+template <typename T, int S>
 __global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dp, float* __restrict__ dx, int n, int H, int W,
-                                                     int C, int Kp, Geo g) {
-    const int cc = C / 4;
-    const size_t total = (size_t)n * H * W * cc;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % cc);
-        const size_t pix = i / cc;
-        const int w = (int)(pix % W), h = (int)((pix / W) % H), img = (int)(pix / ((size_t)W * H));
+                                                     int C, int Kp, Geo g, QuadDecode dec) {
+    const unsigned total = (unsigned)n * H * W * (C / 4);
+    const int st = S ? S : g.stride;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        unsigned c4, pix, w, h, img;
+        dec(i, c4, pix, w, h, img);
         float a[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int tap = 0; tap < g.kh * g.kw; ++tap) {
+        for (int ky = 0; ky < g.kh; ++ky) {
             // output position (ho, wo) whose tap (ky, kx) reads this pixel: ho*stride + ky - pad == h
-            const int th = h + g.pad - tap / g.kw, tw = w + g.pad - tap % g.kw;
-            if (th < 0 || tw < 0 || th % g.stride || tw % g.stride) continue;
-            const int hh = th / g.stride, ww = tw / g.stride;
-            if (hh >= g.Ho || ww >= g.Wo) continue;
-            float t[4];
-            unpack4<T>(*(const u32x2*)(dp + (((size_t)img * g.Ho + hh) * g.Wo + ww) * Kp + tap * C + c4 * 4), t);
+            const int th = (int)h + g.pad - ky;
+            if (th < 0 || th % st) continue;
+            const int hh = th / st;
+            if (hh >= g.Ho) continue;
+            for (int kx = 0; kx < g.kw; ++kx) {
+                const int tw = (int)w + g.pad - kx;
+                if (tw < 0 || tw % st) continue;
+                const int ww = tw / st;
+                if (ww >= g.Wo) continue;
+                float t[4];
+                unpack4<T>(*(const u32x2*)(dp + (((size_t)img * g.Ho + hh) * g.Wo + ww) * Kp + (ky * g.kw + kx) * C + c4 * 4), t);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) a[r] += t[r];
+                for (int r = 0; r < 4; ++r) a[r] += t[r];
+            }
         }
-        *(f32x4*)(dx + pix * C + c4 * 4) = (f32x4){a[0], a[1], a[2], a[3]};
+        *(f32x4*)(dx + (size_t)pix * C + c4 * 4) = (f32x4){a[0], a[1], a[2], a[3]};
     }
 }
 
@@ -223,18 +229,33 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     }
 }
 
-// out[i] = sum_p part[p][i], i < n: 64 columns x 16 row lanes per workgroup (P <= 1024 rows: <= 64 independent loads each)
-__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int P, int n) {
-    __shared__ float l[1024];
-    const int i = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+// out[i] = sum_p part[p][i], i < n: 16 columns x 64 row lanes per workgroup, four independent loads in flight per thread
+// (P <= 1024 rows -> 16 loads each; the 64-columns x 16-lanes version spent 20 us in 64 dependent L2 round trips), fixed
+// summation order.  Optional BatchNorm parameter gradients straight from the sums: p0[i] (i < C), p1[i - C] (i >= C).
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int P, int n,
+                                                               float* __restrict__ p0, float* __restrict__ p1, int C, int accumulate) {
+    __shared__ float l[64][17];
+    const int col = threadIdx.x & 15, lane = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + col;
     float s = 0.f;
-    if (i < n)
-        for (int p = lane; p < P; p += 16) s += part[(size_t)p * n + i];
-    l[threadIdx.x] = s;
+    if (i < n) {
+        int p = lane;
+        for (; p + 192 < P; p += 256) {
+            const float a = part[(size_t)p * n + i], b = part[(size_t)(p + 64) * n + i], c = part[(size_t)(p + 128) * n + i],
+                        d = part[(size_t)(p + 192) * n + i];
+            s += (a + b) + (c + d);
+        }
+        for (; p < P; p += 64) s += part[(size_t)p * n + i];
+    }
+    l[lane][col] = s;
     __syncthreads();
     if (lane == 0 && i < n) {
-        for (int k = 1; k < 16; ++k) s += l[threadIdx.x + 64 * k];
+        for (int k = 1; k < 64; ++k) s += l[k][col];
         out[i] = s;
+        if (p0) {
+            float* dst = i < C ? p0 + i : p1 + (i - C);
+            *dst = accumulate ? *dst + s : s;
+        }
     }
 }
 
@@ -243,20 +264,29 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __re
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int P, float* __restrict__ stats,
                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
                                                            int64_t* __restrict__ nbt, int M, int C, float eps, float momentum) {
-    __shared__ double l[2][1024];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+    __shared__ double l[2][64][17];
+    const int col = threadIdx.x & 15, lane = threadIdx.x >> 4;          // 16 channels x 64 row lanes
+    const int c = blockIdx.x * 16 + col;
     double s = 0.0, q = 0.0;
-    if (c < C)
-        for (int p = lane; p < P; p += 16) {
+    if (c < C) {
+        int p = lane;
+        for (; p + 64 < P; p += 128) {
+            const float s0 = part[(size_t)p * 2 * C + c], q0 = part[(size_t)p * 2 * C + C + c];
+            const float s1 = part[(size_t)(p + 64) * 2 * C + c], q1 = part[(size_t)(p + 64) * 2 * C + C + c];
+            s += (double)s0 + (double)s1;
+            q += (double)q0 + (double)q1;
+        }
+        for (; p < P; p += 64) {
             s += part[(size_t)p * 2 * C + c];
             q += part[(size_t)p * 2 * C + C + c];
         }
-    l[0][threadIdx.x] = s;
-    l[1][threadIdx.x] = q;
+    }
+    l[0][lane][col] = s;
+    l[1][lane][col] = q;
     __syncthreads();
     if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
     if (lane != 0 || c >= C) return;
-    for (int k = 1; k < 16; ++k) { s += l[0][threadIdx.x + 64 * k]; q += l[1][threadIdx.x + 64 * k]; }
+    for (int k = 1; k < 64; ++k) { s += l[0][k][col]; q += l[1][k][col]; }
     const double mean = s / M;
     double var = q / M - mean * mean;
     if (var < 0) var = 0;
@@ -284,13 +314,15 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ stats,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               void* __restrict__ out, T* __restrict__ out16, int n, int H, int W,
-                                                              int C, int P, int nchw_flat, int out_f32, float slope) {
+                                                              int C, int P, int nchw_flat, int out_f32, float slope,
+                                                              QuadDecode dec) {
     const int Ho = H / P, Wo = W / P, cc = C / 4;
-    const size_t total = (size_t)n * Ho * Wo * cc;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % cc) * 4;
-        const size_t op = i / cc;
-        const int wo = (int)(op % Wo), ho = (int)((op / Wo) % Ho), img = (int)(op / ((size_t)Wo * Ho));
+    const unsigned total = (unsigned)n * Ho * Wo * cc;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        unsigned c4, opu, wo, ho, img;
+        dec(i, c4, opu, wo, ho, img);
+        const int c = (int)c4 * 4;
+        const size_t op = opu;
         const f32x4 mu = *(const f32x4*)(stats + c), rs = *(const f32x4*)(stats + C + c);
         f32x4 g = {1.f, 1.f, 1.f, 1.f}, b = {0.f, 0.f, 0.f, 0.f};
         if (gamma) { g = *(const f32x4*)(gamma + c); b = *(const f32x4*)(beta + c); }
@@ -359,10 +391,10 @@ __global__ __launch_bounds__(256) void bn_act_pool_bwd_kernel(const float* __res
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               const float* __restrict__ dout, float* __restrict__ red,
                                                               void* __restrict__ dy, int dy_f32, int n, int H, int W, int C,
-                                                              int nchw_flat, int use_batch_stats, float slope) {
+                                                              int nchw_flat, int use_batch_stats, float slope, QuadDecode dec) {
     extern __shared__ float lds[];                // MODE 0: [2][C] partial sums
     const int Ho = H / P, Wo = W / P, cc = C / 4;
-    const size_t total = (size_t)n * Ho * Wo * cc;
+    const unsigned total = (unsigned)n * Ho * Wo * cc;
     const float invM = 1.0f / ((float)n * H * W);
     if (MODE == 0) {
         for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lds[i] = 0.f;
@@ -371,10 +403,10 @@ __global__ __launch_bounds__(256) void bn_act_pool_bwd_kernel(const float* __res
     // MODE 0: the launch keeps gridDim.x * 256 a multiple of C/4, so a thread sees ONE channel quad for its whole loop
     // and sums in registers; LDS / global atomics only once per thread / workgroup at the end
     float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % cc) * 4;
-        const size_t op = i / cc;
-        const int wo = (int)(op % Wo), ho = (int)((op / Wo) % Ho), img = (int)(op / ((size_t)Wo * Ho));
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        unsigned c4, opu, wo, ho, img;
+        dec(i, c4, opu, wo, ho, img);
+        const int c = (int)c4 * 4;
         const f32x4 mu = *(const f32x4*)(stats + c), rs = *(const f32x4*)(stats + C + c);
         f32x4 g = {1.f, 1.f, 1.f, 1.f}, b = {0.f, 0.f, 0.f, 0.f};
         if (gamma) { g = *(const f32x4*)(gamma + c); b = *(const f32x4*)(beta + c); }
@@ -436,26 +468,31 @@ __global__ __launch_bounds__(256) void bn_act_maxpool_fwd_kernel(const float* __
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  float* __restrict__ out, T* __restrict__ out16,
                                                                  uint8_t* __restrict__ idx, int n, int H, int W, int C, int k,
-                                                                 int stride, int pad, int Ho, int Wo, float slope) {
+                                                                 int stride, int pad, int Ho, int Wo, float slope, QuadDecode dec) {
     const int cc = C / 4;
-    const size_t total = (size_t)n * Ho * Wo * cc;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % cc) * 4;
-        const size_t op = i / cc;
-        const int wo = (int)(op % Wo), ho = (int)((op / Wo) % Ho), img = (int)(op / ((size_t)Wo * Ho));
+    const unsigned total = (unsigned)n * Ho * Wo * cc;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        unsigned c4, opu, wou, hou, img;
+        dec(i, c4, opu, wou, hou, img);
+        const int c = (int)c4 * 4, wo = (int)wou, ho = (int)hou;
+        const size_t op = opu;
         const f32x4 mu = *(const f32x4*)(stats + c), rs = *(const f32x4*)(stats + C + c);
         f32x4 g = {1.f, 1.f, 1.f, 1.f}, b = {0.f, 0.f, 0.f, 0.f};
         if (gamma) { g = *(const f32x4*)(gamma + c); b = *(const f32x4*)(beta + c); }
         float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         int arg[4] = {0, 0, 0, 0};
-        for (int tap = 0; tap < k * k; ++tap) {
-            const int h = ho * stride + tap / k - pad, w = wo * stride + tap % k - pad;
-            if (h < 0 || h >= H || w < 0 || w >= W) continue;
-            const f32x4 v = *(const f32x4*)(y + (((size_t)img * H + h) * W + w) * C + c);
+        for (int ky = 0; ky < k; ++ky) {
+            const int h = ho * stride + ky - pad;
+            if (h < 0 || h >= H) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int w = wo * stride + kx - pad;
+                if (w < 0 || w >= W) continue;
+                const f32x4 v = *(const f32x4*)(y + (((size_t)img * H + h) * W + w) * C + c);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float a = lrelu((v[r] - mu[r]) * rs[r] * g[r] + b[r], slope);
-                if (a > best[r]) { best[r] = a; arg[r] = tap; }
+                for (int r = 0; r < 4; ++r) {
+                    const float a = lrelu((v[r] - mu[r]) * rs[r] * g[r] + b[r], slope);
+                    if (a > best[r]) { best[r] = a; arg[r] = ky * k + kx; }      // taps in increasing order: first maximum wins
+                }
             }
         }
         *(f32x4*)(out + op * C + c) = (f32x4){best[0], best[1], best[2], best[3]};
@@ -474,20 +511,21 @@ __global__ __launch_bounds__(256) void bn_act_maxpool_bwd_kernel(const float* __
                                                                  const float* __restrict__ dout, const uint8_t* __restrict__ idx,
                                                                  float* __restrict__ red, T* __restrict__ dy, int n, int H, int W,
                                                                  int C, int k, int stride, int pad, int Ho, int Wo,
-                                                                 int use_batch_stats, float slope) {
+                                                                 int use_batch_stats, float slope, QuadDecode dec) {
     extern __shared__ float lds[];
     const int cc = C / 4;
-    const size_t total = (size_t)n * H * W * cc;
+    const unsigned total = (unsigned)n * H * W * cc;
     const float invM = 1.0f / ((float)n * H * W);
     if (MODE == 0) {
         for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lds[i] = 0.f;
         __syncthreads();
     }
     float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % cc) * 4;
-        const size_t ip = i / cc;
-        const int w = (int)(ip % W), h = (int)((ip / W) % H), img = (int)(ip / ((size_t)W * H));
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        unsigned c4, ipu, wu, hu, img;
+        dec(i, c4, ipu, wu, hu, img);
+        const int c = (int)c4 * 4, w = (int)wu, h = (int)hu;
+        const size_t ip = ipu;
         const f32x4 mu = *(const f32x4*)(stats + c), rs = *(const f32x4*)(stats + C + c);
         f32x4 g = {1.f, 1.f, 1.f, 1.f}, b = {0.f, 0.f, 0.f, 0.f};
         if (gamma) { g = *(const f32x4*)(gamma + c); b = *(const f32x4*)(beta + c); }
@@ -527,11 +565,6 @@ __global__ __launch_bounds__(256) void bn_act_maxpool_bwd_kernel(const float* __
     if (MODE == 0) block_channel_sums(acc0, acc1, lds, red + (size_t)(1 + blockIdx.x) * 2 * C, C, total);
 }
 
-__global__ __launch_bounds__(256) void add_copy_kernel(float* __restrict__ dst, const float* __restrict__ src, int n, int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = accumulate ? dst[i] + src[i] : src[i];
-}
-
 int grid_for(size_t total) {
     size_t g = (total + 255) / 256;
     if (g > 4096) g = 4096;
@@ -540,6 +573,9 @@ int grid_for(size_t total) {
 }
 
 }  // namespace
+
+// flat (pixel, channel-quad) indices are 32-bit in the streaming kernels (FDiv needs x < 2^31)
+#define EOE_CHECK_IDX(total, who) EOE_CHECK_ARG((size_t)(total) < 0x7fffffffull, "%s: tensor too large for 32-bit indexing", who)
 
 #define DISPATCH_T(dtype, ...)                                  \
     do {                                                        \
@@ -589,9 +625,14 @@ extern "C" int eoe_col2im(const void* dpatches, float* dx, int n, int C, int H, 
     EOE_CHECK_ARG(dpatches && dx && n > 0 && C % 4 == 0 && Kp >= kh * kw * C, "col2im: bad args");
     Geo g;
     EOE_TRY(check_geo("col2im", H, W, kh, kw, stride, pad, g));
+    EOE_CHECK_IDX((size_t)n * H * W * C / 4, "col2im");
     ProfScope ps("col2im", 0, 2.0 * n * g.Ho * g.Wo * kh * kw * C + 4.0 * n * H * W * C, stream);
-    DISPATCH_T(dtype, hipLaunchKernelGGL((col2im_kernel<T>), dim3(grid_for((size_t)n * H * W * C / 4)), dim3(256), 0,
-                                         (hipStream_t)stream, (const T*)dpatches, dx, n, H, W, C, Kp, g));
+    const QuadDecode dec(C / 4, W, H);
+#define EOE_C2I(SS)                                                                                                      \
+    DISPATCH_T(dtype, hipLaunchKernelGGL((col2im_kernel<T, SS>), dim3(grid_for((size_t)n * H * W * C / 4)), dim3(256), 0, \
+                                         (hipStream_t)stream, (const T*)dpatches, dx, n, H, W, C, Kp, g, dec))
+    if (stride == 2) { EOE_C2I(2); } else if (stride == 1) { EOE_C2I(1); } else { EOE_C2I(0); }
+#undef EOE_C2I
     EOE_CHECK_LAUNCH("col2im");
     return 0;
 }
@@ -673,7 +714,7 @@ extern "C" int eoe_bn_stats(const float* y, float* sums_scratch, float* stats, f
     if (vec == 4) hipLaunchKernelGGL(bn_stats_kernel<4>, dim3(gx, gy), dim3(256), 0, s, y, sums_scratch, M, C, cpb);
     else hipLaunchKernelGGL(bn_stats_kernel<1>, dim3(gx, gy), dim3(256), 0, s, y, sums_scratch, M, C, cpb);
     EOE_CHECK_LAUNCH("bn_stats");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, s, (const float*)sums_scratch, gy, stats, running_mean,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(1024), 0, s, (const float*)sums_scratch, gy, stats, running_mean,
                        running_var, num_batches_tracked, M, C, eps, momentum);
     EOE_CHECK_LAUNCH("bn_finalize");
     return 0;
@@ -686,10 +727,12 @@ extern "C" int eoe_bn_act_pool_fwd(const float* y, const float* stats, const flo
     EOE_CHECK_ARG(y && stats && out && n > 0 && C % 4 == 0, "bn_act_pool_fwd: bad args");
     EOE_CHECK_ARG((pool == 1 || pool == 2) && H % pool == 0 && W % pool == 0, "bn_act_pool: pool must be 1 or 2 and divide H, W");
     EOE_CHECK_ARG((gamma == nullptr) == (beta == nullptr), "bn_act_pool: gamma/beta must both be given or both NULL");
+    EOE_CHECK_IDX((size_t)n * H * W * C / 4, "bn_act_pool_fwd");
     ProfScope ps("bn_act_pool_fwd", 0, 4.0 * n * H * W * C + 2.0 * n * H * W * C / (pool * pool), stream);
+    const QuadDecode dec(C / 4, W / pool, H / pool);
     DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_pool_fwd_kernel<T>), dim3(grid_for((size_t)n * (H / pool) * (W / pool) * C / 4)),
                                          dim3(256), 0, (hipStream_t)stream, y, stats, gamma, beta, out, (T*)out16, n, H, W, C,
-                                         pool, nchw_flat, out_f32, slope));
+                                         pool, nchw_flat, out_f32, slope, dec));
     EOE_CHECK_LAUNCH("bn_act_pool_fwd");
     return 0;
 }
@@ -703,7 +746,9 @@ extern "C" int eoe_bn_act_pool_bwd(const float* y, const float* stats, const flo
     EOE_CHECK_ARG((gamma == nullptr) == (beta == nullptr) && (dgamma == nullptr) == (dbeta == nullptr), "bn_act_pool_bwd: gamma/beta pairs");
     EOE_CHECK_ARG(C <= 4096, "bn_act_pool_bwd: C too large");
     hipStream_t s = (hipStream_t)stream;
+    EOE_CHECK_IDX((size_t)n * H * W * C / 4, "bn_act_pool_bwd");
     ProfScope ps("bn_act_pool_bwd", 0, 2 * 4.0 * n * H * W * C + 2.0 * n * H * W * C, stream);
+    const QuadDecode dec(C / 4, W / pool, H / pool);
     const int grid = grid_for((size_t)n * (H / pool) * (W / pool) * C / 4);
     int g0 = grid > EOE_BN_PARTIALS ? EOE_BN_PARTIALS : grid;
     {   // reduce pass: gridDim.x * 256 must be a multiple of C/4 (one channel quad per thread)
@@ -716,20 +761,16 @@ extern "C" int eoe_bn_act_pool_bwd(const float* y, const float* stats, const flo
     }
 #define EOE_BNB(MODE, PP, GRID, LDS)                                                                                  \
     DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_pool_bwd_kernel<T, MODE, PP>), dim3(GRID), dim3(256), LDS, s, y, stats, gamma, \
-                                         beta, dout, red_scratch, dy, dy_f32, n, H, W, C, nchw_flat, training, slope))
+                                         beta, dout, red_scratch, dy, dy_f32, n, H, W, C, nchw_flat, training, slope, dec))
     if (pool == 1) { EOE_BNB(0, 1, g0, 2 * C * sizeof(float)); } else { EOE_BNB(0, 2, g0, 2 * C * sizeof(float)); }
     EOE_CHECK_LAUNCH("bn_act_pool_bwd_reduce");
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * C, 64)), dim3(1024), 0, s, (const float*)(red_scratch + 2 * C), red_scratch, g0,
-                       2 * C);
+    // + dbeta = sum g, dgamma = sum g*xhat
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * C, 16)), dim3(1024), 0, s, (const float*)(red_scratch + 2 * C), red_scratch, g0,
+                       2 * C, dbeta, dgamma, C, accumulate);
     EOE_CHECK_LAUNCH("bn_act_pool_bwd_reduce2");
     if (pool == 1) { EOE_BNB(1, 1, grid, 0); } else { EOE_BNB(1, 2, grid, 0); }
     EOE_CHECK_LAUNCH("bn_act_pool_bwd_apply");
 #undef EOE_BNB
-    if (dgamma) {     // dbeta = sum g, dgamma = sum g*xhat
-        hipLaunchKernelGGL(add_copy_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, dbeta, (const float*)red_scratch, C, accumulate);
-        hipLaunchKernelGGL(add_copy_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, dgamma, (const float*)(red_scratch + C), C, accumulate);
-        EOE_CHECK_LAUNCH("bn_act_pool_bwd_params");
-    }
     return 0;
 }
 
@@ -741,10 +782,12 @@ extern "C" int eoe_bn_act_maxpool_fwd(const float* y, const float* stats, const 
     EOE_CHECK_ARG((gamma == nullptr) == (beta == nullptr), "bn_act_maxpool: gamma/beta must both be given or both NULL");
     const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
     EOE_CHECK_ARG(Ho >= 1 && Wo >= 1, "bn_act_maxpool_fwd: empty output");
+    EOE_CHECK_IDX((size_t)n * H * W * C / 4, "bn_act_maxpool_fwd");
     ProfScope ps("bn_act_maxpool_fwd", 0, 4.0 * n * H * W * C + 7.0 * n * Ho * Wo * C, stream);
+    const QuadDecode dec(C / 4, Wo, Ho);
     DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_maxpool_fwd_kernel<T>), dim3(grid_for((size_t)n * Ho * Wo * C / 4)), dim3(256), 0,
                                          (hipStream_t)stream, y, stats, gamma, beta, out, (T*)out16, idx, n, H, W, C, k, stride, pad, Ho,
-                                         Wo, slope));
+                                         Wo, slope, dec));
     EOE_CHECK_LAUNCH("bn_act_maxpool_fwd");
     return 0;
 }
@@ -757,7 +800,9 @@ extern "C" int eoe_bn_act_maxpool_bwd(const float* y, const float* stats, const 
     EOE_CHECK_ARG((gamma == nullptr) == (beta == nullptr) && (dgamma == nullptr) == (dbeta == nullptr), "bn_act_maxpool_bwd: gamma/beta pairs");
     const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
     hipStream_t s = (hipStream_t)stream;
+    EOE_CHECK_IDX((size_t)n * H * W * C / 4, "bn_act_maxpool_bwd");
     ProfScope ps("bn_act_maxpool_bwd", 0, 2 * 4.0 * n * H * W * C + 2.0 * n * H * W * C + 2 * 5.0 * n * Ho * Wo * C, stream);
+    const QuadDecode dec(C / 4, W, H);
     const int grid = grid_for((size_t)n * H * W * C / 4);
     int g0 = grid > EOE_BN_PARTIALS ? EOE_BN_PARTIALS : grid;
     {
@@ -770,20 +815,15 @@ extern "C" int eoe_bn_act_maxpool_bwd(const float* y, const float* stats, const 
     }
 #define EOE_BMP(MODE, SS, GRID, LDS)                                                                                             \
     DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_maxpool_bwd_kernel<T, MODE, SS>), dim3(GRID), dim3(256), LDS, s, y, stats, gamma, beta, \
-                                         dout, idx, red_scratch, (T*)dy, n, H, W, C, k, stride, pad, Ho, Wo, training, slope))
+                                         dout, idx, red_scratch, (T*)dy, n, H, W, C, k, stride, pad, Ho, Wo, training, slope, dec))
     if (stride == 2) { EOE_BMP(0, 2, g0, 2 * C * sizeof(float)); } else if (stride == 1) { EOE_BMP(0, 1, g0, 2 * C * sizeof(float)); }
     else { EOE_BMP(0, 0, g0, 2 * C * sizeof(float)); }
     EOE_CHECK_LAUNCH("bn_act_maxpool_bwd_reduce");
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * C, 64)), dim3(1024), 0, s, (const float*)(red_scratch + 2 * C), red_scratch, g0,
-                       2 * C);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * C, 16)), dim3(1024), 0, s, (const float*)(red_scratch + 2 * C), red_scratch, g0,
+                       2 * C, dbeta, dgamma, C, 0);
     EOE_CHECK_LAUNCH("bn_act_maxpool_bwd_reduce2");
     if (stride == 2) { EOE_BMP(1, 2, grid, 0); } else if (stride == 1) { EOE_BMP(1, 1, grid, 0); } else { EOE_BMP(1, 0, grid, 0); }
 #undef EOE_BMP
     EOE_CHECK_LAUNCH("bn_act_maxpool_bwd_apply");
-    if (dgamma) {
-        hipLaunchKernelGGL(add_copy_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, dbeta, (const float*)red_scratch, C, 0);
-        hipLaunchKernelGGL(add_copy_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, dgamma, (const float*)(red_scratch + C), C, 0);
-        EOE_CHECK_LAUNCH("bn_act_maxpool_bwd_params");
-    }
     return 0;
 }

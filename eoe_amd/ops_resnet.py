@@ -9,6 +9,7 @@ import torch
 from . import _lib
 from ._lib import check, lib
 from . import ops
+SGATE_RED = 2 + 2 * 512         # EOE_SGATE_RED (include/eoe_hip.h)
 from .ops import BN_SCRATCH, _chk, _grad_target, _p, _stream, scratch, dtype_code
 
 
@@ -119,7 +120,8 @@ class SpatialGateFunction(torch.autograd.Function):
         dx = torch.empty_like(x)
         dscale = scratch("sg_dscale", (n, H, W), torch.float32, dev)
         dcomp = scratch("sg_dcomp", (n, H, W, 2), torch.float32, dev)
-        red = scratch("sg_red", (2,), torch.float32, dev)
+        red = scratch("sg_red", (SGATE_RED,), torch.float32, dev)
+        wpart = scratch("sg_wpart", (n, 98), torch.float32, dev)
         sums = scratch("sg_sums", (BN_SCRATCH,), torch.float32, dev)
         dw = _grad_target(w)
         dg = _grad_target(bn_w) if bn_w is not None else None
@@ -127,7 +129,7 @@ class SpatialGateFunction(torch.autograd.Function):
         wc = w.detach().contiguous()
         f = _lib.SGateArgs(_p(x), None, _p(wc), _p(bn_w), _p(bn_b), None, None, None, _p(comp), _p(argmax), _p(z), _p(stats),
                            _p(scale), _p(sums), n, H, W, Cc, eps, momentum, 1 if training else 0, None, None, 0)
-        b = _lib.SGateBwdArgs(f, _p(dout), _p(dx), _p(dscale), _p(dcomp), _p(red), _p(dw), _p(dg), _p(db))
+        b = _lib.SGateBwdArgs(f, _p(dout), _p(dx), _p(dscale), _p(dcomp), _p(red), _p(dw), _p(dg), _p(db), _p(wpart))
         check(lib.eoe_sgate_bwd(C.byref(b), _stream()), "eoe_sgate_bwd")
         return dx, dw, dg, db, None, None, None, None
 
@@ -173,7 +175,8 @@ class SpatialGateAddReluFunction(torch.autograd.Function):
         dx = torch.empty_like(x)
         dscale = scratch("sg_dscale", (n, H, W), torch.float32, dev)
         dcomp = scratch("sg_dcomp", (n, H, W, 2), torch.float32, dev)
-        red = scratch("sg_red", (2,), torch.float32, dev)
+        red = scratch("sg_red", (SGATE_RED,), torch.float32, dev)
+        wpart = scratch("sg_wpart", (n, 98), torch.float32, dev)
         sums = scratch("sg_sums", (BN_SCRATCH,), torch.float32, dev)
         dw = _grad_target(w)
         dg = _grad_target(bn_w) if bn_w is not None else None
@@ -181,7 +184,7 @@ class SpatialGateAddReluFunction(torch.autograd.Function):
         wc = w.detach().contiguous()
         f = _lib.SGateArgs(_p(x), None, _p(wc), _p(bn_w), _p(bn_b), None, None, None, _p(comp), _p(argmax), _p(z), _p(stats),
                            _p(scale), _p(sums), n, H, W, Cc, eps, momentum, 1 if training else 0, None, None, 0)
-        b = _lib.SGateBwdArgs(f, _p(g), _p(dx), _p(dscale), _p(dcomp), _p(red), _p(dw), _p(dg), _p(db))
+        b = _lib.SGateBwdArgs(f, _p(g), _p(dx), _p(dscale), _p(dcomp), _p(red), _p(dw), _p(dg), _p(db), _p(wpart))
         check(lib.eoe_sgate_bwd(C.byref(b), _stream()), "eoe_sgate_bwd")
         return dx, g, dw, dg, db, None, None, None, None
 

@@ -379,16 +379,19 @@ typedef struct {
     void* out16;          /* optional with res: 16-bit copy of out (operand of the next convolution) */
     int dtype;            /* EOE_F16 | EOE_BF16 of out16 */
 } eoe_sgate_args;
+#define EOE_SGATE_PARTIALS 512
+#define EOE_SGATE_RED (2 + 2 * EOE_SGATE_PARTIALS)
 typedef struct {
     eoe_sgate_args f;
     const float* dout;    /* [n, H, W, C] */
     float* dx;            /* [n, H, W, C] */
     float* dscale;        /* [n, H, W]    scratch */
     float* dcomp;         /* [n, H, W, 2] scratch */
-    float* red;           /* [2] scratch */
+    float* red;           /* [EOE_SGATE_RED] scratch: per-workgroup partial sums of the 1-channel BatchNorm backward */
     float* dw;            /* [1, 2, 7, 7] written */
     float* dgamma;        /* [1] or NULL */
     float* dbeta;         /* [1] or NULL */
+    float* wpart;         /* [n, 98] scratch: per-image partial sums of dw (added up in a fixed order: no atomics) */
 } eoe_sgate_bwd_args;
 int eoe_sgate_fwd(const eoe_sgate_args* a, void* stream);
 int eoe_sgate_bwd(const eoe_sgate_bwd_args* a, void* stream);

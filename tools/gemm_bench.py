@@ -6,6 +6,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import eoe_amd.ops as ops
 
+if os.environ.get("EOE_NT_FLAGS"):
+    from eoe_amd import _lib
+    _lib.check(_lib.lib.eoe_set_option(b"nt_flags", int(os.environ["EOE_NT_FLAGS"])), "eoe_set_option")
 dt = torch.float16 if (len(sys.argv) < 2 or sys.argv[1] == "fp16") else torch.bfloat16
 M = 12800
 shapes_nt = [("qkv fwd", M, 2304, 768, "none"), ("out fwd", M, 768, 768, "res"), ("fc fwd", M, 3072, 768, "gelu"),
