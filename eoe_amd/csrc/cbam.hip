@@ -87,7 +87,30 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restric
     int arg[4] = {0, 0, 0, 0};
     const float* pa = a + (size_t)img * HW * C + c;
     const float* pb = MODE == 1 ? b + (size_t)img * HW * C + c : nullptr;
-    for (int hw = rl; hw < HW; hw += rpb) {
+    // one workgroup per CU at C = 64 (grid = n x 1): keep U independent 16-B loads in flight per thread -- with a single
+    // outstanding load per thread this pass ran at 1.7 TB/s
+    constexpr int U = MODE == 0 ? 8 : 4;
+    int hw = rl;
+    for (; hw + (U - 1) * rpb < HW; hw += U * rpb) {
+        f32x4 v[U], w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v[u] = *(const f32x4*)(pa + (size_t)(hw + u * rpb) * C);
+            if (MODE == 1) w[u] = *(const f32x4*)(pb + (size_t)(hw + u * rpb) * C);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (MODE == 0) {
+                s += v[u];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (v[u][r] > m[r]) { m[r] = v[u][r]; arg[r] = hw + u * rpb; }      // increasing hw: first maximum wins
+            } else {
+                s += v[u] * w[u];
+            }
+        }
+    }
+    for (; hw < HW; hw += rpb) {
         const f32x4 v = *(const f32x4*)(pa + (size_t)hw * C);
         if (MODE == 0) {
             s += v;
@@ -445,15 +468,21 @@ __global__ __launch_bounds__(256) void sgate_conv_bwd_data_kernel(const float* _
         *(f32x2*)(dcomp + p * 2) = (f32x2){a0, a1};
     }
 }
-// dw[ch, ky, kx] = sum_p dz[p] * comp[(y+ky-3, x+kx-3), ch].  One workgroup per image: the image's comp plane sits in LDS, a
-// thread walks its pixels with all 98 taps in registers (98 LDS reads + FMAs per pixel; the first version ran one workgroup
-// per (tap, pixel chunk) and re-read dz / comp 98 times through L2: 52 us average), the workgroup's sums go to
-// part[img][98]; sgate_wpart_sum_kernel adds the images up in a fixed order -- no atomics.
+// dw[ch, ky, kx] = sum_p dz[p] * comp[(y+ky-3, x+kx-3), ch].  One workgroup per image: the image's comp plane sits in LDS with
+// a 3-pixel zero halo (no bounds tests in the tap loop), a thread walks its pixels with all 98 taps in registers (49 8-byte
+// LDS reads + 98 FMAs per pixel; the first version ran one workgroup per (tap, pixel chunk) and re-read dz / comp 98 times
+// through L2: 52 us average).  The 256 x 98 per-thread sums are added through LDS in two halves of 49 taps, in a fixed
+// order, into part[img][98]; sgate_wpart_sum_kernel adds the images up -- no atomics.
 __global__ __launch_bounds__(256) void sgate_conv_bwd_weight_kernel(const float* __restrict__ dz, const float* __restrict__ comp,
                                                                     float* __restrict__ part, int H, int W) {
-    extern __shared__ float lc[];                  // [H*W][2], then reused as [4 waves][98]
-    const int img = blockIdx.x, HW = H * W;
-    for (int i = threadIdx.x; i < HW * 2; i += blockDim.x) lc[i] = comp[(size_t)img * HW * 2 + i];
+    extern __shared__ float lc[];                  // [(H+6)*(W+6)][2] padded plane, then reused as [256][49] + [4][49]
+    const int img = blockIdx.x, HW = H * W, Wp = W + 6, plane = (H + 6) * Wp * 2;
+    for (int i = threadIdx.x; i < plane; i += blockDim.x) lc[i] = 0.f;
+    __syncthreads();
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+        const int y = i / W, x = i - y * W;
+        *(f32x2*)(lc + ((y + 3) * Wp + x + 3) * 2) = *(const f32x2*)(comp + ((size_t)img * HW + i) * 2);
+    }
     __syncthreads();
     float acc[98];
 #pragma unroll
@@ -461,31 +490,35 @@ __global__ __launch_bounds__(256) void sgate_conv_bwd_weight_kernel(const float*
     for (int p = threadIdx.x; p < HW; p += blockDim.x) {
         const int y = p / W, x = p - y * W;
         const float d = dz[(size_t)img * HW + p];
+        const float* base = lc + (y * Wp + x) * 2;         // window origin (y-3, x-3) in padded coordinates
 #pragma unroll
-        for (int ky = 0; ky < 7; ++ky) {
-            const int yy = y + ky - 3;
-            if (yy < 0 || yy >= H) continue;
+        for (int ky = 0; ky < 7; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 7; ++kx) {
-                const int xx = x + kx - 3;
-                if (xx < 0 || xx >= W) continue;
-                const f32x2 c = *(const f32x2*)(lc + (yy * W + xx) * 2);
+                const f32x2 c = *(const f32x2*)(base + (ky * Wp + kx) * 2);
                 acc[ky * 7 + kx] += d * c[0];
                 acc[49 + ky * 7 + kx] += d * c[1];
             }
+    }
+    float* stage = lc;                             // [256][49]
+    float* quarter = lc + 256 * 49;                // [4][49]
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();                           // plane (half 0) / previous stage (half 1) fully consumed
+#pragma unroll
+        for (int t = 0; t < 49; ++t) stage[threadIdx.x * 49 + t] = acc[half * 49 + t];
+        __syncthreads();
+        if (threadIdx.x < 196) {                   // 4 row quarters x 49 taps
+            const int t = threadIdx.x % 49, q = threadIdx.x / 49;
+            float v = 0.f;
+            for (int r = q * 64; r < q * 64 + 64; ++r) v += stage[r * 49 + t];
+            quarter[q * 49 + t] = v;
         }
+        __syncthreads();
+        if (threadIdx.x < 49)
+            part[(size_t)img * 98 + half * 49 + threadIdx.x] =
+                (quarter[threadIdx.x] + quarter[49 + threadIdx.x]) + (quarter[98 + threadIdx.x] + quarter[147 + threadIdx.x]);
     }
-    __syncthreads();                               // everyone is done reading the comp plane
-#pragma unroll
-    for (int t = 0; t < 98; ++t) {
-        float v = acc[t];
-#pragma unroll
-        for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft, 64);
-        if ((threadIdx.x & 63) == 0) lc[(threadIdx.x >> 6) * 98 + t] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < 98)
-        part[(size_t)img * 98 + threadIdx.x] = (lc[threadIdx.x] + lc[98 + threadIdx.x]) + (lc[196 + threadIdx.x] + lc[294 + threadIdx.x]);
 }
 // dw[t] = sum_img part[img][t]: one wavefront per tap
 __global__ __launch_bounds__(64) void sgate_wpart_sum_kernel(const float* __restrict__ part, float* __restrict__ dw, int n) {
@@ -684,7 +717,7 @@ extern "C" int eoe_sgate_bwd(const eoe_sgate_bwd_args* b, void* stream) {
     const eoe_sgate_args* a = &b->f;
     EOE_TRY(check_sgate(a));
     EOE_CHECK_ARG(b->dout && b->dx && b->dscale && b->dcomp && b->red && b->dw && b->wpart, "sgate_bwd: null args");
-    EOE_CHECK_ARG(a->H * a->W <= 8192, "sgate_bwd: feature map too large (%d x %d)", a->H, a->W);
+    EOE_CHECK_ARG((a->H + 6) * (a->W + 6) <= 8192, "sgate_bwd: feature map too large (%d x %d)", a->H, a->W);
     EOE_CHECK_ARG((b->dgamma == nullptr) == (b->dbeta == nullptr), "sgate_bwd: dgamma/dbeta must both be given or both NULL");
     hipStream_t s = (hipStream_t)stream;
     const size_t P = (size_t)a->n * a->H * a->W;
@@ -701,8 +734,8 @@ extern "C" int eoe_sgate_bwd(const eoe_sgate_bwd_args* b, void* stream) {
                        a->H, a->W);
     EOE_CHECK_LAUNCH("sgate_conv_bwd_data");
     {
-        size_t lds = (size_t)a->H * a->W * 2 * sizeof(float);
-        if (lds < 4 * 98 * sizeof(float)) lds = 4 * 98 * sizeof(float);
+        size_t lds = (size_t)(a->H + 6) * (a->W + 6) * 2 * sizeof(float);
+        if (lds < (256 + 4) * 49 * sizeof(float)) lds = (256 + 4) * 49 * sizeof(float);
         hipLaunchKernelGGL(sgate_conv_bwd_weight_kernel, dim3(a->n), dim3(256), lds, s, (const float*)b->dscale, a->comp, b->wpart, a->H,
                            a->W);
         hipLaunchKernelGGL(sgate_wpart_sum_kernel, dim3(98), dim3(64), 0, s, (const float*)b->wpart, b->dw, a->n);

@@ -300,16 +300,33 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
     }
 }
 
-// C[m][n] = alpha * sum_s part[s][m][n] (+ C if accumulate); 4 columns per thread
+// C[m][n] = alpha * sum_s part[s][m][n] (+ C if accumulate).  A workgroup owns 64 column quads; its 4 wavefronts take the
+// splits s = w, w+4, ... with four independent 16-B loads in flight each and are combined through LDS in a fixed order (one
+// thread walking all the splits serially was a chain of up to 85 dependent loads: 18 us average, 62 us worst case).
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, int M, int N, int ldc,
                                                         int splits, float alpha, int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ f32x4 red[4][64];
+    const int q = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + q;
     const int n4 = N / 4;
-    if (i >= M * n4) return;
-    const int m = i / n4, n = (i - m * n4) * 4;
+    const bool valid = i < M * n4;
+    const int m = valid ? i / n4 : 0, n = valid ? (i - m * n4) * 4 : 0;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < splits; ++k) s += *(const f32x4*)(part + ((size_t)k * M + m) * N + n);
-    s *= alpha;
+    if (valid) {
+        const float* p = part + (size_t)m * N + n;
+        const size_t st = (size_t)M * N;
+        int k = w;
+        for (; k + 12 < splits; k += 16) {
+            const f32x4 a = *(const f32x4*)(p + k * st), b = *(const f32x4*)(p + (k + 4) * st);
+            const f32x4 c = *(const f32x4*)(p + (k + 8) * st), d = *(const f32x4*)(p + (k + 12) * st);
+            s += (a + b) + (c + d);
+        }
+        for (; k < splits; k += 4) s += *(const f32x4*)(p + k * st);
+    }
+    red[w][q] = s;
+    __syncthreads();
+    if (w != 0 || !valid) return;
+    s = ((red[0][q] + red[1][q]) + (red[2][q] + red[3][q])) * alpha;
     float* c = C + (size_t)m * ldc + n;
     if ((ldc & 3) == 0) {
         if (accumulate) s += *(const f32x4*)c;
@@ -436,7 +453,7 @@ extern "C" int eoe_gemm_tn_grouped(const eoe_gemm_args* args, int count, void* s
     EOE_CHECK_LAUNCH("gemm_tn_grouped");
     if (g.part) {
         for (int i = 0; i < count; ++i) {
-            hipLaunchKernelGGL(tn_reduce_kernel, dim3(cdiv(args[i].M * (args[i].N / 4), 256)), dim3(256), 0, s,
+            hipLaunchKernelGGL(tn_reduce_kernel, dim3(cdiv(args[i].M * (args[i].N / 4), 64)), dim3(256), 0, s,
                                (const float*)(g.part + g.part_stride[i]), (float*)args[i].C, args[i].M, args[i].N, args[i].ldc, splits,
                                g.alpha, g.accumulate);
         }

@@ -830,6 +830,7 @@ class ConvBnActPoolFunction(torch.autograd.Function):
         if out16 is None:
             return out
         ctx.mark_non_differentiable(out16)
+        ctx.set_materialize_grads(False)       # else autograd zero-fills a gradient for the 16-bit copy every step
         return out, out16
 
     @staticmethod

@@ -30,6 +30,7 @@ class MaxPoolFunction(torch.autograd.Function):
         ctx.save_for_backward(idx)
         ctx.geo = (n, H, W, Cc, k, stride, pad)
         ctx.mark_non_differentiable(out16)
+        ctx.set_materialize_grads(False)       # else autograd zero-fills a gradient for the 16-bit copy every step
         return out, out16
 
     @staticmethod
@@ -161,6 +162,7 @@ class SpatialGateAddReluFunction(torch.autograd.Function):
         ctx.save_for_backward(x, w, bn_w, bn_b, comp, argmax, z, stats, scale, out)
         ctx.cfg = (training, float(eps), float(momentum))
         ctx.mark_non_differentiable(out16)
+        ctx.set_materialize_grads(False)       # else autograd zero-fills a gradient for the 16-bit copy every step
         return out, out16
 
     @staticmethod
@@ -209,6 +211,7 @@ class AddReluFunction(torch.autograd.Function):
               "eoe_add_relu_fwd")
         ctx.save_for_backward(out)
         ctx.mark_non_differentiable(out16)
+        ctx.set_materialize_grads(False)       # else autograd zero-fills a gradient for the 16-bit copy every step
         return out, out16
 
     @staticmethod
