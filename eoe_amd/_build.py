@@ -52,7 +52,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     # link next to the target and rename over it: a process that has the old library mapped keeps a valid image (writing
     # into the mapped file in place leaves it with a torn code object -- every launch then fails with "no ROCm-capable device")
     tmp = LIB + f".tmp{os.getpid()}"
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
+    # --no-undefined: a kernel whose host stub the compiler dropped must fail the build here, not at dlopen on the GPU box
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--no-undefined", "-o", tmp] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

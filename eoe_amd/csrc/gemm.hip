@@ -171,11 +171,11 @@ __device__ __forceinline__ void epilogue_generic(const GemmP& p, f32x4 (&acc)[MI
 // program order after these reads), so that a lane holds 16 consecutive columns of one row: bias / residual / saved
 // pre-activation are read, and the result is written, as 64-byte (fp32) or 32-byte (16-bit) contiguous pieces, 4 lanes
 // per row = whole 128/256-byte lines per row.
-template <typename T, int EPI, int NI>
-__device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[4][NI], int m_base, int n_base, int lane, char* scr) {
+template <typename T, int EPI, int NI, int MI = 4>
+__device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][NI], int m_base, int n_base, int lane, char* scr) {
     const bool fast = ((p.N & 15) == 0) && ((p.ldc & 7) == 0) && ((p.ldaux & 7) == 0) && ((((uintptr_t)p.C) & 15) == 0);
     if (!fast) {
-        epilogue_generic<T, EPI, NI, 4>(p, acc, m_base, n_base, lane);
+        epilogue_generic<T, EPI, NI, MI>(p, acc, m_base, n_base, lane);
         return;
     }
     const int lr = lane & 15, lg = lane >> 4;
@@ -197,7 +197,7 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[4][NI], in
         }
     }
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
         // accumulator layout -> LDS [16 rows][64 cols] fp32, 16-B chunk index XOR row (bank spread)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) *(f32x4*)(scr + lr * 256 + (((ni * 4 + lg) ^ lr) << 4)) = acc[mi][ni];
@@ -545,64 +545,78 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
 // each SIMD holds one wave of each, so one workgroup's stalls are the other's issue slots.  Non-persistent on purpose: one tile
 // per workgroup, dispatched as slots free up, which de-synchronises the two workgroups of a CU (a persistent tile loop with
 // cross-tile prefetch kept them in lockstep and measured 5-13 % slower on the heavy-epilogue shapes).  Tiles XCD-remapped.  Same LDS image / swizzle / fragment layout / epilogues as gemm_nt_kernel.
-constexpr int A128_BYTES = 128 * BK * 2;            // 16 KiB
-constexpr int STAGE128_BYTES = 2 * A128_BYTES;      // A + B: 32 KiB
-constexpr int SMEM128_BYTES = 2 * STAGE128_BYTES;   // 64 KiB: two workgroups per CU
+// MI = 16-row MFMA tiles per wave along M: the workgroup tile is (32*MI) x 128.  MI = 4 (128x128) is the default; MI = 5
+// (160x128) is chosen when it quantises better over the 2 x #CU workgroup slots (N = 768, M = 12800: 480 tiles in one round
+// instead of 600 in two).
+constexpr int B128_BYTES = 128 * BK * 2;                                          // 16 KiB
+constexpr int a128_bytes(int MI) { return 32 * MI * BK * 2; }                     // 16 / 20 KiB
+constexpr int stage128_bytes(int MI) { return a128_bytes(MI) + B128_BYTES; }      // 32 / 36 KiB
+constexpr int smem128_bytes(int MI) { return 2 * stage128_bytes(MI); }            // 64 / 72 KiB: two workgroups per CU
 
-template <typename T, int EPI>
+template <typename T, int EPI, int MI>
 __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmP p) {
+    constexpr int BM = 32 * MI, A128_BYTES = a128_bytes(MI), STAGE128_BYTES = stage128_bytes(MI);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NI = 4;
     const int tiles_n = (p.N + 127) / 128;
-    const int total_tiles = tiles_n * ((p.M + 127) / 128);
+    const int total_tiles = tiles_n * ((p.M + BM - 1) / BM);
     const int r = xcd_remap((int)blockIdx.x, total_tiles);
-    const int m0 = (r / tiles_n) * 128, n0 = (r % tiles_n) * 128;
+    const int m0 = (r / tiles_n) * BM, n0 = (r % tiles_n) * 128;
     const int nk = p.K / BK;
 
     __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.bytesA);
     __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.bytesB);
-    // 128 rows = 16 wave-loads per operand, 4 per wave; lane -> (row, 16-B slot holding chunk slot ^ ((row>>1)&7))
-    unsigned offA[4], offB[4];
+    // a wave-load covers 8 rows: MI per wave for A (BM rows), 4 per wave for B (128 rows);
+    // lane -> (row, 16-B slot holding chunk slot ^ ((row>>1)&7))
+    // offA has a FIXED extent: with `unsigned offA[MI]` feeding the LDS-DMA builtin hipcc (ROCm 7.2) silently drops the HOST
+    // stub of every instantiation of this kernel and the library fails to load with an undefined symbol
+    unsigned offA[5], offB[4];
+    static_assert(MI <= 5, "offA");
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+        const int row = (wave * MI + j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        offA[j] = (m0 + row < p.M) ? (unsigned)(((size_t)(m0 + row) * p.lda + c * 8) * 2) : EOE_OOB;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int row = (wave * 4 + j) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);
-        offA[j] = (m0 + row < p.M) ? (unsigned)(((size_t)(m0 + row) * p.lda + c * 8) * 2) : EOE_OOB;
         offB[j] = (n0 + row < p.N) ? (unsigned)(((size_t)(n0 + row) * p.ldb + c * 8) * 2) : EOE_OOB;
     }
-    auto stage = [&](int slot, int kt) {                 // 8 LDS-DMA instructions per wave per k-tile
-        char* sa = smem + slot * STAGE128_BYTES;
-        char* sb = sa + A128_BYTES;
-        const unsigned k0 = (unsigned)kt * (BK * 2u);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(sa + (wave * 4 + j) * 1024), 16, offA[j] + k0, 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(sb + (wave * 4 + j) * 1024), 16, offB[j] + k0, 0, 0, 0);
-    };
+    // MI + 4 LDS-DMA instructions per wave per k-tile
+#define EOE_STAGE128(slot, kt)                                                                                              \
+    do {                                                                                                                    \
+        char* sa_ = smem + (slot) * STAGE128_BYTES;                                                                         \
+        char* sb_ = sa_ + A128_BYTES;                                                                                       \
+        const unsigned k0_ = (unsigned)(kt) * (BK * 2u);                                                                    \
+        _Pragma("unroll") for (int j = 0; j < MI; ++j)                                                                      \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(sa_ + (wave * MI + j) * 1024), 16, offA[j] + k0_, 0, 0, 0); \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                       \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(sb_ + (wave * 4 + j) * 1024), 16, offB[j] + k0_, 0, 0, 0); \
+    } while (0)
 
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int wm0 = (wave >> 1) * (16 * MI), wn0 = (wave & 1) * 64;
     const int lr = lane & 15, lg = lane >> 4;
     const int sw = (lr >> 1) & 7;                        // wm0, wn0 are multiples of 16: (row>>1)&7 depends on lr only
     const int fragA = (wm0 + lr) * 128, fragB = A128_BYTES + (wn0 + lr) * 128;
     const int ch0 = ((0 + lg) ^ sw) * 16, ch1 = ((4 + lg) ^ sw) * 16;
     typedef typename T16<T>::v8 V8;
 
-    f32x4 acc[4][NI];
+    f32x4 acc[MI][NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
 #define EOE_READ128(XA, WB, base, ks)                                                     \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i)                                        \
         XA[i] = *(const V8*)((base) + fragA + i * 2048 + ((ks) ? ch1 : ch0));             \
-        WB[i] = *(const V8*)((base) + fragB + i * 2048 + ((ks) ? ch1 : ch0));             \
-    }
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                         \
+        WB[i] = *(const V8*)((base) + fragB + i * 2048 + ((ks) ? ch1 : ch0));
 #define EOE_MFMA128(XA, WB)                                               \
-    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                      \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                     \
         _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T16<T>::mfma16(WB[ni], XA[mi], acc[mi][ni]);
 
     // 2-stage ring with register double-buffered fragments (the schedule of gemm_nt_kernel with one stage less):
@@ -611,10 +625,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmP p) {
     //   WAR: stage(kt+2) overwrites slot kt&1 after the barrier behind which every wave's reads of it (F0 in iteration kt-1,
     //        F1 in this one) have completed.   RAW: the DMA of tile kt+1 was issued one iteration ago; each wave waits for its
     //        own pieces before the barrier, the reads come after it.
-    V8 xa0[4], wb0[4], xa1[4], wb1[4];
-    stage(0, 0);
-    if (nk > 1) stage(1, 1);
-    if (nk > 1) { EOE_WAIT_VM(8); } else { EOE_WAIT_VM(0); }
+    V8 xa0[MI], wb0[4], xa1[MI], wb1[4];
+    EOE_STAGE128(0, 0);
+    if (nk > 1) EOE_STAGE128(1, 1);
+    if (nk > 1) {                                  // tile 0 landed, tile 1 (MI + 4 loads per wave) may stay in flight
+        if (MI == 5) { EOE_WAIT_VM(9); } else { EOE_WAIT_VM(8); }
+    } else {
+        EOE_WAIT_VM(0);
+    }
     __builtin_amdgcn_s_barrier();
     EOE_READ128(xa0, wb0, smem, 0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -625,7 +643,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmP p) {
         EOE_WAIT_VM(0);
         EOE_WAIT_LGKM0();
         __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) stage(kt & 1, kt + 2);
+        if (kt + 2 < nk) EOE_STAGE128(kt & 1, kt + 2);
         EOE_READ128(xa0, wb0, sn, 0);          // unconditional (the last one reads a stale slot and is discarded)
         EOE_MFMA128(xa1, wb1);
     }
@@ -633,19 +651,26 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmP p) {
     __builtin_amdgcn_s_barrier();               // every wave is done reading the ring before the epilogue's scratch use
 #undef EOE_READ128
 #undef EOE_MFMA128
+#undef EOE_STAGE128
     GemmP ep;
     load_epilogue_args(ep, p);
     // scratch: this wave's own 4 KiB of slot 0 (all reads of the ring are behind the final barrier)
-    epilogue<T, EPI, NI>(ep, acc, m0 + wm0, n0 + wn0, lane, smem + wave * 4096);
+    epilogue<T, EPI, NI, MI>(ep, acc, m0 + wm0, n0 + wn0, lane, smem + wave * 4096);
 }
 
-template <typename T>
+static int num_cus() {
+    static const int ncu = [] { int d = 0, n = 256; hipDeviceProp_t pr; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) n = pr.multiProcessorCount; return n; }();
+    return ncu;
+}
+extern int g_nt_flags;
+
+template <typename T, int MI>
 int launch_nt128(const GemmP& p, int epi, hipStream_t s) {
-    const int tiles = cdiv(p.M, 128) * cdiv(p.N, 128);
+    const int tiles = cdiv(p.M, 32 * MI) * cdiv(p.N, 128);
 #define EOE_NT128_CASE(E)                                                                   \
     case E:                                                                                 \
-        { static bool once = (hipFuncSetAttribute((const void*)gemm_nt128_kernel<T, E>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM128_BYTES), true); (void)once; } \
-        hipLaunchKernelGGL((gemm_nt128_kernel<T, E>), dim3(tiles), dim3(256), SMEM128_BYTES, s, p); \
+        { static bool once = (hipFuncSetAttribute((const void*)gemm_nt128_kernel<T, E, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem128_bytes(MI)), true); (void)once; } \
+        hipLaunchKernelGGL((gemm_nt128_kernel<T, E, MI>), dim3(tiles), dim3(256), smem128_bytes(MI), s, p); \
         break;
     switch (epi) {
         EOE_NT128_CASE(EOE_EPI_NONE)
@@ -657,6 +682,15 @@ int launch_nt128(const GemmP& p, int epi, hipStream_t s) {
 #undef EOE_NT128_CASE
     EOE_CHECK_LAUNCH("gemm_nt128");
     return 0;
+}
+// 128- or 160-row tiles: whichever needs less (rounds over the 2 x #CU workgroup slots) x (rows per tile)
+template <typename T>
+int launch_nt128_auto(const GemmP& p, int epi, hipStream_t s) {
+    const int slots = 2 * num_cus();
+    const long t4 = (long)cdiv(p.M, 128) * cdiv(p.N, 128), t5 = (long)cdiv(p.M, 160) * cdiv(p.N, 128);
+    const long c4 = (t4 + slots - 1) / slots * 128, c5 = (t5 + slots - 1) / slots * 160;
+    const bool five = (g_nt_flags & 32) || (!(g_nt_flags & 16) && c5 < c4);
+    return five ? launch_nt128<T, 5>(p, epi, s) : launch_nt128<T, 4>(p, epi, s);
 }
 
 // Variants measured and rejected (interleaved A/B on one device with tools/gemm_ab.py, layer total of the 8 forward +
@@ -716,7 +750,7 @@ int launch_nt_ni(const GemmP& p, int epi, int grid, hipStream_t s) {
 
 template <typename T>
 int launch_nt(const GemmP& p, int epi, int gather, hipStream_t s) {
-    static const int ncu = [] { int d = 0, n = 256; hipDeviceProp_t pr; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) n = pr.multiProcessorCount; return n; }();
+    const int ncu = num_cus();
     if (gather || (epi == EOE_EPI_NONE && p.N <= 64)) {
         const bool narrow = p.N <= 64;               // 256x64 tiles: no MFMA / LDS work on columns that do not exist
         const int tiles = cdiv(p.M, BM) * cdiv(p.N, narrow ? 64 : 128);
@@ -726,12 +760,14 @@ int launch_nt(const GemmP& p, int epi, int gather, hipStream_t s) {
         if (gather) return narrow ? launch_nt_conv<T, 2, 1>(p, grid, s) : launch_nt_conv<T, 4, 1>(p, grid, s);
         return launch_nt_conv<T, 2, 0>(p, grid, s);
     }
-    // Tile shape (measured interleaved, tools/gemm_ab.py 5 9, M = 12800): the two-workgroup 128x128 kernel wins on every ViT
-    // shape but the GELU forward (99.9 vs 102.2 us) -- most where the epilogue is heavy against a short K loop (GELU' x dY
-    // 116 -> 97 us, fp32 residual 42 -> 37 us), a few % on the plain ones -- 553 vs 588 us per layer; the persistent 256-row
-    // kernel keeps large square problems (4096^3: 1046 vs 984 TF).  nt_flags bit 3 forces the 128 kernel, bit 2 forbids it.
+    // Tile shape (tools/gemm_bench.py, M = 12800): the two-workgroup kernel (128- or 160-row tiles, launch_nt128_auto) wins on
+    // every ViT shape -- most where the epilogue is heavy against a short K loop (GELU' x dY 116 -> 94 us, fp32 residual
+    // 42 -> 32 us, GELU forward 107 -> 96 us once its epilogue math was cheap) and, with 160-row tiles, on the N = 768 shapes
+    // whose 600 128x128 tiles need two rounds over the 512 workgroup slots (480 tiles of 160x128: one round; K = 3072:
+    // 83 -> 68 us = 887 TF, K = 2304: 61 -> 50 us = 916 TF).  The persistent 256-row kernel keeps large square problems
+    // (4096^3: 1046 vs 984 TF).  nt_flags: bit 3 forces the two-workgroup kernel, bit 2 forbids it, bit 4 / 5 force 128 / 160 rows.
     const bool big = p.K >= 4096 && p.N >= 2048;
-    if ((g_nt_flags & 8) || (epi != EOE_EPI_GELU && !big && !(g_nt_flags & 4))) return launch_nt128<T>(p, epi, s);
+    if ((g_nt_flags & 8) || (!big && !(g_nt_flags & 4))) return launch_nt128_auto<T>(p, epi, s);
     // tile width: 256x128 unless 256x96 needs >= 10 % fewer (rounds x width) units over the CUs
     const int t4 = cdiv(p.M, BM) * cdiv(p.N, 128), t3 = cdiv(p.M, BM) * cdiv(p.N, 96);
     const int c4 = cdiv(t4, ncu) * 4, c3 = cdiv(t3, ncu) * 3;
