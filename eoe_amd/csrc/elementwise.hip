@@ -203,7 +203,7 @@ __global__ __launch_bounds__(512) void layernorm_bwd_kernel(const void* __restri
                                      const float* __restrict__ stats, const float* __restrict__ gamma,
                                      const float* __restrict__ dres, float* __restrict__ dx_out, int ld_out,
                                      T* __restrict__ dx16, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                     float* __restrict__ dxsum, int rows, int D) {
+                                     float* __restrict__ dxsum, float* __restrict__ part, int rows, int D) {
     // 8 waves per workgroup (16 waves per CU at 2 workgroups: enough loads in flight for an HBM-bound kernel)
     constexpr int NW = 8;
     extern __shared__ float red_raw[];               // [3][NW][256*NV]
@@ -281,12 +281,44 @@ __global__ __launch_bounds__(512) void layernorm_bwd_kernel(const void* __restri
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) { a0 += red[0][w][c]; a1 += red[1][w][c]; a2 += red[2][w][c]; }
+        if (part) {                                  // this workgroup's partial row [3][D]; ln_reduce_kernel adds the rows up
+            float* row = part + (size_t)blockIdx.x * 3 * D;
+            row[c] = a0;
+            row[D + c] = a1;
+            row[2 * D + c] = a2;
+            continue;
+        }
         if (dgamma) {
             atomicAdd(dgamma + c, a0);
             atomicAdd(dbeta + c, a1);
         }
         if (dxsum) atomicAdd(dxsum + c, a2);
     }
+}
+// dgamma / dbeta / dxsum += column sums of the P partial rows [P][3][D] written by layernorm_bwd_kernel, in a fixed order:
+// 16 columns x 64 row lanes per workgroup, four independent loads in flight per thread
+__global__ __launch_bounds__(1024) void ln_reduce_kernel(const float* __restrict__ part, int P, int D, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta, float* __restrict__ dxsum) {
+    __shared__ float l[64][17];
+    const int col = threadIdx.x & 15, lane = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + col, n = 3 * D;
+    float s = 0.f;
+    if (i < n) {
+        int p = lane;
+        for (; p + 192 < P; p += 256) {
+            const float a = part[(size_t)p * n + i], b = part[(size_t)(p + 64) * n + i], c = part[(size_t)(p + 128) * n + i],
+                        d = part[(size_t)(p + 192) * n + i];
+            s += (a + b) + (c + d);
+        }
+        for (; p < P; p += 64) s += part[(size_t)p * n + i];
+    }
+    l[lane][col] = s;
+    __syncthreads();
+    if (lane != 0 || i >= n) return;
+    for (int k = 1; k < 64; ++k) s += l[k][col];
+    const int which = i / D, c = i - which * D;
+    float* dst = which == 0 ? dgamma : (which == 1 ? dbeta : dxsum);
+    if (dst) dst[c] += s;
 }
 
 // ------------------------------------------------------------------------------------------ embed + ln_pre
@@ -835,19 +867,25 @@ extern "C" int eoe_layernorm_fwd(const float* x, int ldx, const float* gamma, co
 
 extern "C" int eoe_layernorm_bwd(const void* dy, int dy_f32, const float* x, int ldx, const float* stats,
                                  const float* gamma, const float* dres, float* dx_out, int ld_out, void* dx16,
-                                 float* dgamma, float* dbeta, float* dxsum, int rows, int D, int dtype,
+                                 float* dgamma, float* dbeta, float* dxsum, float* red_scratch, int rows, int D, int dtype,
                                  void* stream) {
     EOE_CHECK_ARG(dy && x && stats && gamma && dx_out && rows > 0, "layernorm_bwd: bad args");
     EOE_CHECK_ARG(D % 256 == 0 && D <= 1024 && ldx % 4 == 0 && ld_out % 4 == 0, "layernorm: D must be a multiple of 256, <= 1024");
     EOE_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma/dbeta must both be given or both NULL");
     ProfScope ps("layernorm_bwd", 0, ((dy_f32 ? 4.0 : 2.0) + 4.0 + (dres ? 4.0 : 0.0) + 4.0 + (dx16 ? 2.0 : 0.0)) * rows * D, stream);
     int grid = cdiv(rows, 8);
-    if (grid > 512) grid = 512;
+    if (grid > EOE_LN_PARTIALS) grid = EOE_LN_PARTIALS;
+    float* part = (dgamma || dxsum) ? red_scratch : nullptr;
     DISPATCH_T(dtype, DISPATCH_NV(D, hipFuncSetAttribute((const void*)layernorm_bwd_kernel<T, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 8 * 256 * NV * 4);
                                   hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV>), dim3(grid), dim3(512), 3 * 8 * 256 * NV * 4, (hipStream_t)stream, dy,
                                          dy_f32, x, ldx, stats, gamma, dres, dx_out, ld_out, (T*)dx16, dgamma, dbeta,
-                                         dxsum, rows, D)));
+                                         dxsum, part, rows, D)));
     EOE_CHECK_LAUNCH("layernorm_bwd");
+    if (part) {
+        hipLaunchKernelGGL(ln_reduce_kernel, dim3(cdiv(3 * D, 16)), dim3(1024), 0, (hipStream_t)stream, (const float*)part, grid, D, dgamma,
+                           dbeta, dxsum);
+        EOE_CHECK_LAUNCH("layernorm_bwd_reduce");
+    }
     return 0;
 }
 

@@ -86,7 +86,7 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
     g = gemm(b->dh, a->w_fc_t, b->d16_b, nullptr, M, D, H, H, H, D, dt);                    // d xn2
     TRY(eoe_gemm_nt(&g, stream));
     TRY(eoe_layernorm_bwd(b->d16_b, 0, a->x_mid, D, a->stats2, a->ln2_g, b->dx_out, b->dx_mid, D, b->d16_c, b->g_ln2_g,
-                          b->g_ln2_b, b->g_b_out, M, D, dt, stream));                       // + db_out = colsum(dx_mid)
+                          b->g_ln2_b, b->g_b_out, b->ln_scratch, M, D, dt, stream));        // + db_out = colsum(dx_mid)
     // ---- attention branch:  x_mid = x_in + out_proj(attn(ln_1(x_in)))
     g = gemm(b->d16_c, a->w_out_t, b->d16_b, nullptr, M, D, D, D, D, D, dt);                // d att
     TRY(eoe_gemm_nt(&g, stream));
@@ -102,6 +102,6 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
     for (int i = 0; i < 4; ++i) { w[i].out_f32 = 1; w[i].accumulate = acc; }
     TRY(eoe_gemm_tn_grouped(w, 4, stream));
     TRY(eoe_layernorm_bwd(b->d16_b, 0, a->x_in, D, a->stats1, a->ln1_g, b->dx_mid, b->dx_in, D, nullptr, b->g_ln1_g,
-                          b->g_ln1_b, nullptr, M, D, dt, stream));
+                          b->g_ln1_b, nullptr, b->ln_scratch, M, D, dt, stream));
     return 0;
 }

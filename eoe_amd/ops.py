@@ -143,13 +143,17 @@ def layernorm_fwd(x, gamma, beta, rows, D, ldx, out, stats, eps=1e-5):
     return out
 
 
+LN_SCRATCH_ROWS = 512          # EOE_LN_PARTIALS (include/eoe_hip.h)
+
+
 def layernorm_bwd(dy, x, stats, gamma, rows, D, ldx, dx_out, ld_out, dres=None, dx16=None, dgamma=None, dbeta=None,
                   dxsum=None):
     _chk(dy, x, stats, gamma, dx_out, dres, dx16, dgamma, dbeta, dxsum)
     dy_f32 = 1 if dy.dtype == torch.float32 else 0
     code = dtype_code(dy.dtype) if not dy_f32 else (dtype_code(dx16.dtype) if dx16 is not None else _lib.EOE_BF16)
+    red = scratch("ln_red", (LN_SCRATCH_ROWS * 3 * D,), torch.float32, dy.device) if (dgamma is not None or dxsum is not None) else None
     check(lib.eoe_layernorm_bwd(_p(dy), dy_f32, _p(x), ldx, _p(stats), _p(gamma), _p(dres), _p(dx_out), ld_out,
-                                _p(dx16), _p(dgamma), _p(dbeta), _p(dxsum), rows, D, code, _stream()), "eoe_layernorm_bwd")
+                                _p(dx16), _p(dgamma), _p(dbeta), _p(dxsum), _p(red), rows, D, code, _stream()), "eoe_layernorm_bwd")
     return dx_out
 
 
@@ -423,6 +427,7 @@ class VitBlockFunction(torch.autograd.Function):
         b.dh = _p(scratch("dh", (M, 4 * D), dt, dev))
         b.dqkv = _p(scratch("dqkv", (M, 3 * D), dt, dev))
         b.dx_mid = _p(scratch("dx_mid", (M, D), torch.float32, dev))
+        b.ln_scratch = _p(scratch("ln_red", (LN_SCRATCH_ROWS * 3 * D,), torch.float32, dev))
         check(lib.eoe_vit_block_bwd(C.byref(b), _stream()), "eoe_vit_block_bwd")
         hook = grad_ready_hooks.get(id(params["ln1_g"]))
         if hook is not None and hook[0]() is params["ln1_g"]:      # (weakref to the parameter, callable)

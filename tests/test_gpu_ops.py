@@ -18,6 +18,19 @@ def ops():
     return o
 
 
+# tile shapes of the NT GEMM (nt_flags of gemm.hip; bit 0 = the shipped fast epilogue): the launcher's own choice, the persistent
+# 256-row kernel, and the two-workgroup kernel with 128- and with 160-row tiles -- every test below must hold for each
+NT_VARIANTS = {"auto": 1, "persistent256": 1 | 4, "two_wg_128": 1 | 8 | 16, "two_wg_160": 1 | 8 | 32}
+
+
+@pytest.fixture(params=list(NT_VARIANTS))
+def nt_variant(request):
+    from eoe_amd import _lib
+    _lib.check(_lib.lib.eoe_set_option(b"nt_flags", NT_VARIANTS[request.param]), "eoe_set_option")
+    yield request.param
+    _lib.check(_lib.lib.eoe_set_option(b"nt_flags", NT_VARIANTS["auto"]), "eoe_set_option")
+
+
 def _qgelu(x):
     return x * torch.sigmoid(1.702 * x)
 
@@ -29,8 +42,8 @@ def _qgelu_grad(x):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (200, 256, 192), (130, 136, 64), (50, 8, 64),
-                                   (12800, 768, 768), (392, 768, 3072), (4, 256, 512)])
-def test_gemm_nt_plain(ops, dtype, M, N, K):
+                                   (12800, 768, 768), (392, 768, 3072), (4, 256, 512), (161, 264, 64), (480, 136, 256)])
+def test_gemm_nt_plain(ops, dtype, M, N, K, nt_variant):
     a, ar = t16(f"nt/a{M}", (M, K), 1.0, dtype)
     b, br = t16(f"nt/b{N}", (N, K), 1.0, dtype)
     bias, biasr = f32("nt/bias", (N,), 1.0)
@@ -48,7 +61,7 @@ def test_gemm_nt_plain(ops, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_gemm_nt_strided_and_epilogues(ops, dtype):
+def test_gemm_nt_strided_and_epilogues(ops, dtype, nt_variant):
     M, N, K = 200, 256, 128
     a, ar = t16("nte/a", (M, K + 64), 1.0, dtype)          # row stride larger than K
     b, br = t16("nte/b", (N, K), 0.2, dtype)
