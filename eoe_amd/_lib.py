@@ -85,7 +85,7 @@ class VitBlockBwdArgs(C.Structure):
                 ("g_b_in", _vp), ("g_b_out", _vp), ("g_b_fc", _vp), ("g_b_proj", _vp),
                 ("g_w_in", _vp), ("g_w_out", _vp), ("g_w_fc", _vp), ("g_w_proj", _vp),
                 ("accumulate", _i32),
-                ("d16_a", _vp), ("d16_b", _vp), ("d16_c", _vp), ("dh", _vp), ("dqkv", _vp), ("dx_mid", _vp), ("ln_scratch", _vp)]
+                ("d16_a", _vp), ("d16_b", _vp), ("d16_c", _vp), ("dh", _vp), ("dqkv", _vp), ("dx_mid", _vp), ("red_scratch", _vp)]
 
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); must match include/eoe_hip.h
@@ -111,7 +111,7 @@ SIGNATURES = {
     "eoe_colsum_det": [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
     "eoe_cast": [_vp, _vp, _sz, C.c_int, _vp],
     "eoe_attn_fwd": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
-    "eoe_attn_bwd": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "eoe_attn_bwd": [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "eoe_hsc_fwd": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _vp],
     "eoe_hsc_bwd": [_vp, _vp, _i64, _vp, _vp, _vp, C.c_int, C.c_int, _f32, C.c_int, _vp],
     "eoe_hsc_score": [_vp, _vp, C.c_int, C.c_int, _vp],

@@ -179,9 +179,55 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const T* __restrict__ qkv,
 }
 
 // ------------------------------------------------------------------------------------------------ backward
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+// sum over the L tokens of a [token = 16 t + lr][4 columns] accumulator set: in-lane over t, then over the 16 lanes sharing lane>>4
+__device__ __forceinline__ f32x4 token_sum(const f32x4 (&o)[4], int L, int lr) {
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (16 * i + lr < L) t += o[i];
+    // the 16 lanes are one DPP row: quad xor 1, quad xor 2, half-row mirror (quads 0<->1, 2<->3 hold equal sums by then), row
+    // mirror -- four VALU instructions per value instead of four ds_bpermute round trips
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float v = t[r];
+        v += dpp_mov<0xB1>(v);      // quad_perm [1,0,3,2]
+        v += dpp_mov<0x4E>(v);      // quad_perm [2,3,0,1]
+        v += dpp_mov<0x141>(v);     // row_half_mirror
+        v += dpp_mov<0x140>(v);     // row_mirror
+        t[r] = v;
+    }
+    return t;
+}
+// out[c] += sum_img part[img][c], fixed order (16 columns x 64 row lanes per workgroup)
+__global__ __launch_bounds__(1024) void attn_bias_sum_kernel(const float* __restrict__ part, int R, int N, float* __restrict__ out) {
+    __shared__ float l[64][17];
+    const int col = threadIdx.x & 15, lane = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + col;
+    float s = 0.f;
+    if (i < N) {
+        int r = lane;
+        for (; r + 192 < R; r += 256) {
+            const float a = part[(size_t)r * N + i], b = part[(size_t)(r + 64) * N + i], c = part[(size_t)(r + 128) * N + i],
+                        d = part[(size_t)(r + 192) * N + i];
+            s += (a + b) + (c + d);
+        }
+        for (; r < R; r += 64) s += part[(size_t)r * N + i];
+    }
+    l[lane][col] = s;
+    __syncthreads();
+    if (lane != 0 || i >= N) return;
+    for (int k = 1; k < 64; ++k) s += l[k][col];
+    out[i] += s;
+}
+
 template <typename T>
-__global__ __launch_bounds__(64) void attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
-                                                      T* __restrict__ dqkv, int L, int heads, float scale) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+                                                      T* __restrict__ dqkv, float* __restrict__ bias_part, int L, int heads,
+                                                      float scale) {
     __shared__ __attribute__((aligned(16))) char smem[3 * TILEB + 2 * 64 * 4];
     char* qs = smem;
     char* ks_ = smem + TILEB;
@@ -197,6 +243,8 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const T* __restrict__ qkv,
     const T* vp = qp + 2 * D;
     const T* dop = dout + (size_t)img * L * D + h * 64;
     T* dqp = dqkv + (size_t)img * L * ld + h * 64;
+    // optional: this (image, head)'s column sums of dQ | dK | dV (the in_proj bias gradient) -> bias_part[img][3D]
+    float* bpart = bias_part ? bias_part + (size_t)img * ld + h * 64 : nullptr;
 
     stage_tile<T>(qs, qp, ld, L, lane);
     stage_tile<T>(ks_, kp, ld, L, lane);
@@ -270,6 +318,10 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const T* __restrict__ qkv,
                 const int query = 16 * tq + lr;
                 if (query < L)
                     *(u32x2*)(dqp + (size_t)query * ld + 16 * td + 4 * lg) = pack4<T>(o[tq][0], o[tq][1], o[tq][2], o[tq][3]);
+            }
+            if (bpart) {
+                const f32x4 cs = token_sum(o, L, lr);
+                if (lr == 0) *(f32x4*)(bpart + 16 * td + 4 * lg) = cs;
             }
         }
     }
@@ -345,6 +397,13 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const T* __restrict__ qkv,
                     *(u32x2*)(dqp + (size_t)key * ld + D + 16 * td + 4 * lg) = pack4<T>(ok[tk][0], ok[tk][1], ok[tk][2], ok[tk][3]);
                 }
             }
+            if (bpart) {
+                const f32x4 cv = token_sum(ov, L, lr), ck = token_sum(ok, L, lr);
+                if (lr == 0) {
+                    *(f32x4*)(bpart + 2 * D + 16 * td + 4 * lg) = cv;
+                    *(f32x4*)(bpart + D + 16 * td + 4 * lg) = ck;
+                }
+            }
         }
     }
 }
@@ -368,20 +427,26 @@ extern "C" int eoe_attn_fwd(const void* qkv, void* out, int n, int L, int heads,
     return 0;
 }
 
-extern "C" int eoe_attn_bwd(const void* qkv, const void* dout, void* dqkv, int n, int L, int heads, int dtype,
-                            void* stream) {
+extern "C" int eoe_attn_bwd(const void* qkv, const void* dout, void* dqkv, float* dbias, float* bias_scratch, int n, int L,
+                            int heads, int dtype, void* stream) {
     EOE_CHECK_ARG(qkv && dout && dqkv && n > 0 && heads > 0, "attn_bwd: bad args");
+    EOE_CHECK_ARG((dbias == nullptr) == (bias_scratch == nullptr), "attn_bwd: dbias and bias_scratch go together");
     EOE_CHECK_ARG(L >= 1 && L <= 64, "attn: sequence length %d not in [1, 64]", L);
     const float scale = 0.125f;
     ProfScope ps("attn_bwd", 14.0 * n * heads * (double)L * L * 64, 2.0 * (double)n * L * heads * 64 * 7, stream);
     if (dtype == EOE_F16)
         hipLaunchKernelGGL((attn_bwd_kernel<f16_t>), dim3(n * heads), dim3(64), 0, (hipStream_t)stream,
-                           (const f16_t*)qkv, (const f16_t*)dout, (f16_t*)dqkv, L, heads, scale);
+                           (const f16_t*)qkv, (const f16_t*)dout, (f16_t*)dqkv, bias_scratch, L, heads, scale);
     else if (dtype == EOE_BF16)
         hipLaunchKernelGGL((attn_bwd_kernel<bf16_t>), dim3(n * heads), dim3(64), 0, (hipStream_t)stream,
-                           (const bf16_t*)qkv, (const bf16_t*)dout, (bf16_t*)dqkv, L, heads, scale);
+                           (const bf16_t*)qkv, (const bf16_t*)dout, (bf16_t*)dqkv, bias_scratch, L, heads, scale);
     else
         return eoe_set_error(EOE_ERR_ARG, "attn_bwd: bad dtype %d", dtype);
     EOE_CHECK_LAUNCH("attn_bwd");
+    if (dbias) {
+        hipLaunchKernelGGL(attn_bias_sum_kernel, dim3(cdiv(3 * heads * 64, 16)), dim3(1024), 0, (hipStream_t)stream,
+                           (const float*)bias_scratch, n, 3 * heads * 64, dbias);
+        EOE_CHECK_LAUNCH("attn_bwd_bias");
+    }
     return 0;
 }

@@ -33,6 +33,7 @@ constexpr int SMEM_BYTES = NSTAGE * STAGE_BYTES;  // 144 KiB: one 8-wave workgro
 
 struct GemmP {
     const void* A; const void* B; void* C; const float* bias; const void* aux; void* aux_out; float* colsum;
+    float* colsum_part;            // column sums through partial rows [ceil(M / rows per wave)][N] + colsum_finish_kernel (no atomics)
     int M, N, K, lda, ldb, ldc, ldaux, out_f32, accumulate;
     float alpha;
     unsigned bytesA, bytesB;
@@ -158,7 +159,9 @@ __device__ __forceinline__ void epilogue_generic(const GemmP& p, f32x4 (&acc)[MI
                 float t = cs[ni][r];
                 t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
                 const int n = n_base + ni * 16 + lg * 4 + r;
-                if (lr == 0 && n < p.N) atomicAdd(p.colsum + n, t);
+                if (lr != 0 || n >= p.N) continue;
+                if (p.colsum_part) { if (m_base < p.M) p.colsum_part[(size_t)(m_base / (16 * MI)) * p.N + n] = t; }
+                else atomicAdd(p.colsum + n, t);
             }
         }
     }
@@ -260,7 +263,19 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][NI], i
             *(u32x4*)(c + 8) = pack8<T>(v + 8);
         }
     }
-    if (EPI != EOE_EPI_GELU && p.colsum) {
+    if (EPI != EOE_EPI_GELU && p.colsum && p.colsum_part) {
+        // partial-row form: the lanes' 16-column sums go through the wave's LDS scratch ([16 rows][64 cols], the band
+        // transposition's swizzle), lane j then adds column j over the 16 rows and stores ONE float of this wave's partial row
+        // (64 cross-lane shuffles + 64 scattered stores in the atomic form below cost more than a separate pass over C)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *(f32x4*)(scr + rrow * 256 + (((rq * 4 + q) ^ rrow) << 4)) = (f32x4){cs[q * 4], cs[q * 4 + 1], cs[q * 4 + 2], cs[q * 4 + 3]};
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += *(const float*)(scr + r * 256 + ((((lane >> 2) ^ r) << 4) | ((lane & 3) << 2)));
+        const int nn = n_base + lane;
+        if (lane < 16 * NI && nn < p.N && m_base < p.M) p.colsum_part[(size_t)(m_base / (16 * MI)) * p.N + nn] = t;
+    } else if (EPI != EOE_EPI_GELU && p.colsum) {
         // the 16 rows of a band sit on lanes with equal lane&3: xor-reduce over lane>>2, then 4 lanes x 16 atomics
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
@@ -658,6 +673,35 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmP p) {
     epilogue<T, EPI, NI, MI>(ep, acc, m0 + wm0, n0 + wn0, lane, smem + wave * 4096);
 }
 
+// colsum[c] += sum_r part[r][c] (the epilogues' per-wave-row partial column sums), fixed order: 16 columns x 64 row lanes
+__global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __restrict__ part, int R, int N, float* __restrict__ out) {
+    __shared__ float l[64][17];
+    const int col = threadIdx.x & 15, lane = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + col;
+    float s = 0.f;
+    if (i < N) {
+        int r = lane;
+        for (; r + 192 < R; r += 256) {
+            const float a = part[(size_t)r * N + i], b = part[(size_t)(r + 64) * N + i], c = part[(size_t)(r + 128) * N + i],
+                        d = part[(size_t)(r + 192) * N + i];
+            s += (a + b) + (c + d);
+        }
+        for (; r < R; r += 64) s += part[(size_t)r * N + i];
+    }
+    l[lane][col] = s;
+    __syncthreads();
+    if (lane != 0 || i >= N) return;
+    for (int k = 1; k < 64; ++k) s += l[k][col];
+    out[i] += s;
+}
+static int finish_colsum(const GemmP& p, int epi, int mi, hipStream_t s) {
+    if (!p.colsum_part || !p.colsum || epi == EOE_EPI_GELU) return 0;
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(p.N, 16)), dim3(1024), 0, s, (const float*)p.colsum_part, cdiv(p.M, 16 * mi), p.N,
+                       p.colsum);
+    EOE_CHECK_LAUNCH("gemm_nt_colsum");
+    return 0;
+}
+
 static int num_cus() {
     static const int ncu = [] { int d = 0, n = 256; hipDeviceProp_t pr; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) n = pr.multiProcessorCount; return n; }();
     return ncu;
@@ -681,7 +725,7 @@ int launch_nt128(const GemmP& p, int epi, hipStream_t s) {
     }
 #undef EOE_NT128_CASE
     EOE_CHECK_LAUNCH("gemm_nt128");
-    return 0;
+    return finish_colsum(p, epi, MI, s);
 }
 // 128- or 160-row tiles: whichever needs less (rounds over the 2 x #CU workgroup slots) x (rows per tile)
 template <typename T>
@@ -720,7 +764,7 @@ int launch_nt_f(const GemmP& p, int epi, int grid, hipStream_t s) {
     }
 #undef EOE_NT_CASE
     EOE_CHECK_LAUNCH("gemm_nt");
-    return 0;
+    return finish_colsum(p, epi, 4, s);
 }
 
 // convolution variants (plain epilogue only): implicit patch matrix and / or the 256x64 tile for cout = 64
@@ -731,7 +775,7 @@ int launch_nt_conv(const GemmP& p, int grid, hipStream_t s) {
     (void)once;
     hipLaunchKernelGGL((gemm_nt_kernel<T, EOE_EPI_NONE, NI, EOE_NT_DEFAULT_FLAGS, GATHER>), dim3(grid), dim3(512), SMEM_BYTES, s, p);
     EOE_CHECK_LAUNCH("gemm_nt");
-    return 0;
+    return finish_colsum(p, EOE_EPI_NONE, 4, s);
 }
 
 template <typename T, int NI>
@@ -787,6 +831,7 @@ int fill_params(const eoe_gemm_args* a, GemmP& p) {
     EOE_CHECK_ARG((((uintptr_t)a->A | (uintptr_t)a->B) & 15) == 0, "gemm: A/B must be 16-B aligned");
     EOE_CHECK_ARG(!a->accumulate || a->out_f32, "gemm: accumulate needs an fp32 C");
     p.A = a->A; p.B = a->B; p.C = a->C; p.bias = a->bias; p.aux = a->aux; p.aux_out = a->aux_out; p.colsum = a->colsum;
+    p.colsum_part = nullptr;
     p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ldaux = a->ldaux;
     p.out_f32 = a->out_f32; p.accumulate = a->accumulate; p.alpha = a->alpha;
     EOE_CHECK_ARG((a->K % BK) == 0, "gemm_nt: K=%d must be a multiple of %d", a->K, BK);
@@ -856,6 +901,9 @@ extern "C" int eoe_gemm_nt(const eoe_gemm_args* a, void* stream) {
                      (a->epilogue == EOE_EPI_GELU ? 2 : 1) + (a->epilogue == EOE_EPI_RESIDUAL ? 4.0 * a->M * a->N : 0.0) +
                      (a->epilogue == EOE_EPI_GELU_BWD ? 2.0 * a->M * a->N : 0.0), stream);
     const int mode = (a->gather == 1 && p.gkh) ? 3 : a->gather;      // narrow-channel geometry -> per-piece tap decoding
+    // fused column sums: through partial rows in the workspace (one row per 64 / 80 output rows) when it is large enough
+    if (a->colsum && a->workspace && a->workspace_bytes >= (int64_t)EOE_NT_COLSUM_WORKSPACE_BYTES(a->M, a->N))
+        p.colsum_part = (float*)a->workspace;
     return a->dtype == EOE_F16 ? launch_nt<f16_t>(p, a->epilogue, mode, (hipStream_t)stream)
                                : launch_nt<bf16_t>(p, a->epilogue, mode, (hipStream_t)stream);
 }

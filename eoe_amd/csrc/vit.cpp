@@ -80,20 +80,27 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
     TRY(eoe_cast_colsum(b->dx_out, b->d16_a, b->g_b_proj, M, D, dt, 1, stream));          // dY of c_proj + db_proj
     g = gemm(b->d16_a, a->w_proj_t, b->dh, nullptr, M, H, D, D, D, H, dt);                  // d hact, then * gelu'(hpre)
     g.epilogue = EOE_EPI_GELU_BWD; g.aux = a->hpre; g.ldaux = H;
-    TRY(eoe_gemm_nt(&g, stream));
-    // db_fc: a separate column-sum pass (17.6 us) is cheaper than the GEMM's fused column-sum epilogue (+45 us measured)
-    TRY(eoe_colsum(b->dh, H, b->g_b_fc, M, H, dt, 1, stream));
+    if (b->red_scratch) {
+        // db_fc = column sums of dh, from the GEMM's epilogue through per-wave partial rows in the scratch (with fp32 atomics
+        // instead, the fused sums cost +45 us -- more than a separate 16-us pass over dh)
+        g.colsum = b->g_b_fc; g.workspace = b->red_scratch; g.workspace_bytes = (int64_t)EOE_NT_COLSUM_WORKSPACE_BYTES(M, H);
+        TRY(eoe_gemm_nt(&g, stream));
+    } else {
+        TRY(eoe_gemm_nt(&g, stream));
+        TRY(eoe_colsum(b->dh, H, b->g_b_fc, M, H, dt, 1, stream));
+    }
     g = gemm(b->dh, a->w_fc_t, b->d16_b, nullptr, M, D, H, H, H, D, dt);                    // d xn2
     TRY(eoe_gemm_nt(&g, stream));
     TRY(eoe_layernorm_bwd(b->d16_b, 0, a->x_mid, D, a->stats2, a->ln2_g, b->dx_out, b->dx_mid, D, b->d16_c, b->g_ln2_g,
-                          b->g_ln2_b, b->g_b_out, b->ln_scratch, M, D, dt, stream));        // + db_out = colsum(dx_mid)
+                          b->g_ln2_b, b->g_b_out, b->red_scratch, M, D, dt, stream));        // + db_out = colsum(dx_mid)
     // ---- attention branch:  x_mid = x_in + out_proj(attn(ln_1(x_in)))
     g = gemm(b->d16_c, a->w_out_t, b->d16_b, nullptr, M, D, D, D, D, D, dt);                // d att
     TRY(eoe_gemm_nt(&g, stream));
-    TRY(eoe_attn_bwd(a->qkv, b->d16_b, b->dqkv, a->n, a->L, a->heads, dt, stream));
+    // + db_in = column sums of dqkv, from the attention kernel's accumulators when the scratch is there
+    TRY(eoe_attn_bwd(a->qkv, b->d16_b, b->dqkv, b->red_scratch ? b->g_b_in : nullptr, b->red_scratch, a->n, a->L, a->heads, dt, stream));
     g = gemm(b->dqkv, a->w_in_t, b->d16_b, nullptr, M, D, 3 * D, 3 * D, 3 * D, D, dt);      // d xn1
     TRY(eoe_gemm_nt(&g, stream));
-    TRY(eoe_colsum(b->dqkv, 3 * D, b->g_b_in, M, 3 * D, dt, 1, stream));
+    if (!b->red_scratch) TRY(eoe_colsum(b->dqkv, 3 * D, b->g_b_in, M, 3 * D, dt, 1, stream));
     // ---- the four weight gradients of the block in one grouped launch (every dY and X is still live)
     w[0] = gemm(b->dh, a->xn2, b->g_w_fc, nullptr, H, D, M, H, D, D, dt);                    // dW_fc[4D,D]   = dh^T xn2
     w[1] = gemm(b->d16_a, a->hact, b->g_w_proj, nullptr, D, H, M, D, H, H, dt);             // dW_proj[D,4D] = dY^T hact
@@ -102,6 +109,6 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
     for (int i = 0; i < 4; ++i) { w[i].out_f32 = 1; w[i].accumulate = acc; }
     TRY(eoe_gemm_tn_grouped(w, 4, stream));
     TRY(eoe_layernorm_bwd(b->d16_b, 0, a->x_in, D, a->stats1, a->ln1_g, b->dx_mid, b->dx_in, D, nullptr, b->g_ln1_g,
-                          b->g_ln1_b, nullptr, b->ln_scratch, M, D, dt, stream));
+                          b->g_ln1_b, nullptr, b->red_scratch, M, D, dt, stream));
     return 0;
 }

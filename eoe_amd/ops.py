@@ -60,7 +60,7 @@ def _chk(*ts):
 
 # ------------------------------------------------------------------------------------------------ raw ops
 def gemm_nt(a, b, out, bias=None, epilogue=EPI_NONE, aux=None, aux_out=None, accumulate=False, alpha=1.0,
-            colsum_out=None):
+            colsum_out=None, colsum_atomic=False):
     """out[M,N] = a[M,K] @ b[N,K]^T  (+ epilogue); a, b 16-bit row-major (row stride may exceed K)"""
     _chk(a, b, out, bias, aux, aux_out, colsum_out)
     M, K = a.shape
@@ -70,6 +70,9 @@ def gemm_nt(a, b, out, bias=None, epilogue=EPI_NONE, aux=None, aux_out=None, acc
     g = GemmArgs(_p(a), _p(b), _p(out), _p(bias), _p(aux), _p(aux_out), _p(colsum_out), M, N, K, a.stride(0), b.stride(0),
                  out.stride(0), aux.stride(0) if aux is not None else 0, dtype_code(a.dtype), epilogue,
                  1 if out.dtype == torch.float32 else 0, 1 if accumulate else 0, float(alpha))
+    if colsum_out is not None and not colsum_atomic:      # fused column sums through partial rows (no atomics)
+        nbytes = (M + 63) // 64 * N * 4            # EOE_NT_COLSUM_WORKSPACE_BYTES
+        g.workspace, g.workspace_bytes = _p(scratch("nt_colsum_ws", (nbytes,), torch.uint8, a.device)), nbytes
     check(lib.eoe_gemm_nt(C.byref(g), _stream()), "eoe_gemm_nt")
     return out
 
@@ -163,9 +166,12 @@ def attn_fwd(qkv, out, n, L, heads):
     return out
 
 
-def attn_bwd(qkv, dout, dqkv, n, L, heads):
-    _chk(qkv, dout, dqkv)
-    check(lib.eoe_attn_bwd(_p(qkv), _p(dout), _p(dqkv), n, L, heads, dtype_code(qkv.dtype), _stream()), "eoe_attn_bwd")
+def attn_bwd(qkv, dout, dqkv, n, L, heads, dbias=None):
+    """dqkv from (qkv, dout); dbias (optional fp32 [3D]) += column sums of dqkv (the in_proj bias gradient)"""
+    _chk(qkv, dout, dqkv, dbias)
+    part = scratch("attn_bias_part", (n * 3 * heads * 64,), torch.float32, qkv.device) if dbias is not None else None
+    check(lib.eoe_attn_bwd(_p(qkv), _p(dout), _p(dqkv), _p(dbias), _p(part), n, L, heads, dtype_code(qkv.dtype), _stream()),
+          "eoe_attn_bwd")
     return dqkv
 
 
@@ -427,7 +433,8 @@ class VitBlockFunction(torch.autograd.Function):
         b.dh = _p(scratch("dh", (M, 4 * D), dt, dev))
         b.dqkv = _p(scratch("dqkv", (M, 3 * D), dt, dev))
         b.dx_mid = _p(scratch("dx_mid", (M, D), torch.float32, dev))
-        b.ln_scratch = _p(scratch("ln_red", (LN_SCRATCH_ROWS * 3 * D,), torch.float32, dev))
+        nred = max(LN_SCRATCH_ROWS * 3 * D, (M + 63) // 64 * 4 * D, ctx.args.n * 3 * D)          # EOE_VIT_RED_SCRATCH(n, L, D)
+        b.red_scratch = _p(scratch("vit_red", (nred,), torch.float32, dev))
         check(lib.eoe_vit_block_bwd(C.byref(b), _stream()), "eoe_vit_block_bwd")
         hook = grad_ready_hooks.get(id(params["ln1_g"]))
         if hook is not None and hook[0]() is params["ln1_g"]:      # (weakref to the parameter, callable)

@@ -77,11 +77,12 @@ def test_gemm_nt_strided_and_epilogues(ops, dtype, nt_variant):
     assert_close(pre, acc, 2 * EPS16[dtype], 1e-4, "gelu epilogue: pre-activation")
     assert_close(act, _qgelu(pre.float().cpu().double()), 2 * EPS16[dtype], 1e-4, "gelu epilogue: activation of the stored pre")
     dz = torch.empty((M, N), dtype=dtype, device="cuda")
-    cs = torch.full((N,), 2.0, dtype=torch.float32, device="cuda")
-    ops.gemm_nt(a[:, :K], b, dz, epilogue=ops.EPI_GELU_BWD, aux=pre, colsum_out=cs)
     ref = (ar[:, :K].double() @ br.double().t()) * _qgelu_grad(pre.float().cpu().double())
-    assert_close(dz, ref, 2 * EPS16[dtype], 2e-4, "gelu-backward epilogue")
-    assert_close(cs, 2.0 + ref.sum(0), 1e-4, 1e-3, "fused column sums of the epilogue result (M tail masked)")
+    for atomic in (False, True):           # column sums through partial rows in a workspace (default) / fp32 atomics
+        cs = torch.full((N,), 2.0, dtype=torch.float32, device="cuda")
+        ops.gemm_nt(a[:, :K], b, dz, epilogue=ops.EPI_GELU_BWD, aux=pre, colsum_out=cs, colsum_atomic=atomic)
+        assert_close(dz, ref, 2 * EPS16[dtype], 2e-4, "gelu-backward epilogue")
+        assert_close(cs, 2.0 + ref.sum(0), 1e-4, 1e-3, "fused column sums of the epilogue result (M tail masked)")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -230,6 +231,12 @@ def test_attention(ops, dtype, n, L, heads):
     scale = qkvr.grad.abs().max().item()
     assert_close(dqkv, qkvr.grad, 8 * EPS16[dtype], 8 * EPS16[dtype] * scale, f"attention bwd L={L}")
     assert rel_rms(dqkv, qkvr.grad) < 3 * EPS16[dtype]
+    # fused in_proj bias gradient: dbias += column sums of dqkv (from the fp32 accumulators), same dqkv
+    db = torch.full((3 * D,), 2.0, dtype=torch.float32, device="cuda")
+    dqkv2 = torch.full((n * L, 3 * D), float("nan"), dtype=dtype, device="cuda")
+    ops.attn_bwd(qkv, do, dqkv2, n, L, heads, dbias=db)
+    assert torch.equal(dqkv2, dqkv)
+    assert_close(db, 2.0 + qkvr.grad.sum(0), 1e-3, 8 * EPS16[dtype] * scale * math.sqrt(n * L), f"attention bwd bias sums L={L}")
 
 
 def test_hsc_bce(ops):
