@@ -63,6 +63,10 @@ class SGateBwdArgs(C.Structure):
                 ("dgamma", _vp), ("dbeta", _vp), ("wpart", _vp)]
 
 
+class CastJob(C.Structure):
+    _fields_ = [("src", _vp), ("dst", _vp), ("dst_t", _vp), ("rows", _i32), ("cols", _i32)]
+
+
 class ProfEntry(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("launches", _i64), ("total_ms", C.c_double), ("flops", C.c_double),
                 ("bytes", C.c_double)]
@@ -97,6 +101,7 @@ SIGNATURES = {
     "eoe_gemm_tn": [C.POINTER(GemmArgs), _vp],
     "eoe_gemm_tn_grouped": [C.POINTER(GemmArgs), C.c_int, _vp],
     "eoe_cast_transpose": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
+    "eoe_cast_transpose_multi": [_vp, C.c_int, C.c_int, _vp],
     "eoe_patchify": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "eoe_embed_lnpre_fwd": [_vp] * 8 + [C.c_int, C.c_int, C.c_int, _f32, _vp],
     "eoe_embed_lnpre_bwd": [_vp] * 9 + [C.c_int, C.c_int, C.c_int, C.c_int, _vp],

@@ -78,6 +78,53 @@ __global__ __launch_bounds__(256) void cast_transpose_vec_kernel(const float* __
     }
 }
 
+// the same for a batch of matrices in ONE launch (the 48 weight matrices of a 12-block ViT are each too small to fill the chip:
+// 51 launches of 6 us against 0.14 ms of HBM time): workgroup -> (job, 64x64 tile) through the batch's tile prefix sums
+constexpr int CT_MAX_JOBS = 56;
+struct CtBatch {
+    const float* src[CT_MAX_JOBS];
+    void* dst[CT_MAX_JOBS];
+    void* dst_t[CT_MAX_JOBS];
+    int rows[CT_MAX_JOBS], cols[CT_MAX_JOBS];
+    int tile_start[CT_MAX_JOBS + 1];
+    int count;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void cast_transpose_multi_kernel(CtBatch b) {
+    __shared__ T tile[64][68];
+    int j = 0;
+    while (j + 1 < b.count && (int)blockIdx.x >= b.tile_start[j + 1]) ++j;          // uniform scan over <= 56 entries
+    const int t = blockIdx.x - b.tile_start[j];
+    const int rows = b.rows[j], cols = b.cols[j], tc = (cols + 63) >> 6;
+    const float* __restrict__ src = b.src[j];
+    T* __restrict__ dst = (T*)b.dst[j];
+    T* __restrict__ dst_t = (T*)b.dst_t[j];
+    const int c0 = (t % tc) * 64, r0 = (t / tc) * 64;
+    const int sub = threadIdx.x >> 4, q4 = (threadIdx.x & 15) * 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = p * 16 + sub, gr = r0 + r, gc = c0 + q4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gr < rows && gc < cols) {
+            v = *(const f32x4*)(src + (size_t)gr * cols + gc);
+            if (dst) *(u32x2*)(dst + (size_t)gr * cols + gc) = pack4<T>(v[0], v[1], v[2], v[3]);
+        }
+        tile[r][q4 + 0] = (T)v[0]; tile[r][q4 + 1] = (T)v[1]; tile[r][q4 + 2] = (T)v[2]; tile[r][q4 + 3] = (T)v[3];
+    }
+    __syncthreads();
+    if (dst_t) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int c = p * 16 + sub, gc = c0 + c, gr = r0 + q4;
+            if (gc < cols && gr < rows) {
+                typename T16<T>::v4 o;
+                o[0] = tile[q4 + 0][c]; o[1] = tile[q4 + 1][c]; o[2] = tile[q4 + 2][c]; o[3] = tile[q4 + 3][c];
+                *(u32x2*)(dst_t + (size_t)gc * rows + gr) = __builtin_bit_cast(u32x2, o);
+            }
+        }
+    }
+}
+
 // fp32 [rows, cols] -> 16-bit copy + column sums (bias gradient of the layer whose dY this is), one pass
 template <typename T>
 __global__ __launch_bounds__(256) void cast_colsum_kernel(const float* __restrict__ x, T* __restrict__ dst,
@@ -838,6 +885,33 @@ extern "C" int eoe_cast_transpose(const float* src, void* dst, void* dst_t, int 
                                              (T*)dst, (T*)dst_t, rows, cols));
     }
     EOE_CHECK_LAUNCH("cast_transpose");
+    return 0;
+}
+
+extern "C" int eoe_cast_transpose_multi(const eoe_cast_job* jobs, int count, int dtype, void* stream) {
+    EOE_CHECK_ARG(jobs && count > 0, "cast_transpose_multi: bad args");
+    double bytes = 0;
+    for (int i = 0; i < count; ++i) {
+        const eoe_cast_job& j = jobs[i];
+        EOE_CHECK_ARG(j.src && (j.dst || j.dst_t) && j.rows > 0 && j.cols > 0 && (j.rows & 3) == 0 && (j.cols & 3) == 0,
+                      "cast_transpose_multi: job %d: null pointers or rows / cols not multiples of 4", i);
+        bytes += ((j.dst ? 2.0 : 0.0) + (j.dst_t ? 2.0 : 0.0) + 4.0) * j.rows * j.cols;
+    }
+    ProfScope ps("cast_transpose", 0, bytes, stream);
+    for (int first = 0; first < count; first += CT_MAX_JOBS) {
+        CtBatch b;
+        b.count = count - first < CT_MAX_JOBS ? count - first : CT_MAX_JOBS;
+        int tiles = 0;
+        for (int i = 0; i < b.count; ++i) {
+            const eoe_cast_job& j = jobs[first + i];
+            b.src[i] = j.src; b.dst[i] = j.dst; b.dst_t[i] = j.dst_t; b.rows[i] = j.rows; b.cols[i] = j.cols;
+            b.tile_start[i] = tiles;
+            tiles += cdiv(j.rows, 64) * cdiv(j.cols, 64);
+        }
+        b.tile_start[b.count] = tiles;
+        DISPATCH_T(dtype, hipLaunchKernelGGL((cast_transpose_multi_kernel<T>), dim3(tiles), dim3(256), 0, (hipStream_t)stream, b));
+        EOE_CHECK_LAUNCH("cast_transpose_multi");
+    }
     return 0;
 }
 

@@ -109,6 +109,10 @@ class VisualTransformer(nn.Module):
             raise RuntimeError("eoe_amd.VisualTransformer runs on the GPU only (no CPU fallback)")
         n = x.shape[0]
         mean, std = self.normalize if self.normalize is not None else (None, None)
+        # all 16-bit weight copies that the optimiser step made stale, in one launch (48 matrices for 12 blocks)
+        ops.shadow.refresh([w for blk in self.transformer.resblocks
+                            for w in (blk.attn.in_proj_weight, blk.attn.out_proj.weight, blk.mlp.c_fc.weight, blk.mlp.c_proj.weight)]
+                           + [self.proj])
         tok = ops.VitEmbedFunction.apply(x, self.conv1.weight, self.class_embedding, self.positional_embedding,
                                          self.ln_pre.weight, self.ln_pre.bias, self.patch_size, mean, std)
         for blk in self.transformer.resblocks:

@@ -216,6 +216,34 @@ class _Shadow:
         return d, dt
 
 
+    def refresh(self, params):
+        """bring the [out,in] + transposed copies of all (2-D, contiguous) `params` up to date with ONE batched launch
+        (`eoe_cast_transpose_multi`); the per-use `get` calls of the step then hit the cache.  No-op under graph capture."""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        jobs, entries = [], []
+        for p in params:
+            tag = (p._version, p.data_ptr(), _compute_dtype, True, True)
+            hit = self.cache.get(id(p))
+            if hit is not None and hit[0]() is p and hit[1] == tag:
+                continue
+            src = p.detach()
+            if src.dim() != 2 or not src.is_contiguous() or src.shape[0] % 4 or src.shape[1] % 4 or not src.is_cuda:
+                continue                                    # left to the per-use path
+            R, Cc = src.shape
+            d = torch.empty((R, Cc), dtype=_compute_dtype, device=src.device)
+            dt = torch.empty((Cc, R), dtype=_compute_dtype, device=src.device)
+            jobs.append(_lib.CastJob(_p(src), _p(d), _p(dt), R, Cc))
+            entries.append((p, tag, d, dt))
+        if not jobs:
+            return
+        arr = (_lib.CastJob * len(jobs))(*jobs)
+        check(lib.eoe_cast_transpose_multi(arr, len(jobs), dtype_code(_compute_dtype), _stream()), "eoe_cast_transpose_multi")
+        for p, tag, d, dt in entries:
+            key = id(p)
+            self.cache[key] = (weakref.ref(p, lambda _r, k=key, c=self.cache: c.pop(k, None)), tag, d, dt)
+
+
 shadow = _Shadow()
 
 _scratch = {}

@@ -105,6 +105,15 @@ int eoe_gemm_tn_grouped(const eoe_gemm_args* args, int count, void* stream);
 /* fp32 [rows, cols] -> 16-bit copy [rows, cols] and (if dst_t != NULL) transposed 16-bit copy [cols, rows].
  * Produces the MFMA operand copies of the fp32 master weights once per optimiser step. */
 int eoe_cast_transpose(const float* src, void* dst, void* dst_t, int rows, int cols, int dtype, void* stream);
+/* the same for `count` matrices (rows, cols multiples of 4) in one launch per 56 jobs: the per-step refresh of all 16-bit
+ * weight copies of a model (each matrix alone is too small to fill the chip) */
+typedef struct {
+    const float* src;   /* fp32 [rows, cols] */
+    void* dst;          /* 16-bit [rows, cols] or NULL */
+    void* dst_t;        /* 16-bit [cols, rows] or NULL */
+    int32_t rows, cols;
+} eoe_cast_job;
+int eoe_cast_transpose_multi(const eoe_cast_job* jobs, int count, int dtype, void* stream);
 
 /* per-channel affine + patch extraction: x fp32 [n,3,res,res] (NCHW, as the reference feeds it,
  * ad_trainer.py:411-429) -> 16-bit patch matrix [n*(res/p)^2, 3*p*p], column = c*p*p + ky*p + kx

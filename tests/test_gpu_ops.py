@@ -159,6 +159,20 @@ def test_cast_transpose_colsum(ops, dtype):
     assert torch.equal(d2.cpu(), w2r.to(dtype)) and torch.equal(dt2.cpu(), w2r.to(dtype).t().contiguous())
     v, vr = f32("ct/v", (1027,), 1.0)
     assert torch.equal(ops.cast16(v, dtype).cpu(), vr.to(dtype))
+    # batched refresh of many weight copies in one launch (more jobs than one launch's table holds, ragged 64x64 tile tails)
+    ops.set_compute_dtype(dtype)
+    try:
+        shapes = [(768, 768), (132, 200), (64, 4), (4, 64), (260, 68)] + [(8 + 4 * i, 12 + 8 * (i % 5)) for i in range(60)]
+        params = [torch.nn.Parameter(f32(f"ct/m{i}", sh, 1.0)[0]) for i, sh in enumerate(shapes)]
+        ops.shadow.refresh(params)
+        for prm in params:
+            hit = ops.shadow.cache[id(prm)]
+            want = prm.detach().cpu().to(dtype)
+            assert torch.equal(hit[2].cpu(), want) and torch.equal(hit[3].cpu(), want.t().contiguous())
+            d, dt = ops.shadow.get(prm, True, True)                 # served from the refreshed cache
+            assert d is hit[2] and dt is hit[3]
+    finally:
+        ops.set_compute_dtype(torch.float16)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
