@@ -246,6 +246,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // optional: this (image, head)'s column sums of dQ | dK | dV (the in_proj bias gradient) -> bias_part[img][3D]
     float* bpart = bias_part ? bias_part + (size_t)img * ld + h * 64 : nullptr;
 
+    // V is only ever an MFMA operand in fragment layout: its 8 fragments are loaded straight from global memory ONCE, up front
+    // (both phases use the same ones; loading them inside the phases exposed two more global round trips per wave)
+    V8<T> vfr[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) vfr[ks][t] = gfrag<T>(vp, ld, L, t, ks, lane);
     stage_tile<T>(qs, qp, ld, L, lane);
     stage_tile<T>(ks_, kp, ld, L, lane);
     stage_tile<T>(dos, dop, D, L, lane);
@@ -269,7 +276,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             for (int t = 0; t < 4; ++t) {
                 kf[t] = lfrag<T>(ks_, t, ks, lane);
                 qf[t] = lfrag<T>(qs, t, ks, lane);
-                vf[t] = gfrag<T>(vp, ld, L, t, ks, lane);
+                vf[t] = vfr[ks][t];
                 df[t] = lfrag<T>(dos, t, ks, lane);
             }
 #pragma unroll
@@ -345,7 +352,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             for (int t = 0; t < 4; ++t) {
                 kf[t] = lfrag<T>(ks_, t, ks, lane);
                 qf[t] = lfrag<T>(qs, t, ks, lane);
-                vf[t] = gfrag<T>(vp, ld, L, t, ks, lane);
+                vf[t] = vfr[ks][t];
                 df[t] = lfrag<T>(dos, t, ks, lane);
             }
 #pragma unroll
