@@ -30,7 +30,7 @@ class GemmArgs(C.Structure):
                 ("M", _i32), ("N", _i32), ("K", _i32),
                 ("lda", _i32), ("ldb", _i32), ("ldc", _i32), ("ldaux", _i32),
                 ("dtype", _i32), ("epilogue", _i32), ("out_f32", _i32), ("accumulate", _i32), ("alpha", _f32),
-                ("workspace", _vp), ("workspace_bytes", _i64), ("gather", _i32), ("geo", ConvGeometry)]
+                ("workspace", _vp), ("workspace_bytes", _i64), ("gather", _i32), ("geo", ConvGeometry), ("colstats", _i32)]
 
 
 class AdamChunk(C.Structure):
@@ -134,6 +134,7 @@ SIGNATURES = {
     "eoe_stem_pack_weight": [_vp, _vp] + [C.c_int] * 4 + [_vp],
     "eoe_stem_unpack_wgrad": [_vp, _vp] + [C.c_int] * 3 + [_vp],
     "eoe_bn_stats": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _f32, C.c_int, _vp],
+    "eoe_bn_stats_partials": [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _f32, _vp],
     "eoe_bn_act_pool_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32,
                             C.c_int, _vp],
     "eoe_bn_act_pool_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -259,6 +259,18 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __re
     }
 }
 
+// out[p][w] = sum of rows p, p + P, p + 2P, ... of in[R][width] (fixed order): R partial rows -> P
+__global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int width, int P) {
+    const int p = blockIdx.x;
+    for (int w = threadIdx.x; w < width; w += blockDim.x) {
+        float s0 = 0.f, s1 = 0.f;
+        int r = p;
+        for (; r + P < R; r += 2 * P) { s0 += in[(size_t)r * width + w]; s1 += in[(size_t)(r + P) * width + w]; }
+        if (r < R) s0 += in[(size_t)r * width + w];
+        out[(size_t)p * width + w] = s0 + s1;
+    }
+}
+
 // sums -> stats[0..C) = mean, stats[C..2C) = rstd; running buffers updated as nn.BatchNorm does (momentum 0.1,
 // unbiased variance for the running estimate)
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int P, float* __restrict__ stats,
@@ -716,6 +728,25 @@ extern "C" int eoe_bn_stats(const float* y, float* sums_scratch, float* stats, f
     EOE_CHECK_LAUNCH("bn_stats");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(1024), 0, s, (const float*)sums_scratch, gy, stats, running_mean,
                        running_var, num_batches_tracked, M, C, eps, momentum);
+    EOE_CHECK_LAUNCH("bn_finalize");
+    return 0;
+}
+
+extern "C" int eoe_bn_stats_partials(const float* part, int R, float* sums_scratch, float* stats, float* running_mean,
+                                     float* running_var, int64_t* num_batches_tracked, int M, int C, float eps, float momentum,
+                                     void* stream) {
+    EOE_CHECK_ARG(part && sums_scratch && stats && R > 0 && M > 0 && C > 0, "bn_stats_partials: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    const float* rows = part;
+    int P = R;
+    if (R > EOE_BN_PARTIALS) {          // fold R rows into EOE_BN_PARTIALS (a streaming pass over the partial buffer)
+        P = EOE_BN_PARTIALS;
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(P), dim3(256), 0, s, part, sums_scratch, R, 2 * C, P);
+        EOE_CHECK_LAUNCH("bn_fold_partials");
+        rows = sums_scratch;
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(1024), 0, s, rows, P, stats, running_mean, running_var,
+                       num_batches_tracked, M, C, eps, momentum);
     EOE_CHECK_LAUNCH("bn_finalize");
     return 0;
 }

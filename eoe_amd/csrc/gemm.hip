@@ -34,6 +34,7 @@ constexpr int SMEM_BYTES = NSTAGE * STAGE_BYTES;  // 144 KiB: one 8-wave workgro
 struct GemmP {
     const void* A; const void* B; void* C; const float* bias; const void* aux; void* aux_out; float* colsum;
     float* colsum_part;            // column sums through partial rows [ceil(M / rows per wave)][N] + colsum_finish_kernel (no atomics)
+    int colsum_sq;                 // partial rows are [.][2][N]: sums and sums of squares (BatchNorm statistics); no finish kernel
     int M, N, K, lda, ldb, ldc, ldaux, out_f32, accumulate;
     float alpha;
     unsigned bytesA, bytesB;
@@ -185,9 +186,9 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][NI], i
     const int rrow = lane >> 2, rq = lane & 3;                 // read side: row of the band, 16-column group
     const int n = n_base + rq * 16;
     const bool col_ok = (rq < NI) && (n < p.N);
-    float cs[16];
+    float cs[16], cs2[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) cs[c] = 0.f;
+    for (int c = 0; c < 16; ++c) { cs[c] = 0.f; cs2[c] = 0.f; }
     float bias[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) bias[c] = 0.f;
@@ -249,6 +250,10 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][NI], i
         }
 #pragma unroll
         for (int c = 0; c < 16; ++c) cs[c] += v[c];
+        if (p.colsum_sq) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) cs2[c] += v[c] * v[c];
+        }
         if (p.out_f32) {
             float* c = (float*)p.C + off;
 #pragma unroll
@@ -263,7 +268,7 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][NI], i
             *(u32x4*)(c + 8) = pack8<T>(v + 8);
         }
     }
-    if (EPI != EOE_EPI_GELU && p.colsum && p.colsum_part) {
+    if (EPI != EOE_EPI_GELU && p.colsum_part) {
         // partial-row form: the lanes' 16-column sums go through the wave's LDS scratch ([16 rows][64 cols], the band
         // transposition's swizzle), lane j then adds column j over the 16 rows and stores ONE float of this wave's partial row
         // (64 cross-lane shuffles + 64 scattered stores in the atomic form below cost more than a separate pass over C)
@@ -274,7 +279,20 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][NI], i
 #pragma unroll
         for (int r = 0; r < 16; ++r) t += *(const float*)(scr + r * 256 + ((((lane >> 2) ^ r) << 4) | ((lane & 3) << 2)));
         const int nn = n_base + lane;
-        if (lane < 16 * NI && nn < p.N && m_base < p.M) p.colsum_part[(size_t)(m_base / (16 * MI)) * p.N + nn] = t;
+        const bool st_ok = lane < 16 * NI && nn < p.N && m_base < p.M;
+        if (!p.colsum_sq) {
+            if (st_ok) p.colsum_part[(size_t)(m_base / (16 * MI)) * p.N + nn] = t;
+        } else {
+            // BatchNorm statistics: row [2][N] = (sum, sum of squares) of this wave's 16*MI output rows
+            if (st_ok) p.colsum_part[((size_t)(m_base / (16 * MI)) * 2) * p.N + nn] = t;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *(f32x4*)(scr + rrow * 256 + (((rq * 4 + q) ^ rrow) << 4)) = (f32x4){cs2[q * 4], cs2[q * 4 + 1], cs2[q * 4 + 2], cs2[q * 4 + 3]};
+            float t2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t2 += *(const float*)(scr + r * 256 + ((((lane >> 2) ^ r) << 4) | ((lane & 3) << 2)));
+            if (st_ok) p.colsum_part[((size_t)(m_base / (16 * MI)) * 2 + 1) * p.N + nn] = t2;
+        }
     } else if (EPI != EOE_EPI_GELU && p.colsum) {
         // the 16 rows of a band sit on lanes with equal lane&3: xor-reduce over lane>>2, then 4 lanes x 16 atomics
 #pragma unroll
@@ -695,7 +713,7 @@ __global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __rest
     out[i] += s;
 }
 static int finish_colsum(const GemmP& p, int epi, int mi, hipStream_t s) {
-    if (!p.colsum_part || !p.colsum || epi == EOE_EPI_GELU) return 0;
+    if (!p.colsum_part || !p.colsum || p.colsum_sq || epi == EOE_EPI_GELU) return 0;
     hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(p.N, 16)), dim3(1024), 0, s, (const float*)p.colsum_part, cdiv(p.M, 16 * mi), p.N,
                        p.colsum);
     EOE_CHECK_LAUNCH("gemm_nt_colsum");
@@ -811,7 +829,7 @@ int launch_nt(const GemmP& p, int epi, int gather, hipStream_t s) {
     // 83 -> 68 us = 887 TF, K = 2304: 61 -> 50 us = 916 TF).  The persistent 256-row kernel keeps large square problems
     // (4096^3: 1046 vs 984 TF).  nt_flags: bit 3 forces the two-workgroup kernel, bit 2 forbids it, bit 4 / 5 force 128 / 160 rows.
     const bool big = p.K >= 4096 && p.N >= 2048;
-    if ((g_nt_flags & 8) || (!big && !(g_nt_flags & 4))) return launch_nt128_auto<T>(p, epi, s);
+    if (!p.colsum_sq && ((g_nt_flags & 8) || (!big && !(g_nt_flags & 4)))) return launch_nt128_auto<T>(p, epi, s);
     // tile width: 256x128 unless 256x96 needs >= 10 % fewer (rounds x width) units over the CUs
     const int t4 = cdiv(p.M, BM) * cdiv(p.N, 128), t3 = cdiv(p.M, BM) * cdiv(p.N, 96);
     const int c4 = cdiv(t4, ncu) * 4, c3 = cdiv(t3, ncu) * 3;
@@ -831,7 +849,7 @@ int fill_params(const eoe_gemm_args* a, GemmP& p) {
     EOE_CHECK_ARG((((uintptr_t)a->A | (uintptr_t)a->B) & 15) == 0, "gemm: A/B must be 16-B aligned");
     EOE_CHECK_ARG(!a->accumulate || a->out_f32, "gemm: accumulate needs an fp32 C");
     p.A = a->A; p.B = a->B; p.C = a->C; p.bias = a->bias; p.aux = a->aux; p.aux_out = a->aux_out; p.colsum = a->colsum;
-    p.colsum_part = nullptr;
+    p.colsum_part = nullptr; p.colsum_sq = 0;
     p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ldaux = a->ldaux;
     p.out_f32 = a->out_f32; p.accumulate = a->accumulate; p.alpha = a->alpha;
     EOE_CHECK_ARG((a->K % BK) == 0, "gemm_nt: K=%d must be a multiple of %d", a->K, BK);
@@ -904,6 +922,16 @@ extern "C" int eoe_gemm_nt(const eoe_gemm_args* a, void* stream) {
     // fused column sums: through partial rows in the workspace (one row per 64 / 80 output rows) when it is large enough
     if (a->colsum && a->workspace && a->workspace_bytes >= (int64_t)EOE_NT_COLSUM_WORKSPACE_BYTES(a->M, a->N))
         p.colsum_part = (float*)a->workspace;
+    if (a->colstats) {
+        // per-64-row partial sums and sums of squares of the fp32 result (BatchNorm batch statistics without a pass over C)
+        EOE_CHECK_ARG(a->epilogue != EOE_EPI_GELU && !a->colsum, "gemm_nt: colstats goes with neither the GELU epilogue nor colsum");
+        EOE_CHECK_ARG(a->workspace && a->workspace_bytes >= 2 * (int64_t)EOE_NT_COLSUM_WORKSPACE_BYTES(a->M, a->N),
+                      "gemm_nt: colstats needs a workspace of 2 * EOE_NT_COLSUM_WORKSPACE_BYTES(M, N)");
+        EOE_CHECK_ARG((a->N & 15) == 0 && (a->ldc & 7) == 0 && (a->ldaux & 7) == 0 && (((uintptr_t)a->C) & 15) == 0,
+                      "gemm_nt: colstats needs N %% 16 == 0 and 16-byte aligned rows of C");
+        p.colsum_part = (float*)a->workspace;
+        p.colsum_sq = 1;
+    }
     return a->dtype == EOE_F16 ? launch_nt<f16_t>(p, a->epilogue, mode, (hipStream_t)stream)
                                : launch_nt<bf16_t>(p, a->epilogue, mode, (hipStream_t)stream);
 }

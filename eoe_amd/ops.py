@@ -60,8 +60,9 @@ def _chk(*ts):
 
 # ------------------------------------------------------------------------------------------------ raw ops
 def gemm_nt(a, b, out, bias=None, epilogue=EPI_NONE, aux=None, aux_out=None, accumulate=False, alpha=1.0,
-            colsum_out=None, colsum_atomic=False):
-    """out[M,N] = a[M,K] @ b[N,K]^T  (+ epilogue); a, b 16-bit row-major (row stride may exceed K)"""
+            colsum_out=None, colsum_atomic=False, colstats_ws=None):
+    """out[M,N] = a[M,K] @ b[N,K]^T  (+ epilogue); a, b 16-bit row-major (row stride may exceed K).
+    colstats_ws: fp32 [ceil(M/64), 2, N] -> receives the per-64-row column sums / sums of squares of the fp32 result"""
     _chk(a, b, out, bias, aux, aux_out, colsum_out)
     M, K = a.shape
     N = b.shape[0]
@@ -73,6 +74,8 @@ def gemm_nt(a, b, out, bias=None, epilogue=EPI_NONE, aux=None, aux_out=None, acc
     if colsum_out is not None and not colsum_atomic:      # fused column sums through partial rows (no atomics)
         nbytes = (M + 63) // 64 * N * 4            # EOE_NT_COLSUM_WORKSPACE_BYTES
         g.workspace, g.workspace_bytes = _p(scratch("nt_colsum_ws", (nbytes,), torch.uint8, a.device)), nbytes
+    if colstats_ws is not None:
+        g.workspace, g.workspace_bytes, g.colstats = _p(colstats_ws), colstats_ws.numel() * 4, 1
     check(lib.eoe_gemm_nt(C.byref(g), _stream()), "eoe_gemm_nt")
     return out
 
@@ -752,6 +755,15 @@ def _stem_weight_copy(w: torch.Tensor):
 _implicit_conv = True
 
 
+_fused_bn_stats = True
+
+
+def set_fused_bn_stats(on: bool):
+    """BatchNorm batch statistics from the conv GEMM's epilogue (default) or from a separate pass over its output"""
+    global _fused_bn_stats
+    _fused_bn_stats = bool(on)
+
+
 def set_implicit_conv(on: bool):
     """A/B switch: True (default) = convolutions with cin % 64 == 0 fetch their patches inside the GEMM's LDS stage
     (implicit GEMM); False = every convolution materialises its patch matrix with eoe_im2col"""
@@ -759,7 +771,7 @@ def set_implicit_conv(on: bool):
     _implicit_conv = bool(on)
 
 
-def conv_gemm_fwd(x16, w16, y, geo, bias=None, mode=1):
+def conv_gemm_fwd(x16, w16, y, geo, bias=None, mode=1, colstats_ws=None):
     """y[n*Ho*Wo, cout] (fp32) = patches(x16) @ w16^T without materialising the patches; x16 16-bit NHWC [n,H,W,C]
     (mode 2: the zero-padded NHWC4 image of eoe_stem_pack_image, packed k axis)"""
     n, H, W, Cc, kh, kw, stride, pad, Ho, Wo = geo
@@ -768,6 +780,8 @@ def conv_gemm_fwd(x16, w16, y, geo, bias=None, mode=1):
     g = GemmArgs(_p(x16), _p(w16), _p(y), _p(bias), None, None, None, M, N, K, 0, w16.stride(0), y.stride(0), 0,
                  dtype_code(x16.dtype), EPI_NONE, 1 if y.dtype == torch.float32 else 0, 0, 1.0, None, 0, mode,
                  _lib.ConvGeometry(*geo))
+    if colstats_ws is not None:       # BatchNorm batch statistics from the epilogue: per-64-row partial (sum, sum of squares)
+        g.workspace, g.workspace_bytes, g.colstats = _p(colstats_ws), colstats_ws.numel() * 4, 1
     check(lib.eoe_gemm_nt(C.byref(g), _stream()), "eoe_gemm_nt")
     return y
 
@@ -815,6 +829,10 @@ class ConvBnActPoolFunction(torch.autograd.Function):
         stem = _implicit_conv and is_image and cin == 3 and kw <= 8 and stride % 2 == 0
         img8 = _implicit_conv and is_image and cin == 3 and not stem           # NHWC8 image, per-piece tap decoding
         y = torch.empty((M, cout), dtype=torch.float32, device=dev)
+        # training: the conv GEMM's epilogue leaves per-64-row (sum, sum of squares) of y in `part`, so that the batch
+        # statistics need no pass over y (eoe_bn_stats_partials); eval: running statistics
+        R = (M + 63) // 64
+        part = scratch("bn_part", (R * 2 * cout,), torch.float32, dev) if (training and _fused_bn_stats and cout % 16 == 0) else None
         if stem:
             # packed first layer: normalised 16-bit NHWC4 image with physical zero padding, gathered inside the GEMM
             Hp, Wp = (H - 1) * stride + (kh + 1) // 2 * 2, ((W - 1) * stride + 8 + 1) // 2 * 2
@@ -823,30 +841,35 @@ class ConvBnActPoolFunction(torch.autograd.Function):
             check(lib.eoe_stem_pack_image(_p(x), _p(mean), _p(std), _p(operand), n, Hi, Wi, Hp, Wp, pad, 4, code, _stream()),
                   "eoe_stem_pack_image")
             implicit = 2
-            conv_gemm_fwd(operand, _stem_weight_copy(conv_w), y, (n, Hp, Wp, 4, kh, kw, stride, 0, H, W), bias=conv_b, mode=2)
+            conv_gemm_fwd(operand, _stem_weight_copy(conv_w), y, (n, Hp, Wp, 4, kh, kw, stride, 0, H, W), bias=conv_b, mode=2,
+                          colstats_ws=part)
         elif img8:
             operand = torch.empty((n, Hi, Wi, 8), dtype=dt, device=dev)
             check(lib.eoe_stem_pack_image(_p(x), _p(mean), _p(std), _p(operand), n, Hi, Wi, Hi, Wi, 0, 8, code, _stream()),
                   "eoe_stem_pack_image")
             implicit = 3
             w16, _, _ = _conv_weight_copies(conv_w, 8)
-            conv_gemm_fwd(operand, w16, y, (n, Hi, Wi, 8, kh, kw, stride, pad, H, W), bias=conv_b)
+            conv_gemm_fwd(operand, w16, y, (n, Hi, Wi, 8, kh, kw, stride, pad, H, W), bias=conv_b, colstats_ws=part)
         elif implicit:
             w16, _, _ = _conv_weight_copies(conv_w)
             if x16 is None or x16.dtype != dt or x16.shape != x.shape:
                 x16 = cast16(x.view(-1, cin)).view(n, Hi, Wi, cin)
             operand = x16
-            conv_gemm_fwd(x16, w16, y, (n, Hi, Wi, cin, kh, kw, stride, pad, H, W), bias=conv_b)
+            conv_gemm_fwd(x16, w16, y, (n, Hi, Wi, cin, kh, kw, stride, pad, H, W), bias=conv_b, colstats_ws=part)
         else:
             w16, _, _ = _conv_weight_copies(conv_w)
             operand = torch.empty((M, kp), dtype=dt, device=dev)
             check(lib.eoe_im2col(_p(x), 1 if is_image else 2, _p(mean), _p(std), _p(operand), n, cin, Hi, Wi, kh, kw, stride, pad,
                                  kp, code, _stream()), "eoe_im2col")
-            gemm_nt(operand, w16, y, bias=conv_b)
+            gemm_nt(operand, w16, y, bias=conv_b, colstats_ws=part)
         stats = torch.empty(2 * cout, dtype=torch.float32, device=dev)
         sums = scratch("bn_sums", (BN_SCRATCH * cout,), torch.float32, dev)
-        check(lib.eoe_bn_stats(_p(y), _p(sums), _p(stats), _p(rm), _p(rv), _p(nbt), M, cout, float(eps), float(momentum),
-                               1 if training else 0, _stream()), "eoe_bn_stats")
+        if part is not None:
+            check(lib.eoe_bn_stats_partials(_p(part), R, _p(sums), _p(stats), _p(rm), _p(rv), _p(nbt), M, cout, float(eps),
+                                            float(momentum), _stream()), "eoe_bn_stats_partials")
+        else:
+            check(lib.eoe_bn_stats(_p(y), _p(sums), _p(stats), _p(rm), _p(rv), _p(nbt), M, cout, float(eps), float(momentum),
+                                   1 if training else 0, _stream()), "eoe_bn_stats")
         want16 = bool(cfg[10]) if len(cfg) > 10 else False
         idx = None
         if isinstance(pool, tuple):

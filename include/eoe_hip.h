@@ -87,6 +87,9 @@ typedef struct {
                          * 2: A is the zero-padded NHWC4 image of eoe_stem_pack_image (geo.C = 4, geo.pad = 0, geo.H/W = Hp/Wp),
                          *    K (NT) / M (TN) = ceil(kh/2)*64 */
     eoe_conv_geometry geo;
+    int32_t colstats;   /* NT only: the workspace (>= 2 * EOE_NT_COLSUM_WORKSPACE_BYTES(M, N)) receives, per 64 output rows, the column
+                         * sums and sums of squares of the fp32 epilogue result: [ceil(M/64)][2][N] floats -- BatchNorm batch
+                         * statistics without a pass over C (eoe_bn_stats_partials reduces them); N % 16 == 0 */
 } eoe_gemm_args;
 #define EOE_NT_COLSUM_WORKSPACE_BYTES(M, N) ((size_t)(((M) + 63) / 64) * (size_t)(N) * 4)
 
@@ -318,6 +321,9 @@ int eoe_stem_unpack_wgrad(const float* g, float* dw, int cout, int kh, int kw, v
  * the running buffers.  sums_scratch: EOE_BN_SCRATCH(C) floats (per-workgroup partial sums: no atomics). */
 #define EOE_BN_PARTIALS 1024
 #define EOE_BN_SCRATCH(C) ((EOE_BN_PARTIALS + 1) * 2 * (C))
+/* the same statistics from the partial rows [R][2][C] an eoe_gemm_nt call with `colstats` left in its workspace (R = ceil(M/64)) */
+int eoe_bn_stats_partials(const float* part, int R, float* sums_scratch, float* stats, float* running_mean, float* running_var,
+                          int64_t* num_batches_tracked, int M, int C, float eps, float momentum, void* stream);
 int eoe_bn_stats(const float* y, float* sums_scratch, float* stats, float* running_mean, float* running_var,
                  int64_t* num_batches_tracked, int M, int C, float eps, float momentum, int training, void* stream);
 /* out = maxpool_{pool}(act(bn(y))), act(z) = z > 0 ? z : slope*z (slope 0.01 = LeakyReLU of cnn.py, 0 = ReLU of

@@ -86,6 +86,45 @@ def test_gemm_nt_strided_and_epilogues(ops, dtype, nt_variant):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(300, 64, 128), (1000, 256, 64), (70000, 32, 64)])
+def test_gemm_nt_colstats_and_bn_stats_partials(ops, dtype, M, N, K):
+    """BatchNorm batch statistics from the GEMM epilogue: per-64-row (sum, sum of squares) partial rows, reduced by
+    eoe_bn_stats_partials, equal the statistics eoe_bn_stats computes from the stored output (ragged M tail, > 1024 rows)"""
+    from eoe_amd import _lib
+    a, ar = t16(f"cs/a{M}", (M, K), 1.0, dtype)
+    b, br = t16(f"cs/b{N}", (N, K), 0.3, dtype)
+    bias, biasr = f32("cs/bias", (N,), 1.0)
+    y = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    R = (M + 63) // 64
+    part = torch.full((R, 2, N), float("nan"), dtype=torch.float32, device="cuda")
+    ops.gemm_nt(a, b, y, bias=bias, colstats_ws=part)
+    yr = y.double().cpu()
+    pr = part.double().cpu()
+    assert torch.isfinite(pr).all()
+    for r in (0, R // 2, R - 1):
+        blk = yr[r * 64:(r + 1) * 64]
+        assert_close(pr[r, 0], blk.sum(0), 1e-5, 1e-4, "partial sums")
+        assert_close(pr[r, 1], (blk * blk).sum(0), 1e-5, 1e-3, "partial sums of squares")
+    stats = torch.empty(2 * N, dtype=torch.float32, device="cuda")
+    stats_ref = torch.empty(2 * N, dtype=torch.float32, device="cuda")
+    sums = torch.empty(ops.BN_SCRATCH * N, dtype=torch.float32, device="cuda")
+    rm, rv = torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")
+    rm2, rv2 = torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")
+    nbt, nbt2 = torch.zeros(1, dtype=torch.int64, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    _lib.check(_lib.lib.eoe_bn_stats_partials(part.data_ptr(), R, sums.data_ptr(), stats.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+                                              nbt.data_ptr(), M, N, 1e-5, 0.1, s), "eoe_bn_stats_partials")
+    _lib.check(_lib.lib.eoe_bn_stats(y.data_ptr(), sums.data_ptr(), stats_ref.data_ptr(), rm2.data_ptr(), rv2.data_ptr(),
+                                     nbt2.data_ptr(), M, N, 1e-5, 0.1, 1, s), "eoe_bn_stats")
+    assert_close(stats[:N], yr.mean(0), 1e-5, 1e-5, "mean")
+    assert_close(stats[N:], 1.0 / torch.sqrt(yr.var(0, unbiased=False) + 1e-5), 1e-4, 1e-5, "rstd")
+    assert_close(stats, stats_ref.double().cpu(), 1e-4, 1e-5, "fused == separate pass")
+    assert_close(rm, rm2.double().cpu(), 1e-5, 1e-6, "running mean")
+    assert_close(rv, rv2.double().cpu(), 1e-4, 1e-6, "running var")
+    assert int(nbt) == 1
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("T,M,N", [(64, 128, 128), (200, 256, 128), (50, 8, 16), (1000, 136, 264), (12800, 768, 768),
                                    (12544, 768, 3072), (4, 256, 512), (4100, 128, 128)])
 def test_gemm_tn(ops, dtype, T, M, N):
