@@ -16,11 +16,11 @@ def conv3x3(in_planes, out_planes, stride=1):
     return nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)
 
 
-def _conv_bn(x, conv, bn, training, slope, is_image=False, normalize=None, want16=False, pool=1):
+def _conv_bn(x, conv, bn, training, slope, is_image=False, normalize=None, want16=False, pool=1, passthrough=False):
     """conv (no bias) -> BatchNorm2d -> ReLU (slope 0) or nothing (slope 1); fp32 NHWC in/out"""
     mean, std = normalize if (is_image and normalize is not None) else (None, None)
     k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
-    cfg = (training, bn.eps, bn.momentum, pool, is_image, mean, std, False, (k, k, s, p), slope, want16)
+    cfg = (training, bn.eps, bn.momentum, pool, is_image, mean, std, False, (k, k, s, p), slope, want16, passthrough)
     return ops.conv_bn_act_pool(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                 bn.num_batches_tracked, cfg)
 
@@ -40,9 +40,14 @@ class BasicBlock(nn.Module):
         self.cbam = CBAM(planes, 16) if use_cbam else None
 
     def forward(self, x):      # x: fp32 NHWC (resnet.py:130-149)
-        out = _conv_bn(x, self.conv1, self.bn1, self.training, 0.0, want16=True)       # feeds conv2 only
-        out = _conv_bn(out, self.conv2, self.bn2, self.training, 1.0)
+        # identity shortcut: conv1 hands its input through as the junction's shortcut operand, so that the shortcut's
+        # gradient reaches conv1's backward and is accumulated by its dgrad GEMM (no separate gradient add)
+        fuse = self.downsample is None and x.requires_grad and torch.is_grad_enabled()
+        out = _conv_bn(x, self.conv1, self.bn1, self.training, 0.0, want16=True, passthrough=fuse)       # feeds conv2 only
         residual = x
+        if fuse:
+            out, residual = out
+        out = _conv_bn(out, self.conv2, self.bn2, self.training, 1.0)
         if self.downsample is not None:
             residual = _conv_bn(x, self.downsample[0], self.downsample[1], self.training, 1.0)
         if self.cbam is not None and not self.cbam.no_spatial:

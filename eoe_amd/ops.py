@@ -771,14 +771,14 @@ def set_implicit_conv(on: bool):
     _implicit_conv = bool(on)
 
 
-def conv_gemm_fwd(x16, w16, y, geo, bias=None, mode=1, colstats_ws=None):
+def conv_gemm_fwd(x16, w16, y, geo, bias=None, mode=1, colstats_ws=None, accumulate=False):
     """y[n*Ho*Wo, cout] (fp32) = patches(x16) @ w16^T without materialising the patches; x16 16-bit NHWC [n,H,W,C]
     (mode 2: the zero-padded NHWC4 image of eoe_stem_pack_image, packed k axis)"""
     n, H, W, Cc, kh, kw, stride, pad, Ho, Wo = geo
     M, K, N = n * Ho * Wo, (_conv_kp(Cc, kh * kw) if mode == 1 else (kh + 1) // 2 * 64), w16.shape[0]
     assert x16.is_contiguous() and w16.shape[1] == K and w16.stride(1) == 1 and y.shape == (M, N) and y.stride(1) == 1
     g = GemmArgs(_p(x16), _p(w16), _p(y), _p(bias), None, None, None, M, N, K, 0, w16.stride(0), y.stride(0), 0,
-                 dtype_code(x16.dtype), EPI_NONE, 1 if y.dtype == torch.float32 else 0, 0, 1.0, None, 0, mode,
+                 dtype_code(x16.dtype), EPI_NONE, 1 if y.dtype == torch.float32 else 0, 1 if accumulate else 0, 1.0, None, 0, mode,
                  _lib.ConvGeometry(*geo))
     if colstats_ws is not None:       # BatchNorm batch statistics from the epilogue: per-64-row partial (sum, sum of squares)
         g.workspace, g.workspace_bytes, g.colstats = _p(colstats_ws), colstats_ws.numel() * 4, 1
@@ -815,6 +815,11 @@ class ConvBnActPoolFunction(torch.autograd.Function):
         training, eps, momentum, pool, is_image, mean, std, flat_out = cfg[:8]
         kh, kw, stride, pad = cfg[8] if len(cfg) > 8 else (5, 5, 1, 2)
         slope = float(cfg[9]) if len(cfg) > 9 else 0.01
+        # cfg[11]: also return the input itself (third output).  A residual block hands THAT to its junction as the shortcut,
+        # so the junction's gradient for the shortcut arrives here (backward's d_pass) and the dgrad GEMM accumulates onto
+        # it -- instead of autograd adding the two gradients of the block input with a separate elementwise pass
+        passthrough = bool(cfg[11]) if len(cfg) > 11 else False
+        x_in = x
         x16 = getattr(x, "_eoe16", None)
         x = x.contiguous().float()
         cout, cin = conv_w.shape[0], conv_w.shape[1]
@@ -890,14 +895,23 @@ class ConvBnActPoolFunction(torch.autograd.Function):
                                           1 if flat_out else 0, 1, slope, code, _stream()), "eoe_bn_act_pool_fwd")
         ctx.save_for_backward(operand, y, stats, conv_w, conv_b, bn_w, bn_b, idx)
         ctx.cfg = (n, H, W, cin, cout, kp, pool, flat_out, training, is_image, Hi, Wi, kh, kw, stride, pad, slope, implicit)
-        if out16 is None:
+        ctx.has16, ctx.passthrough = out16 is not None, passthrough
+        if out16 is None and not passthrough:
             return out
-        ctx.mark_non_differentiable(out16)
         ctx.set_materialize_grads(False)       # else autograd zero-fills a gradient for the 16-bit copy every step
-        return out, out16
+        outs = [out]
+        if out16 is not None:
+            ctx.mark_non_differentiable(out16)
+            outs.append(out16)
+        if passthrough:
+            outs.append(x_in)
+        return tuple(outs)
 
     @staticmethod
-    def backward(ctx, dout, _d16=None):
+    def backward(ctx, dout, *more):
+        d_pass = more[-1] if (ctx.passthrough and more) else None
+        if dout is None:                         # only the pass-through output was used downstream
+            return (d_pass,) + (None,) * 8
         operand, y, stats, conv_w, conv_b, bn_w, bn_b, idx = ctx.saved_tensors
         n, H, W, cin, cout, kp, pool, flat_out, training, is_image, Hi, Wi, kh, kw, stride, pad, slope, implicit = ctx.cfg
         dev, dt = y.device, operand.dtype
@@ -939,26 +953,35 @@ class ConvBnActPoolFunction(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0] and not is_image:
             _, w16t, w16d = _conv_weight_copies(conv_w)
-            dx = torch.empty((n, Hi, Wi, cin), dtype=torch.float32, device=dev)
+            acc = (d_pass is not None and d_pass.dtype == torch.float32 and d_pass.is_contiguous()
+                   and d_pass.shape == (n, Hi, Wi, cin))
             if _implicit_conv and stride == 1 and kh == kw and cout % 64 == 0:
-                # dx = conv of dy with the flipped kernel: the same implicit GEMM, gathering from dy16 [n, H, W, cout]
+                # dx = conv of dy with the flipped kernel: the same implicit GEMM, gathering from dy16 [n, H, W, cout];
+                # with a shortcut gradient it accumulates onto that tensor (C += in the epilogue)
+                dx = d_pass if acc else torch.empty((n, Hi, Wi, cin), dtype=torch.float32, device=dev)
                 conv_gemm_fwd(dy16.view(n, H, W, cout), w16d, dx.view(-1, cin),
-                              (n, H, W, cout, kh, kw, 1, kh - 1 - pad, Hi, Wi))
+                              (n, H, W, cout, kh, kw, 1, kh - 1 - pad, Hi, Wi), accumulate=acc)
+                d_pass = None
             else:
+                dx = torch.empty((n, Hi, Wi, cin), dtype=torch.float32, device=dev)
                 dpatches = torch.empty((M, kp), dtype=dt, device=dev)
                 gemm_nt(dy16, w16t, dpatches)
                 check(lib.eoe_col2im(_p(dpatches), _p(dx), n, cin, Hi, Wi, kh, kw, stride, pad, kp, code, _stream()), "eoe_col2im")
+        if d_pass is not None:
+            dx = d_pass if dx is None else dx.add_(d_pass)
         return dx, dw, dcb, dg, db, None, None, None, None
 
 
 def conv_bn_act_pool(x, conv_w, conv_b, bn_w, bn_b, rm, rv, nbt, cfg):
     """ConvBnActPoolFunction + the 16-bit copy of its output attached as `._eoe16` (consumed by the next convolution)"""
     r = ConvBnActPoolFunction.apply(x, conv_w, conv_b, bn_w, bn_b, rm, rv, nbt, cfg)
-    if isinstance(r, tuple):
-        out, out16 = r
-        out._eoe16 = out16
-        return out
-    return r
+    passthrough = bool(cfg[11]) if len(cfg) > 11 else False
+    if not isinstance(r, tuple):
+        return r
+    out = r[0]
+    if len(r) - (1 if passthrough else 0) == 2:
+        out._eoe16 = r[1]
+    return (out, r[-1]) if passthrough else out
 
 
 class BnActFunction(torch.autograd.Function):
