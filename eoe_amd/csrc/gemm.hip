@@ -691,6 +691,145 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmP p) {
     epilogue<T, EPI, NI, MI>(ep, acc, m0 + wm0, n0 + wn0, lane, smem + wave * 4096);
 }
 
+// ------------------------------------------------------------------------------------------------ NT, N <= 64
+// Third tile shape, for cout = 64 layers (plain epilogue): 256x64x64, four waves stacked along M (64x64 each -- the same
+// 16 MFMAs per 8 fragment reads as the other kernels; the 256x64 tile of the persistent kernel gives a wave 64x32 = 8 MFMAs
+// per 6 reads and ran the 64-channel WideResNet convolutions at 355 TF), 2-stage 80 KB ring, two non-persistent workgroups
+// per CU, the schedule of gemm_nt128_kernel.  GATHER = 1: A is the implicit patch matrix (C % 64 == 0: one tap per k-tile).
+constexpr int A64_BYTES = 256 * BK * 2;             // 32 KiB
+constexpr int B64_BYTES = 64 * BK * 2;              // 8 KiB
+constexpr int STAGE64_BYTES = A64_BYTES + B64_BYTES;
+constexpr int SMEM64_BYTES = 2 * STAGE64_BYTES;     // 80 KiB: two workgroups fill the CU's 160 KiB
+
+template <typename T, int GATHER>
+__global__ __launch_bounds__(256, 2) void gemm_nt64_kernel(GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NI = 4;
+    const int total_tiles = (p.M + 255) / 256;
+    const int m0 = xcd_remap((int)blockIdx.x, total_tiles) * 256;
+    const int nk = p.K / BK;
+
+    __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.bytesA);
+    __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.bytesB);
+    // a wave-load covers 8 rows: 8 per wave for A (256 rows), 2 per wave for B (64 rows)
+    unsigned offA[8], offB[2];
+    int gh[8], gw[8];
+    int g_ky = 0, g_kx = 0, g_c0 = 0;              // GATHER: tap / channel offset of the next k-tile to be staged (uniform)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row = (wave * 8 + j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const int ga = m0 + row;
+        if (GATHER == 1) {
+            if (ga < p.M) {
+                const int img = ga / p.gHoWo, rem = ga - img * p.gHoWo;
+                const int ho = rem / p.gWo, wo = rem - ho * p.gWo;
+                gh[j] = ho * p.gstride - p.gpad;
+                gw[j] = wo * p.gstride - p.gpad;
+                offA[j] = (unsigned)((((img * p.gH + gh[j]) * p.gW + gw[j]) * p.gC + c * 8) * 2);   // wraps for h < 0: only used when valid
+            } else {
+                gh[j] = -(1 << 24);
+                gw[j] = 0;
+                offA[j] = 0;
+            }
+        } else {
+            gh[j] = 0; gw[j] = 0;
+            offA[j] = (ga < p.M) ? (unsigned)(((size_t)ga * p.lda + c * 8) * 2) : EOE_OOB;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave * 2 + j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        offB[j] = (row < p.N) ? (unsigned)(((size_t)row * p.ldb + c * 8) * 2) : EOE_OOB;
+    }
+    // 10 LDS-DMA instructions per wave per k-tile; k-tiles are staged in order 0, 1, 2, ... (the tap cursor advances with them)
+#define EOE_STAGE64(slot, kt)                                                                                                \
+    do {                                                                                                                     \
+        char* sa_ = smem + (slot) * STAGE64_BYTES;                                                                           \
+        char* sb_ = sa_ + A64_BYTES;                                                                                         \
+        const unsigned k0_ = (unsigned)(kt) * (BK * 2u);                                                                     \
+        if (GATHER == 1) {                                                                                                   \
+            const unsigned delta_ = (unsigned)(((g_ky * p.gW + g_kx) * p.gC + g_c0) * 2);                                    \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                  \
+                const bool ok_ = (unsigned)(gh[j] + g_ky) < (unsigned)p.gH && (unsigned)(gw[j] + g_kx) < (unsigned)p.gW;     \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(sa_ + (wave * 8 + j) * 1024), 16,                 \
+                                                         ok_ ? offA[j] + delta_ : EOE_OOB, 0, 0, 0);                         \
+            }                                                                                                                \
+            g_c0 += BK;                                                                                                      \
+            if (g_c0 == p.gC) {                                                                                              \
+                g_c0 = 0;                                                                                                    \
+                if (++g_kx == p.gkw) { g_kx = 0; ++g_ky; }                                                                   \
+            }                                                                                                                \
+        } else {                                                                                                             \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                    \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(sa_ + (wave * 8 + j) * 1024), 16, offA[j] + k0_, 0, 0, 0); \
+        }                                                                                                                    \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                        \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(sb_ + (wave * 2 + j) * 1024), 16, offB[j] + k0_, 0, 0, 0); \
+    } while (0)
+
+    const int wm0 = wave * 64;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int sw = (lr >> 1) & 7;
+    const int fragA = (wm0 + lr) * 128, fragB = A64_BYTES + lr * 128;
+    const int ch0 = ((0 + lg) ^ sw) * 16, ch1 = ((4 + lg) ^ sw) * 16;
+    typedef typename T16<T>::v8 V8;
+
+    f32x4 acc[4][NI];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#define EOE_READ64(XA, WB, base, ks)                                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
+        XA[i] = *(const V8*)((base) + fragA + i * 2048 + ((ks) ? ch1 : ch0));             \
+        WB[i] = *(const V8*)((base) + fragB + i * 2048 + ((ks) ? ch1 : ch0));             \
+    }
+#define EOE_MFMA64(XA, WB)                                                \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                      \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T16<T>::mfma16(WB[ni], XA[mi], acc[mi][ni]);
+
+    // schedule, WAR / RAW argument: gemm_nt128_kernel
+    V8 xa0[4], wb0[4], xa1[4], wb1[4];
+    EOE_STAGE64(0, 0);
+    if (nk > 1) EOE_STAGE64(1, 1);
+    if (nk > 1) { EOE_WAIT_VM(10); } else { EOE_WAIT_VM(0); }
+    __builtin_amdgcn_s_barrier();
+    EOE_READ64(xa0, wb0, smem, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* sc = smem + (kt & 1) * STAGE64_BYTES;
+        const char* sn = smem + ((kt + 1) & 1) * STAGE64_BYTES;
+        EOE_READ64(xa1, wb1, sc, 1);
+        EOE_MFMA64(xa0, wb0);
+        EOE_WAIT_VM(0);
+        EOE_WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) EOE_STAGE64(kt & 1, kt + 2);
+        EOE_READ64(xa0, wb0, sn, 0);           // unconditional (the last one reads a stale slot and is discarded)
+        EOE_MFMA64(xa1, wb1);
+    }
+    EOE_WAIT_LGKM0();
+    __builtin_amdgcn_s_barrier();               // every wave is done reading the ring before the epilogue's scratch use
+#undef EOE_READ64
+#undef EOE_MFMA64
+#undef EOE_STAGE64
+    GemmP ep;
+    load_epilogue_args(ep, p);
+    epilogue<T, EOE_EPI_NONE, NI, 4>(ep, acc, m0 + wm0, 0, lane, smem + wave * 4096);
+}
+
+template <typename T, int GATHER>
+int launch_nt64(const GemmP& p, hipStream_t s) {
+    static bool once = (hipFuncSetAttribute((const void*)gemm_nt64_kernel<T, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM64_BYTES), true);
+    (void)once;
+    hipLaunchKernelGGL((gemm_nt64_kernel<T, GATHER>), dim3(cdiv(p.M, 256)), dim3(256), SMEM64_BYTES, s, p);
+    EOE_CHECK_LAUNCH("gemm_nt64");
+    return 0;
+}
+
 // colsum[c] += sum_r part[r][c] (the epilogues' per-wave-row partial column sums), fixed order: 16 columns x 64 row lanes
 __global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __restrict__ part, int R, int N, float* __restrict__ out) {
     __shared__ float l[64][17];
@@ -813,6 +952,11 @@ int launch_nt_ni(const GemmP& p, int epi, int grid, hipStream_t s) {
 template <typename T>
 int launch_nt(const GemmP& p, int epi, int gather, hipStream_t s) {
     const int ncu = num_cus();
+    if (epi == EOE_EPI_NONE && p.N <= 64 && (gather == 0 || gather == 1) && !(g_nt_flags & 64)) {
+        // cout <= 64: four 64x64 waves per 256x64 tile, two workgroups per CU (nt_flags bit 6: the persistent 256x64 kernel instead)
+        const int rc = gather ? launch_nt64<T, 1>(p, s) : launch_nt64<T, 0>(p, s);
+        return rc ? rc : finish_colsum(p, EOE_EPI_NONE, 4, s);
+    }
     if (gather || (epi == EOE_EPI_NONE && p.N <= 64)) {
         const bool narrow = p.N <= 64;               // 256x64 tiles: no MFMA / LDS work on columns that do not exist
         const int tiles = cdiv(p.M, BM) * cdiv(p.N, narrow ? 64 : 128);

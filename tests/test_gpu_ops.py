@@ -18,9 +18,10 @@ def ops():
     return o
 
 
-# tile shapes of the NT GEMM (nt_flags of gemm.hip; bit 0 = the shipped fast epilogue): the launcher's own choice, the persistent
-# 256-row kernel, and the two-workgroup kernel with 128- and with 160-row tiles -- every test below must hold for each
-NT_VARIANTS = {"auto": 1, "persistent256": 1 | 4, "two_wg_128": 1 | 8 | 16, "two_wg_160": 1 | 8 | 32}
+# tile shapes of the NT GEMM (nt_flags of gemm.hip; bit 0 = the shipped fast epilogue): the launcher's own choice (which includes
+# the 256x64 two-workgroup kernel for N <= 64), the persistent 256-row kernel (also for N <= 64: bit 6), and the two-workgroup
+# kernel with 128- and with 160-row tiles -- every test below must hold for each
+NT_VARIANTS = {"auto": 1, "persistent256": 1 | 4 | 64, "two_wg_128": 1 | 8 | 16, "two_wg_160": 1 | 8 | 32}
 
 
 @pytest.fixture(params=list(NT_VARIANTS))
@@ -42,7 +43,7 @@ def _qgelu_grad(x):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (200, 256, 192), (130, 136, 64), (50, 8, 64),
-                                   (12800, 768, 768), (392, 768, 3072), (4, 256, 512), (161, 264, 64), (480, 136, 256)])
+                                   (12800, 768, 768), (392, 768, 3072), (4, 256, 512), (161, 264, 64), (480, 136, 256), (1000, 64, 192), (300, 48, 64)])
 def test_gemm_nt_plain(ops, dtype, M, N, K, nt_variant):
     a, ar = t16(f"nt/a{M}", (M, K), 1.0, dtype)
     b, br = t16(f"nt/b{N}", (N, K), 1.0, dtype)
