@@ -662,6 +662,84 @@ __global__ __launch_bounds__(256) void rowobj_bwd_kernel(const float* __restrict
     }
 }
 
+// CLIP text-prompt objective (training/clip.py:66-103): one wavefront per sample.  l_j = 100 * <f / |f|, t_j>, j < T <= 64;
+//   loss_i = -(log_softmax l)[pick],  pick = T-1 (anomalous), 0 (nominal, one_vs_rest) or argmax_{j < T-1} (nominal,
+//   leave_one_out); samples whose label is neither contribute 0 (clip.py:89-91);  score_i = softmax(l)[T-1].
+// The logits live one per lane (lane j holds l_j after the T wave reductions).
+__device__ __forceinline__ float clip_logits(const float* __restrict__ f, const float* __restrict__ text, int row, int d, int T,
+                                             int lane, float& inv_norm) {
+    float ss = 0.f;
+    for (int c = lane; c < d; c += 64) { const float v = f[(size_t)row * d + c]; ss += v * v; }
+    inv_norm = 1.0f / sqrtf(wave_sum(ss));
+    float mine = -INFINITY;
+    for (int j = 0; j < T; ++j) {
+        float dot = 0.f;
+        for (int c = lane; c < d; c += 64) dot += f[(size_t)row * d + c] * text[(size_t)j * d + c];
+        dot = wave_sum(dot);
+        if (lane == j) mine = 100.0f * dot * inv_norm;
+    }
+    return mine;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v = fmaxf(v, __shfl_xor(v, s, 64));
+    return v;
+}
+// lane j: p = softmax(l)_j, returns the picked column (uniform); lse through the reference argument
+__device__ __forceinline__ int clip_pick(float l, int lane, int T, int64_t label, int64_t nominal, int leave_one_out, float& p, float& lse) {
+    const float m = wave_max(l);
+    const float e = lane < T ? __expf(l - m) : 0.f;
+    const float se = wave_sum(e);
+    p = e / se;
+    lse = m + __logf(se);
+    if (label == 1 - nominal) return T - 1;
+    if (label != nominal) return -1;
+    if (!leave_one_out) return 0;
+    // first maximum over j < T-1 (torch.max returns the first index among equal maxima on CPU; ties are measure-zero here)
+    const float cand = lane < T - 1 ? l : -INFINITY;
+    const float mx = wave_max(cand);
+    const unsigned long long hit = __ballot(cand == mx && lane < T - 1);
+    return __ffsll((long long)hit) - 1;
+}
+__global__ __launch_bounds__(256) void clip_rows_kernel(const float* __restrict__ f, const float* __restrict__ text,
+                                                        const int64_t* __restrict__ labels, int64_t nominal, int leave_one_out,
+                                                        float* __restrict__ scores, float* __restrict__ losses, int n, int d, int T) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    float inv_norm;
+    const float l = clip_logits(f, text, row, d, T, lane, inv_norm);
+    float p, lse;
+    const int pick = clip_pick(l, lane, T, labels ? labels[row] : nominal, nominal, leave_one_out, p, lse);
+    if (scores && lane == T - 1) scores[row] = p;
+    if (losses) {
+        const float lp = __shfl(l, pick < 0 ? 0 : pick, 64);
+        if (lane == 0) losses[row] = pick < 0 ? 0.f : lse - lp;
+    }
+}
+// df = coef * (100 * sum_j g_j t_j - fhat * sum_j g_j l_j) / |f|,  g_j = softmax_j - [j == pick]
+__global__ __launch_bounds__(256) void clip_bwd_kernel(const float* __restrict__ f, const float* __restrict__ text,
+                                                       const int64_t* __restrict__ labels, int64_t nominal, int leave_one_out,
+                                                       const float* __restrict__ gscale, float* __restrict__ df, int n, int d, int T,
+                                                       float inv_count) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    float inv_norm;
+    const float l = clip_logits(f, text, row, d, T, lane, inv_norm);
+    float p, lse;
+    const int pick = clip_pick(l, lane, T, labels[row], nominal, leave_one_out, p, lse);
+    const float coef = inv_count * (gscale ? gscale[0] : 1.0f);
+    float g = (pick < 0 || lane >= T) ? 0.f : (p - (lane == pick ? 1.f : 0.f));
+    const float gl = wave_sum(lane < T ? g * l : 0.f);
+    for (int c = lane; c < d; c += 64) {
+        float acc = 0.f;
+        for (int j = 0; j < T; ++j) acc += __shfl(g, j, 64) * text[(size_t)j * d + c];
+        const float fh = f[(size_t)row * d + c] * inv_norm;
+        df[(size_t)row * d + c] = coef * (100.0f * acc - fh * gl) * inv_norm;
+    }
+}
+
 // focal loss on logits (focal.py:11-24): b = bce(x, y), pt = clamp(exp(-b), eps, 1 - eps), loss = (1 - pt)^gamma * b
 __global__ __launch_bounds__(256) void focal_rows_kernel(const float* __restrict__ x, const int64_t* __restrict__ labels, int64_t nominal,
                                                          float* __restrict__ scores, float* __restrict__ losses, int n, float gamma,
@@ -785,6 +863,30 @@ __global__ __launch_bounds__(256) void linear_small_dw_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------ Adam
+// fused multi-tensor SGD with momentum / Nesterov (torch.optim.SGD, dampening 0; ad_trainer.py:380-381): g += wd * p;
+// buf = momentum * buf + g (buf starts at 0, which reproduces torch's "first step: buf = g"); p -= lr * (nesterov ? g + momentum * buf : buf).
+// Same chunk tables as the Adam kernel (m_off = the momentum buffer, v_off unused).
+__global__ __launch_bounds__(256) void sgd_multi_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                        const eoe_adam_chunk* __restrict__ chunks, float lr, float momentum, float wd,
+                                                        int nesterov) {
+    const eoe_adam_chunk ck = chunks[blockIdx.x];
+    float* pp = p + ck.p_off;
+    const float* gg = g + ck.g_off;
+    float* bb = buf + ck.m_off;
+    for (int i = threadIdx.x; i < ck.n; i += blockDim.x) {
+        const float pv = pp[i];
+        float gv = gg[i];
+        if (wd != 0.f) gv = gv + wd * pv;
+        float step = gv;
+        if (momentum != 0.f) {
+            const float bv = momentum * bb[i] + gv;
+            bb[i] = bv;
+            step = nesterov ? gv + momentum * bv : bv;
+        }
+        pp[i] = pv - lr * step;
+    }
+}
+
 // one block per chunk of <= EOE_ADAM_CHUNK elements; float4 accesses (chunk offsets are multiples of 4 for
 // 16-B aligned parameter starts; scalar path otherwise).
 template <typename T>
@@ -1212,6 +1314,47 @@ extern "C" int eoe_focal_bwd(const float* x, const int64_t* labels, const float*
     hipLaunchKernelGGL(focal_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, labels, gscale, dx, n, inv_count,
                        gamma, eps);
     EOE_CHECK_LAUNCH("focal_bwd");
+    return 0;
+}
+
+extern "C" int eoe_clip_fwd(const float* f, const float* text, const int64_t* labels, int64_t nominal_label, int leave_one_out,
+                            float* loss, float* scores, float* losses, int n, int d, int T, float inv_count, void* stream) {
+    EOE_CHECK_ARG(f && text && labels && n > 0 && d > 0 && T >= 2 && T <= 64, "clip_fwd: bad args (2 <= T <= 64)");
+    EOE_CHECK_ARG(!loss || losses, "clip_fwd: the loss needs the per-sample `losses` buffer");
+    hipLaunchKernelGGL(clip_rows_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, f, text, labels, nominal_label, leave_one_out,
+                       scores, losses, n, d, T);
+    EOE_CHECK_LAUNCH("clip_rows");
+    if (loss) {
+        hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, losses, loss, n, inv_count);
+        EOE_CHECK_LAUNCH("clip_sum");
+    }
+    return 0;
+}
+
+extern "C" int eoe_clip_bwd(const float* f, const float* text, const int64_t* labels, int64_t nominal_label, int leave_one_out,
+                            const float* gscale, float* df, int n, int d, int T, float inv_count, void* stream) {
+    EOE_CHECK_ARG(f && text && labels && df && n > 0 && d > 0 && T >= 2 && T <= 64, "clip_bwd: bad args (2 <= T <= 64)");
+    hipLaunchKernelGGL(clip_bwd_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, f, text, labels, nominal_label, leave_one_out,
+                       gscale, df, n, d, T, inv_count);
+    EOE_CHECK_LAUNCH("clip_bwd");
+    return 0;
+}
+
+extern "C" int eoe_clip_score(const float* f, const float* text, float* scores, int n, int d, int T, void* stream) {
+    EOE_CHECK_ARG(f && text && scores && n > 0 && d > 0 && T >= 2 && T <= 64, "clip_score: bad args (2 <= T <= 64)");
+    hipLaunchKernelGGL(clip_rows_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, f, text, (const int64_t*)nullptr, (int64_t)0, 0,
+                       scores, (float*)nullptr, n, d, T);
+    EOE_CHECK_LAUNCH("clip_score");
+    return 0;
+}
+
+extern "C" int eoe_sgd_multi(float* p, const float* g, float* buf, const eoe_adam_chunk* chunks, int n_chunks, float lr,
+                             float momentum, float weight_decay, int nesterov, void* stream) {
+    EOE_CHECK_ARG(p && g && chunks && n_chunks > 0 && (buf || momentum == 0.f), "sgd_multi: bad args");
+    ProfScope ps("sgd_multi", 0, 20.0 * n_chunks * EOE_ADAM_CHUNK, stream);
+    hipLaunchKernelGGL(sgd_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, p, g, buf, chunks, lr, momentum, weight_decay,
+                       nesterov);
+    EOE_CHECK_LAUNCH("sgd_multi");
     return 0;
 }
 

@@ -64,6 +64,9 @@ def gemm_nt(a, b, out, bias=None, epilogue=EPI_NONE, aux=None, aux_out=None, acc
     """out[M,N] = a[M,K] @ b[N,K]^T  (+ epilogue); a, b 16-bit row-major (row stride may exceed K).
     colstats_ws: fp32 [ceil(M/64), 2, N] -> receives the per-64-row column sums / sums of squares of the fp32 result"""
     _chk(a, b, out, bias, aux, aux_out, colsum_out)
+    if a.shape[1] % 64:               # the MFMA k-tile is 64 deep: zero-pad ragged reductions (CNN28: K = 1568, 32)
+        pad = (a.shape[1] + 63) // 64 * 64 - a.shape[1]
+        a, b = torch.nn.functional.pad(a, (0, pad)), torch.nn.functional.pad(b, (0, pad))
     M, K = a.shape
     N = b.shape[0]
     assert b.shape[1] == K and out.shape == (M, N), (a.shape, b.shape, out.shape)
@@ -600,6 +603,52 @@ def bce_score(feats, nominal_label=0):
 
 
 # ------------------------------------------------------------------------------------------------ autograd: other objectives
+class ClipLossFunction(torch.autograd.Function):
+    """ADClipTrainer.loss (training/clip.py:81-103): -mean log_softmax(100 f/|f| T^T)[pick]"""
+
+    @staticmethod
+    def forward(ctx, feats, labels, text, nominal_label, leave_one_out, inv_count):
+        _chk(feats, labels, text)
+        f = feats.contiguous().float()
+        n, d = f.shape
+        t = text.detach().contiguous().float()
+        assert t.dim() == 2 and t.shape[1] == d and 2 <= t.shape[0] <= 64, t.shape
+        labels = labels.contiguous().to(torch.int64)
+        loss = torch.empty(1, dtype=torch.float32, device=f.device)
+        losses = torch.empty(n, dtype=torch.float32, device=f.device)
+        inv = float(inv_count) if inv_count is not None else 1.0 / n
+        check(lib.eoe_clip_fwd(_p(f), _p(t), _p(labels), int(nominal_label), 1 if leave_one_out else 0, _p(loss), None, _p(losses),
+                               n, d, t.shape[0], inv, _stream()), "eoe_clip_fwd")
+        ctx.save_for_backward(f, t, labels)
+        ctx.cfg = (int(nominal_label), 1 if leave_one_out else 0, inv)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        f, t, labels = ctx.saved_tensors
+        nominal, loo, inv = ctx.cfg
+        df = torch.empty_like(f)
+        gs = gout.contiguous().float().reshape(1)
+        check(lib.eoe_clip_bwd(_p(f), _p(t), _p(labels), nominal, loo, _p(gs), _p(df), f.shape[0], f.shape[1], t.shape[0], inv,
+                               _stream()), "eoe_clip_bwd")
+        return df, None, None, None, None, None
+
+
+def clip_loss(feats, labels, text, nominal_label=0, leave_one_out=False, inv_count=None):
+    return ClipLossFunction.apply(feats, labels, text, nominal_label, leave_one_out, inv_count)
+
+
+def clip_score(feats, text):
+    """ADClipTrainer.compute_anomaly_score (clip.py:66-79): softmax(100 f/|f| (T/|T|)^T)[:, -1]"""
+    _chk(feats, text)
+    f = feats.detach().contiguous().float()
+    t = text.detach().float()
+    t = (t / t.norm(dim=-1, keepdim=True)).contiguous()           # T x d, tiny: clip.py:69
+    out = torch.empty(f.shape[0], dtype=torch.float32, device=f.device)
+    check(lib.eoe_clip_score(_p(f), _p(t), _p(out), f.shape[0], f.shape[1], t.shape[0], _stream()), "eoe_clip_score")
+    return out
+
+
 class DsadLossFunction(torch.autograd.Function):
     """DSADTrainer.loss (dsad.py:17-21)"""
 

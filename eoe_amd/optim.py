@@ -106,3 +106,70 @@ class FusedAdam(torch.optim.Optimizer):
                                      None, _lib.EOE_BF16, torch.cuda.current_stream().cuda_stream), "eoe_adam_multi")
             torch._C._increment_version(active)     # the kernel wrote in place: invalidate 16-bit weight copies
         return loss
+
+
+class FusedSGD(torch.optim.Optimizer):
+    """`torch.optim.SGD(params, lr, momentum=0.9, nesterov=True, weight_decay=wdk)` as the reference constructs it for CLIP models
+    (`ad_trainer.py:380-381`), one kernel per step (`eoe_sgd_multi`): same Optimizer API, dampening 0, L2-in-gradient weight decay,
+    momentum buffers created at the first step (zero-initialised arena: `buf = momentum * 0 + g` is torch's first-step `buf = g`)."""
+
+    def __init__(self, params, lr=1e-3, momentum=0.0, weight_decay=0.0, nesterov=False, dampening=0.0):
+        if dampening != 0.0:
+            raise NotImplementedError("dampening is not used by the reference trainer (ad_trainer.py:381)")
+        if nesterov and momentum <= 0:
+            raise ValueError("Nesterov momentum requires a momentum")
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=nesterov, dampening=0.0))
+        self._tables = {}
+
+    def _init_state(self, group):
+        need = [p for p in group["params"] if p.grad is not None and "momentum_buffer" not in self.state[p]]
+        if not need:
+            return
+        tot = sum((p.numel() + 3) // 4 * 4 for p in need)
+        arena = torch.zeros(tot, dtype=torch.float32, device=need[0].device)
+        off = 0
+        for p in need:
+            n = p.numel()
+            self.state[p]["momentum_buffer"] = arena[off:off + n].view(p.shape)
+            off += (n + 3) // 4 * 4
+
+    def _table(self, gi, active):
+        sig = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["momentum_buffer"].data_ptr(), p.numel()) for p in active)
+        hit = self._tables.get(gi)
+        if hit is not None and hit[0] == sig:
+            return hit[1:]
+        pb = min(p.data_ptr() for p in active)
+        gb = min(p.grad.data_ptr() for p in active)
+        mb = min(self.state[p]["momentum_buffer"].data_ptr() for p in active)
+        rows = []
+        for p in active:
+            po, go = (p.data_ptr() - pb) // 4, (p.grad.data_ptr() - gb) // 4
+            mo = (self.state[p]["momentum_buffer"].data_ptr() - mb) // 4
+            n = p.numel()
+            for c0 in range(0, n, _lib.ADAM_CHUNK):
+                rows.append((po + c0, go + c0, mo + c0, 0, min(_lib.ADAM_CHUNK, n - c0), 0))
+        arr = np.array(rows, dtype=_CHUNK_DT)
+        tab = torch.from_numpy(arr.view(np.uint8).copy()).to(active[0].device)
+        self._tables[gi] = (sig, tab, len(rows), (pb, gb, mb))
+        return tab, len(rows), (pb, gb, mb)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            active = [p for p in group["params"] if p.grad is not None]
+            if not active:
+                continue
+            for p in active:
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
+                    raise RuntimeError("FusedSGD needs contiguous fp32 parameters and gradients on the GPU")
+            self._init_state(group)
+            tab, n_chunks, bases = self._table(gi, active)
+            check(lib.eoe_sgd_multi(bases[0], bases[1], bases[2], tab.data_ptr(), n_chunks, float(group["lr"]),
+                                    float(group["momentum"]), float(group["weight_decay"]), 1 if group["nesterov"] else 0,
+                                    torch.cuda.current_stream().cuda_stream), "eoe_sgd_multi")
+            torch._C._increment_version(active)
+        return loss

@@ -209,13 +209,17 @@ class ADTrainer(ABC):
         std = torch.as_tensor(norm[1], dtype=torch.float32, device=self.device).view(1, -1, 1, 1)
         raise NotImplementedError("this encoder has no fused normalise; add one to its first kernel")
 
+    def make_optimizer(self, model: torch.nn.Module):
+        """Adam for every encoder (ad_trainer.py:383); the CLIP objective overrides this with SGD-Nesterov (:380-381)"""
+        return FusedAdam(model.parameters(), lr=self.lr, weight_decay=self.wdk, amsgrad=False)
+
     def train_cls(self, model: torch.nn.Module, ds, cls: int, clsstr: str, seed: int,
                   load: Union[torch.nn.Module, str] = None):
         """the inner loop, `ad_trainer.py:356-471`; returns (model on the CPU in eval mode, training ROC)"""
         model = model.to(self.device).train()
         epochs = self.epochs
         cls_roc = None
-        opt = FusedAdam(model.parameters(), lr=self.lr, weight_decay=self.wdk, amsgrad=False)          # :383
+        opt = self.make_optimizer(model)                                                              # :380-383
         sched = torch.optim.lr_scheduler.MultiStepLR(opt, self.milestones, 0.1)                       # :384
         loader, _ = ds.loaders(self.batch_size, num_workers=self.workers, persistent=True)              # :385
         ep = self.load(load if isinstance(load, str) else None, model, opt, sched)                      # :396

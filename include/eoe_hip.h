@@ -234,6 +234,10 @@ typedef struct {                        /* per step-count group, computed on the
     float bc2_sqrt[EOE_ADAM_GROUPS];    /*   sqrt(1 - beta2**step)                                             */
 } eoe_adam_scalars;
 
+/* fused multi-tensor SGD with momentum / Nesterov = torch.optim.SGD(..., dampening=0) as constructed for CLIP models
+ * (ad_trainer.py:380-381: momentum 0.9, nesterov): the same chunk tables (m_off = momentum buffer, zero-initialised; v_off unused) */
+int eoe_sgd_multi(float* p, const float* g, float* buf, const eoe_adam_chunk* chunks /*device*/, int n_chunks, float lr,
+                  float momentum, float weight_decay, int nesterov, void* stream);
 int eoe_adam_multi(float* p, const float* g, float* m, float* v, const eoe_adam_chunk* chunks /*device*/,
                    int n_chunks, const eoe_adam_scalars* scalars /*host*/, float beta1, float beta2, float eps,
                    float weight_decay, void* shadow16, int dtype, void* stream);
@@ -443,6 +447,16 @@ int eoe_avgpool_bwd(const float* dout, float* dx, int n, int HW, int C, void* st
  *   DSVDD (dsvdd.py:24-27): loss_i = score_i = |f - center|^2 (center fp32 [d], from prepare_metric dsvdd.py:10-22)
  *   focal (focal.py:11-36): b = bce_with_logits(x, y), pt = clamp(exp(-b), eps, 1 - eps), loss_i = (1 - pt)^gamma * b;
  *                           scores = sigmoid(x) (1 - sigmoid if nominal_label != 0) */
+/* CLIP text-prompt objective (training/clip.py:66-103): f fp32 [n, d] image features, text fp32 [T, d]
+ * (2 <= T <= 64; the frozen, l2-normalised text features prepare_metric returns, clip.py:50-64), l = 100 * f/|f| . text^T;
+ *   loss_i = -log_softmax(l)[pick]: pick = T-1 for the anomalous label (1 - nominal), 0 for the nominal label (one_vs_rest) or
+ *   the arg max over j < T-1 (leave_one_out); other labels contribute 0;  scores = softmax(l)[:, T-1] (any of scores / loss NULL).
+ * eoe_clip_score: the same score for text rows the caller has l2-normalised (compute_anomaly_score, clip.py:66-79). */
+int eoe_clip_fwd(const float* f, const float* text, const int64_t* labels, int64_t nominal_label, int leave_one_out, float* loss,
+                 float* scores, float* losses, int n, int d, int T, float inv_count, void* stream);
+int eoe_clip_bwd(const float* f, const float* text, const int64_t* labels, int64_t nominal_label, int leave_one_out,
+                 const float* gscale, float* df, int n, int d, int T, float inv_count, void* stream);
+int eoe_clip_score(const float* f, const float* text, float* scores, int n, int d, int T, void* stream);
 int eoe_dsad_fwd(const float* f, const int64_t* labels, int64_t nominal_label, float* loss, float* losses, int n, int d,
                  float inv_count, void* stream);
 int eoe_dsad_bwd(const float* f, const int64_t* labels, int64_t nominal_label, const float* gscale, float* df, int n, int d,

@@ -238,6 +238,31 @@ class CNN32(nn.Module):
         return self.linear(x) if self.clf else x
 
 
+class CNN28(nn.Module):
+    # cnn.py:5-41 (1-channel 28x28 variant: two conv blocks, FC 1568 -> 64 -> rep_dim)
+    def __init__(self, rep_dim=32, bias=False, clf=False):
+        super().__init__()
+        self.clf, self.rep_dim = clf, rep_dim
+        self.conv1 = _Conv(1, 16, 5, bias)
+        self.bn2d1 = _BN(16, 1e-4, bias)
+        self.conv2 = _Conv(16, 32, 5, bias)
+        self.bn2d2 = _BN(32, 1e-4, bias)
+        self.fc1 = _Lin(32 * 7 * 7, 64, bias)
+        self.bn1d1 = _BN(64, 1e-4, bias)
+        self.fc2 = _Lin(64, rep_dim, bias)
+        if clf:
+            self.linear = _Lin(rep_dim, 1)
+
+    def forward(self, x):
+        x = x.reshape(-1, 1, 28, 28)
+        x = F.max_pool2d(F.leaky_relu(self.bn2d1(CNN32._conv(x, self.conv1)), 0.01), 2, 2)
+        x = F.max_pool2d(F.leaky_relu(self.bn2d2(CNN32._conv(x, self.conv2)), 0.01), 2, 2)
+        x = x.reshape(x.shape[0], -1)
+        x = F.leaky_relu(self.bn1d1(self.fc1(x)), 0.01)
+        x = self.fc2(x)
+        return self.linear(x) if self.clf else x
+
+
 # ---------------------------------------------------------------------------------------------------------
 # deterministic initialisation (shapes and scales of the reference's own init, values from oracle.fill)
 # ---------------------------------------------------------------------------------------------------------

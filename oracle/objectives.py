@@ -142,3 +142,34 @@ def focal_loss_grad(logits, labels, gamma: float = 2.0, eps: float = 1e-7, inv_c
     inside = (raw >= eps) & (raw <= 1.0 - eps)
     g = (1.0 - pt) ** gamma * db + torch.where(inside, gamma * (1.0 - pt) ** (gamma - 1.0) * pt * db * b, torch.zeros_like(b))
     return (g * inv).reshape(logits.shape)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CLIP text-prompt objective: training/clip.py:66-103
+# ---------------------------------------------------------------------------------------------------------
+def clip_logits(image_features: torch.Tensor, text_features: torch.Tensor) -> torch.Tensor:
+    # clip.py:84-85  image_features / norm;  100 * f @ T^T
+    f = image_features / image_features.norm(dim=-1, keepdim=True)
+    return 100.0 * f @ text_features.T
+
+
+def clip_losses(image_features, labels, text_features, nominal_label: int = 0, leave_one_out: bool = False) -> torch.Tensor:
+    # clip.py:85-101: log_softmax, anomalous samples pick the last prompt, nominal ones prompt 0 (one_vs_rest) or the best of
+    # the class prompts (leave_one_out); samples with any other label keep loss 0; sign flipped
+    sim = clip_logits(image_features, text_features).log_softmax(dim=-1)
+    anom = 1 - nominal_label
+    loss = torch.zeros_like(sim[:, 0])
+    loss = torch.where(labels == anom, sim[:, -1], loss)
+    nom = sim[:, :-1].max(-1)[0] if leave_one_out else sim[:, 0]
+    loss = torch.where(labels == nominal_label, nom, loss)
+    return -loss
+
+
+def clip_loss(image_features, labels, text_features, nominal_label: int = 0, leave_one_out: bool = False):
+    return clip_losses(image_features, labels, text_features, nominal_label, leave_one_out).mean()      # clip.py:102
+
+
+def clip_score(image_features, center):
+    # clip.py:66-79: the text features are normalised again; anomaly score = softmax probability of the last prompt
+    t = center / center.norm(dim=-1, keepdim=True)
+    return clip_logits(image_features, t).softmax(dim=-1)[:, -1]

@@ -44,3 +44,27 @@ def multistep_lr(base_lr: float, milestones: List[int], epoch: int, gamma: float
     """learning rate in effect during `epoch` (0-based) when sched.step() is called at each epoch end."""
     k = sum(1 for m in milestones if epoch >= m)
     return base_lr * (gamma ** k)
+
+
+class SgdState:
+    def __init__(self, params):
+        self.buf = [None for _ in params]
+
+
+def sgd_step(params, grads, state: SgdState, lr: float, momentum: float = 0.9, weight_decay: float = 0.0,
+             nesterov: bool = True) -> None:
+    """in-place `torch.optim.SGD` update (dampening 0) as constructed for CLIP models, `ad_trainer.py:380-381`;
+    third-party arithmetic: torch's single-tensor SGD (first step: buf = grad)."""
+    with torch.no_grad():
+        for i, (p, g) in enumerate(zip(params, grads)):
+            if g is None:
+                continue
+            if weight_decay != 0:
+                g = g + weight_decay * p
+            if momentum != 0:
+                if state.buf[i] is None:
+                    state.buf[i] = g.clone()
+                else:
+                    state.buf[i].mul_(momentum).add_(g)
+                g = g + momentum * state.buf[i] if nesterov else state.buf[i]
+            p.add_(g * (-lr))

@@ -30,7 +30,7 @@ sys.dont_write_bytecode = True
 
 from oracle import fill, models as omodels, trainer as otrainer  # noqa: E402  (only for the fill rule / batches)
 
-from eoe.models.cnn import CNN32 as RefCNN32                       # noqa: E402
+from eoe.models.cnn import CNN32 as RefCNN32, CNN28 as RefCNN28    # noqa: E402
 from eoe.models.custom_base import CustomNet as RefCustomNet       # noqa: E402
 
 _spec = importlib.util.spec_from_file_location(
@@ -299,7 +299,74 @@ def g8():
     save("g8_adam", **out)
 
 
+# ----------------------------------------------------------------------------------------------- G10 CLIP objective + SGD (N2)
+def clip_loss_ref(image_features, labels, text_features, nominal_label=0, ad_mode="one_vs_rest"):   # training/clip.py:81-103
+    anom_label = 1 - nominal_label
+    image_features = image_features / image_features.norm(dim=-1, keepdim=True)
+    similarity = (100.0 * image_features @ text_features.T).log_softmax(dim=-1)
+    aloss = similarity[labels == anom_label][:, -1]
+    if ad_mode == "one_vs_rest":
+        nloss = similarity[labels == nominal_label][:, 0]
+    else:
+        nloss = similarity[labels == nominal_label][:, :-1].max(-1)[0]
+    loss = torch.zeros_like(similarity[:, 0])
+    loss[labels == anom_label] = aloss
+    loss[labels == nominal_label] = nloss
+    return loss.mul(-1).mean()
+
+
+def clip_score_ref(image_features, center):                                                        # training/clip.py:66-79
+    text_features = center / center.norm(dim=-1, keepdim=True)
+    image_features = image_features / image_features.norm(dim=-1, keepdim=True)
+    return (100.0 * image_features @ text_features.T).softmax(dim=-1)[:, -1]
+
+
+def g10():
+    out = {}
+    f = torch.from_numpy(fill.fill("g10/features", (24, 512), std=0.4))
+    y = torch.from_numpy(fill.fill_int("g10/labels", (24,), 0, 2))
+    y[5] = 7                                            # a label that is neither nominal nor anomalous: loss 0 (clip.py:89-91)
+    for mode, T in (("one_vs_rest", 2), ("leave_one_out", 30)):
+        t = torch.from_numpy(fill.fill(f"g10/text{T}", (T, 512), std=1.0))
+        t = t / t.norm(dim=-1, keepdim=True)            # prepare_metric, clip.py:62
+        t = t * 0.25 + 0.75 * t[:1]                     # prompts of one dataset are close to each other: soft, non-saturated softmax
+        t = t / t.norm(dim=-1, keepdim=True)
+        for nominal in (0, 1):
+            ff = f.clone().requires_grad_(True)
+            loss = clip_loss_ref(ff, y, t, nominal, mode)
+            loss.backward()
+            out[f"{mode}/n{nominal}/loss"], out[f"{mode}/n{nominal}/grad"] = loss.item(), ff.grad.numpy().copy()
+        out[f"{mode}/scores"] = clip_score_ref(f, t * 3.0).numpy()        # un-normalised centre: the score normalises it again
+    # SGD with Nesterov momentum as constructed for CLIP models (ad_trainer.py:380-381), incl. a parameter without gradient
+    for wd in (0.0, 1e-3):
+        ps = [torch.nn.Parameter(torch.from_numpy(fill.fill(f"g10/p{i}", s, std=0.5))) for i, s in enumerate(((7, 5), (33,), (4, 3, 2)))]
+        opt = torch.optim.SGD(ps, lr=1e-2, weight_decay=wd, momentum=0.9, nesterov=True)
+        for step in range(5):
+            opt.zero_grad()
+            for i, p in enumerate(ps):
+                if i == 1 and step in (0, 1):
+                    p.grad = None                       # its momentum buffer is created at the first step that has a gradient
+                else:
+                    p.grad = torch.from_numpy(fill.fill(f"g10/g{i}/t{step}", tuple(p.shape), std=0.1))
+            opt.step()
+        for i, p in enumerate(ps):
+            out[f"sgd/wd{wd}/p{i}"] = p.detach().numpy().copy()
+    save("g10_clip_objective", **out)
+
+
+# ----------------------------------------------------------------------------------------------- G11 CNN28 (N4)
+def g11():
+    m = RefCNN28(bias=True, clf=False)
+    omodels.deterministic_init(m, tag="cnn28")
+    batches = []
+    for i in range(4):
+        imgs, lbls = otrainer.synthetic_batch(f"g11/b{i}", 8, 8, 28)
+        batches.append((imgs[:, :1].contiguous(), lbls))               # 1-channel 28x28
+    losses, scores, first = run_trajectory(m, batches, "hsc", lr=1e-3, wd=0.0)
+    save("g11_cnn28_hsc", losses=losses, scores=scores, **first)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11"]
     for w in which:
         globals()[w]()

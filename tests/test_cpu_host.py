@@ -112,7 +112,7 @@ def test_state_dict_names_match_reference_names():
 
 def test_trainer_registry_and_hooks():
     from eoe_amd.training import TRAINER, ADTrainer
-    assert set(TRAINER) == {"hsc", "bce", "dsvdd", "dsad", "focal"}          # training/__init__.py:8-11 minus 'clip'
+    assert set(TRAINER) == {"hsc", "bce", "dsvdd", "dsad", "focal", "clip"}  # training/__init__.py:8-11
     for cls in TRAINER.values():
         assert issubclass(cls, ADTrainer)
         for hook in ("prepare_metric", "compute_anomaly_score", "loss", "train_cls", "eval_cls", "run", "load"):

@@ -214,3 +214,46 @@ def test_cnn32_step_is_bitwise_reproducible():
         assert losses == runs[0][0]
         for k in sd:
             assert torch.equal(sd[k], runs[0][1][k]), k
+
+
+def test_cnn28_trajectory_vs_golden(golden):
+    """N4: CNN28(bias=True) + HSC + Adam(1e-3), 4 steps of 8+8 one-channel 28x28 images against the fixture generated from the
+    reference's own CNN28 (tests/golden/make_golden.py g11)"""
+    import eoe_amd
+    from eoe_amd.models import CNN28
+    eoe_amd.set_compute_dtype("fp16")
+    g = golden("g11_cnn28_hsc")
+    m = omodels.deterministic_init(CNN28(bias=True), tag="cnn28").cuda().train()
+    opt = eoe_amd.FusedAdam(m.parameters(), lr=1e-3, weight_decay=0.0)
+    losses, scores = [], []
+    for it in range(4):
+        imgs, lbls = otrainer.synthetic_batch(f"g11/b{it}", 8, 8, 28)
+        imgs, lbls = imgs[:, :1].contiguous().cuda(), lbls.cuda()
+        opt.zero_grad()
+        feats = m(imgs)
+        if it == 0:
+            f0 = feats.detach().clone()
+            bufs0 = {k: v.detach().clone() for k, v in m.named_buffers()}
+        loss = eoe_amd.hsc_loss(feats, lbls, 0)
+        loss.backward()
+        if it == 0:
+            grads0 = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+        opt.step()
+        losses.append(loss.item())
+        scores.append(eoe_amd.hsc_score(feats).cpu().numpy())
+    rf = rel_rms(f0, torch.from_numpy(g["features0"]))
+    dl = np.abs(np.array(losses) - g["losses"]) / np.maximum(1.0, np.abs(g["losses"]))
+    print(f"[cnn28] features rel rms {rf:.2e}; loss dev per step {dl}")
+    assert rf < 3e-3
+    assert dl[0] < 3e-4 and dl[1] < 2e-3 and dl.max() < 1e-2, (losses, g["losses"])
+    assert np.abs(scores[0] - g["scores"][0]).max() < 1e-3 and np.abs(np.stack(scores) - g["scores"]).max() < 2e-2
+    for k, v in bufs0.items():
+        np.testing.assert_allclose(v.cpu().numpy(), g[f"buf0/{k}"], rtol=2e-3, atol=2e-3)
+    worst = 0.0
+    for k, gr in grads0.items():
+        ref = float(g[f"gnorm/{k}"])
+        if ref < 1e-5:
+            continue
+        worst = max(worst, abs(gr.double().norm().item() - ref) / ref)
+    print(f"   worst grad-norm deviation {worst:.2e}")
+    assert worst < 2e-2

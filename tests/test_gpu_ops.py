@@ -1,5 +1,6 @@
 """GPU tier 2: every HIP op, called through the C ABI (ctypes), against the CPU oracle / fp64 math on the same
 seeded inputs; edge cases: ragged M / N / T tails, sequence shorter than the MFMA tile, accumulate, both dtypes."""
+import ctypes as C
 import math
 
 import numpy as np
@@ -171,8 +172,17 @@ def test_gemm_rejects_bad_shapes(ops):
     a = torch.zeros((8, 40), dtype=torch.bfloat16, device="cuda")
     b = torch.zeros((8, 40), dtype=torch.bfloat16, device="cuda")
     out = torch.zeros((8, 8), dtype=torch.float32, device="cuda")
-    with pytest.raises(RuntimeError):
-        ops.gemm_nt(a, b, out)          # K not a multiple of 64
+    # the C ABI rejects a reduction length that is not a multiple of the 64-deep MFMA k-tile ...
+    from eoe_amd import _lib
+    g = _lib.GemmArgs(a.data_ptr(), b.data_ptr(), out.data_ptr(), None, None, None, None, 8, 8, 40, 40, 40, 8, 0, _lib.EOE_BF16, 0, 1, 0, 1.0)
+    assert _lib.lib.eoe_gemm_nt(C.byref(g), None) == 1 and b"multiple of 64" in _lib.lib.eoe_last_error()
+    # ... the Python wrapper zero-pads it (CNN28's 1568- and 32-long reductions)
+    a2, a2r = t16("bad/a", (8, 40), 1.0, torch.bfloat16)
+    b2, b2r = t16("bad/b", (8, 40), 1.0, torch.bfloat16)
+    ops.gemm_nt(a2, b2, out)
+    assert_close(out, a2r.double() @ b2r.double().t(), 2e-6, 2e-5 * math.sqrt(40), "ragged K")
+    with pytest.raises((RuntimeError, AssertionError)):
+        ops.gemm_nt(a.float(), b, out)          # operands must be 16-bit and of one type
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -423,3 +433,74 @@ def test_other_objective_trainers_run(objective):
     assert np.isfinite(tr.last_losses).all() and tr.last_losses[-1] < tr.last_losses[0]
     if objective != "dsvdd":
         assert res["mean_auc"] > 0.8, res
+
+
+def test_clip_objective_n2_vs_golden_and_oracle(golden):
+    """N2: eoe_clip_fwd / bwd / score against the fixture (reference formulas) and the oracle on larger random inputs"""
+    import eoe_amd.ops as o
+    g = golden("g10_clip_objective")
+    f = torch.from_numpy(fill.fill("g10/features", (24, 512), std=0.4))
+    y = torch.from_numpy(fill.fill_int("g10/labels", (24,), 0, 2))
+    y[5] = 7
+    for mode, T in (("one_vs_rest", 2), ("leave_one_out", 30)):
+        t = torch.from_numpy(fill.fill(f"g10/text{T}", (T, 512), std=1.0))
+        t = t / t.norm(dim=-1, keepdim=True)
+        t = t * 0.25 + 0.75 * t[:1]
+        t = t / t.norm(dim=-1, keepdim=True)
+        for nominal in (0, 1):
+            ff = f.cuda().requires_grad_(True)
+            loss = o.clip_loss(ff, y.cuda(), t.cuda(), nominal, mode == "leave_one_out")
+            loss.backward()
+            assert abs(loss.item() - float(g[f"{mode}/n{nominal}/loss"])) < 2e-5 * max(1.0, abs(float(g[f"{mode}/n{nominal}/loss"])))
+            assert_close(ff.grad, torch.from_numpy(g[f"{mode}/n{nominal}/grad"]), 2e-4, 2e-6, f"clip grad {mode} nominal={nominal}")
+            assert float(ff.grad[5].abs().max()) == 0.0              # neither label: no loss, no gradient
+        assert_close(o.clip_score(f.cuda(), (t * 3.0).cuda()), torch.from_numpy(g[f"{mode}/scores"]), 2e-4, 2e-6, f"clip score {mode}")
+    # ragged sizes against the oracle: n not a multiple of 4 rows per workgroup, d = 256, T = 5, upstream gradient scale
+    n, d, T = 301, 256, 5
+    f = torch.from_numpy(fill.fill("clipx/f", (n, d), std=1.0))
+    y = torch.from_numpy(fill.fill_int("clipx/y", (n,), 0, 2))
+    t = torch.from_numpy(fill.fill("clipx/t", (T, d), std=1.0))
+    t = t / t.norm(dim=-1, keepdim=True) * 0.2 + 0.05
+    for loo in (False, True):
+        fr = f.clone().requires_grad_(True)
+        (objectives.clip_loss(fr, y, t, 0, loo) * 3.0).backward()
+        fg = f.cuda().requires_grad_(True)
+        lg = o.clip_loss(fg, y.cuda(), t.cuda(), 0, loo)
+        (lg * 3.0).backward()
+        assert abs(lg.item() - objectives.clip_loss(f, y, t, 0, loo).item()) < 1e-4
+        assert_close(fg.grad, fr.grad, 5e-4, 1e-6, f"clip grad vs oracle loo={loo}")
+
+
+def test_fused_sgd_vs_golden(golden):
+    """SGD with Nesterov momentum (ad_trainer.py:380-381) = torch.optim.SGD, incl. a parameter whose gradient appears late"""
+    import eoe_amd
+    g = golden("g10_clip_objective")
+    for wd in (0.0, 1e-3):
+        ps = [torch.nn.Parameter(torch.from_numpy(fill.fill(f"g10/p{i}", s, std=0.5)).cuda()) for i, s in enumerate(((7, 5), (33,), (4, 3, 2)))]
+        opt = eoe_amd.FusedSGD(ps, lr=1e-2, weight_decay=wd, momentum=0.9, nesterov=True)
+        for step in range(5):
+            opt.zero_grad()
+            for i, p in enumerate(ps):
+                p.grad = None if (i == 1 and step in (0, 1)) else torch.from_numpy(fill.fill(f"g10/g{i}/t{step}", tuple(p.shape), std=0.1)).cuda()
+            opt.step()
+        for i, p in enumerate(ps):
+            np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"sgd/wd{wd}/p{i}"], rtol=2e-6, atol=2e-7)
+
+
+def test_clip_trainer_runs():
+    """ADClipTrainer on a small encoder with caller-supplied text features: loss decreases, scores separate the halves"""
+    import eoe_amd
+    from eoe_amd.training import TRAINER
+    from eoe_amd.data import SyntheticAD
+    from eoe_amd.models import CNN32
+    torch.manual_seed(0)
+    model = CNN32(rep_dim=64, bias=True)
+    text = torch.nn.functional.normalize(torch.randn(2, 64), dim=-1)
+    ds = SyntheticAD(n_train_normal=64, n_oe=64, n_test=64, res=32, shift=1.0, seed=1)
+    tr = TRAINER["clip"](model, dataset=ds, epochs=3, lr=1e-2, batch_size=32, text_features=text)
+    models, res = tr.run()
+    assert np.isfinite(tr.last_losses).all() and tr.last_losses[-1] < tr.last_losses[0]
+    # (no AUC bar: 100 x cosine logits saturate the softmax score to exactly 0 / 1 on this toy task, which ties the ranking)
+    assert set(res) >= {"mean_auc", "mean_avg_prec", "std_auc", "cls_aucs"} and np.isfinite(res["mean_auc"])
+    assert isinstance(tr.center, torch.Tensor) and tuple(tr.center.shape) == (2, 64)
+    assert torch.allclose(tr.center.norm(dim=-1).cpu(), torch.ones(2), atol=1e-5)          # prepare_metric normalises (clip.py:62)

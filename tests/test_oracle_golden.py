@@ -237,3 +237,57 @@ def test_other_objectives_n4(golden):
     assert abs(objectives.focal_loss(x, yy).item() - float(g["focal_loss"])) <= 1e-5 * abs(float(g["focal_loss"]))
     np.testing.assert_allclose(objectives.focal_loss_grad(x, yy).numpy(), g["focal_grad"], rtol=2e-4, atol=1e-7)
     np.testing.assert_allclose(objectives.bce_score(x).numpy(), g["focal_scores"], rtol=1e-6)
+
+
+def test_clip_objective_and_sgd(golden):
+    """N2: the CLIP text-prompt objective (training/clip.py:66-103) and SGD-Nesterov (ad_trainer.py:380-381) restatements against
+    the fixture generated with the reference's formulas / torch.optim.SGD (make_golden.py g10)"""
+    from oracle import objectives, optim as ooptim
+    g = golden("g10_clip_objective")
+    f = torch.from_numpy(fill.fill("g10/features", (24, 512), std=0.4))
+    y = torch.from_numpy(fill.fill_int("g10/labels", (24,), 0, 2))
+    y[5] = 7
+    for mode, T in (("one_vs_rest", 2), ("leave_one_out", 30)):
+        t = torch.from_numpy(fill.fill(f"g10/text{T}", (T, 512), std=1.0))
+        t = t / t.norm(dim=-1, keepdim=True)
+        t = t * 0.25 + 0.75 * t[:1]
+        t = t / t.norm(dim=-1, keepdim=True)
+        for nominal in (0, 1):
+            ff = f.clone().requires_grad_(True)
+            loss = objectives.clip_loss(ff, y, t, nominal, mode == "leave_one_out")
+            loss.backward()
+            assert abs(loss.item() - float(g[f"{mode}/n{nominal}/loss"])) < 1e-5
+            np.testing.assert_allclose(ff.grad.numpy(), g[f"{mode}/n{nominal}/grad"], rtol=1e-4, atol=1e-6)
+            assert float(objectives.clip_losses(f, y, t, nominal, mode == "leave_one_out")[5]) == 0.0
+        np.testing.assert_allclose(objectives.clip_score(f, t * 3.0).numpy(), g[f"{mode}/scores"], rtol=1e-4, atol=1e-6)
+    for wd in (0.0, 1e-3):
+        ps = [torch.from_numpy(fill.fill(f"g10/p{i}", s, std=0.5)) for i, s in enumerate(((7, 5), (33,), (4, 3, 2)))]
+        st = ooptim.SgdState(ps)
+        for step in range(5):
+            grads = [None if (i == 1 and step in (0, 1)) else torch.from_numpy(fill.fill(f"g10/g{i}/t{step}", tuple(p.shape), std=0.1))
+                     for i, p in enumerate(ps)]
+            ooptim.sgd_step(ps, grads, st, lr=1e-2, momentum=0.9, weight_decay=wd, nesterov=True)
+        for i, p in enumerate(ps):
+            np.testing.assert_allclose(p.numpy(), g[f"sgd/wd{wd}/p{i}"], rtol=1e-6, atol=1e-7)
+
+
+def test_cnn28(golden):
+    """N4: the CNN28 restatement against the fixture generated from the reference's own CNN28 (make_golden.py g11)"""
+    g = golden("g11_cnn28_hsc")
+    batches = []
+    for i in range(4):
+        imgs, lbls = trainer.synthetic_batch(f"g11/b{i}", 8, 8, 28)
+        batches.append((imgs[:, :1].contiguous(), lbls))
+    m = models.deterministic_init(models.CNN28(bias=True), tag="cnn28").train()
+    f0 = m(batches[0][0])
+    np.testing.assert_allclose(f0.detach().numpy(), g["features0"], rtol=1e-4, atol=1e-5)
+    for n, b in m.named_buffers():
+        np.testing.assert_allclose(b.numpy(), g[f"buf0/{n}"], rtol=1e-5, atol=1e-6)
+    m = models.deterministic_init(models.CNN28(bias=True), tag="cnn28")
+    out = trainer.train_steps(m, batches, "hsc", lr=1e-3, weight_decay=0.0, collect_grads=True)
+    assert abs(out["loss"][0] - g["losses"][0]) <= 1e-5 * abs(g["losses"][0])
+    np.testing.assert_allclose(out["loss"], g["losses"], rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(np.stack(out["scores"]), g["scores"], rtol=1e-3, atol=1e-3)
+    for n, gr in out["grads"].items():
+        ref = float(g[f"gnorm/{n}"])
+        assert abs(gr.double().norm().item() - ref) <= 5e-4 * ref + 2e-6, n
