@@ -151,6 +151,7 @@ SIGNATURES = {
     "eoe_relu_bwd": [_vp, _vp, _vp, _i64, _vp],
     "eoe_avgpool_fwd": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
     "eoe_avgpool_bwd": [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
+    "eoe_auc_ap": [_vp, _vp, _i64, _vp, _vp, C.c_int, _vp],
     "eoe_clip_fwd": [_vp, _vp, _vp, _i64, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _f32, _vp],
     "eoe_clip_bwd": [_vp, _vp, _vp, _i64, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _f32, _vp],
     "eoe_clip_score": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],

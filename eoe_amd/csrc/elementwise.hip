@@ -662,6 +662,67 @@ __global__ __launch_bounds__(256) void rowobj_bwd_kernel(const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------ rank metrics on the device
+// AUC (tie-averaged rank statistic = trapezoidal ROC area, ad_trainer.py:452-455,517-519) and average precision (:520-521) from
+// EXACT integer pair counts -- no sort: for every positive i
+//     wins2_i = 2 #{j negative: s_j < s_i} + #{j negative: s_j == s_i}            AUC = sum_i wins2_i / (2 P N)
+//     prec_i  = #{j positive: s_j >= s_i} / #{j: s_j >= s_i}                      AP  = sum_i prec_i / P
+// (precision at a positive's own threshold; tied positives share it, which is sklearn's step-wise sum over distinct thresholds).
+// Thread i walks all j through LDS tiles: n^2 compares (n = 10^4 test scores: 10^8), partial sums per workgroup, fixed-order finish.
+__global__ __launch_bounds__(256) void rank_pairs_kernel(const float* __restrict__ s, const int64_t* __restrict__ labels, int64_t positive,
+                                                         unsigned long long* __restrict__ part_wins, double* __restrict__ part_prec,
+                                                         unsigned long long* __restrict__ part_pos, int n) {
+    __shared__ float ts[256];
+    __shared__ int tp[256];
+    __shared__ unsigned long long rw[256];
+    __shared__ double rp[256];
+    __shared__ unsigned long long rc[256];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < n;
+    const float si = live ? s[i] : 0.f;
+    const bool pi = live && labels[i] == positive;
+    unsigned lt_neg = 0, eq_neg = 0, ge_pos = 0, ge_all = 0;
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        const int j = j0 + threadIdx.x;
+        ts[threadIdx.x] = j < n ? s[j] : 0.f;
+        tp[threadIdx.x] = j < n ? (labels[j] == positive ? 1 : 0) : -1;
+        __syncthreads();
+        const int m = n - j0 < 256 ? n - j0 : 256;
+        for (int k = 0; k < m; ++k) {
+            const float sj = ts[k];
+            const int pj = tp[k];
+            lt_neg += (pj == 0 && sj < si);
+            eq_neg += (pj == 0 && sj == si);
+            ge_pos += (pj == 1 && sj >= si);
+            ge_all += (sj >= si);
+        }
+        __syncthreads();
+    }
+    rw[threadIdx.x] = pi ? 2ull * lt_neg + eq_neg : 0ull;
+    rp[threadIdx.x] = pi ? (double)ge_pos / (double)ge_all : 0.0;
+    rc[threadIdx.x] = pi ? 1ull : 0ull;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long w = 0, c = 0;
+        double p = 0.0;
+        for (int k = 0; k < 256; ++k) { w += rw[k]; p += rp[k]; c += rc[k]; }
+        part_wins[blockIdx.x] = w;
+        part_prec[blockIdx.x] = p;
+        part_pos[blockIdx.x] = c;
+    }
+}
+__global__ void rank_finish_kernel(const unsigned long long* __restrict__ part_wins, const double* __restrict__ part_prec,
+                                   const unsigned long long* __restrict__ part_pos, int nb, int n, double* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned long long w = 0, P = 0;
+    double p = 0.0;
+    for (int b = 0; b < nb; ++b) { w += part_wins[b]; p += part_prec[b]; P += part_pos[b]; }
+    const unsigned long long N = (unsigned long long)n - P;
+    const double nan = __builtin_nan("");
+    out[0] = (P == 0 || N == 0) ? nan : (double)w / (2.0 * (double)P * (double)N);
+    out[1] = P == 0 ? nan : p / (double)P;
+}
+
 // CLIP text-prompt objective (training/clip.py:66-103): one wavefront per sample.  l_j = 100 * <f / |f|, t_j>, j < T <= 64;
 //   loss_i = -(log_softmax l)[pick],  pick = T-1 (anomalous), 0 (nominal, one_vs_rest) or argmax_{j < T-1} (nominal,
 //   leave_one_out); samples whose label is neither contribute 0 (clip.py:89-91);  score_i = softmax(l)[T-1].
@@ -1314,6 +1375,21 @@ extern "C" int eoe_focal_bwd(const float* x, const int64_t* labels, const float*
     hipLaunchKernelGGL(focal_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, labels, gscale, dx, n, inv_count,
                        gamma, eps);
     EOE_CHECK_LAUNCH("focal_bwd");
+    return 0;
+}
+
+extern "C" int eoe_auc_ap(const float* scores, const int64_t* labels, int64_t positive_label, double* out, void* scratch, int n,
+                          void* stream) {
+    EOE_CHECK_ARG(scores && labels && out && scratch && n > 0, "auc_ap: bad args");
+    const int nb = cdiv(n, 256);
+    unsigned long long* pw = (unsigned long long*)scratch;
+    double* pp = (double*)(pw + nb);
+    unsigned long long* pc = (unsigned long long*)(pp + nb);
+    hipLaunchKernelGGL(rank_pairs_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, scores, labels, positive_label, pw, pp, pc, n);
+    EOE_CHECK_LAUNCH("auc_ap_pairs");
+    hipLaunchKernelGGL(rank_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned long long*)pw, (const double*)pp,
+                       (const unsigned long long*)pc, nb, n, out);
+    EOE_CHECK_LAUNCH("auc_ap_finish");
     return 0;
 }
 

@@ -59,3 +59,21 @@ def average_precision(labels, scores) -> float:
     tp, fp = tp[last], fp[last]
     recall = tp / n_pos
     return float(np.sum(np.diff(np.concatenate([[0.0], recall])) * (tp / (tp + fp))))
+
+
+def auc_ap_device(labels, scores):
+    """(ROC AUC, average precision) of GPU-resident scores without the host round trip: `eoe_auc_ap` (exact integer pair counts,
+    tie-aware; equals `roc_auc` / `average_precision` above up to fp64 rounding).  labels: int tensor [n] (1 = anomalous)."""
+    import torch
+    from ._lib import check, lib
+    if not scores.is_cuda:
+        raise RuntimeError("auc_ap_device needs GPU tensors (use roc_auc / average_precision on the host)")
+    sc = scores.detach().reshape(-1).contiguous().float()
+    la = labels.to(sc.device).reshape(-1).contiguous().to(torch.int64)
+    n = sc.numel()
+    out = torch.empty(2, dtype=torch.float64, device=sc.device)
+    scratch = torch.empty(((n + 255) // 256) * 24, dtype=torch.uint8, device=sc.device)
+    check(lib.eoe_auc_ap(sc.data_ptr(), la.data_ptr(), 1, out.data_ptr(), scratch.data_ptr(), n, torch.cuda.current_stream().cuda_stream),
+          "eoe_auc_ap")
+    auc, ap = out.cpu().tolist()
+    return auc, ap

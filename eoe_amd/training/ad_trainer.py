@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from .. import ops, parallel
-from ..metrics import ROC, PRC, roc_auc, average_precision
+from ..metrics import ROC, PRC, roc_auc, average_precision, auc_ap_device
 from ..optim import FusedAdam
 
 
@@ -275,12 +275,12 @@ class ADTrainer(ABC):
                 if world > 1:
                     la, sc = parallel.all_gather_1d(la), parallel.all_gather_1d(sc)
                     torch.distributed.all_reduce(ls)          # local losses are already divided by the global batch
-                la, sc = la.cpu().numpy(), sc.cpu().numpy()
                 self.last_losses.extend(ls.cpu().tolist())
-                if np.isnan(sc).sum() > 0:
+                if bool(torch.isnan(sc).any()):
                     raise NanGradientsError()                                                           # :448-449
-                if (la == 1).sum() > 0:
-                    cls_roc = ROC(roc_auc(la, sc))                                                      # :452-455
+                if bool((la == 1).any()):
+                    # the epoch's AUC from the GPU-resident scores (eoe_auc_ap: exact pair counts), no host copy of the scores
+                    cls_roc = ROC(auc_ap_device(la, sc)[0] if sc.is_cuda else roc_auc(la.cpu().numpy(), sc.cpu().numpy()))   # :452-455
                 sched.step()                                                                            # :468
         finally:
             if arena is not None:
@@ -305,13 +305,16 @@ class ADTrainer(ABC):
             ep_scores.append(self.compute_anomaly_score(feats, center, inputs=imgs, nominal_label=nominal))
             ep_labels.append(lbls)
             ep_idcs.append(batch[2] if len(batch) > 2 else torch.arange(len(lbls)))
-        la = torch.cat(ep_labels).cpu().numpy()
-        sc = torch.cat(ep_scores).reshape(-1).cpu().numpy()
+        la_t, sc_t = torch.cat(ep_labels), torch.cat(ep_scores).reshape(-1)
+        la = la_t.cpu().numpy()
+        sc = sc_t.cpu().numpy()                        # host copy only for the per-sample score log below
         idc = torch.cat(ep_idcs).cpu().numpy()
         if (la == 0).sum() > 0 and (la == 1).sum() > 0:
-            keep = la >= 0
-            cls_roc = ROC(roc_auc(la[keep], sc[keep]))
-            cls_prc = PRC(average_precision(la[keep], sc[keep]))
+            if sc_t.is_cuda:                           # AUC / AP on the device (ad_trainer.py:517-521)
+                auc, ap = auc_ap_device(la_t, sc_t)
+            else:
+                auc, ap = roc_auc(la, sc), average_precision(la, sc)
+            cls_roc, cls_prc = ROC(auc), PRC(ap)
             self.logger.logtxt(f'Eval: class "{clsstr}" yields {cls_roc.auc * 100:04.2f}% AUC and '
                                f'{cls_prc.avg_prec * 100:04.2f}% average precision (seed {seed}).')
         else:

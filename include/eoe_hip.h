@@ -447,6 +447,13 @@ int eoe_avgpool_bwd(const float* dout, float* dx, int n, int HW, int C, void* st
  *   DSVDD (dsvdd.py:24-27): loss_i = score_i = |f - center|^2 (center fp32 [d], from prepare_metric dsvdd.py:10-22)
  *   focal (focal.py:11-36): b = bce_with_logits(x, y), pt = clamp(exp(-b), eps, 1 - eps), loss_i = (1 - pt)^gamma * b;
  *                           scores = sigmoid(x) (1 - sigmoid if nominal_label != 0) */
+/* Epoch-tail metrics on the device (ad_trainer.py:452-455,517-521): out[0] = ROC AUC (tie-averaged rank
+ * statistic = sklearn's trapezoidal area), out[1] = average precision (sklearn's step-wise sum), both fp64, NaN when a class is
+ * missing; scores fp32 [n], labels int64 [n] (positive_label = the anomalous label, 1); computed from exact integer pair counts
+ * (n^2 compares, no sort).  scratch: EOE_AUC_SCRATCH_BYTES(n) bytes. */
+#define EOE_AUC_SCRATCH_BYTES(n) ((size_t)(((n) + 255) / 256) * 24)
+int eoe_auc_ap(const float* scores, const int64_t* labels, int64_t positive_label, double* out, void* scratch, int n, void* stream);
+
 /* CLIP text-prompt objective (training/clip.py:66-103): f fp32 [n, d] image features, text fp32 [T, d]
  * (2 <= T <= 64; the frozen, l2-normalised text features prepare_metric returns, clip.py:50-64), l = 100 * f/|f| . text^T;
  *   loss_i = -log_softmax(l)[pick]: pick = T-1 for the anomalous label (1 - nominal), 0 for the nominal label (one_vs_rest) or

@@ -504,3 +504,40 @@ def test_clip_trainer_runs():
     assert set(res) >= {"mean_auc", "mean_avg_prec", "std_auc", "cls_aucs"} and np.isfinite(res["mean_auc"])
     assert isinstance(tr.center, torch.Tensor) and tuple(tr.center.shape) == (2, 64)
     assert torch.allclose(tr.center.norm(dim=-1).cpu(), torch.ones(2), atol=1e-5)          # prepare_metric normalises (clip.py:62)
+
+
+def test_auc_ap_on_device_vs_oracle_and_golden(golden):
+    """N3: eoe_auc_ap (exact pair counts on the GPU) against the oracle's rank statistic / step-wise AP and the sklearn fixture g7:
+    ties, heavy ties, ragged n, a large set, single-class inputs"""
+    from eoe_amd import metrics
+    from oracle import metrics as ometrics
+    g = golden("g7_metrics")
+    for i in range(4):
+        n, ties = int(g[f"n{i}"]), bool(g[f"ties{i}"])
+        s = fill.fill(f"g7/s{i}", (n,), std=1.0)
+        if ties:
+            s = np.round(s * 4) / 4
+        y = fill.fill_int(f"g7/y{i}", (n,), 0, 2)
+        y[0], y[1] = 0, 1
+        auc, ap = metrics.auc_ap_device(torch.from_numpy(y), torch.from_numpy(s.astype(np.float32)).cuda())
+        assert abs(auc - float(g[f"auc{i}"])) < 1e-12 and abs(ap - float(g[f"ap{i}"])) < 1e-12
+    rng = np.random.default_rng(3)
+    for n, levels in ((1, None), (255, 3), (257, None), (1000, 7), (20011, 50), (20011, None)):
+        s = rng.standard_normal(n).astype(np.float32)
+        if levels:
+            s = np.round(s * levels) / levels
+        y = (rng.random(n) < 0.3).astype(np.int64)
+        auc, ap = metrics.auc_ap_device(torch.from_numpy(y).cuda(), torch.from_numpy(s).cuda())
+        ra, rp = ometrics.roc_auc(y, s), ometrics.average_precision(y, s)
+        if np.isnan(ra):
+            assert np.isnan(auc)
+        else:
+            assert abs(auc - ra) < 1e-12, (n, levels, auc, ra)
+        if np.isnan(rp):
+            assert np.isnan(ap)
+        else:
+            assert abs(ap - rp) < 1e-10, (n, levels, ap, rp)
+    auc, ap = metrics.auc_ap_device(torch.ones(5, dtype=torch.int64), torch.arange(5.0).cuda())
+    assert np.isnan(auc) and abs(ap - 1.0) < 1e-15
+    auc, ap = metrics.auc_ap_device(torch.zeros(5, dtype=torch.int64), torch.arange(5.0).cuda())
+    assert np.isnan(auc) and np.isnan(ap)
