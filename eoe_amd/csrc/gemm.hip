@@ -1,7 +1,12 @@
-// MFMA GEMM (NT) for gfx950.  Main shape: 256x128x64 tiles (256x96 / 256x64 where they quantise or fit better), 8 wavefronts
-// (4x2, 64x64 each; two per SIMD), one persistent workgroup per CU, 3-stage LDS ring.  Second shape (gemm_nt128_kernel): 128x128x64,
-// 4 wavefronts, 2-stage ring, two workgroups per CU -- the default for everything but the GELU forward and large square problems.
-// Both: v_mfma_f32_16x16x32_{f16,bf16}, operands staged global -> LDS with bounds-checked LDS-DMA (buffer_load ... lds,
+// MFMA GEMM (NT) for gfx950.  Three tile shapes, chosen per problem by launch_nt:
+//   gemm_nt128_kernel  128x128x64 or 160x128x64 (whichever needs fewer rounds over the 2 x #CU workgroup slots), 4 wavefronts
+//                      (2x2, 64x64 or 80x64 each), 2-stage ring, two non-persistent workgroups per CU -- the default;
+//   gemm_nt_kernel     256x128x64 (256x96 / 256x64 where they quantise or fit better), 8 wavefronts (4x2, 64x64 each; two per
+//                      SIMD), one persistent workgroup per CU, 3-stage ring -- large square problems and the implicit-GEMM
+//                      convolutions (GATHER modes);
+//   gemm_nt64_kernel   256x64x64, 4 wavefronts stacked along M (64x64 each), 2-stage ring, two workgroups per CU -- N <= 64
+//                      (the 64-channel convolutions, with or without gather).
+// All: v_mfma_f32_16x16x32_{f16,bf16}, operands staged global -> LDS with bounds-checked LDS-DMA (buffer_load ... lds,
 // 16 B per lane; an out-of-range lane reads 0, which is the zero padding of ragged M / N tails), and -- GATHER modes -- the A
 // operand of a convolution fetched piece by piece from the NHWC activation (implicit GEMM, no im2col).
 //
