@@ -663,6 +663,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmP p) {
     //   WAR: stage(kt+2) overwrites slot kt&1 after the barrier behind which every wave's reads of it (F0 in iteration kt-1,
     //        F1 in this one) have completed.   RAW: the DMA of tile kt+1 was issued one iteration ago; each wave waits for its
     //        own pieces before the barrier, the reads come after it.
+    // diagnostics (EOE_GEMM_STAMP=1): 8 words per workgroup = entry, operands landed, main loop done, exit, HW_ID, XCC_ID
+    unsigned long long* stp = (p.stamp && blockIdx.x < 8192) ? p.stamp + (size_t)blockIdx.x * 8 : nullptr;
+    if (stp && tid == 0) {
+        stp[0] = __builtin_amdgcn_s_memtime();
+        stp[4] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        stp[5] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
     V8 xa0[MI], wb0[4], xa1[MI], wb1[4];
     EOE_STAGE128(0, 0);
     if (nk > 1) EOE_STAGE128(1, 1);
@@ -672,15 +679,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmP p) {
         EOE_WAIT_VM(0);
     }
     __builtin_amdgcn_s_barrier();
+    if (stp && tid == 0) stp[1] = __builtin_amdgcn_s_memtime();
     EOE_READ128(xa0, wb0, smem, 0);
     for (int kt = 0; kt < nk; ++kt) {
         const char* sc = smem + (kt & 1) * STAGE128_BYTES;
         const char* sn = smem + ((kt + 1) & 1) * STAGE128_BYTES;
         EOE_READ128(xa1, wb1, sc, 1);
         EOE_MFMA128(xa0, wb0);
-        EOE_WAIT_VM(0);
-        EOE_WAIT_LGKM0();
-        __builtin_amdgcn_s_barrier();
+        if (stp) {                                 // diagnostics: cycles wave 0 spends waiting for the DMA / at the barrier
+            const unsigned long long t_a = __builtin_amdgcn_s_memtime();
+            EOE_WAIT_VM(0);
+            EOE_WAIT_LGKM0();
+            const unsigned long long t_b = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_barrier();
+            if (tid == 0) { stp[6] += t_b - t_a; stp[7] += __builtin_amdgcn_s_memtime() - t_b; }
+        } else {
+            EOE_WAIT_VM(0);
+            EOE_WAIT_LGKM0();
+            __builtin_amdgcn_s_barrier();
+        }
         if (kt + 2 < nk) EOE_STAGE128(kt & 1, kt + 2);
         EOE_READ128(xa0, wb0, sn, 0);          // unconditional (the last one reads a stale slot and is discarded)
         EOE_MFMA128(xa1, wb1);
@@ -690,10 +707,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmP p) {
 #undef EOE_READ128
 #undef EOE_MFMA128
 #undef EOE_STAGE128
+    if (stp && tid == 0) stp[2] = __builtin_amdgcn_s_memtime();
     GemmP ep;
     load_epilogue_args(ep, p);
     // scratch: this wave's own 4 KiB of slot 0 (all reads of the ring are behind the final barrier)
     epilogue<T, EPI, NI, MI>(ep, acc, m0 + wm0, n0 + wn0, lane, smem + wave * 4096);
+    if (stp && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // diagnostics only: the stores of wave 0 have left
+        stp[3] = __builtin_amdgcn_s_memtime();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ NT, N <= 64
@@ -899,6 +921,14 @@ int launch_nt128_auto(const GemmP& p, int epi, hipStream_t s) {
     return five ? launch_nt128<T, 5>(p, epi, s) : launch_nt128<T, 4>(p, epi, s);
 }
 
+// Measured on the two-workgroup kernel (tools/gemm128_timeline.py, s_memtime stamps + HW_ID per workgroup): the two workgroups of a CU
+// run in LOCKSTEP for the whole launch (they start, finish and are replaced together), so the MFMA loops of a CU cover only 72 % of its
+// time on the GELU GEMM (91 % on the plain K = 768 one).  De-phasing them (the second arrival of the first round sits out half a tile
+// period, found through a per-CU atomic counter) raises the coverage to 94 % and makes every GEMM SLOWER (fc forward 100 -> 108 us,
+// QKV 57 -> 61 us): a workgroup's MFMA loop is a latency chain that does not run faster alone, and the neighbour's epilogue takes
+// issue slots from it.  Two loops side by side are the better packing; kept as is.  Inside the loop wave 0 spends < 2 % waiting for
+// the LDS-DMA and 13-21 % at the per-k-tile barrier (skew between the four waves); s_setprio(1) around the MFMA clusters: null (+-1 %).
+//
 // Variants measured and rejected (interleaved A/B on one device with tools/gemm_ab.py, layer total of the 8 forward +
 // dgrad GEMMs of a ViT-B/32 block at M = 12800; the kept kernel = 546 us stand-alone, 8.1 ms/step in the full step):
 //   * sched_barrier pinning "8 fragment reads, then 16 MFMAs" per half iteration ........ 613 us (-11 %)
@@ -1045,8 +1075,8 @@ int fill_params(const eoe_gemm_args* a, GemmP& p) {
     p.stamp = nullptr;
     static const int stampon = getenv("EOE_GEMM_STAMP") ? atoi(getenv("EOE_GEMM_STAMP")) : 0;
     if (stampon) {
-        static unsigned long long* buf = [] { void* b = nullptr; (void)hipMalloc(&b, 1024 * 16 * 8); return (unsigned long long*)b; }();
-        (void)hipMemsetAsync(buf, 0, 1024 * 16 * 8, 0);
+        static unsigned long long* buf = [] { void* b = nullptr; (void)hipMalloc(&b, 4096 * 16 * 8); return (unsigned long long*)b; }();
+        (void)hipMemsetAsync(buf, 0, 4096 * 16 * 8, 0);
         p.stamp = buf;
         g_stamp_buf = buf;
     }
