@@ -107,9 +107,18 @@ class GradArena:
             if not self._installed:
                 self.handles.append(dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             else:
-                # the non-block parameters are few and small (embeddings, ln_pre/post, proj, head) except conv1
-                for p in inarena:
-                    self.handles.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                # the parameters outside the per-block buckets, as maximal contiguous runs of the arena: two collectives for the
+                # ViT (embedding / ln_pre in front of the blocks, ln_post / proj / head behind them), one for the CNNs -- not one
+                # small all-reduce per parameter
+                spans = sorted((self.offsets[id(p)], self.offsets[id(p)] + (p.numel() + 63) // 64 * 64) for p in inarena)
+                runs = [list(spans[0])]
+                for lo, hi in spans[1:]:
+                    if lo == runs[-1][1]:
+                        runs[-1][1] = hi
+                    else:
+                        runs.append([lo, hi])
+                for lo, hi in runs:
+                    self.handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for p in stray:
             self.handles.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for h in self.handles:

@@ -27,7 +27,7 @@ def _per_sample_loss(f, y):
     return torch.where(y == 0, d, -torch.log(1 - torch.exp(-d) + 1e-9))
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, hooks=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     from eoe_amd import parallel
     r, w, _ = parallel.init_from_env("gloo")
@@ -37,6 +37,8 @@ def _worker(rank, world, port, out):
     y = torch.cat([torch.zeros(5, dtype=torch.long), torch.ones(5, dtype=torch.long)])
     m = _model()
     arena = parallel.GradArena(m)
+    if hooks:
+        arena.install_hooks()          # the non-block parameters then go out as contiguous runs of the arena
     rows = parallel.shard_rows(5, 5, rank, world)
     loss = _per_sample_loss(m(x[rows]), y[rows]).sum() / 10.0          # sum(local) / GLOBAL batch
     loss.backward()
@@ -55,10 +57,14 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_gradients_equal_full_batch(tmp_path):
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("hooks", [False, True])
+def test_two_rank_gradients_equal_full_batch(tmp_path, hooks):
     out = str(tmp_path / "r0.pt")
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, out, hooks), nprocs=2, join=True)
     got = torch.load(out)
     g = torch.Generator().manual_seed(1)
     x = torch.randn(10, 6, generator=g)
