@@ -10,7 +10,6 @@
 #include "../../include/eoe_hip.h"
 
 thread_local char g_eoe_err[512] = {0};
-
 int eoe_set_error(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);

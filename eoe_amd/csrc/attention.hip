@@ -450,7 +450,7 @@ extern "C" int eoe_attn_bwd(const void* qkv, const void* dout, void* dqkv, float
     else
         return eoe_set_error(EOE_ERR_ARG, "attn_bwd: bad dtype %d", dtype);
     EOE_CHECK_LAUNCH("attn_bwd");
-    if (dbias) {
+    if (dbias && !eoe_defer_reduce(bias_scratch, n, 3 * heads * 64, 3 * heads * 64, dbias, nullptr, nullptr)) {
         hipLaunchKernelGGL(attn_bias_sum_kernel, dim3(cdiv(3 * heads * 64, 16)), dim3(1024), 0, (hipStream_t)stream,
                            (const float*)bias_scratch, n, 3 * heads * 64, dbias);
         EOE_CHECK_LAUNCH("attn_bwd_bias");

@@ -35,6 +35,25 @@ int eoe_set_error(int code, const char* fmt, ...);
 bool eoe_prof_active();
 int eoe_prof_begin(const char* name, double flops, double bytes, hipStream_t s);
 void eoe_prof_finish(int idx, hipStream_t s);
+// Deferred finish of partial-row column reductions: out[c / seg][c % seg] += sum_r part[r][c] for c < N.  The host wrappers that
+// normally launch their own tiny finish kernel (LayerNorm backward, the GEMM's fused column sums, the attention backward's bias sums)
+// append a job here instead while `eoe_tls_defer` is set; eoe_vit_block_bwd then finishes all jobs of a block in ONE launch
+// (each finish kernel is a dependent 4-5 us bubble in the stream: 4 per block otherwise).
+struct EoeRedJob {
+    const float* part;
+    int R, N, seg;            // R partial rows of width N; output segment length (N for a single output)
+    float* out[3];            // segment s = c / seg is added into out[s] (NULL = skip)
+};
+struct EoeRedJobs {
+    EoeRedJob job[4];
+    int tile_start[5];        // prefix sums of ceil(N / 16) workgroups per job
+    int count;
+};
+extern thread_local EoeRedJobs* eoe_tls_defer;
+// appends to the deferred list if one is active (returns true), else returns false and the caller launches its own finish
+bool eoe_defer_reduce(const float* part, int R, int N, int seg, float* o0, float* o1, float* o2);
+int eoe_flush_reduce(EoeRedJobs* jobs, void* stream);      // elementwise.hip
+
 struct ProfScope {
     int idx; hipStream_t s;
     ProfScope(const char* name, double flops, double bytes, void* stream) : idx(-1), s((hipStream_t)stream) {

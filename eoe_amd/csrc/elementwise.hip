@@ -342,6 +342,34 @@ __global__ __launch_bounds__(512) void layernorm_bwd_kernel(const void* __restri
         if (dxsum) atomicAdd(dxsum + c, a2);
     }
 }
+// all deferred finish reductions of a block in one launch (EoeRedJobs, common.h): the same 16 columns x 64 row lanes scheme
+__global__ __launch_bounds__(1024) void multi_reduce_kernel(EoeRedJobs jobs) {
+    __shared__ float l[64][17];
+    int j = 0;
+    while (j + 1 < jobs.count && (int)blockIdx.x >= jobs.tile_start[j + 1]) ++j;
+    const EoeRedJob jb = jobs.job[j];
+    const float* __restrict__ part = jb.part;
+    const int col = threadIdx.x & 15, lane = threadIdx.x >> 4;
+    const int i = (blockIdx.x - jobs.tile_start[j]) * 16 + col, n = jb.N, P = jb.R;
+    float s = 0.f;
+    if (i < n) {
+        int p = lane;
+        for (; p + 192 < P; p += 256) {
+            const float a = part[(size_t)p * n + i], b = part[(size_t)(p + 64) * n + i], c = part[(size_t)(p + 128) * n + i],
+                        d = part[(size_t)(p + 192) * n + i];
+            s += (a + b) + (c + d);
+        }
+        for (; p < P; p += 64) s += part[(size_t)p * n + i];
+    }
+    l[lane][col] = s;
+    __syncthreads();
+    if (lane != 0 || i >= n) return;
+    for (int k = 1; k < 64; ++k) s += l[k][col];
+    const int which = i / jb.seg, c = i - which * jb.seg;
+    float* dst = jb.out[which];
+    if (dst) dst[c] += s;
+}
+
 // dgamma / dbeta / dxsum += column sums of the P partial rows [P][3][D] written by layernorm_bwd_kernel, in a fixed order:
 // 16 columns x 64 row lanes per workgroup, four independent loads in flight per thread
 __global__ __launch_bounds__(1024) void ln_reduce_kernel(const float* __restrict__ part, int P, int D, float* __restrict__ dgamma,
@@ -1118,11 +1146,31 @@ extern "C" int eoe_layernorm_bwd(const void* dy, int dy_f32, const float* x, int
                                          dy_f32, x, ldx, stats, gamma, dres, dx_out, ld_out, (T*)dx16, dgamma, dbeta,
                                          dxsum, part, rows, D)));
     EOE_CHECK_LAUNCH("layernorm_bwd");
-    if (part) {
+    if (part && !eoe_defer_reduce(part, grid, 3 * D, D, dgamma, dbeta, dxsum)) {
         hipLaunchKernelGGL(ln_reduce_kernel, dim3(cdiv(3 * D, 16)), dim3(1024), 0, (hipStream_t)stream, (const float*)part, grid, D, dgamma,
                            dbeta, dxsum);
         EOE_CHECK_LAUNCH("layernorm_bwd_reduce");
     }
+    return 0;
+}
+
+thread_local EoeRedJobs* eoe_tls_defer = nullptr;
+
+bool eoe_defer_reduce(const float* part, int R, int N, int seg, float* o0, float* o1, float* o2) {
+    EoeRedJobs* j = eoe_tls_defer;
+    if (!j || j->count >= 4) return false;
+    EoeRedJob& r = j->job[j->count];
+    r.part = part; r.R = R; r.N = N; r.seg = seg; r.out[0] = o0; r.out[1] = o1; r.out[2] = o2;
+    j->tile_start[j->count + 1] = j->tile_start[j->count] + (N + 15) / 16;
+    j->count += 1;
+    return true;
+}
+
+int eoe_flush_reduce(EoeRedJobs* jobs, void* stream) {
+    if (!jobs || jobs->count == 0) return 0;
+    hipLaunchKernelGGL(multi_reduce_kernel, dim3(jobs->tile_start[jobs->count]), dim3(1024), 0, (hipStream_t)stream, *jobs);
+    EOE_CHECK_LAUNCH("multi_reduce");
+    jobs->count = 0;
     return 0;
 }
 

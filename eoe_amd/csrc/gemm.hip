@@ -880,6 +880,7 @@ __global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __rest
 }
 static int finish_colsum(const GemmP& p, int epi, int mi, hipStream_t s) {
     if (!p.colsum_part || !p.colsum || p.colsum_sq || epi == EOE_EPI_GELU) return 0;
+    if (eoe_defer_reduce(p.colsum_part, cdiv(p.M, 16 * mi), p.N, p.N, p.colsum, nullptr, nullptr)) return 0;
     hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(p.N, 16)), dim3(1024), 0, s, (const float*)p.colsum_part, cdiv(p.M, 16 * mi), p.N,
                        p.colsum);
     EOE_CHECK_LAUNCH("gemm_nt_colsum");

@@ -1,9 +1,6 @@
 // Fused launch chains for one ViT residual block (clip/model.py:167-188 and its backward): the host side only
 // enqueues kernels on the caller's stream; there is no host synchronisation and no allocation in here.
-#include <hip/hip_runtime.h>
-#include "../../include/eoe_hip.h"
-
-int eoe_set_error(int code, const char* fmt, ...);
+#include "common.h"
 
 #define TRY(expr)                   \
     do {                            \
@@ -74,6 +71,18 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
         const int zn[8] = {D, D, D, D, H, D, D, 3 * D};
         TRY(eoe_zero_multi(zp, zn, 8, stream));
     }
+    // the four partial-row column reductions of the block (db_fc, LayerNorm-2 parameters + db_out, db_in, LayerNorm-1 parameters)
+    // each get their own piece of the scratch and are finished together by ONE kernel at the end of the block
+    EoeRedJobs jobs;
+    jobs.count = 0; jobs.tile_start[0] = 0;
+    struct DeferGuard {
+        explicit DeferGuard(EoeRedJobs* j) { eoe_tls_defer = j; }
+        ~DeferGuard() { eoe_tls_defer = nullptr; }
+    } guard(b->red_scratch ? &jobs : nullptr);
+    float* red_fc = b->red_scratch;
+    float* red_ln2 = red_fc ? red_fc + (size_t)((M + 63) / 64) * H : nullptr;
+    float* red_attn = red_fc ? red_ln2 + EOE_LN_SCRATCH(D) : nullptr;
+    float* red_ln1 = red_fc ? red_attn + (size_t)a->n * 3 * D : nullptr;
     eoe_gemm_args g, w[4];
     // ---- MLP branch:  x_out = x_mid + c_proj(gelu(c_fc(ln_2(x_mid))))
     // bias gradients are column sums of the dY tensors: fused into the kernels that produce them (fp32 atomics)
@@ -83,7 +92,7 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
     if (b->red_scratch) {
         // db_fc = column sums of dh, from the GEMM's epilogue through per-wave partial rows in the scratch (with fp32 atomics
         // instead, the fused sums cost +45 us -- more than a separate 16-us pass over dh)
-        g.colsum = b->g_b_fc; g.workspace = b->red_scratch; g.workspace_bytes = (int64_t)EOE_NT_COLSUM_WORKSPACE_BYTES(M, H);
+        g.colsum = b->g_b_fc; g.workspace = red_fc; g.workspace_bytes = (int64_t)EOE_NT_COLSUM_WORKSPACE_BYTES(M, H);
         TRY(eoe_gemm_nt(&g, stream));
     } else {
         TRY(eoe_gemm_nt(&g, stream));
@@ -92,12 +101,12 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
     g = gemm(b->dh, a->w_fc_t, b->d16_b, nullptr, M, D, H, H, H, D, dt);                    // d xn2
     TRY(eoe_gemm_nt(&g, stream));
     TRY(eoe_layernorm_bwd(b->d16_b, 0, a->x_mid, D, a->stats2, a->ln2_g, b->dx_out, b->dx_mid, D, b->d16_c, b->g_ln2_g,
-                          b->g_ln2_b, b->g_b_out, b->red_scratch, M, D, dt, stream));        // + db_out = colsum(dx_mid)
+                          b->g_ln2_b, b->g_b_out, red_ln2, M, D, dt, stream));        // + db_out = colsum(dx_mid)
     // ---- attention branch:  x_mid = x_in + out_proj(attn(ln_1(x_in)))
     g = gemm(b->d16_c, a->w_out_t, b->d16_b, nullptr, M, D, D, D, D, D, dt);                // d att
     TRY(eoe_gemm_nt(&g, stream));
     // + db_in = column sums of dqkv, from the attention kernel's accumulators when the scratch is there
-    TRY(eoe_attn_bwd(a->qkv, b->d16_b, b->dqkv, b->red_scratch ? b->g_b_in : nullptr, b->red_scratch, a->n, a->L, a->heads, dt, stream));
+    TRY(eoe_attn_bwd(a->qkv, b->d16_b, b->dqkv, red_attn ? b->g_b_in : nullptr, red_attn, a->n, a->L, a->heads, dt, stream));
     g = gemm(b->dqkv, a->w_in_t, b->d16_b, nullptr, M, D, 3 * D, 3 * D, 3 * D, D, dt);      // d xn1
     TRY(eoe_gemm_nt(&g, stream));
     if (!b->red_scratch) TRY(eoe_colsum(b->dqkv, 3 * D, b->g_b_in, M, 3 * D, dt, 1, stream));
@@ -109,6 +118,7 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
     for (int i = 0; i < 4; ++i) { w[i].out_f32 = 1; w[i].accumulate = acc; }
     TRY(eoe_gemm_tn_grouped(w, 4, stream));
     TRY(eoe_layernorm_bwd(b->d16_b, 0, a->x_in, D, a->stats1, a->ln1_g, b->dx_mid, b->dx_in, D, nullptr, b->g_ln1_g,
-                          b->g_ln1_b, nullptr, b->red_scratch, M, D, dt, stream));
+                          b->g_ln1_b, nullptr, red_ln1, M, D, dt, stream));
+    TRY(eoe_flush_reduce(b->red_scratch ? &jobs : nullptr, stream));
     return 0;
 }

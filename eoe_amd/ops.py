@@ -467,7 +467,7 @@ class VitBlockFunction(torch.autograd.Function):
         b.dh = _p(scratch("dh", (M, 4 * D), dt, dev))
         b.dqkv = _p(scratch("dqkv", (M, 3 * D), dt, dev))
         b.dx_mid = _p(scratch("dx_mid", (M, D), torch.float32, dev))
-        nred = max(LN_SCRATCH_ROWS * 3 * D, (M + 63) // 64 * 4 * D, ctx.args.n * 3 * D)          # EOE_VIT_RED_SCRATCH(n, L, D)
+        nred = (M + 63) // 64 * 4 * D + 2 * LN_SCRATCH_ROWS * 3 * D + ctx.args.n * 3 * D          # EOE_VIT_RED_SCRATCH(n, L, D)
         b.red_scratch = _p(scratch("vit_red", (nred,), torch.float32, dev))
         check(lib.eoe_vit_block_bwd(C.byref(b), _stream()), "eoe_vit_block_bwd")
         hook = grad_ready_hooks.get(id(params["ln1_g"]))

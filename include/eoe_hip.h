@@ -280,11 +280,10 @@ typedef struct {
                          * partial rows and fixed-order reduce kernels instead of fp32 atomics / separate passes */
 } eoe_vit_block_bwd_args;
 
-/* floats: max(LayerNorm partial rows, partial rows of the fc dgrad GEMM's fused column sums [ceil(n*L/64)][4D], the attention
- * backward's per-image in_proj bias sums [n][3D]) */
-#define EOE_MAX_(a, b) ((a) > (b) ? (a) : (b))
+/* floats: partial rows of the fc dgrad GEMM's fused column sums [ceil(n*L/64)][4D] + of the two LayerNorm backwards + the attention
+ * backward's per-image in_proj bias sums [n][3D] (separate pieces: one kernel finishes all four at the end of the block) */
 #define EOE_VIT_RED_SCRATCH(n, L, D) \
-    EOE_MAX_(EOE_MAX_(EOE_LN_SCRATCH(D), (size_t)(((size_t)(n) * (L) + 63) / 64) * 4 * (D)), (size_t)(n) * 3 * (D))
+    ((size_t)(((size_t)(n) * (L) + 63) / 64) * 4 * (D) + 2 * EOE_LN_SCRATCH(D) + (size_t)(n) * 3 * (D))
 int eoe_vit_block_fwd(const eoe_vit_block_fwd_args* a, void* stream);
 int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* a, void* stream);
 
