@@ -104,14 +104,14 @@ SIGNATURES = {
     "eoe_cast_transpose_multi": [_vp, C.c_int, C.c_int, _vp],
     "eoe_patchify": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "eoe_embed_lnpre_fwd": [_vp] * 8 + [C.c_int, C.c_int, C.c_int, _f32, _vp],
-    "eoe_embed_lnpre_bwd": [_vp] * 9 + [C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "eoe_embed_lnpre_bwd": [_vp] * 10 + [C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "eoe_layernorm_fwd": [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, C.c_int, C.c_int, _vp],
     "eoe_layernorm_bwd": [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int,
                           C.c_int, C.c_int, _vp],
     "eoe_linear_small_fwd": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
     "eoe_linear_small_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "eoe_zero_multi": [C.POINTER(_vp), C.POINTER(C.c_int), C.c_int, _vp],
-    "eoe_cast_colsum": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "eoe_cast_colsum": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "eoe_colsum": [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "eoe_colsum_det": [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
     "eoe_cast": [_vp, _vp, _sz, C.c_int, _vp],

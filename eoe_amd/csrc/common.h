@@ -45,9 +45,10 @@ struct EoeRedJob {
     float* out[3];            // segment s = c / seg is added into out[s] (NULL = skip)
 };
 struct EoeRedJobs {
-    EoeRedJob job[4];
-    int tile_start[5];        // prefix sums of ceil(N / 16) workgroups per job
+    EoeRedJob job[6];
+    int tile_start[7];        // prefix sums of ceil(N / 16) workgroups per job
     int count;
+    int overwrite;            // 1: out = sum (no zero-initialised accumulators needed), 0: out += sum
 };
 extern thread_local EoeRedJobs* eoe_tls_defer;
 // appends to the deferred list if one is active (returns true), else returns false and the caller launches its own finish

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void cast_transpose_multi_kernel(CtBatch b) {
 // fp32 [rows, cols] -> 16-bit copy + column sums (bias gradient of the layer whose dY this is), one pass
 template <typename T>
 __global__ __launch_bounds__(256) void cast_colsum_kernel(const float* __restrict__ x, T* __restrict__ dst,
-                                                          float* __restrict__ out, int rows, int cols) {
+                                                          float* __restrict__ out, float* __restrict__ part, int rows, int cols) {
     __shared__ float red[4][256];
     const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.x * 256 + cg * 4;
@@ -145,7 +145,10 @@ __global__ __launch_bounds__(256) void cast_colsum_kernel(const float* __restric
     for (int k = 0; k < 4; ++k) red[rl][cg * 4 + k] = a[k];
     __syncthreads();
     const int cc = blockIdx.x * 256 + threadIdx.x;
-    if (cc < cols) atomicAdd(out + cc, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (cc >= cols) return;
+    const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (part) part[(size_t)blockIdx.y * cols + cc] = t;       // this workgroup row's partial sums; a finish kernel adds the rows up
+    else atomicAdd(out + cc, t);
 }
 
 // zero up to EOE_ZERO_MAX small fp32 buffers in one launch (gradient accumulators filled by atomics)
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(1024) void multi_reduce_kernel(EoeRedJobs jobs) {
     for (int k = 1; k < 64; ++k) s += l[k][col];
     const int which = i / jb.seg, c = i - which * jb.seg;
     float* dst = jb.out[which];
-    if (dst) dst[c] += s;
+    if (dst) dst[c] = jobs.overwrite ? s : dst[c] + s;
 }
 
 // dgamma / dbeta / dxsum += column sums of the P partial rows [P][3][D] written by layernorm_bwd_kernel, in a fixed order:
@@ -441,7 +444,8 @@ template <typename T, int NV>
 __global__ __launch_bounds__(256) void embed_lnpre_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x0,
                                        const float* __restrict__ stats, const float* __restrict__ gamma,
                                        T* __restrict__ dtok, float* __restrict__ dcls, float* __restrict__ dpos,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int n, int L, int D) {
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ part, int n, int L,
+                                       int D) {
     __shared__ float red[3][4][1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l = blockIdx.x;
@@ -504,8 +508,13 @@ __global__ __launch_bounds__(256) void embed_lnpre_bwd_kernel(const float* __res
         const float sg = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
         const float sb = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
         const float sp = red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c];
-        atomicAdd(dgamma + c, sg);
-        atomicAdd(dbeta + c, sb);
+        if (part) {                                  // this token position's partial row [2][D]; a finish kernel adds the L rows up
+            part[(size_t)l * 2 * D + c] = sg;
+            part[(size_t)l * 2 * D + D + c] = sb;
+        } else {
+            atomicAdd(dgamma + c, sg);
+            atomicAdd(dbeta + c, sb);
+        }
         dpos[(size_t)l * D + c] += sp;
         if (l == 0) dcls[c] += sp;
     }
@@ -1158,7 +1167,7 @@ thread_local EoeRedJobs* eoe_tls_defer = nullptr;
 
 bool eoe_defer_reduce(const float* part, int R, int N, int seg, float* o0, float* o1, float* o2) {
     EoeRedJobs* j = eoe_tls_defer;
-    if (!j || j->count >= 4) return false;
+    if (!j || j->count >= 6) return false;
     EoeRedJob& r = j->job[j->count];
     r.part = part; r.R = R; r.N = N; r.seg = seg; r.out[0] = o0; r.out[1] = o1; r.out[2] = o2;
     j->tile_start[j->count + 1] = j->tile_start[j->count] + (N + 15) / 16;
@@ -1186,14 +1195,22 @@ extern "C" int eoe_embed_lnpre_fwd(const float* tok, const float* cls, const flo
 }
 
 extern "C" int eoe_embed_lnpre_bwd(const float* dy, const float* x0, const float* stats, const float* gamma,
-                                   void* dtok, float* dcls, float* dpos, float* dgamma, float* dbeta, int n, int L,
-                                   int D, int dtype, void* stream) {
+                                   void* dtok, float* dcls, float* dpos, float* dgamma, float* dbeta, float* scratch, int n,
+                                   int L, int D, int dtype, void* stream) {
     EOE_CHECK_ARG(dy && x0 && stats && gamma && dtok && dcls && dpos && dgamma && dbeta && n > 0 && L > 1,
                   "embed_lnpre_bwd: bad args");
     EOE_CHECK_ARG(D % 256 == 0 && D <= 1024, "embed_lnpre: D must be a multiple of 256, <= 1024");
     DISPATCH_T(dtype, DISPATCH_NV(D, hipLaunchKernelGGL((embed_lnpre_bwd_kernel<T, NV>), dim3(L), dim3(256), 0, (hipStream_t)stream, dy, x0,
-                                         stats, gamma, (T*)dtok, dcls, dpos, dgamma, dbeta, n, L, D)));
+                                         stats, gamma, (T*)dtok, dcls, dpos, dgamma, dbeta, scratch, n, L, D)));
     EOE_CHECK_LAUNCH("embed_lnpre_bwd");
+    if (scratch && !eoe_defer_reduce(scratch, L, 2 * D, D, dgamma, dbeta, nullptr)) {
+        EoeRedJobs one;
+        one.count = 0; one.tile_start[0] = 0; one.overwrite = 0;
+        eoe_tls_defer = &one;
+        eoe_defer_reduce(scratch, L, 2 * D, D, dgamma, dbeta, nullptr);
+        eoe_tls_defer = nullptr;
+        EOE_TRY(eoe_flush_reduce(&one, stream));
+    }
     return 0;
 }
 
@@ -1288,20 +1305,31 @@ extern "C" int eoe_zero_multi(float* const* ptrs, const int* counts, int n, void
     return 0;
 }
 
-extern "C" int eoe_cast_colsum(const float* x, void* dst, float* out, int rows, int cols, int dtype, int accumulate,
+extern "C" int eoe_cast_colsum(const float* x, void* dst, float* out, float* scratch, int rows, int cols, int dtype, int accumulate,
                                void* stream) {
     EOE_CHECK_ARG(x && dst && out && rows > 0 && cols > 0, "cast_colsum: bad args");
     EOE_CHECK_ARG(cols % 4 == 0, "cast_colsum: cols must be a multiple of 4");
     ProfScope ps("cast_colsum", 0, 6.0 * rows * cols, stream);
-    if (!accumulate) {
+    int gy = cdiv(rows, 4 * 8);
+    if (gy > EOE_CAST_COLSUM_PARTIALS) gy = EOE_CAST_COLSUM_PARTIALS;
+    // with a scratch: per-workgroup-row partial sums + a fixed-order finish (deferred into the caller's batch when one is open);
+    // a deferred finish follows the batch's overwrite / accumulate mode, so nothing is zeroed here
+    const bool deferred_mode = scratch && eoe_tls_defer;
+    if (!accumulate && !deferred_mode) {
         if (hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), (hipStream_t)stream) != hipSuccess)
             return eoe_set_error(EOE_ERR_LAUNCH, "cast_colsum: memset failed");
     }
-    int gy = cdiv(rows, 4 * 8);
-    if (gy > 256) gy = 256;
     DISPATCH_T(dtype, hipLaunchKernelGGL((cast_colsum_kernel<T>), dim3(cdiv(cols, 256), gy), dim3(256), 0,
-                                         (hipStream_t)stream, x, (T*)dst, out, rows, cols));
+                                         (hipStream_t)stream, x, (T*)dst, out, scratch, rows, cols));
     EOE_CHECK_LAUNCH("cast_colsum");
+    if (scratch && !eoe_defer_reduce(scratch, gy, cols, cols, out, nullptr, nullptr)) {
+        EoeRedJobs one;
+        one.count = 0; one.tile_start[0] = 0; one.overwrite = 0;
+        eoe_tls_defer = &one;
+        eoe_defer_reduce(scratch, gy, cols, cols, out, nullptr, nullptr);
+        eoe_tls_defer = nullptr;
+        EOE_TRY(eoe_flush_reduce(&one, stream));
+    }
     return 0;
 }
 

@@ -65,16 +65,17 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
         return eoe_set_error(EOE_ERR_ARG, "vit_block_bwd: null pointer in arguments");
     const int M = a->n * a->L, D = a->D, H = 4 * a->D, dt = a->dtype, acc = b->accumulate;
     hipStream_t s = (hipStream_t)stream;
-    if (!acc) {
-        // gradients accumulated with fp32 atomics (LayerNorm parameters, fused bias column sums): one zeroing launch
+    if (!acc && !b->red_scratch) {
+        // without the reduction scratch these gradients are accumulated with fp32 atomics: one zeroing launch
         float* zp[8] = {b->g_ln1_g, b->g_ln1_b, b->g_ln2_g, b->g_ln2_b, b->g_b_fc, b->g_b_out, b->g_b_proj, b->g_b_in};
         const int zn[8] = {D, D, D, D, H, D, D, 3 * D};
         TRY(eoe_zero_multi(zp, zn, 8, stream));
     }
-    // the four partial-row column reductions of the block (db_fc, LayerNorm-2 parameters + db_out, db_in, LayerNorm-1 parameters)
-    // each get their own piece of the scratch and are finished together by ONE kernel at the end of the block
+    // the five partial-row column reductions of the block (db_proj, db_fc, LayerNorm-2 parameters + db_out, db_in, LayerNorm-1
+    // parameters) each get their own piece of the scratch and are finished together by ONE kernel at the end of the block, which
+    // overwrites (or, with `accumulate`, adds to) the eight small gradient vectors: no atomics, no zeroing launch
     EoeRedJobs jobs;
-    jobs.count = 0; jobs.tile_start[0] = 0;
+    jobs.count = 0; jobs.tile_start[0] = 0; jobs.overwrite = acc ? 0 : 1;
     struct DeferGuard {
         explicit DeferGuard(EoeRedJobs* j) { eoe_tls_defer = j; }
         ~DeferGuard() { eoe_tls_defer = nullptr; }
@@ -83,10 +84,11 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
     float* red_ln2 = red_fc ? red_fc + (size_t)((M + 63) / 64) * H : nullptr;
     float* red_attn = red_fc ? red_ln2 + EOE_LN_SCRATCH(D) : nullptr;
     float* red_ln1 = red_fc ? red_attn + (size_t)a->n * 3 * D : nullptr;
+    float* red_cast = red_fc ? red_ln1 + EOE_LN_SCRATCH(D) : nullptr;
     eoe_gemm_args g, w[4];
     // ---- MLP branch:  x_out = x_mid + c_proj(gelu(c_fc(ln_2(x_mid))))
     // bias gradients are column sums of the dY tensors: fused into the kernels that produce them (fp32 atomics)
-    TRY(eoe_cast_colsum(b->dx_out, b->d16_a, b->g_b_proj, M, D, dt, 1, stream));          // dY of c_proj + db_proj
+    TRY(eoe_cast_colsum(b->dx_out, b->d16_a, b->g_b_proj, red_cast, M, D, dt, 1, stream));     // dY of c_proj + db_proj
     g = gemm(b->d16_a, a->w_proj_t, b->dh, nullptr, M, H, D, D, D, H, dt);                  // d hact, then * gelu'(hpre)
     g.epilogue = EOE_EPI_GELU_BWD; g.aux = a->hpre; g.ldaux = H;
     if (b->red_scratch) {

@@ -126,7 +126,8 @@ def cast_colsum(x: torch.Tensor, out16: torch.Tensor, colsum_out: torch.Tensor, 
     """out16 = 16-bit copy of x (fp32 [rows, cols]); colsum_out[c] (+)= sum_r x[r, c]"""
     _chk(x, out16, colsum_out)
     rows, cols = x.shape
-    check(lib.eoe_cast_colsum(_p(x), _p(out16), _p(colsum_out), rows, cols, dtype_code(out16.dtype),
+    part = scratch("cast_colsum_part", (256 * cols,), torch.float32, x.device)          # EOE_CAST_COLSUM_PARTIALS rows: no atomics
+    check(lib.eoe_cast_colsum(_p(x), _p(out16), _p(colsum_out), _p(part), rows, cols, dtype_code(out16.dtype),
                               1 if accumulate else 0, _stream()), "eoe_cast_colsum")
     return out16
 
@@ -389,7 +390,8 @@ class VitEmbedFunction(torch.autograd.Function):
         dcls, dpos, dg, db = (_grad_target(t) for t in (cls, pos, g, b))
         for t in (dcls, dpos, dg, db):
             t.zero_()
-        check(lib.eoe_embed_lnpre_bwd(_p(dy), _p(x0), _p(stats), _p(g), _p(dtok), _p(dcls), _p(dpos), _p(dg), _p(db),
+        part = scratch("embed_ln_part", (L * 2 * D,), torch.float32, dy.device)          # ln_pre parameter gradients without atomics
+        check(lib.eoe_embed_lnpre_bwd(_p(dy), _p(x0), _p(stats), _p(g), _p(dtok), _p(dcls), _p(dpos), _p(dg), _p(db), _p(part),
                                       n, L, D, dtype_code(patches.dtype), _stream()), "eoe_embed_lnpre_bwd")
         dw = _grad_target(conv_w)
         gemm_tn(dtok, patches, dw.view(D, -1))
@@ -467,7 +469,7 @@ class VitBlockFunction(torch.autograd.Function):
         b.dh = _p(scratch("dh", (M, 4 * D), dt, dev))
         b.dqkv = _p(scratch("dqkv", (M, 3 * D), dt, dev))
         b.dx_mid = _p(scratch("dx_mid", (M, D), torch.float32, dev))
-        nred = (M + 63) // 64 * 4 * D + 2 * LN_SCRATCH_ROWS * 3 * D + ctx.args.n * 3 * D          # EOE_VIT_RED_SCRATCH(n, L, D)
+        nred = (M + 63) // 64 * 4 * D + 2 * LN_SCRATCH_ROWS * 3 * D + ctx.args.n * 3 * D + 256 * D          # EOE_VIT_RED_SCRATCH(n, L, D)
         b.red_scratch = _p(scratch("vit_red", (nred,), torch.float32, dev))
         check(lib.eoe_vit_block_bwd(C.byref(b), _stream()), "eoe_vit_block_bwd")
         hook = grad_ready_hooks.get(id(params["ln1_g"]))

@@ -132,9 +132,10 @@ int eoe_embed_lnpre_fwd(const float* tok, const float* cls, const float* pos, co
                         const float* beta, float* x0, float* y, float* stats, int n, int L, int D, float eps,
                         void* stream);
 /* backward of the above: dy fp32 [n*L, D] -> dtok 16-bit [n*(L-1), D] (operand of the conv1 wgrad GEMM),
- * dcls[D] +=, dpos[L,D] +=, dgamma[D] +=, dbeta[D] += (fp32 atomics; caller zeroes or accumulates). */
+ * dcls[D] +=, dpos[L,D] +=, dgamma[D] +=, dbeta[D] += (caller zeroes or accumulates).  scratch: optional, L * 2 * D floats ->
+ * dgamma / dbeta through per-token-position partial rows + a fixed-order finish kernel instead of fp32 atomics. */
 int eoe_embed_lnpre_bwd(const float* dy, const float* x0, const float* stats, const float* gamma, void* dtok,
-                        float* dcls, float* dpos, float* dgamma, float* dbeta, int n, int L, int D, int dtype,
+                        float* dcls, float* dpos, float* dgamma, float* dbeta, float* scratch, int n, int L, int D, int dtype,
                         void* stream);
 
 /* LayerNorm over the last dim (clip/model.py:153-159, fp32 statistics, biased variance):
@@ -162,8 +163,10 @@ int eoe_colsum(const void* x, int ldx, float* out, int rows, int cols, int dtype
 #define EOE_COLSUM_PARTIALS 256
 int eoe_colsum_det(const void* x, int ldx, float* out, float* scratch, int rows, int cols, int dtype, void* stream);
 
-/* dst = 16-bit copy of x fp32 [rows, cols] and out[c] (+)= sum_r x[r, c] in one pass */
-int eoe_cast_colsum(const float* x, void* dst, float* out, int rows, int cols, int dtype, int accumulate, void* stream);
+/* dst = 16-bit copy of x fp32 [rows, cols] and out[c] (+)= sum_r x[r, c] in one pass.  scratch: optional, EOE_CAST_COLSUM_PARTIALS * cols
+ * floats -> the sums go through per-workgroup partial rows + a fixed-order finish kernel instead of fp32 atomics */
+#define EOE_CAST_COLSUM_PARTIALS 256
+int eoe_cast_colsum(const float* x, void* dst, float* out, float* scratch, int rows, int cols, int dtype, int accumulate, void* stream);
 
 /* narrow linear head, N <= 8 outputs, exact fp32 (the 1-wide `final_linear` of CustomNet(clf=True),
  * custom_base.py:25-26, used by the BCE objective): y[M,N] = x[M,K] w[N,K]^T + bias;
@@ -283,7 +286,7 @@ typedef struct {
 /* floats: partial rows of the fc dgrad GEMM's fused column sums [ceil(n*L/64)][4D] + of the two LayerNorm backwards + the attention
  * backward's per-image in_proj bias sums [n][3D] (separate pieces: one kernel finishes all four at the end of the block) */
 #define EOE_VIT_RED_SCRATCH(n, L, D) \
-    ((size_t)(((size_t)(n) * (L) + 63) / 64) * 4 * (D) + 2 * EOE_LN_SCRATCH(D) + (size_t)(n) * 3 * (D))
+    ((size_t)(((size_t)(n) * (L) + 63) / 64) * 4 * (D) + 2 * EOE_LN_SCRATCH(D) + (size_t)(n) * 3 * (D) + (size_t)EOE_CAST_COLSUM_PARTIALS * (D))
 int eoe_vit_block_fwd(const eoe_vit_block_fwd_args* a, void* stream);
 int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* a, void* stream);
 

@@ -121,3 +121,33 @@ def test_state_dict_interchange():
         got = m(x.cuda())
         want = ref(x)
     assert rel_rms(got, want) < 2e-2
+
+
+def test_vit_step_is_bitwise_reproducible():
+    """three runs of 4 Adam steps of a 2-layer ViT-B/32 from the same state give identical bits: every reduction of the step
+    (LayerNorm parameter / bias gradients, wgrad split sums, loss) goes through partial rows and fixed-order finish kernels -- an
+    fp32 atomic or a race anywhere would show up here"""
+    import copy
+    import eoe_amd
+    from eoe_amd.models import ClipViTB32Custom
+    eoe_amd.set_compute_dtype("fp16")
+    torch.manual_seed(5)
+    m0 = ClipViTB32Custom(prediction_head=True, clf=False, layers=2).cuda().train()
+    x, y = otrainer.synthetic_batch("det/vit", 12, 12, 224)
+    x, y = x.cuda(), y.cuda()
+    runs = []
+    for _ in range(3):
+        m = copy.deepcopy(m0)
+        opt = eoe_amd.FusedAdam(m.parameters(), lr=1e-4, weight_decay=1e-3)
+        losses = []
+        for _ in range(4):
+            opt.zero_grad()
+            loss = eoe_amd.hsc_loss(m(x), y, 0)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        runs.append((losses, {k: v.detach().clone() for k, v in m.state_dict().items()}))
+    for losses, sd in runs[1:]:
+        assert losses == runs[0][0]
+        for k in sd:
+            assert torch.equal(sd[k], runs[0][1][k]), k
