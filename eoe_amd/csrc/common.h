@@ -46,7 +46,7 @@ struct EoeRedJob {
 };
 struct EoeRedJobs {
     EoeRedJob job[6];
-    int tile_start[7];        // prefix sums of ceil(N / 16) workgroups per job
+    int tile_start[7];        // prefix sums of ceil(N / 64) workgroups per job
     int count;
     int overwrite;            // 1: out = sum (no zero-initialised accumulators needed), 0: out += sum
 };

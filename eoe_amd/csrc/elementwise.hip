@@ -345,32 +345,51 @@ __global__ __launch_bounds__(512) void layernorm_bwd_kernel(const void* __restri
         if (dxsum) atomicAdd(dxsum + c, a2);
     }
 }
-// all deferred finish reductions of a block in one launch (EoeRedJobs, common.h): the same 16 columns x 64 row lanes scheme
+// all deferred finish reductions of a block in one launch (EoeRedJobs, common.h): a workgroup owns 64 columns (256-B row segments)
+// = 16 thread-columns of one float4 x 64 row lanes, so that a thread's <= 8 rows (R <= 512) are ONE batch of independent 16-B loads:
+// the partial rows were written hundreds of microseconds earlier and come back from HBM, and with four dependent batches per
+// thread this kernel took 23 us (as long as the five launches it replaces).  Fixed summation order; N and seg multiples of 4.
 __global__ __launch_bounds__(1024) void multi_reduce_kernel(EoeRedJobs jobs) {
-    __shared__ float l[64][17];
+    __shared__ f32x4 l[64][17];
     int j = 0;
     while (j + 1 < jobs.count && (int)blockIdx.x >= jobs.tile_start[j + 1]) ++j;
     const EoeRedJob jb = jobs.job[j];
     const float* __restrict__ part = jb.part;
-    const int col = threadIdx.x & 15, lane = threadIdx.x >> 4;
-    const int i = (blockIdx.x - jobs.tile_start[j]) * 16 + col, n = jb.N, P = jb.R;
-    float s = 0.f;
+    const int cq = threadIdx.x & 15, lane = threadIdx.x >> 4;
+    const int i = (blockIdx.x - jobs.tile_start[j]) * 64 + cq * 4, n = jb.N, P = jb.R;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (i < n) {
         int p = lane;
-        for (; p + 192 < P; p += 256) {
-            const float a = part[(size_t)p * n + i], b = part[(size_t)(p + 64) * n + i], c = part[(size_t)(p + 128) * n + i],
-                        d = part[(size_t)(p + 192) * n + i];
-            s += (a + b) + (c + d);
+        for (; p + 448 < P; p += 512) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(part + (size_t)(p + 64 * u) * n + i);
+            s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
         }
-        for (; p < P; p += 64) s += part[(size_t)p * n + i];
+        if (p < P) {                               // ragged tail: still one batch (rows beyond P are not read)
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[u] = (p + 64 * u < P) ? *(const f32x4*)(part + (size_t)(p + 64 * u) * n + i) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
     }
-    l[lane][col] = s;
+    l[lane][cq] = s;
+    __syncthreads();
+    if (lane >= 8) return;
+    // 64 lanes -> 8 -> 1, in a fixed order
+    f32x4 t = l[lane][cq];
+    for (int k = 1; k < 8; ++k) t += l[lane + 8 * k][cq];
+    __syncthreads();
+    l[lane][cq] = t;
     __syncthreads();
     if (lane != 0 || i >= n) return;
-    for (int k = 1; k < 64; ++k) s += l[k][col];
-    const int which = i / jb.seg, c = i - which * jb.seg;
+    for (int k = 1; k < 8; ++k) t += l[k][cq];
+    const int which = i / jb.seg, c = i - which * jb.seg;          // seg % 4 == 0: the four columns share a segment
     float* dst = jb.out[which];
-    if (dst) dst[c] = jobs.overwrite ? s : dst[c] + s;
+    if (!dst) return;
+    if (!jobs.overwrite) t += *(const f32x4*)(dst + c);
+    *(f32x4*)(dst + c) = t;
 }
 
 // dgamma / dbeta / dxsum += column sums of the P partial rows [P][3][D] written by layernorm_bwd_kernel, in a fixed order:
@@ -1167,10 +1186,10 @@ thread_local EoeRedJobs* eoe_tls_defer = nullptr;
 
 bool eoe_defer_reduce(const float* part, int R, int N, int seg, float* o0, float* o1, float* o2) {
     EoeRedJobs* j = eoe_tls_defer;
-    if (!j || j->count >= 6) return false;
+    if (!j || j->count >= 6 || (N & 3) || (seg & 3)) return false;
     EoeRedJob& r = j->job[j->count];
     r.part = part; r.R = R; r.N = N; r.seg = seg; r.out[0] = o0; r.out[1] = o1; r.out[2] = o2;
-    j->tile_start[j->count + 1] = j->tile_start[j->count] + (N + 15) / 16;
+    j->tile_start[j->count + 1] = j->tile_start[j->count] + (N + 63) / 64;
     j->count += 1;
     return true;
 }
