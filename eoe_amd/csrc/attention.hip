@@ -202,28 +202,6 @@ __device__ __forceinline__ f32x4 token_sum(const f32x4 (&o)[4], int L, int lr) {
     }
     return t;
 }
-// out[c] += sum_img part[img][c], fixed order (16 columns x 64 row lanes per workgroup)
-__global__ __launch_bounds__(1024) void attn_bias_sum_kernel(const float* __restrict__ part, int R, int N, float* __restrict__ out) {
-    __shared__ float l[64][17];
-    const int col = threadIdx.x & 15, lane = threadIdx.x >> 4;
-    const int i = blockIdx.x * 16 + col;
-    float s = 0.f;
-    if (i < N) {
-        int r = lane;
-        for (; r + 192 < R; r += 256) {
-            const float a = part[(size_t)r * N + i], b = part[(size_t)(r + 64) * N + i], c = part[(size_t)(r + 128) * N + i],
-                        d = part[(size_t)(r + 192) * N + i];
-            s += (a + b) + (c + d);
-        }
-        for (; r < R; r += 64) s += part[(size_t)r * N + i];
-    }
-    l[lane][col] = s;
-    __syncthreads();
-    if (lane != 0 || i >= N) return;
-    for (int k = 1; k < 64; ++k) s += l[k][col];
-    out[i] += s;
-}
-
 template <typename T>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                       T* __restrict__ dqkv, float* __restrict__ bias_part, int L, int heads,
@@ -243,8 +221,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const T* vp = qp + 2 * D;
     const T* dop = dout + (size_t)img * L * D + h * 64;
     T* dqp = dqkv + (size_t)img * L * ld + h * 64;
-    // optional: this (image, head)'s column sums of dQ | dK | dV (the in_proj bias gradient) -> bias_part[img][3D]
-    float* bpart = bias_part ? bias_part + (size_t)img * ld + h * 64 : nullptr;
+    // optional: this (image, head)'s column sums of dQ | dK | dV (the in_proj bias gradient) -> partial row `img` of width 3D in
+    // the blocked layout (eoe_part_index): a head's 64 columns of dQ / dK / dV are column blocks h, heads + h, 2 heads + h
+    const int n_img = gridDim.x / heads;
+    float* bpart = bias_part ? bias_part + ((size_t)h * n_img + img) * 64 : nullptr;
+    const size_t bseg = (size_t)heads * n_img * 64;          // from the dQ block to the dK block to the dV block
 
     // V is only ever an MFMA operand in fragment layout: its 8 fragments are loaded straight from global memory ONCE, up front
     // (both phases use the same ones; loading them inside the phases exposed two more global round trips per wave)
@@ -407,8 +388,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             if (bpart) {
                 const f32x4 cv = token_sum(ov, L, lr), ck = token_sum(ok, L, lr);
                 if (lr == 0) {
-                    *(f32x4*)(bpart + 2 * D + 16 * td + 4 * lg) = cv;
-                    *(f32x4*)(bpart + D + 16 * td + 4 * lg) = ck;
+                    *(f32x4*)(bpart + 2 * bseg + 16 * td + 4 * lg) = cv;
+                    *(f32x4*)(bpart + bseg + 16 * td + 4 * lg) = ck;
                 }
             }
         }
@@ -450,10 +431,6 @@ extern "C" int eoe_attn_bwd(const void* qkv, const void* dout, void* dqkv, float
     else
         return eoe_set_error(EOE_ERR_ARG, "attn_bwd: bad dtype %d", dtype);
     EOE_CHECK_LAUNCH("attn_bwd");
-    if (dbias && !eoe_defer_reduce(bias_scratch, n, 3 * heads * 64, 3 * heads * 64, dbias, nullptr, nullptr)) {
-        hipLaunchKernelGGL(attn_bias_sum_kernel, dim3(cdiv(3 * heads * 64, 16)), dim3(1024), 0, (hipStream_t)stream,
-                           (const float*)bias_scratch, n, 3 * heads * 64, dbias);
-        EOE_CHECK_LAUNCH("attn_bwd_bias");
-    }
+    if (dbias) EOE_TRY(eoe_finish_reduce(bias_scratch, n, 3 * heads * 64, 3 * heads * 64, dbias, nullptr, nullptr, 1, stream));
     return 0;
 }

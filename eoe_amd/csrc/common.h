@@ -42,8 +42,15 @@ void eoe_prof_finish(int idx, hipStream_t s);
 struct EoeRedJob {
     const float* part;
     int R, N, seg;            // R partial rows of width N; output segment length (N for a single output)
+    int blocked;              // layout of `part`: 0 = [R][N];  1 = [N/64][R][64] (eoe_part_index)
     float* out[3];            // segment s = c / seg is added into out[s] (NULL = skip)
 };
+// Where producer row r puts its partial sum of column c.  Blocked layout (N % 64 == 0): all R partial values of a 64-column block
+// are contiguous (R x 256 B), so the finish kernel's workgroup streams one contiguous range; with the plain [R][N] layout it reads
+// 256-byte pieces 4N bytes apart -- from HBM (the rows are hundreds of microseconds old) that ran at 0.7 TB/s.
+__host__ __device__ __forceinline__ size_t eoe_part_index(int c, int r, int R, int N, int blocked) {
+    return blocked ? ((size_t)(c >> 6) * R + r) * 64 + (c & 63) : (size_t)r * N + c;
+}
 struct EoeRedJobs {
     EoeRedJob job[6];
     int tile_start[7];        // prefix sums of ceil(N / 64) workgroups per job
@@ -52,8 +59,10 @@ struct EoeRedJobs {
 };
 extern thread_local EoeRedJobs* eoe_tls_defer;
 // appends to the deferred list if one is active (returns true), else returns false and the caller launches its own finish
-bool eoe_defer_reduce(const float* part, int R, int N, int seg, float* o0, float* o1, float* o2);
+bool eoe_defer_reduce(const float* part, int R, int N, int seg, float* o0, float* o1, float* o2, int blocked);
 int eoe_flush_reduce(EoeRedJobs* jobs, void* stream);      // elementwise.hip
+// appends to the open batch, or (none open) finishes this one job right away with `out += sum`
+int eoe_finish_reduce(const float* part, int R, int N, int seg, float* o0, float* o1, float* o2, int blocked, void* stream);
 
 struct ProfScope {
     int idx; hipStream_t s;

@@ -128,7 +128,8 @@ __global__ __launch_bounds__(256) void cast_transpose_multi_kernel(CtBatch b) {
 // fp32 [rows, cols] -> 16-bit copy + column sums (bias gradient of the layer whose dY this is), one pass
 template <typename T>
 __global__ __launch_bounds__(256) void cast_colsum_kernel(const float* __restrict__ x, T* __restrict__ dst,
-                                                          float* __restrict__ out, float* __restrict__ part, int rows, int cols) {
+                                                          float* __restrict__ out, float* __restrict__ part, int rows, int cols,
+                                                          int blocked) {
     __shared__ float red[4][256];
     const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.x * 256 + cg * 4;
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256) void cast_colsum_kernel(const float* __restric
     const int cc = blockIdx.x * 256 + threadIdx.x;
     if (cc >= cols) return;
     const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    if (part) part[(size_t)blockIdx.y * cols + cc] = t;       // this workgroup row's partial sums; a finish kernel adds the rows up
+    if (part) part[eoe_part_index(cc, blockIdx.y, gridDim.y, cols, blocked)] = t;     // this workgroup row's partial sums
     else atomicAdd(out + cc, t);
 }
 
@@ -331,11 +332,10 @@ __global__ __launch_bounds__(512) void layernorm_bwd_kernel(const void* __restri
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) { a0 += red[0][w][c]; a1 += red[1][w][c]; a2 += red[2][w][c]; }
-        if (part) {                                  // this workgroup's partial row [3][D]; ln_reduce_kernel adds the rows up
-            float* row = part + (size_t)blockIdx.x * 3 * D;
-            row[c] = a0;
-            row[D + c] = a1;
-            row[2 * D + c] = a2;
+        if (part) {                                  // this workgroup's partial row (width 3D, blocked layout); a finish kernel adds the rows up
+            part[eoe_part_index(c, blockIdx.x, gridDim.x, 3 * D, 1)] = a0;
+            part[eoe_part_index(D + c, blockIdx.x, gridDim.x, 3 * D, 1)] = a1;
+            part[eoe_part_index(2 * D + c, blockIdx.x, gridDim.x, 3 * D, 1)] = a2;
             continue;
         }
         if (dgamma) {
@@ -357,20 +357,23 @@ __global__ __launch_bounds__(1024) void multi_reduce_kernel(EoeRedJobs jobs) {
     const float* __restrict__ part = jb.part;
     const int cq = threadIdx.x & 15, lane = threadIdx.x >> 4;
     const int i = (blockIdx.x - jobs.tile_start[j]) * 64 + cq * 4, n = jb.N, P = jb.R;
+    // row p of this thread's column quad: blocked layout = contiguous R x 256 B per 64-column block
+    const float* base = jb.blocked ? part + (size_t)(i >> 6) * P * 64 + (i & 63) : part + i;
+    const size_t pitch = jb.blocked ? 64 : (size_t)n;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (i < n) {
         int p = lane;
         for (; p + 448 < P; p += 512) {
             f32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(part + (size_t)(p + 64 * u) * n + i);
+            for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(base + (size_t)(p + 64 * u) * pitch);
             s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
         }
         if (p < P) {                               // ragged tail: still one batch (rows beyond P are not read)
             f32x4 v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                v[u] = (p + 64 * u < P) ? *(const f32x4*)(part + (size_t)(p + 64 * u) * n + i) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                v[u] = (p + 64 * u < P) ? *(const f32x4*)(base + (size_t)(p + 64 * u) * pitch) : (f32x4){0.f, 0.f, 0.f, 0.f};
             s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
         }
     }
@@ -390,32 +393,6 @@ __global__ __launch_bounds__(1024) void multi_reduce_kernel(EoeRedJobs jobs) {
     if (!dst) return;
     if (!jobs.overwrite) t += *(const f32x4*)(dst + c);
     *(f32x4*)(dst + c) = t;
-}
-
-// dgamma / dbeta / dxsum += column sums of the P partial rows [P][3][D] written by layernorm_bwd_kernel, in a fixed order:
-// 16 columns x 64 row lanes per workgroup, four independent loads in flight per thread
-__global__ __launch_bounds__(1024) void ln_reduce_kernel(const float* __restrict__ part, int P, int D, float* __restrict__ dgamma,
-                                                         float* __restrict__ dbeta, float* __restrict__ dxsum) {
-    __shared__ float l[64][17];
-    const int col = threadIdx.x & 15, lane = threadIdx.x >> 4;
-    const int i = blockIdx.x * 16 + col, n = 3 * D;
-    float s = 0.f;
-    if (i < n) {
-        int p = lane;
-        for (; p + 192 < P; p += 256) {
-            const float a = part[(size_t)p * n + i], b = part[(size_t)(p + 64) * n + i], c = part[(size_t)(p + 128) * n + i],
-                        d = part[(size_t)(p + 192) * n + i];
-            s += (a + b) + (c + d);
-        }
-        for (; p < P; p += 64) s += part[(size_t)p * n + i];
-    }
-    l[lane][col] = s;
-    __syncthreads();
-    if (lane != 0 || i >= n) return;
-    for (int k = 1; k < 64; ++k) s += l[k][col];
-    const int which = i / D, c = i - which * D;
-    float* dst = which == 0 ? dgamma : (which == 1 ? dbeta : dxsum);
-    if (dst) dst[c] += s;
 }
 
 // ------------------------------------------------------------------------------------------ embed + ln_pre
@@ -527,9 +504,9 @@ __global__ __launch_bounds__(256) void embed_lnpre_bwd_kernel(const float* __res
         const float sg = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
         const float sb = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
         const float sp = red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c];
-        if (part) {                                  // this token position's partial row [2][D]; a finish kernel adds the L rows up
-            part[(size_t)l * 2 * D + c] = sg;
-            part[(size_t)l * 2 * D + D + c] = sb;
+        if (part) {                                  // this token position's partial row (width 2D, blocked layout); a finish kernel adds the L rows up
+            part[eoe_part_index(c, l, L, 2 * D, 1)] = sg;
+            part[eoe_part_index(D + c, l, L, 2 * D, 1)] = sb;
         } else {
             atomicAdd(dgamma + c, sg);
             atomicAdd(dbeta + c, sb);
@@ -1174,24 +1151,31 @@ extern "C" int eoe_layernorm_bwd(const void* dy, int dy_f32, const float* x, int
                                          dy_f32, x, ldx, stats, gamma, dres, dx_out, ld_out, (T*)dx16, dgamma, dbeta,
                                          dxsum, part, rows, D)));
     EOE_CHECK_LAUNCH("layernorm_bwd");
-    if (part && !eoe_defer_reduce(part, grid, 3 * D, D, dgamma, dbeta, dxsum)) {
-        hipLaunchKernelGGL(ln_reduce_kernel, dim3(cdiv(3 * D, 16)), dim3(1024), 0, (hipStream_t)stream, (const float*)part, grid, D, dgamma,
-                           dbeta, dxsum);
-        EOE_CHECK_LAUNCH("layernorm_bwd_reduce");
-    }
+    if (part) EOE_TRY(eoe_finish_reduce(part, grid, 3 * D, D, dgamma, dbeta, dxsum, 1, stream));
     return 0;
 }
 
 thread_local EoeRedJobs* eoe_tls_defer = nullptr;
 
-bool eoe_defer_reduce(const float* part, int R, int N, int seg, float* o0, float* o1, float* o2) {
+bool eoe_defer_reduce(const float* part, int R, int N, int seg, float* o0, float* o1, float* o2, int blocked) {
     EoeRedJobs* j = eoe_tls_defer;
     if (!j || j->count >= 6 || (N & 3) || (seg & 3)) return false;
     EoeRedJob& r = j->job[j->count];
-    r.part = part; r.R = R; r.N = N; r.seg = seg; r.out[0] = o0; r.out[1] = o1; r.out[2] = o2;
+    r.part = part; r.R = R; r.N = N; r.seg = seg; r.blocked = blocked; r.out[0] = o0; r.out[1] = o1; r.out[2] = o2;
     j->tile_start[j->count + 1] = j->tile_start[j->count] + (N + 63) / 64;
     j->count += 1;
     return true;
+}
+
+int eoe_finish_reduce(const float* part, int R, int N, int seg, float* o0, float* o1, float* o2, int blocked, void* stream) {
+    if (eoe_defer_reduce(part, R, N, seg, o0, o1, o2, blocked)) return 0;
+    EOE_CHECK_ARG(!eoe_tls_defer && (N & 3) == 0 && (seg & 3) == 0, "finish_reduce: batch full or widths not multiples of 4");
+    EoeRedJobs one;
+    one.count = 0; one.tile_start[0] = 0; one.overwrite = 0;
+    eoe_tls_defer = &one;
+    eoe_defer_reduce(part, R, N, seg, o0, o1, o2, blocked);
+    eoe_tls_defer = nullptr;
+    return eoe_flush_reduce(&one, stream);
 }
 
 int eoe_flush_reduce(EoeRedJobs* jobs, void* stream) {
@@ -1222,14 +1206,7 @@ extern "C" int eoe_embed_lnpre_bwd(const float* dy, const float* x0, const float
     DISPATCH_T(dtype, DISPATCH_NV(D, hipLaunchKernelGGL((embed_lnpre_bwd_kernel<T, NV>), dim3(L), dim3(256), 0, (hipStream_t)stream, dy, x0,
                                          stats, gamma, (T*)dtok, dcls, dpos, dgamma, dbeta, scratch, n, L, D)));
     EOE_CHECK_LAUNCH("embed_lnpre_bwd");
-    if (scratch && !eoe_defer_reduce(scratch, L, 2 * D, D, dgamma, dbeta, nullptr)) {
-        EoeRedJobs one;
-        one.count = 0; one.tile_start[0] = 0; one.overwrite = 0;
-        eoe_tls_defer = &one;
-        eoe_defer_reduce(scratch, L, 2 * D, D, dgamma, dbeta, nullptr);
-        eoe_tls_defer = nullptr;
-        EOE_TRY(eoe_flush_reduce(&one, stream));
-    }
+    if (scratch) EOE_TRY(eoe_finish_reduce(scratch, L, 2 * D, D, dgamma, dbeta, nullptr, 1, stream));
     return 0;
 }
 
@@ -1334,21 +1311,15 @@ extern "C" int eoe_cast_colsum(const float* x, void* dst, float* out, float* scr
     // with a scratch: per-workgroup-row partial sums + a fixed-order finish (deferred into the caller's batch when one is open);
     // a deferred finish follows the batch's overwrite / accumulate mode, so nothing is zeroed here
     const bool deferred_mode = scratch && eoe_tls_defer;
+    const int blocked = (cols & 63) == 0;
     if (!accumulate && !deferred_mode) {
         if (hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), (hipStream_t)stream) != hipSuccess)
             return eoe_set_error(EOE_ERR_LAUNCH, "cast_colsum: memset failed");
     }
     DISPATCH_T(dtype, hipLaunchKernelGGL((cast_colsum_kernel<T>), dim3(cdiv(cols, 256), gy), dim3(256), 0,
-                                         (hipStream_t)stream, x, (T*)dst, out, scratch, rows, cols));
+                                         (hipStream_t)stream, x, (T*)dst, out, scratch, rows, cols, blocked));
     EOE_CHECK_LAUNCH("cast_colsum");
-    if (scratch && !eoe_defer_reduce(scratch, gy, cols, cols, out, nullptr, nullptr)) {
-        EoeRedJobs one;
-        one.count = 0; one.tile_start[0] = 0; one.overwrite = 0;
-        eoe_tls_defer = &one;
-        eoe_defer_reduce(scratch, gy, cols, cols, out, nullptr, nullptr);
-        eoe_tls_defer = nullptr;
-        EOE_TRY(eoe_flush_reduce(&one, stream));
-    }
+    if (scratch) EOE_TRY(eoe_finish_reduce(scratch, gy, cols, cols, out, nullptr, nullptr, blocked, stream));
     return 0;
 }
 

@@ -38,7 +38,8 @@ constexpr int SMEM_BYTES = NSTAGE * STAGE_BYTES;  // 144 KiB: one 8-wave workgro
 
 struct GemmP {
     const void* A; const void* B; void* C; const float* bias; const void* aux; void* aux_out; float* colsum;
-    float* colsum_part;            // column sums through partial rows [ceil(M / rows per wave)][N] + colsum_finish_kernel (no atomics)
+    float* colsum_part;            // column sums through per-wave partial rows (eoe_part_index layout) + a finish kernel (no atomics)
+    int colsum_blocked;            // layout of the partial rows: N % 64 == 0 -> blocked (BatchNorm statistics: always plain [R][2][N])
     int colsum_sq;                 // partial rows are [.][2][N]: sums and sums of squares (BatchNorm statistics); no finish kernel
     int M, N, K, lda, ldb, ldc, ldaux, out_f32, accumulate;
     float alpha;
@@ -166,7 +167,10 @@ __device__ __forceinline__ void epilogue_generic(const GemmP& p, f32x4 (&acc)[MI
                 t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
                 const int n = n_base + ni * 16 + lg * 4 + r;
                 if (lr != 0 || n >= p.N) continue;
-                if (p.colsum_part) { if (m_base < p.M) p.colsum_part[(size_t)(m_base / (16 * MI)) * p.N + n] = t; }
+                if (p.colsum_part) {
+                    if (m_base < p.M)
+                        p.colsum_part[eoe_part_index(n, m_base / (16 * MI), (p.M + 16 * MI - 1) / (16 * MI), p.N, p.colsum_blocked)] = t;
+                }
                 else atomicAdd(p.colsum + n, t);
             }
         }
@@ -286,7 +290,7 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][NI], i
         const int nn = n_base + lane;
         const bool st_ok = lane < 16 * NI && nn < p.N && m_base < p.M;
         if (!p.colsum_sq) {
-            if (st_ok) p.colsum_part[(size_t)(m_base / (16 * MI)) * p.N + nn] = t;
+            if (st_ok) p.colsum_part[eoe_part_index(nn, m_base / (16 * MI), (p.M + 16 * MI - 1) / (16 * MI), p.N, p.colsum_blocked)] = t;
         } else {
             // BatchNorm statistics: row [2][N] = (sum, sum of squares) of this wave's 16*MI output rows
             if (st_ok) p.colsum_part[((size_t)(m_base / (16 * MI)) * 2) * p.N + nn] = t;
@@ -857,34 +861,9 @@ int launch_nt64(const GemmP& p, hipStream_t s) {
     return 0;
 }
 
-// colsum[c] += sum_r part[r][c] (the epilogues' per-wave-row partial column sums), fixed order: 16 columns x 64 row lanes
-__global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __restrict__ part, int R, int N, float* __restrict__ out) {
-    __shared__ float l[64][17];
-    const int col = threadIdx.x & 15, lane = threadIdx.x >> 4;
-    const int i = blockIdx.x * 16 + col;
-    float s = 0.f;
-    if (i < N) {
-        int r = lane;
-        for (; r + 192 < R; r += 256) {
-            const float a = part[(size_t)r * N + i], b = part[(size_t)(r + 64) * N + i], c = part[(size_t)(r + 128) * N + i],
-                        d = part[(size_t)(r + 192) * N + i];
-            s += (a + b) + (c + d);
-        }
-        for (; r < R; r += 64) s += part[(size_t)r * N + i];
-    }
-    l[lane][col] = s;
-    __syncthreads();
-    if (lane != 0 || i >= N) return;
-    for (int k = 1; k < 64; ++k) s += l[k][col];
-    out[i] += s;
-}
 static int finish_colsum(const GemmP& p, int epi, int mi, hipStream_t s) {
     if (!p.colsum_part || !p.colsum || p.colsum_sq || epi == EOE_EPI_GELU) return 0;
-    if (eoe_defer_reduce(p.colsum_part, cdiv(p.M, 16 * mi), p.N, p.N, p.colsum, nullptr, nullptr)) return 0;
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(p.N, 16)), dim3(1024), 0, s, (const float*)p.colsum_part, cdiv(p.M, 16 * mi), p.N,
-                       p.colsum);
-    EOE_CHECK_LAUNCH("gemm_nt_colsum");
-    return 0;
+    return eoe_finish_reduce(p.colsum_part, cdiv(p.M, 16 * mi), p.N, p.N, p.colsum, nullptr, nullptr, p.colsum_blocked, s);
 }
 
 static int num_cus() {
@@ -1029,7 +1008,7 @@ int fill_params(const eoe_gemm_args* a, GemmP& p) {
     EOE_CHECK_ARG((((uintptr_t)a->A | (uintptr_t)a->B) & 15) == 0, "gemm: A/B must be 16-B aligned");
     EOE_CHECK_ARG(!a->accumulate || a->out_f32, "gemm: accumulate needs an fp32 C");
     p.A = a->A; p.B = a->B; p.C = a->C; p.bias = a->bias; p.aux = a->aux; p.aux_out = a->aux_out; p.colsum = a->colsum;
-    p.colsum_part = nullptr; p.colsum_sq = 0;
+    p.colsum_part = nullptr; p.colsum_sq = 0; p.colsum_blocked = 0;
     p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ldaux = a->ldaux;
     p.out_f32 = a->out_f32; p.accumulate = a->accumulate; p.alpha = a->alpha;
     EOE_CHECK_ARG((a->K % BK) == 0, "gemm_nt: K=%d must be a multiple of %d", a->K, BK);
@@ -1101,7 +1080,7 @@ extern "C" int eoe_gemm_nt(const eoe_gemm_args* a, void* stream) {
     const int mode = (a->gather == 1 && p.gkh) ? 3 : a->gather;      // narrow-channel geometry -> per-piece tap decoding
     // fused column sums: through partial rows in the workspace (one row per 64 / 80 output rows) when it is large enough
     if (a->colsum && a->workspace && a->workspace_bytes >= (int64_t)EOE_NT_COLSUM_WORKSPACE_BYTES(a->M, a->N))
-        p.colsum_part = (float*)a->workspace;
+        p.colsum_part = (float*)a->workspace, p.colsum_blocked = ((a->N & 63) == 0 && (a->N & 3) == 0) ? 1 : 0;
     if (a->colstats) {
         // per-64-row partial sums and sums of squares of the fp32 result (BatchNorm batch statistics without a pass over C)
         EOE_CHECK_ARG(a->epilogue != EOE_EPI_GELU && !a->colsum, "gemm_nt: colstats goes with neither the GELU epilogue nor colsum");
@@ -1111,6 +1090,7 @@ extern "C" int eoe_gemm_nt(const eoe_gemm_args* a, void* stream) {
                       "gemm_nt: colstats needs N %% 16 == 0 and 16-byte aligned rows of C");
         p.colsum_part = (float*)a->workspace;
         p.colsum_sq = 1;
+        p.colsum_blocked = 0;
     }
     return a->dtype == EOE_F16 ? launch_nt<f16_t>(p, a->epilogue, mode, (hipStream_t)stream)
                                : launch_nt<bf16_t>(p, a->epilogue, mode, (hipStream_t)stream);
