@@ -63,6 +63,11 @@ class SGateBwdArgs(C.Structure):
                 ("dgamma", _vp), ("dbeta", _vp), ("wpart", _vp)]
 
 
+class ConvPackJob(C.Structure):
+    _fields_ = [("w", _vp), ("w16", _vp), ("w16t", _vp), ("w16d", _vp), ("cout", _i32), ("cin", _i32), ("cpad", _i32), ("kh", _i32),
+                ("kw", _i32), ("Kp", _i32)]
+
+
 class CastJob(C.Structure):
     _fields_ = [("src", _vp), ("dst", _vp), ("dst_t", _vp), ("rows", _i32), ("cols", _i32)]
 
@@ -102,6 +107,7 @@ SIGNATURES = {
     "eoe_gemm_tn_grouped": [C.POINTER(GemmArgs), C.c_int, _vp],
     "eoe_cast_transpose": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
     "eoe_cast_transpose_multi": [_vp, C.c_int, C.c_int, _vp],
+    "eoe_conv_pack_weight_multi": [_vp, C.c_int, C.c_int, _vp],
     "eoe_patchify": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "eoe_embed_lnpre_fwd": [_vp] * 8 + [C.c_int, C.c_int, C.c_int, _f32, _vp],
     "eoe_embed_lnpre_bwd": [_vp] * 10 + [C.c_int, C.c_int, C.c_int, C.c_int, _vp],

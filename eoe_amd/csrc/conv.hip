@@ -100,20 +100,59 @@ __global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dp, f
 
 // ---------------------------------------------------------------------------------------------- weights
 // w fp32 [cout, cin, 5, 5] -> w16 [cout, Kp] (column = tap*cin + c) and w16t [Kp, cout]
+// a batch of conv weights in one launch (the 19 block convolutions of the WideResNet re-pack their weights after every optimiser
+// step): 64 x 64 tiles, job found through prefix sums
+constexpr int PACK_MAX_JOBS = 32;
+struct PackBatch {
+    const float* w[PACK_MAX_JOBS];
+    void* w16[PACK_MAX_JOBS];
+    void* w16t[PACK_MAX_JOBS];
+    void* w16d[PACK_MAX_JOBS];
+    int cout[PACK_MAX_JOBS], cin[PACK_MAX_JOBS], cpad[PACK_MAX_JOBS], Kp[PACK_MAX_JOBS], taps[PACK_MAX_JOBS];
+    int block_start[PACK_MAX_JOBS + 1];
+    int count;
+};
+// A workgroup owns a 64 (output channels) x 64 (patch columns) tile: it reads w and writes w16 with the column index on the lanes,
+// turns the tile through LDS, and writes the two transposed copies with the OUTPUT CHANNEL on the lanes -- both have cout as their
+// contiguous dimension (with one element per thread in (o, col) order those were 2-byte writes cout elements apart: 300 us for
+// the 11 M weights of the WideResNet).
 template <typename T>
-__global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict__ w, T* __restrict__ w16, T* __restrict__ w16t,
-                                                        T* __restrict__ w16d, int cout, int cin, int cpad, int Kp, int taps) {
-    // cpad >= cin: channels per tap in the column order (the channel-padded NHWC image of a 3-channel first layer)
-    const int total = cout * Kp;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int o = i / Kp, col = i % Kp;
-        const int tap = col / cpad, c = col % cpad;
-        float v = 0.f;
-        if (tap < taps && c < cin) v = w[((size_t)o * cin + c) * taps + tap];
-        w16[i] = (T)v;
-        if (w16t) w16t[(size_t)col * cout + o] = (T)v;
+__global__ __launch_bounds__(256) void conv_pack_multi_kernel(PackBatch b) {
+    __shared__ float tile[64][65];
+    int j = 0;
+    while (j + 1 < b.count && (int)blockIdx.x >= b.block_start[j + 1]) ++j;
+    const float* __restrict__ w = b.w[j];
+    T* __restrict__ w16 = (T*)b.w16[j];
+    T* __restrict__ w16t = (T*)b.w16t[j];
+    T* __restrict__ w16d = (T*)b.w16d[j];
+    const int cout = b.cout[j], cin = b.cin[j], cpad = b.cpad[j], Kp = b.Kp[j], taps = b.taps[j];
+    const int tiles_c = (Kp + 63) >> 6, t = blockIdx.x - b.block_start[j];
+    const int o0 = (t / tiles_c) * 64, col0 = (t % tiles_c) * 64;
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    {
+        const int col = col0 + lx, tap = col / cpad, c = col - tap * cpad;
+        const bool real = col < Kp && tap < taps && c < cin;
+#pragma unroll 4
+        for (int r = 0; r < 16; ++r) {
+            const int ol = r * 4 + ly, o = o0 + ol;
+            float v = 0.f;
+            if (o < cout && real) v = w[((size_t)o * cin + c) * taps + tap];
+            if (o < cout && col < Kp) w16[(size_t)o * Kp + col] = (T)v;
+            tile[ol][lx] = v;
+        }
+    }
+    __syncthreads();
+    if (!w16t && !w16d) return;
+    const int o = o0 + lx;
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+        const int cl = r * 4 + ly, col = col0 + cl;
+        if (o >= cout || col >= Kp) continue;
+        const T v = (T)tile[lx][cl];
+        if (w16t) w16t[(size_t)col * cout + o] = v;
+        const int tap = col / cpad, c = col - tap * cpad;
         // dgrad operand of a stride-1 convolution: [cin, (taps reversed) x cout] (dx = conv of dy with the flipped kernel)
-        if (w16d && tap < taps && c < cin) w16d[((size_t)c * taps + (taps - 1 - tap)) * cout + o] = (T)v;
+        if (w16d && tap < taps && c < cin) w16d[((size_t)c * taps + (taps - 1 - tap)) * cout + o] = v;
     }
 }
 // g fp32 [cout, Kp] (or transposed: [taps*cin, cout]) -> dw fp32 [cout, cin, kh, kw] (+= if accumulate)
@@ -649,13 +688,33 @@ extern "C" int eoe_col2im(const void* dpatches, float* dx, int n, int C, int H, 
     return 0;
 }
 
+extern "C" int eoe_conv_pack_weight_multi(const eoe_conv_pack_job* jobs, int count, int dtype, void* stream) {
+    EOE_CHECK_ARG(jobs && count > 0, "conv_pack_weight_multi: bad args");
+    for (int first = 0; first < count; first += PACK_MAX_JOBS) {
+        PackBatch b;
+        b.count = count - first < PACK_MAX_JOBS ? count - first : PACK_MAX_JOBS;
+        int blocks = 0;
+        for (int i = 0; i < b.count; ++i) {
+            const eoe_conv_pack_job& j = jobs[first + i];
+            EOE_CHECK_ARG(j.w && j.w16 && j.cout > 0 && j.cin > 0 && j.cpad >= j.cin && j.Kp >= j.kh * j.kw * j.cpad,
+                          "conv_pack_weight_multi: job %d: bad args", first + i);
+            EOE_CHECK_IDX((size_t)j.cout * j.Kp, "conv_pack_weight_multi");
+            b.w[i] = j.w; b.w16[i] = j.w16; b.w16t[i] = j.w16t; b.w16d[i] = j.w16d;
+            b.cout[i] = j.cout; b.cin[i] = j.cin; b.cpad[i] = j.cpad; b.Kp[i] = j.Kp; b.taps[i] = j.kh * j.kw;
+            b.block_start[i] = blocks;
+            blocks += cdiv(j.cout, 64) * cdiv(j.Kp, 64);
+        }
+        b.block_start[b.count] = blocks;
+        DISPATCH_T(dtype, hipLaunchKernelGGL((conv_pack_multi_kernel<T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, b));
+        EOE_CHECK_LAUNCH("conv_pack_weight_multi");
+    }
+    return 0;
+}
+
 extern "C" int eoe_conv_pack_weight(const float* w, void* w16, void* w16t, void* w16d, int cout, int cin, int cpad, int kh, int kw,
                                     int Kp, int dtype, void* stream) {
-    EOE_CHECK_ARG(w && w16 && cout > 0 && cin > 0 && cpad >= cin && Kp >= kh * kw * cpad, "conv_pack_weight: bad args");
-    DISPATCH_T(dtype, hipLaunchKernelGGL((conv_pack_kernel<T>), dim3(grid_for((size_t)cout * Kp)), dim3(256), 0,
-                                         (hipStream_t)stream, w, (T*)w16, (T*)w16t, (T*)w16d, cout, cin, cpad, Kp, kh * kw));
-    EOE_CHECK_LAUNCH("conv_pack_weight");
-    return 0;
+    eoe_conv_pack_job job = {w, w16, w16t, w16d, cout, cin, cpad, kh, kw, Kp};
+    return eoe_conv_pack_weight_multi(&job, 1, dtype, stream);
 }
 
 extern "C" int eoe_conv_unpack_wgrad(const float* g, float* dw, int cout, int cin, int cpad, int kh, int kw, int Kp, int transposed,

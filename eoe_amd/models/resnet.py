@@ -123,6 +123,10 @@ class WideResNet(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("eoe_amd.WideResNet runs on the GPU only (no CPU fallback)")
         x = x.view(-1, 3, 224, 224)
+        # all 16-bit weight copies that the optimiser step made stale, in one launch (the 19 block / down-sampling convolutions)
+        ops.refresh_conv_weight_copies([m.weight for layer in (self.layer1, self.layer2, self.layer3, self.layer4)
+                                        for m in layer.modules() if isinstance(m, nn.Conv2d) and m.weight.shape[1] % 8 == 0
+                                        and m.weight.shape[2] != 7])
         mp = self.maxpool
         # conv1 -> bn1 -> relu -> maxpool in one unit: the 112x112x64 activation is never written; fp32 NHWC from here
         x = _conv_bn(x, self.conv1, self.bn1, self.training, 0.0, is_image=True, normalize=self.normalize, want16=True,

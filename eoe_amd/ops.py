@@ -786,6 +786,38 @@ def _conv_weight_copies(w: torch.Tensor, cpad=None):
     return w16, w16t, w16d
 
 
+def refresh_conv_weight_copies(weights):
+    """bring the 16-bit copies of all conv weights in `weights` (tensors, or (tensor, cpad) pairs) up to date with ONE batched
+    launch (`eoe_conv_pack_weight_multi`); the per-layer `_conv_weight_copies` calls of the step then hit the cache.  No-op under
+    graph capture (the per-layer path packs inside the graph)."""
+    if torch.cuda.is_current_stream_capturing():
+        return
+    jobs, entries = [], []
+    for item in weights:
+        w, cpad = item if isinstance(item, tuple) else (item, None)
+        cpad = int(cpad or w.shape[1])
+        key = ("conv", id(w), cpad)
+        tag = (w._version, w.data_ptr(), _compute_dtype)
+        hit = shadow.cache.get(key)
+        if hit is not None and hit[0]() is w and hit[1] == tag:
+            continue
+        if not (w.is_cuda and w.is_contiguous() and w.dim() == 4):
+            continue
+        cout, cin, kh, kw = w.shape
+        kp = _conv_kp(cpad, kh * kw)
+        w16 = torch.empty((cout, kp), dtype=_compute_dtype, device=w.device)
+        w16t = torch.empty((kp, cout), dtype=_compute_dtype, device=w.device)
+        w16d = torch.empty((cin, kh * kw * cout), dtype=_compute_dtype, device=w.device)
+        jobs.append(_lib.ConvPackJob(_p(w.detach()), _p(w16), _p(w16t), _p(w16d), cout, cin, cpad, kh, kw, kp))
+        entries.append((key, w, tag, w16, w16t, w16d))
+    if not jobs:
+        return
+    arr = (_lib.ConvPackJob * len(jobs))(*jobs)
+    check(lib.eoe_conv_pack_weight_multi(arr, len(jobs), dtype_code(_compute_dtype), _stream()), "eoe_conv_pack_weight_multi")
+    for key, w, tag, w16, w16t, w16d in entries:
+        shadow.cache[key] = (weakref.ref(w, lambda _r, k=key, c=shadow.cache: c.pop(k, None)), tag, w16, w16t, w16d)
+
+
 def _stem_weight_copy(w: torch.Tensor):
     """16-bit [cout, ceil(kh/2)*64] copy of a 3-channel first-layer weight in the packed (ky, kx, c4) column order"""
     key = ("stem", id(w))

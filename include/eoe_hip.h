@@ -307,6 +307,13 @@ int eoe_col2im(const void* dpatches, float* dx, int n, int C, int H, int W, int 
  * operand of the implicit stride-1 dgrad [cin, (kh*kw reversed) x cout] (dx = conv of dy with the flipped kernel);
  * and the inverse reorder of the fp32 weight gradient [cout,Kp] (or, transposed, [kh*kw*cpad, cout]) -> [cout,cin,kh,kw].
  * cpad >= cin = channels per tap in the column order (8 for the channel-padded NHWC8 image of a 3-channel first layer). */
+typedef struct {      /* one eoe_conv_pack_weight call */
+    const float* w;
+    void *w16, *w16t, *w16d;
+    int32_t cout, cin, cpad, kh, kw, Kp;
+} eoe_conv_pack_job;
+/* `count` weight packs in one launch per 32 jobs: the per-step refresh of all 16-bit conv weight copies of a model */
+int eoe_conv_pack_weight_multi(const eoe_conv_pack_job* jobs, int count, int dtype, void* stream);
 int eoe_conv_pack_weight(const float* w, void* w16, void* w16t, void* w16d, int cout, int cin, int cpad, int kh, int kw,
                          int Kp, int dtype, void* stream);
 int eoe_conv_unpack_wgrad(const float* g, float* dw, int cout, int cin, int cpad, int kh, int kw, int Kp, int transposed,
