@@ -133,7 +133,7 @@ SIGNATURES = {
     "eoe_vit_block_fwd": [C.POINTER(VitBlockFwdArgs), _vp],
     "eoe_vit_block_bwd": [C.POINTER(VitBlockBwdArgs), _vp],
     "eoe_im2col": [_vp, C.c_int, _vp, _vp, _vp] + [C.c_int] * 10 + [_vp],
-    "eoe_col2im": [_vp, _vp] + [C.c_int] * 10 + [_vp],
+    "eoe_col2im": [_vp, _vp] + [C.c_int] * 11 + [_vp],
     "eoe_conv_pack_weight": [_vp, _vp, _vp, _vp] + [C.c_int] * 7 + [_vp],
     "eoe_conv_unpack_wgrad": [_vp, _vp] + [C.c_int] * 8 + [_vp],
     "eoe_stem_pack_image": [_vp, _vp, _vp, _vp] + [C.c_int] * 8 + [_vp],

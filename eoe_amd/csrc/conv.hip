@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void im2col_nhwc_kernel(const void* __restrict
 // S = the stride as a compile-time constant (1 or 2; 0 = run-time value): the tap loop tests divisibility by it.
 template <typename T, int S>
 __global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dp, float* __restrict__ dx, int n, int H, int W,
-                                                     int C, int Kp, Geo g, QuadDecode dec) {
+                                                     int C, int Kp, Geo g, QuadDecode dec, int accumulate) {
     const unsigned total = (unsigned)n * H * W * (C / 4);
     const int st = S ? S : g.stride;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -94,7 +94,9 @@ __global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dp, f
                 for (int r = 0; r < 4; ++r) a[r] += t[r];
             }
         }
-        *(f32x4*)(dx + (size_t)pix * C + c4 * 4) = (f32x4){a[0], a[1], a[2], a[3]};
+        f32x4 o = {a[0], a[1], a[2], a[3]};
+        if (accumulate) o += *(const f32x4*)(dx + (size_t)pix * C + c4 * 4);
+        *(f32x4*)(dx + (size_t)pix * C + c4 * 4) = o;
     }
 }
 
@@ -672,7 +674,7 @@ extern "C" int eoe_im2col(const void* x, int x_kind, const float* mean, const fl
 }
 
 extern "C" int eoe_col2im(const void* dpatches, float* dx, int n, int C, int H, int W, int kh, int kw, int stride, int pad,
-                          int Kp, int dtype, void* stream) {
+                          int Kp, int dtype, int accumulate, void* stream) {
     EOE_CHECK_ARG(dpatches && dx && n > 0 && C % 4 == 0 && Kp >= kh * kw * C, "col2im: bad args");
     Geo g;
     EOE_TRY(check_geo("col2im", H, W, kh, kw, stride, pad, g));
@@ -681,7 +683,7 @@ extern "C" int eoe_col2im(const void* dpatches, float* dx, int n, int C, int H, 
     const QuadDecode dec(C / 4, W, H);
 #define EOE_C2I(SS)                                                                                                      \
     DISPATCH_T(dtype, hipLaunchKernelGGL((col2im_kernel<T, SS>), dim3(grid_for((size_t)n * H * W * C / 4)), dim3(256), 0, \
-                                         (hipStream_t)stream, (const T*)dpatches, dx, n, H, W, C, Kp, g, dec))
+                                         (hipStream_t)stream, (const T*)dpatches, dx, n, H, W, C, Kp, g, dec, accumulate))
     if (stride == 2) { EOE_C2I(2); } else if (stride == 1) { EOE_C2I(1); } else { EOE_C2I(0); }
 #undef EOE_C2I
     EOE_CHECK_LAUNCH("col2im");

@@ -42,14 +42,16 @@ class BasicBlock(nn.Module):
     def forward(self, x):      # x: fp32 NHWC (resnet.py:130-149)
         # identity shortcut: conv1 hands its input through as the junction's shortcut operand, so that the shortcut's
         # gradient reaches conv1's backward and is accumulated by its dgrad GEMM (no separate gradient add)
-        fuse = self.downsample is None and x.requires_grad and torch.is_grad_enabled()
+        # (down-sampling blocks: the 1x1 convolution of the shortcut reads the handed-through input, so ITS input gradient is the
+        # one that arrives at conv1's backward and is accumulated by conv1's col2im)
+        fuse = x.requires_grad and torch.is_grad_enabled()
         out = _conv_bn(x, self.conv1, self.bn1, self.training, 0.0, want16=True, passthrough=fuse)       # feeds conv2 only
         residual = x
         if fuse:
             out, residual = out
         out = _conv_bn(out, self.conv2, self.bn2, self.training, 1.0)
         if self.downsample is not None:
-            residual = _conv_bn(x, self.downsample[0], self.downsample[1], self.training, 1.0)
+            residual = _conv_bn(residual, self.downsample[0], self.downsample[1], self.training, 1.0)
         if self.cbam is not None and not self.cbam.no_spatial:
             # channel gate, then the spatial gate fused with the residual junction (the gated tensor is never written)
             out = self.cbam.ChannelGate(out)

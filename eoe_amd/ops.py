@@ -1046,10 +1046,14 @@ class ConvBnActPoolFunction(torch.autograd.Function):
                               (n, H, W, cout, kh, kw, 1, kh - 1 - pad, Hi, Wi), accumulate=acc)
                 d_pass = None
             else:
-                dx = torch.empty((n, Hi, Wi, cin), dtype=torch.float32, device=dev)
+                # materialised dgrad (the stride-2 convolutions): patches of dx, gathered back; onto the shortcut gradient if one came
+                dx = d_pass if acc else torch.empty((n, Hi, Wi, cin), dtype=torch.float32, device=dev)
                 dpatches = torch.empty((M, kp), dtype=dt, device=dev)
                 gemm_nt(dy16, w16t, dpatches)
-                check(lib.eoe_col2im(_p(dpatches), _p(dx), n, cin, Hi, Wi, kh, kw, stride, pad, kp, code, _stream()), "eoe_col2im")
+                check(lib.eoe_col2im(_p(dpatches), _p(dx), n, cin, Hi, Wi, kh, kw, stride, pad, kp, code, 1 if acc else 0, _stream()),
+                      "eoe_col2im")
+                if acc:
+                    d_pass = None
         if d_pass is not None:
             dx = d_pass if dx is None else dx.add_(d_pass)
         return dx, dw, dcb, dg, db, None, None, None, None
@@ -1064,7 +1068,12 @@ def conv_bn_act_pool(x, conv_w, conv_b, bn_w, bn_b, rm, rv, nbt, cfg):
     out = r[0]
     if len(r) - (1 if passthrough else 0) == 2:
         out._eoe16 = r[1]
-    return (out, r[-1]) if passthrough else out
+    if passthrough:
+        x16 = getattr(x, "_eoe16", None)
+        if x16 is not None:
+            r[-1]._eoe16 = x16          # the handed-through input keeps its 16-bit copy (a down-sampling conv reads it next)
+        return out, r[-1]
+    return out
 
 
 class BnActFunction(torch.autograd.Function):

@@ -302,7 +302,7 @@ int eoe_im2col(const void* x, int x_kind, const float* mean, const float* std, v
                int kh, int kw, int stride, int pad, int Kp, int dtype, void* stream);
 /* dx fp32 NHWC [n,H,W,C] = transpose of im2col applied to dpatches 16-bit [n*Ho*Wo, Kp] */
 int eoe_col2im(const void* dpatches, float* dx, int n, int C, int H, int W, int kh, int kw, int stride, int pad, int Kp,
-               int dtype, void* stream);
+               int dtype, int accumulate /* dx += (a shortcut gradient already in dx) */, void* stream);
 /* conv weight fp32 [cout,cin,kh,kw] -> 16-bit [cout,Kp] (patch column order), optionally its transpose [Kp,cout] and the
  * operand of the implicit stride-1 dgrad [cin, (kh*kw reversed) x cout] (dx = conv of dy with the flipped kernel);
  * and the inverse reorder of the fp32 weight gradient [cout,Kp] (or, transposed, [kh*kw*cpad, cout]) -> [cout,cin,kh,kw].

@@ -52,7 +52,7 @@ for cin, H, cout, k, s, p, cnt in SHAPES:
         dx4 = dx.view(N, H, H, cin)
         def dg():
             ops.gemm_nt(dy16, w16t, dpat)
-            check(lib.eoe_col2im(dpat.data_ptr(), dx4.data_ptr(), N, cin, H, H, k, k, s, p, kp, 1, ops._stream()), "col2im")
+            check(lib.eoe_col2im(dpat.data_ptr(), dx4.data_ptr(), N, cin, H, H, k, k, s, p, kp, 1, 0, ops._stream()), "col2im")
         t_d = timeit(dg)
     stats = torch.empty(2 * cout, device=dev)
     sums = ops.scratch("bn_sums", (ops.BN_SCRATCH * cout,), torch.float32, dev)
