@@ -134,19 +134,23 @@ __global__ __launch_bounds__(256) void conv_pack_multi_kernel(PackBatch b) {
     {
         const int col = col0 + lx, tap = col / cpad, c = col - tap * cpad;
         const bool real = col < Kp && tap < taps && c < cin;
-#pragma unroll 4
+        float v[16];                               // all 16 loads of the thread in flight (small weights: latency-bound)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + r * 4 + ly;
+            v[r] = (o < cout && real) ? w[((size_t)o * cin + c) * taps + tap] : 0.f;
+        }
+#pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ol = r * 4 + ly, o = o0 + ol;
-            float v = 0.f;
-            if (o < cout && real) v = w[((size_t)o * cin + c) * taps + tap];
-            if (o < cout && col < Kp) w16[(size_t)o * Kp + col] = (T)v;
-            tile[ol][lx] = v;
+            if (o < cout && col < Kp) w16[(size_t)o * Kp + col] = (T)v[r];
+            tile[ol][lx] = v[r];
         }
     }
     __syncthreads();
     if (!w16t && !w16d) return;
     const int o = o0 + lx;
-#pragma unroll 4
+#pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int cl = r * 4 + ly, col = col0 + cl;
         if (o >= cout || col >= Kp) continue;

@@ -56,6 +56,8 @@ class CNN32(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("eoe_amd.CNN32 runs on the GPU only (no CPU fallback)")
         x = x.view(-1, 3, 32, 32)
+        if ops._implicit_conv:          # the three weight packs in one launch (conv1 gathers from the channel-padded NHWC8 image)
+            ops.refresh_conv_weight_copies([(self.conv1.weight, 8), self.conv2.weight, self.conv3.weight])
         x = self._layer(x, self.conv1, self.bn2d1, True, False)
         x = self._layer(x, self.conv2, self.bn2d2, False, False)
         x = self._layer(x, self.conv3, self.bn2d3, False, True)          # NCHW-flattened [n, 2048] (cnn.py:83)

@@ -774,6 +774,8 @@ def _conv_weight_copies(w: torch.Tensor, cpad=None):
     hit = shadow.cache.get(key)
     if not capturing and hit is not None and hit[0]() is w and hit[1] == tag:
         return hit[2], hit[3], hit[4]
+    if capturing and key in _capture_packs:                        # packed by this capture's batched refresh
+        return _capture_packs[key]
     cout, cin, kh, kw = w.shape
     kp = _conv_kp(cpad, kh * kw)
     w16 = torch.empty((cout, kp), dtype=_compute_dtype, device=w.device)
@@ -786,12 +788,15 @@ def _conv_weight_copies(w: torch.Tensor, cpad=None):
     return w16, w16t, w16d
 
 
+_capture_packs = {}
+
+
 def refresh_conv_weight_copies(weights):
     """bring the 16-bit copies of all conv weights in `weights` (tensors, or (tensor, cpad) pairs) up to date with ONE batched
-    launch (`eoe_conv_pack_weight_multi`); the per-layer `_conv_weight_copies` calls of the step then hit the cache.  No-op under
-    graph capture (the per-layer path packs inside the graph)."""
-    if torch.cuda.is_current_stream_capturing():
-        return
+    launch (`eoe_conv_pack_weight_multi`); the per-layer `_conv_weight_copies` calls of the step then hit the cache.  Under graph
+    capture the batched pack becomes part of the graph and its outputs are handed to the per-layer calls of the same capture."""
+    capturing = torch.cuda.is_current_stream_capturing()
+    _capture_packs.clear()
     jobs, entries = [], []
     for item in weights:
         w, cpad = item if isinstance(item, tuple) else (item, None)
@@ -799,7 +804,7 @@ def refresh_conv_weight_copies(weights):
         key = ("conv", id(w), cpad)
         tag = (w._version, w.data_ptr(), _compute_dtype)
         hit = shadow.cache.get(key)
-        if hit is not None and hit[0]() is w and hit[1] == tag:
+        if not capturing and hit is not None and hit[0]() is w and hit[1] == tag:
             continue
         if not (w.is_cuda and w.is_contiguous() and w.dim() == 4):
             continue
@@ -815,7 +820,10 @@ def refresh_conv_weight_copies(weights):
     arr = (_lib.ConvPackJob * len(jobs))(*jobs)
     check(lib.eoe_conv_pack_weight_multi(arr, len(jobs), dtype_code(_compute_dtype), _stream()), "eoe_conv_pack_weight_multi")
     for key, w, tag, w16, w16t, w16d in entries:
-        shadow.cache[key] = (weakref.ref(w, lambda _r, k=key, c=shadow.cache: c.pop(k, None)), tag, w16, w16t, w16d)
+        if capturing:                   # part of the graph: every replay re-packs; the per-layer calls of THIS capture pick these up
+            _capture_packs[key] = (w16, w16t, w16d)
+        else:
+            shadow.cache[key] = (weakref.ref(w, lambda _r, k=key, c=shadow.cache: c.pop(k, None)), tag, w16, w16t, w16d)
 
 
 def _stem_weight_copy(w: torch.Tensor):
