@@ -419,3 +419,31 @@ def test_stem_conv_bn_relu_maxpool_fused(dtype):
     for name, got, ref in (("dw", wg.grad, wd.grad), ("dgamma", gg.grad, gd.grad), ("dbeta", bg.grad, bd.grad)):
         r = rel_rms(got, ref)
         assert r < tol, (name, r)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_weight_pack_batched(dtype):
+    """eoe_conv_pack_weight_multi (64x64-tile kernel, > 32 jobs = two launches, ragged tiles, channel padding) against the layout
+    definition: w16[o, tap*cpad + c] = w[o, c, tap], w16t = its transpose, w16d[c, (taps-1-tap)*cout + o] = w[o, c, tap]"""
+    import eoe_amd
+    from eoe_amd import ops
+    eoe_amd.set_compute_dtype(dtype)
+    try:
+        shapes = [(64, 64, 3, None), (128, 64, 1, None), (72, 16, 5, None), (32, 3, 5, 8), (8, 8, 3, None), (200, 136, 3, None)]
+        shapes += [(16 + 8 * (i % 4), 8 * (1 + i % 3), 3, None) for i in range(34)]
+        ws = [torch.nn.Parameter(torch.randn(co, ci, k, k, device="cuda")) for co, ci, k, _ in shapes]
+        ops.refresh_conv_weight_copies([(w, cp) if cp else w for w, (_, _, _, cp) in zip(ws, shapes)])
+        for w, (co, ci, k, cp) in zip(ws, shapes):
+            cpad, taps = cp or ci, k * k
+            w16, w16t, w16d = ops._conv_weight_copies(w, cp)                     # served from the refreshed cache
+            kp = w16.shape[1]
+            assert kp % 64 == 0 and kp >= taps * cpad
+            ref = torch.zeros(co, kp, device="cuda")
+            ref.view(co, -1)[:, :taps * cpad].view(co, taps, cpad)[:, :, :ci] = w.detach().reshape(co, ci, taps).permute(0, 2, 1)
+            ref = ref.to(dtype)
+            assert torch.equal(w16, ref), (co, ci, k, cp)
+            assert torch.equal(w16t, ref.t().contiguous())
+            refd = w.detach().reshape(co, ci, taps).flip(2).permute(1, 2, 0).reshape(ci, taps * co).to(dtype)
+            assert torch.equal(w16d, refd), (co, ci, k, cp)
+    finally:
+        eoe_amd.set_compute_dtype("fp16")
