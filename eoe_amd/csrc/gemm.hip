@@ -24,6 +24,7 @@
 
 unsigned long long* g_stamp_buf = nullptr;
 extern int g_tn_flags;     // gemm_tn.hip
+extern int g_vit_side_stream;   // vit.cpp
 
 namespace {
 
@@ -1110,5 +1111,6 @@ extern "C" int eoe_debug_gemm_stamps(unsigned long long* out, int n_words) {
 extern "C" int eoe_set_option(const char* name, int value) {
     if (name && !strcmp(name, "nt_flags")) { g_nt_flags = value; return 0; }
     if (name && !strcmp(name, "tn_flags")) { g_tn_flags = value; return 0; }
+    if (name && !strcmp(name, "vit_side_stream")) { g_vit_side_stream = value; return 0; }
     return eoe_set_error(EOE_ERR_ARG, "unknown option");
 }
