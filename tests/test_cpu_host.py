@@ -117,3 +117,16 @@ def test_trainer_registry_and_hooks():
         assert issubclass(cls, ADTrainer)
         for hook in ("prepare_metric", "compute_anomaly_score", "loss", "train_cls", "eval_cls", "run", "load"):
             assert callable(getattr(cls, hook))
+
+
+def test_header_is_plain_c():
+    """the drop-in boundary must be consumable from C (cgo / JNI / ctypes generators): include/eoe_hip.h parses as C99"""
+    import os
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "eoe_hip.h")
+    r = subprocess.run([gcc, "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Werror", hdr], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
