@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the CDLL below)
 from . import _build
 
 ABI_VERSION = 1
-EOE_F16, EOE_BF16 = 1, 2
+EOE_F16, EOE_BF16, EOE_F32 = 1, 2, 3
 EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_GELU_BWD = 0, 1, 2, 3
 ADAM_CHUNK, ADAM_GROUPS = 8192, 4
 
@@ -147,6 +147,10 @@ SIGNATURES = {
                             C.c_int, C.c_int, _f32, C.c_int, _vp],
     "eoe_bn_act_maxpool_fwd": [_vp] * 7 + [C.c_int] * 7 + [_f32, C.c_int, _vp],
     "eoe_bn_act_maxpool_bwd": [_vp] * 10 + [C.c_int] * 8 + [_f32, C.c_int, _vp],
+    "eoe_conv_f32_fwd": [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.POINTER(ConvGeometry), C.c_int, _vp],
+    "eoe_conv_f32_dgrad": [_vp, _vp, _vp, C.POINTER(ConvGeometry), C.c_int, C.c_int, _vp],
+    "eoe_conv_f32_wgrad_workspace": [C.POINTER(ConvGeometry), C.c_int],
+    "eoe_conv_f32_wgrad": [_vp, C.c_int, _vp, _vp, _vp, _vp, C.POINTER(ConvGeometry), C.c_int, _vp, _sz, _vp],
     "eoe_maxpool_fwd": [_vp, _vp, _vp, _vp] + [C.c_int] * 8 + [_vp],
     "eoe_maxpool_bwd": [_vp, _vp, _vp] + [C.c_int] * 7 + [_vp],
     "eoe_cgate_fwd": [C.POINTER(CGateArgs), _vp],
@@ -174,7 +178,7 @@ SIGNATURES = {
     "eoe_debug_gemm_stamps": [_vp, C.c_int],
     "eoe_prof_collect": [C.POINTER(ProfEntry), C.c_int, C.POINTER(C.c_int)],
 }
-_RESTYPES = {"eoe_last_error": C.c_char_p}
+_RESTYPES = {"eoe_last_error": C.c_char_p, "eoe_conv_f32_wgrad_workspace": _sz}
 
 
 def header_symbols():

@@ -617,7 +617,10 @@ __global__ __launch_bounds__(256) void bn_act_maxpool_bwd_kernel(const float* __
                 o4[r] = use_batch_stats ? g[r] * rs[r] * (gz - s1 * invM - xh * s2 * invM) : g[r] * rs[r] * gz;
             }
         }
-        if (MODE == 1) *(u32x2*)(dy + ip * C + c) = pack4<T>(o4[0], o4[1], o4[2], o4[3]);
+        if (MODE == 1) {
+            if constexpr (sizeof(T) == 4) *(f32x4*)(dy + ip * C + c) = f32x4{o4[0], o4[1], o4[2], o4[3]};      // parity mode: fp32 dY
+            else *(u32x2*)(dy + ip * C + c) = pack4<T>(o4[0], o4[1], o4[2], o4[3]);
+        }
     }
     if (MODE == 0) block_channel_sums(acc0, acc1, lds, red + (size_t)(1 + blockIdx.x) * 2 * C, C, total);
 }
@@ -909,9 +912,14 @@ extern "C" int eoe_bn_act_maxpool_bwd(const float* y, const float* stats, const 
         g0 = g0 / q * q;
         if (g0 < q) g0 = q;
     }
-#define EOE_BMP(MODE, SS, GRID, LDS)                                                                                             \
-    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_maxpool_bwd_kernel<T, MODE, SS>), dim3(GRID), dim3(256), LDS, s, y, stats, gamma, beta, \
-                                         dout, idx, red_scratch, (T*)dy, n, H, W, C, k, stride, pad, Ho, Wo, training, slope, dec))
+#define EOE_BMP_T(MODE, SS, GRID, LDS)                                                                                        \
+    hipLaunchKernelGGL((bn_act_maxpool_bwd_kernel<T, MODE, SS>), dim3(GRID), dim3(256), LDS, s, y, stats, gamma, beta, dout, idx, \
+                       red_scratch, (T*)dy, n, H, W, C, k, stride, pad, Ho, Wo, training, slope, dec)
+#define EOE_BMP(MODE, SS, GRID, LDS)                                                                                          \
+    do {                                                                                                                      \
+        if (dtype == EOE_F32) { typedef float T; EOE_BMP_T(MODE, SS, GRID, LDS); }      /* parity mode: dY in fp32 */        \
+        else DISPATCH_T(dtype, EOE_BMP_T(MODE, SS, GRID, LDS));                                                               \
+    } while (0)
     if (stride == 2) { EOE_BMP(0, 2, g0, 2 * C * sizeof(float)); } else if (stride == 1) { EOE_BMP(0, 1, g0, 2 * C * sizeof(float)); }
     else { EOE_BMP(0, 0, g0, 2 * C * sizeof(float)); }
     EOE_CHECK_LAUNCH("bn_act_maxpool_bwd_reduce");
@@ -920,6 +928,7 @@ extern "C" int eoe_bn_act_maxpool_bwd(const float* y, const float* stats, const 
     EOE_CHECK_LAUNCH("bn_act_maxpool_bwd_reduce2");
     if (stride == 2) { EOE_BMP(1, 2, grid, 0); } else if (stride == 1) { EOE_BMP(1, 1, grid, 0); } else { EOE_BMP(1, 0, grid, 0); }
 #undef EOE_BMP
+#undef EOE_BMP_T
     EOE_CHECK_LAUNCH("bn_act_maxpool_bwd_apply");
     return 0;
 }

@@ -257,8 +257,9 @@ _scratch = {}
 
 
 def scratch(name, shape, dtype, device):
-    """persistent scratch buffers reused across calls (backward is sequential, one set per shape is enough)"""
-    key = (name, tuple(shape), dtype, device)
+    """persistent scratch buffers reused across calls, one set per (device, stream): work on one stream is sequential, so one
+    buffer per shape is enough there, while two streams (or two models driven from two streams) never share one"""
+    key = (name, tuple(shape), dtype, device, _stream())
     t = _scratch.get(key)
     if t is None:
         t = torch.empty(shape, dtype=dtype, device=device)
@@ -353,7 +354,9 @@ class LinearSmallFunction(torch.autograd.Function):
 
 def linear(x, weight, bias=None):
     if weight.shape[0] <= 8:
-        return LinearSmallFunction.apply(x, weight, bias)
+        return LinearSmallFunction.apply(x, weight, bias)          # exact fp32 already
+    if _parity:
+        return LinearParityFunction.apply(x, weight, bias)
     return LinearFunction.apply(x, weight, bias)
 
 
@@ -889,6 +892,173 @@ def conv_gemm_wgrad(x16, dy16, gT, geo, mode=1):
     return gT
 
 
+# ------------------------------------------------------------------------------------------------ parity mode (fp32 conv / linear)
+_parity = False
+
+
+def set_parity_mode(on: bool):
+    """Parity mode: the convolutions and linear layers of the BatchNorm encoders (CNN32 / CNN28 / WideResNet, and
+    `CustomNet.final_linear`) run as plain fp32 implicit GEMMs (csrc/parity.hip: fp32 activations and fp32 master weights as
+    operands, no 16-bit rounding) instead of the 16-bit MFMA path.  A correctness instrument for the K-step trajectory tests
+    (SURVEY.md section 8d "Parity run"), orders of magnitude slower than the fast path.  The ViT blocks are not affected: their
+    fast path meets the 1e-3 bar at the benchmark batch (tests/test_gpu_parity_big.py)."""
+    global _parity
+    _parity = bool(on)
+
+
+def parity_mode() -> bool:
+    return _parity
+
+
+def _geo(n, H, W, C, kh, kw, stride, pad, Ho, Wo):
+    from ._lib import ConvGeometry
+    return ConvGeometry(n, H, W, C, kh, kw, stride, pad, Ho, Wo)
+
+
+def _f32_colsum(x2d: torch.Tensor, out: torch.Tensor):
+    """out[c] = sum_r x[r, c] of an fp32 matrix through the partial-row (atomics-free) path of eoe_cast_colsum"""
+    rows, cols = x2d.shape
+    dummy = scratch("parity_colsum_dst", (rows * cols,), torch.float16, x2d.device)
+    part = scratch("parity_colsum_part", (256 * cols,), torch.float32, x2d.device)
+    check(lib.eoe_cast_colsum(_p(x2d), _p(dummy), _p(out), _p(part), rows, cols, _lib.EOE_F16, 0, _stream()), "eoe_cast_colsum")
+
+
+class ConvBnActPoolParityFunction(torch.autograd.Function):
+    """ConvBnActPoolFunction with the convolution in fp32 (parity mode); BatchNorm / activation / pooling are the same fp32
+    kernels as on the fast path.  Same cfg tuple; never emits 16-bit copies."""
+
+    @staticmethod
+    def forward(ctx, x, conv_w, conv_b, bn_w, bn_b, rm, rv, nbt, cfg):
+        _chk(x, conv_w, conv_b, bn_w, bn_b, rm, rv)
+        training, eps, momentum, pool, is_image, mean, std, flat_out = cfg[:8]
+        kh, kw, stride, pad = cfg[8] if len(cfg) > 8 else (5, 5, 1, 2)
+        slope = float(cfg[9]) if len(cfg) > 9 else 0.01
+        passthrough = bool(cfg[11]) if len(cfg) > 11 else False
+        x_in = x
+        x = x.contiguous().float()
+        cout, cin = conv_w.shape[0], conv_w.shape[1]
+        if is_image:
+            n, _, Hi, Wi = x.shape
+        else:
+            n, Hi, Wi, _ = x.shape
+        H, W = (Hi + 2 * pad - kh) // stride + 1, (Wi + 2 * pad - kw) // stride + 1
+        M, dev = n * H * W, x.device
+        geo = _geo(n, Hi, Wi, cin, kh, kw, stride, pad, H, W)
+        w = conv_w.contiguous()
+        y = torch.empty((M, cout), dtype=torch.float32, device=dev)
+        check(lib.eoe_conv_f32_fwd(_p(x), 1 if is_image else 0, _p(mean) if is_image else None, _p(std) if is_image else None, _p(w),
+                                   _p(conv_b), _p(y), geo, cout, _stream()), "eoe_conv_f32_fwd")
+        stats = torch.empty(2 * cout, dtype=torch.float32, device=dev)
+        sums = scratch("bn_sums", (BN_SCRATCH * cout,), torch.float32, dev)
+        check(lib.eoe_bn_stats(_p(y), _p(sums), _p(stats), _p(rm), _p(rv), _p(nbt), M, cout, float(eps), float(momentum),
+                               1 if training else 0, _stream()), "eoe_bn_stats")
+        idx = None
+        code = dtype_code(_compute_dtype)
+        if isinstance(pool, tuple):
+            pk, pstride, ppad = pool
+            Ho, Wo = (H + 2 * ppad - pk) // pstride + 1, (W + 2 * ppad - pk) // pstride + 1
+            out = torch.empty((n, Ho, Wo, cout), dtype=torch.float32, device=dev)
+            idx = torch.empty((n, Ho, Wo, cout), dtype=torch.uint8, device=dev)
+            check(lib.eoe_bn_act_maxpool_fwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(out), None, _p(idx), n, H, W, cout, pk,
+                                             pstride, ppad, slope, code, _stream()), "eoe_bn_act_maxpool_fwd")
+        else:
+            Ho, Wo = H // pool, W // pool
+            out = torch.empty((n, cout * Ho * Wo) if flat_out else (n, Ho, Wo, cout), dtype=torch.float32, device=dev)
+            check(lib.eoe_bn_act_pool_fwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(out), None, n, H, W, cout, pool,
+                                          1 if flat_out else 0, 1, slope, code, _stream()), "eoe_bn_act_pool_fwd")
+        ctx.save_for_backward(x, y, stats, conv_w, conv_b, bn_w, bn_b, idx, mean if is_image else None, std if is_image else None)
+        ctx.cfg = (n, H, W, cin, cout, pool, flat_out, training, is_image, Hi, Wi, kh, kw, stride, pad, slope)
+        ctx.passthrough = passthrough
+        if not passthrough:
+            return out
+        ctx.set_materialize_grads(False)
+        return out, x_in
+
+    @staticmethod
+    def backward(ctx, dout, *more):
+        d_pass = more[-1] if (ctx.passthrough and more) else None
+        if dout is None:
+            return (d_pass,) + (None,) * 8
+        x, y, stats, conv_w, conv_b, bn_w, bn_b, idx, mean, std = ctx.saved_tensors
+        n, H, W, cin, cout, pool, flat_out, training, is_image, Hi, Wi, kh, kw, stride, pad, slope = ctx.cfg
+        dev = y.device
+        M = n * H * W
+        dout = dout.contiguous().float()
+        dy = torch.empty((M, cout), dtype=torch.float32, device=dev)
+        dg = _grad_target(bn_w) if bn_w is not None else None
+        db = _grad_target(bn_b) if bn_b is not None else None
+        red = scratch("bn_red", (BN_SCRATCH * cout,), torch.float32, dev)
+        if isinstance(pool, tuple):
+            check(lib.eoe_bn_act_maxpool_bwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(dout), _p(idx), _p(red), _p(dy), _p(dg), _p(db),
+                                             n, H, W, cout, pool[0], pool[1], pool[2], 1 if training else 0, slope, _lib.EOE_F32, _stream()),
+                  "eoe_bn_act_maxpool_bwd")
+        else:
+            check(lib.eoe_bn_act_pool_bwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(dout), _p(red), _p(dy), 1, _p(dg), _p(db), n, H,
+                                          W, cout, pool, 1 if flat_out else 0, 1 if training else 0, 0, slope,
+                                          dtype_code(_compute_dtype), _stream()), "eoe_bn_act_pool_bwd")
+        geo = _geo(n, Hi, Wi, cin, kh, kw, stride, pad, H, W)
+        w = conv_w.contiguous()
+        dw = _grad_target(conv_w)
+        ws_bytes = int(lib.eoe_conv_f32_wgrad_workspace(geo, cout))
+        ws = scratch("parity_wgrad_ws", (ws_bytes // 4,), torch.float32, dev)
+        check(lib.eoe_conv_f32_wgrad(_p(x), 1 if is_image else 0, _p(mean), _p(std), _p(dy), _p(dw), geo, cout, _p(ws), ws_bytes,
+                                     _stream()), "eoe_conv_f32_wgrad")
+        dcb = None
+        if conv_b is not None:
+            dcb = _grad_target(conv_b)
+            _f32_colsum(dy, dcb)
+        dx = None
+        if ctx.needs_input_grad[0] and not is_image:
+            acc = (d_pass is not None and d_pass.dtype == torch.float32 and d_pass.is_contiguous()
+                   and d_pass.shape == (n, Hi, Wi, cin))
+            dx = d_pass if acc else torch.empty((n, Hi, Wi, cin), dtype=torch.float32, device=dev)
+            check(lib.eoe_conv_f32_dgrad(_p(dy), _p(w), _p(dx), geo, cout, 1 if acc else 0, _stream()), "eoe_conv_f32_dgrad")
+            if acc:
+                d_pass = None
+        if d_pass is not None:
+            dx = d_pass if dx is None else dx.add_(d_pass)
+        return dx, dw, dcb, dg, db, None, None, None, None
+
+
+class LinearParityFunction(torch.autograd.Function):
+    """y = x @ W^T + b in fp32 (parity mode): a 1x1 convolution on 1x1 images through the fp32 kernels"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _chk(x, weight, bias)
+        x2 = x.reshape(-1, x.shape[-1]).contiguous().float()
+        M, K = x2.shape
+        N = weight.shape[0]
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        check(lib.eoe_conv_f32_fwd(_p(x2), 0, None, None, _p(weight.contiguous()), _p(bias), _p(y), _geo(M, 1, 1, K, 1, 1, 1, 0, 1, 1), N,
+                                   _stream()), "eoe_conv_f32_fwd")
+        ctx.save_for_backward(x2, weight, bias)
+        ctx.in_shape, ctx.x_dtype = x.shape, x.dtype
+        return y.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, bias = ctx.saved_tensors
+        M, K = x2.shape
+        N = weight.shape[0]
+        dy2 = dy.reshape(M, N).contiguous().float()
+        geo = _geo(M, 1, 1, K, 1, 1, 1, 0, 1, 1)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+            check(lib.eoe_conv_f32_dgrad(_p(dy2), _p(weight.contiguous()), _p(dx), geo, N, 0, _stream()), "eoe_conv_f32_dgrad")
+            dx = dx.reshape(ctx.in_shape).to(ctx.x_dtype)
+        if ctx.needs_input_grad[1]:
+            dw = _grad_target(weight)
+            ws_bytes = int(lib.eoe_conv_f32_wgrad_workspace(geo, N))
+            ws = scratch("parity_wgrad_ws", (ws_bytes // 4,), torch.float32, dy.device)
+            check(lib.eoe_conv_f32_wgrad(_p(x2), 0, None, None, _p(dy2), _p(dw), geo, N, _p(ws), ws_bytes, _stream()), "eoe_conv_f32_wgrad")
+        if bias is not None and ctx.needs_input_grad[2]:
+            db = _grad_target(bias)
+            _f32_colsum(dy2, db)
+        return dx, dw, db
+
+
 class ConvBnActPoolFunction(torch.autograd.Function):
     """conv (+ bias) -> BatchNorm2d -> act -> MaxPool(pool), one layer per call: conv5x5(pad 2) + LeakyReLU(0.01) + pool 2
     for `cnn.py:73-82` (the default when cfg has 8 entries); cfg[8] = (kh, kw, stride, pad) and cfg[9] = the activation's
@@ -1069,6 +1239,8 @@ class ConvBnActPoolFunction(torch.autograd.Function):
 
 def conv_bn_act_pool(x, conv_w, conv_b, bn_w, bn_b, rm, rv, nbt, cfg):
     """ConvBnActPoolFunction + the 16-bit copy of its output attached as `._eoe16` (consumed by the next convolution)"""
+    if _parity:
+        return ConvBnActPoolParityFunction.apply(x, conv_w, conv_b, bn_w, bn_b, rm, rv, nbt, cfg)
     r = ConvBnActPoolFunction.apply(x, conv_w, conv_b, bn_w, bn_b, rm, rv, nbt, cfg)
     passthrough = bool(cfg[11]) if len(cfg) > 11 else False
     if not isinstance(r, tuple):

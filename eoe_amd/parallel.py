@@ -5,8 +5,13 @@ SURVEY.md section 8e: every rank holds full weights and optimiser state, takes r
 normal half and of the OE half of each step batch, computes  sum(local per-sample losses) / GLOBAL batch size,
 and the parameter gradients are summed across ranks.  Gradients live in one flat fp32 arena in parameter order;
 each ViT block's slice (28 MB for ViT-B/32) is one bucket whose all-reduce is issued from inside that block's
-backward (RCCL runs it on its own stream, overlapped with the remaining backward kernels); the embedding /
-head / remaining parameters form the last bucket.
+backward (RCCL runs it on its own stream, overlapped with the remaining backward kernels); all other parameters
+(and every layer of the conv nets) go out in ~8 MB runs as their gradients arrive (`GradArena`).
+
+BatchNorm encoders (CNN32 / CNN28 / WideResNet + CBAM) under data parallelism use PER-RANK batch statistics, exactly as
+`torch.nn.parallel.DistributedDataParallel` without SyncBatchNorm does: their activations and gradients are those of R
+independent half-batches, not of the single-device full batch, and each rank's running statistics follow its own shard
+(snapshots take rank 0's).  The ViT headline model has no BatchNorm and is exact.
 """
 import os
 import weakref
@@ -39,9 +44,17 @@ def shard_rows(n_normal: int, n_oe: int, rank: int, world: int) -> torch.Tensor:
 
 
 class GradArena:
-    """flat fp32 gradient arena over the trainable parameters of `model` (+ bucketed, overlapped all-reduce)"""
+    """flat fp32 gradient arena over the trainable parameters of `model` + bucketed all-reduce overlapped with backward.
 
-    def __init__(self, model: torch.nn.Module, process_group=None):
+    Buckets are contiguous slices of the arena: one per module with a fused backward (a ViT block: 28 MB, its all-reduce is
+    issued from inside `VitBlockFunction.backward` as soon as the block's kernels are enqueued), and the remaining parameters
+    (embedding / head of the ViT; every layer of CNN32 / CNN28 / WideResNet) in runs of about `bucket_bytes`, each issued by
+    `post_accumulate_grad` hooks when the last gradient of the run has arrived -- backward reaches the layers last to first,
+    so the deep layers' gradients travel while the shallow layers are still being differentiated.  RCCL runs the collectives on
+    its own stream behind an event of the compute stream.  The sequence of collectives is the same on every rank (it depends
+    only on the autograd graph), which is what RCCL needs."""
+
+    def __init__(self, model: torch.nn.Module, process_group=None, bucket_bytes: int = 8 << 20):
         self.model = model
         self.group = process_group
         params = [p for p in model.parameters() if p.requires_grad]
@@ -53,12 +66,12 @@ class GradArena:
         tot = 0
         for p in params:
             self.offsets[id(p)] = tot
-            tot += (p.numel() + 63) // 64 * 64          # 256-B aligned slices
+            tot += self._span(p)
         self.flat = torch.zeros(tot, dtype=torch.float32, device=dev)
         for p in params:
             o = self.offsets[id(p)]
             p._eoe_grad_buf = self.flat[o:o + p.numel()].view(p.shape)
-        # buckets: one per module that owns a fused backward (ViT blocks), the rest in a final bucket
+        # buckets of the fused blocks
         self.block_buckets = []
         covered = set()
         for mod in model.modules():
@@ -67,69 +80,112 @@ class GradArena:
                 if not ps:
                     continue
                 lo = min(self.offsets[id(p)] for p in ps)
-                hi = max(self.offsets[id(p)] + (p.numel() + 63) // 64 * 64 for p in ps)
-                if hi - lo != sum((p.numel() + 63) // 64 * 64 for p in ps):
-                    continue                              # not contiguous in the arena: leave to the final bucket
+                hi = max(self.offsets[id(p)] + self._span(p) for p in ps)
+                if hi - lo != sum(self._span(p) for p in ps):
+                    continue                              # not contiguous in the arena: leave to the generic buckets
                 self.block_buckets.append((ps[0], lo, hi))
                 covered.update(id(p) for p in ps)
         self.rest = [p for p in params if id(p) not in covered]
+        # generic buckets over the rest: maximal contiguous runs of the arena, cut every `bucket_bytes`
+        self.run_buckets = []                             # [params, lo, hi]
+        cur, cur_lo, cur_hi = [], None, None
+        for p in self.rest:                               # arena order = parameter order
+            lo, hi = self.offsets[id(p)], self.offsets[id(p)] + self._span(p)
+            if cur and (lo != cur_hi or (cur_hi - cur_lo) * 4 >= bucket_bytes):
+                self.run_buckets.append((cur, cur_lo, cur_hi))
+                cur = []
+            if not cur:
+                cur_lo = lo
+            cur.append(p)
+            cur_hi = hi
+        if cur:
+            self.run_buckets.append((cur, cur_lo, cur_hi))
         self.handles: List = []
         self._installed = False
+        self._hook_handles = []
+        self._pending = {}
+        self.issued = []                                  # (lo, hi) of the collectives of the current step, in issue order
 
-    # -- overlap: called from VitBlockFunction.backward right after the block's kernels were enqueued
+    @staticmethod
+    def _span(p) -> int:
+        return (p.numel() + 63) // 64 * 64                # 256-B aligned slices
+
+    # -- overlap
     def install_hooks(self):
+        """fused blocks: called from VitBlockFunction.backward right after the block's kernels were enqueued; everything else:
+        post-accumulate hooks that count a run's gradients in"""
         for first, lo, hi in self.block_buckets:
             ops.grad_ready_hooks[id(first)] = (weakref.ref(first), (lambda lo=lo, hi=hi: self._reduce_slice(lo, hi)))
+        for b, (ps, lo, hi) in enumerate(self.run_buckets):
+            self._pending[b] = len(ps)
+            for p in ps:
+                self._hook_handles.append(p.register_post_accumulate_grad_hook(lambda p, b=b: self._arrived(p, b)))
         self._installed = True
 
     def remove_hooks(self):
         for first, _, _ in self.block_buckets:
             ops.grad_ready_hooks.pop(id(first), None)
+        for h in self._hook_handles:
+            h.remove()
+        self._hook_handles.clear()
         self._installed = False
 
+    def _into_arena(self, p):
+        """a gradient autograd produced outside the arena (an op without a fused write target) is moved into its slice"""
+        if p.grad is not None and p.grad.data_ptr() != p._eoe_grad_buf.data_ptr():
+            p._eoe_grad_buf.copy_(p.grad)
+            p.grad = p._eoe_grad_buf
+
+    def _arrived(self, p, b):
+        self._into_arena(p)
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            ps, lo, hi = self.run_buckets[b]
+            self._reduce_slice(lo, hi)
+
     def _reduce_slice(self, lo, hi):
+        self.issued.append((lo, hi))
         if dist.is_initialized() and dist.get_world_size(self.group) > 1:
             self.handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
-        """all-reduce whatever was not reduced from inside backward, then wait for every bucket.  Gradients that
-        autograd did not place in the arena (p.grad is not the arena view) are reduced individually."""
-        if not (dist.is_initialized() and dist.get_world_size(self.group) > 1):
-            self.handles.clear()
-            return
+        """all-reduce whatever was not reduced from inside backward, then wait for every collective of the step.  What is sent
+        depends only on the model (never on which gradients happen to be None or outside the arena on this rank), so that all
+        ranks issue the same sequence."""
         if self._installed:
-            todo = self.rest
+            for b, (ps, lo, hi) in enumerate(self.run_buckets):
+                if self._pending[b] != 0:                 # a run with a parameter that received no gradient this step
+                    for p in ps:
+                        self._into_arena(p)
+                    self._reduce_slice(lo, hi)
+                self._pending[b] = len(ps)
         else:
-            todo = self.params
-        stray = [p for p in todo if p.grad is not None and p.grad.data_ptr() != p._eoe_grad_buf.data_ptr()]
-        inarena = [p for p in todo if p.grad is not None and p.grad.data_ptr() == p._eoe_grad_buf.data_ptr()]
-        if inarena:
-            if not self._installed:
-                self.handles.append(dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-            else:
-                # the parameters outside the per-block buckets, as maximal contiguous runs of the arena: two collectives for the
-                # ViT (embedding / ln_pre in front of the blocks, ln_post / proj / head behind them), one for the CNNs -- not one
-                # small all-reduce per parameter
-                spans = sorted((self.offsets[id(p)], self.offsets[id(p)] + (p.numel() + 63) // 64 * 64) for p in inarena)
-                runs = [list(spans[0])]
-                for lo, hi in spans[1:]:
-                    if lo == runs[-1][1]:
-                        runs[-1][1] = hi
-                    else:
-                        runs.append([lo, hi])
-                for lo, hi in runs:
-                    self.handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        for p in stray:
-            self.handles.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            for p in self.params:
+                self._into_arena(p)
+            self._reduce_slice(0, self.flat.numel())
         for h in self.handles:
             h.wait()
         self.handles.clear()
+        self.issued = []
 
 
 def all_gather_1d(t: torch.Tensor, group=None) -> torch.Tensor:
-    """concatenate equal-length 1-D tensors from all ranks (scores / labels for the epoch AUC)"""
+    """concatenate 1-D tensors from all ranks in rank order (scores / labels for the epoch AUC).  Lengths may differ: the
+    reference keeps the ragged last batch (no drop_last, `bases.py:231-235`) and `shard_rows` splits it by floor, so ranks
+    hold different numbers of rows (possibly none).  Lengths are exchanged first, payloads padded to the longest."""
     if not (dist.is_initialized() and dist.get_world_size(group) > 1):
         return t
-    out = [torch.empty_like(t) for _ in range(dist.get_world_size(group))]
-    dist.all_gather(out, t.contiguous(), group=group)
-    return torch.cat(out)
+    world = dist.get_world_size(group)
+    t = t.contiguous().reshape(-1)
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+    lens = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(lens, n, group=group)
+    lens = [int(v.item()) for v in lens]
+    cap = max(lens)
+    if cap == 0:
+        return t
+    pad = torch.zeros(cap, dtype=t.dtype, device=t.device)
+    pad[:t.numel()] = t
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad, group=group)
+    return torch.cat([o[:k] for o, k in zip(out, lens)])

@@ -44,7 +44,10 @@ class JsonLogger:
     snapshot dict layout {net, opt, sched, epoch, ds_statistics} (`logger.py:318-340`)"""
 
     def __init__(self, logdir: Optional[str] = None, active: bool = True):
-        self.dir, self.active = logdir, active and logdir is not None
+        # under data parallelism every rank runs the trainer; only rank 0 writes files (the ranks' weights are identical, and
+        # for BatchNorm encoders rank 0's running statistics are the ones kept)
+        rank0 = int(os.environ.get("RANK", "0")) == 0
+        self.dir, self.active = logdir, active and logdir is not None and rank0
         if self.active:
             os.makedirs(os.path.join(logdir, "snapshots"), exist_ok=True)
 
@@ -119,79 +122,84 @@ class ADTrainer(ABC):
             return self.dsstr(c, seed)
         raise ValueError("dataset must be a step-batch source or a callable (cls, seed) -> source")
 
+    NAN_ATTEMPTS, NAN_GIVE_UP_AT = 5, 3      # ad_trainer.py:257-280: up to five tries; the third failure clears the result
+
+    def _fresh_model(self, preset) -> torch.nn.Module:
+        """the model one (class, seed) run starts from (ad_trainer.py:232-243): a module handed in through `load` as is,
+        otherwise a copy of the CPU master with every layer re-initialised through its own `reset_parameters`"""
+        if isinstance(preset, torch.nn.Module):
+            model = deepcopy(preset)
+        else:
+            model = deepcopy(self.model)
+            model.apply(weight_reset)
+        for p in model.parameters():
+            p.detach_().requires_grad_()
+        return model
+
+    def _train_with_retries(self, c: int, cstr: str, seed: int, preset, train: bool):
+        """NaN scores abort a run (`NanGradientsError`); the reference then starts over on a freshly built dataset with fresh
+        weights.  Returns (model, training ROC, dataset); the model is None only if the reference would return None"""
+        ds = self._dataset(c, seed)
+        model = roc = None
+        for attempt in range(self.NAN_ATTEMPTS):
+            model = self._fresh_model(preset)
+            try:
+                if train:
+                    model, roc = self.train_cls(model, ds, c, cstr, seed, preset)
+                return model, roc, ds
+            except NanGradientsError:
+                self.logger.warning(f'NaN scores while training class {c} "{cstr}", seed {seed} (failure {attempt + 1} of '
+                                    f'{self.NAN_ATTEMPTS}); retrying with fresh weights and data.')
+                ds = self._dataset(c, seed)
+                if attempt + 1 == self.NAN_GIVE_UP_AT:
+                    model = roc = None
+        return model, roc, ds
+
     def run(self, run_classes: List[int] = None, run_seeds: int = 1, load: List[List] = None, test: bool = True,
             train: bool = True) -> Tuple[List[List[torch.nn.Module]], dict]:
-        """class x seed loop (`ad_trainer.py:177-354`); returns (models, results) with the reference's keys"""
-        classes = self.classes
-        run_classes = run_classes if run_classes is not None else list(range(len(classes)))
-        train_rocs = [[] for _ in classes]
-        eval_rocs = [[] for _ in classes]
-        eval_prcs = [[] for _ in classes]
-        models = [[] for _ in classes]
-        for c, cstr in ((c, cstr) for c, cstr in enumerate(classes) if c in run_classes):
+        """every requested class x `run_seeds` repetitions (`ad_trainer.py:177-354`): train, evaluate, snapshot.
+        Returns (models[class][seed], {'mean_auc', 'mean_avg_prec', 'std_auc', 'cls_aucs'})"""
+        n_cls = len(self.classes)
+        wanted = set(range(n_cls)) if run_classes is None else set(run_classes)
+        models, train_rocs = [[] for _ in range(n_cls)], [[] for _ in range(n_cls)]
+        eval_rocs, eval_prcs = [[] for _ in range(n_cls)], [[] for _ in range(n_cls)]
+        for c, cstr in enumerate(self.classes):
+            if c not in wanted:
+                continue
             for seed in range(run_seeds):
                 self.logger.print(f'------ start training cls {c} "{cstr}" ------')
-                cur_load = load[c][seed] if (load is not None and len(load) > c and len(load[c]) > seed) else None
-
-                def copy_model():
-                    # ad_trainer.py:232-243: deepcopy of the CPU master + reset_parameters on every module
-                    if cur_load is not None and isinstance(cur_load, torch.nn.Module):
-                        model = deepcopy(cur_load)
-                    else:
-                        model = deepcopy(self.model)
-                        model.apply(weight_reset)
-                    for n, p in model.named_parameters():
-                        p.detach_().requires_grad_()
-                    return model
-
-                ds = self._dataset(c, seed)
-                model, roc = None, None
-                for i in range(5):
-                    try:
-                        model = copy_model()
-                        if train:
-                            model, roc = self.train_cls(model, ds, c, cstr, seed, cur_load)
-                        break
-                    except NanGradientsError:
-                        self.logger.warning(f'Gradients got NaN for class {c} "{cstr}" and seed {seed}. '
-                                            f'Happened {i} times so far. Try once more.')
-                        ds = self._dataset(c, seed)
-                        if i == 3 - 1:
-                            model, roc = None, None
-                models[c].append(model)
+                preset = None
+                if load is not None and c < len(load) and seed < len(load[c]):
+                    preset = load[c][seed]
+                model, roc, ds = self._train_with_retries(c, cstr, seed, preset, train)
                 train_rocs[c].append(roc)
+                roc = prc = None
                 if test and model is not None:
                     roc, prc = self.eval_cls(model, ds, c, cstr, seed)
-                else:
-                    roc, prc = None, None
                 eval_rocs[c].append(roc)
                 eval_prcs[c].append(prc)
                 if model is not None:
                     self.logger.snapshot(f"snapshot_cls{c}_it{seed}", model, epoch=self.epochs,
                                          ds_statistics=getattr(ds, "ds_statistics", None))
-                    if not ADTrainer.KEEP_SNAPSHOT_IN_RAM:
-                        models[c][-1] = None
+                models[c].append(model if (model is None or ADTrainer.KEEP_SNAPSHOT_IN_RAM) else None)
 
-        def cls_means(rocs, attr):
-            out = []
-            for lst in rocs:
-                vals = [getattr(r, attr) for r in lst if r is not None]
-                out.append((float(np.mean(vals)), float(np.std(vals))) if vals else None)
-            return out
+        def per_class(curves, attr):
+            """mean over the seeds of each class that produced a curve"""
+            return [float(np.mean([getattr(r, attr) for r in lst if r is not None]))
+                    for lst in curves if any(r is not None for r in lst)]
 
+        mean_auc = std_auc = mean_avg_prec = float("nan")
         if test:
-            m = [x for x in cls_means(eval_rocs, "auc") if x is not None]
-            pm = [x for x in cls_means(eval_prcs, "avg_prec") if x is not None]
-            mean_auc = float(np.mean([a for a, _ in m])) if m else float("nan")
-            std_auc = float(np.std([a for a, _ in m])) if m else float("nan")
-            mean_avg_prec = float(np.mean([a for a, _ in pm])) if pm else float("nan")
+            aucs, aps = per_class(eval_rocs, "auc"), per_class(eval_prcs, "avg_prec")
+            if aucs:
+                mean_auc, std_auc = float(np.mean(aucs)), float(np.std(aucs))
+            if aps:
+                mean_avg_prec = float(np.mean(aps))
             self.logger.logtxt(f"Eval: Overall {mean_auc * 100:04.2f}% +- {std_auc * 100:04.2f}% AUC.")
-        else:
-            mean_auc = std_auc = mean_avg_prec = float("nan")
-        cls_aucs = [[roc.get_score() if roc is not None else None for roc in cls_roc] for cls_roc in eval_rocs]
+        cls_aucs = [[None if r is None else r.get_score() for r in lst] for lst in eval_rocs]
         self.logger.logjson("results", {"eval_mean_auc": mean_auc, "eval_std_auc": std_auc,
                                         "eval_mean_avg_prec": mean_avg_prec, "eval_cls_rocs": cls_aucs,
-                                        "classes": classes})
+                                        "classes": self.classes})
         return models, {"mean_auc": mean_auc, "mean_avg_prec": mean_avg_prec, "std_auc": std_auc, "cls_aucs": cls_aucs}
 
     # ------------------------------------------------------------------------------------------- hot loop
@@ -241,16 +249,24 @@ class ADTrainer(ABC):
                     imgs, lbls = batch[0], batch[1]
                     n_norm = int((lbls == nominal).sum())
                     n_glob = lbls.shape[0]
+                    inv_count, keep_scores = 1.0 / n_glob, True
                     if world > 1:
-                        rows = parallel.shard_rows(n_norm, n_glob - n_norm, rank, world)
-                        imgs, lbls = imgs[rows], lbls[rows]
+                        halves = [h for h in (n_norm, n_glob - n_norm) if h > 0]
+                        if min(halves) >= world:
+                            rows = parallel.shard_rows(n_norm, n_glob - n_norm, rank, world)
+                            imgs, lbls = imgs[rows], lbls[rows]
+                        else:
+                            # a ragged last batch with fewer rows than ranks in one half (no drop_last, bases.py:231-235): every
+                            # rank computes the whole batch, weighted 1 / world, so that the summed gradient is the full-batch
+                            # one and all ranks issue the same collectives; rank 0 alone reports its scores
+                            inv_count, keep_scores = 1.0 / (n_glob * world), rank == 0
                     imgs = imgs.to(self.device, non_blocking=True)                                      # :411
                     lbls = lbls.to(self.device, non_blocking=True)                                      # :412
                     opt.zero_grad()                                                                     # :428
                     if self.graph_steps and world == 1 and graphed is None:
                         from ..graph import GraphedStep
                         graphed = (tuple(imgs.shape), GraphedStep(
-                            model, lambda f, y: self.loss(f, y, center, inputs=None, nominal_label=nominal, inv_count=(1.0 / n_glob)),
+                            model, lambda f, y: self.loss(f, y, center, inputs=None, nominal_label=nominal, inv_count=inv_count),
                             lambda f: self.compute_anomaly_score(f, center, inputs=None, nominal_label=nominal), imgs, lbls))
                     if graphed is not None and graphed[0] == tuple(imgs.shape):
                         loss, scores = graphed[1](imgs, lbls)                                           # :429-431,434 replayed
@@ -259,18 +275,20 @@ class ADTrainer(ABC):
                     else:
                         feats = model(imgs)                                                             # :429
                         loss = self.loss(feats, lbls, center, inputs=imgs, nominal_label=nominal,
-                                         inv_count=(1.0 / n_glob))                                      # :430
+                                         inv_count=inv_count)                                           # :430
                         loss.backward()                                                                 # :431
                         if arena is not None:
                             arena.finish()
                         opt.step()                                                                      # :432
                         opt.zero_grad()                                                                 # :433
                         scores = self.compute_anomaly_score(feats, center, inputs=imgs, nominal_label=nominal)   # :434
-                    ep_labels.append(lbls)
-                    ep_scores.append(scores.detach())
+                    if keep_scores:
+                        ep_labels.append(lbls)
+                        ep_scores.append(scores.detach().reshape(-1))
                     ep_losses.append(loss.detach())
                 # ---- epoch tail (:447-469): one host copy per epoch
-                la, sc = torch.cat(ep_labels), torch.cat(ep_scores).reshape(-1)
+                la = torch.cat(ep_labels) if ep_labels else torch.zeros(0, dtype=torch.int64, device=self.device)
+                sc = torch.cat(ep_scores) if ep_scores else torch.zeros(0, dtype=torch.float32, device=self.device)
                 ls = torch.stack(ep_losses)
                 if world > 1:
                     la, sc = parallel.all_gather_1d(la), parallel.all_gather_1d(sc)
@@ -325,36 +343,35 @@ class ADTrainer(ABC):
 
     # ------------------------------------------------------------------------------------------- snapshots
     def load(self, path: str, model: torch.nn.Module, opt=None, sched=None) -> int:
-        """`ad_trainer.py:552-598`: restores {net, opt, sched, epoch} or a bare feature-model state_dict; always
-        triggers freeze_parts() when the model has it"""
+        """restore a snapshot file into (model, opt, sched) and return the epoch to resume from (`ad_trainer.py:552-598`).
+        Two layouts are understood (`unify_snapshot_style`): the trainer's own {net, opt, sched, epoch, ...} and a bare
+        state_dict, which is taken as pre-trained encoder weights of a `CustomNet`.  With or without a file, a model that can
+        freeze its encoder does so here -- this is where the reference applies `freeze_parts` (:593-596)."""
         epoch = 0
         if path is not None:
-            snapshot = self.unify_snapshot_style(torch.load(path, map_location="cpu"))
-            feature_model_state = snapshot.pop("feature_model", None)
-            if feature_model_state is not None:
+            snap = self.unify_snapshot_style(torch.load(path, map_location="cpu"))
+            encoder_weights = snap.get("feature_model")
+            if encoder_weights is not None:
                 if not hasattr(model, "load_feature_model_weights"):
-                    raise ValueError(f"Found weights for a pre-trained feature model of a CustomNet at {path}. "
-                                     f"However, the AD model ({model.__class__}) is not a CustomNet!")
-                model.load_feature_model_weights(feature_model_state)
-            net_state, opt_state = snapshot.pop("net", None), snapshot.pop("opt", None)
-            sched_state, epoch = snapshot.pop("sched", None), snapshot.pop("epoch", 0)
-            if net_state is not None:
-                model.load_state_dict(net_state)
-            if opt_state is not None and opt is not None:
-                opt.load_state_dict(opt_state)
-            if sched_state is not None and sched is not None:
-                sched.load_state_dict(sched_state)
+                    raise ValueError(f"{path} holds encoder weights for a CustomNet, but the model to train is a "
+                                     f"{type(model).__name__}, which has no feature model to load them into.")
+                model.load_feature_model_weights(encoder_weights)
+            for key, target in (("net", model), ("opt", opt), ("sched", sched)):
+                state = snap.get(key)
+                if state is not None and target is not None:
+                    target.load_state_dict(state)
+            epoch = snap.get("epoch") or 0
         if hasattr(model, "freeze_parts"):
             model.freeze_parts()
         return epoch
 
     def unify_snapshot_style(self, snapshot: dict) -> dict:
-        # ad_trainer.py:608-615
-        if "net" in snapshot and isinstance(snapshot["net"], dict):
+        """map both accepted file layouts onto one dict (`ad_trainer.py:608-615`)"""
+        if isinstance(snapshot.get("net"), dict):
             return snapshot
-        if all(isinstance(t, torch.Tensor) for t in snapshot.values()):
+        if snapshot and all(torch.is_tensor(v) for v in snapshot.values()):
             return {"feature_model": snapshot}
-        raise ValueError("Cannot parse snapshot.")
+        raise ValueError("unrecognised snapshot layout: neither a trainer snapshot with a 'net' state_dict nor a bare state_dict")
 
     # ------------------------------------------------------------------------------------------- objective hooks
     @abstractmethod

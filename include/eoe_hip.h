@@ -25,7 +25,7 @@ extern "C" {
 #define EOE_ABI_VERSION 1
 
 enum { EOE_OK = 0, EOE_ERR_ARG = 1, EOE_ERR_LAUNCH = 2, EOE_ERR_UNSUPPORTED = 3 };
-enum { EOE_F16 = 1, EOE_BF16 = 2 };
+enum { EOE_F16 = 1, EOE_BF16 = 2, EOE_F32 = 3 /* only where an entry point says so */ };
 
 int eoe_abi_version(void);
 /* sizeof of an argument struct as compiled into the library: 0 eoe_gemm_args, 1 eoe_conv_geometry, 2 eoe_adam_chunk,
@@ -353,13 +353,32 @@ int eoe_bn_act_pool_bwd(const float* y, const float* stats, const float* gamma, 
 
 /* BatchNorm + activation + OVERLAPPING MaxPool2d(k, stride, pad) in one pass (the stem of resnet.py:93-96: the
  * 112x112x64 post-ReLU activation is never written): out fp32 [n,Ho,Wo,C], optional 16-bit copy, idx = winning tap;
- * backward: dout fp32 [n,Ho,Wo,C] -> dy 16-bit [n*H*W, C] (gather form), dgamma, dbeta; red_scratch EOE_BN_SCRATCH(C). */
+ * backward: dout fp32 [n,Ho,Wo,C] -> dy 16-bit [n*H*W, C] (gather form; fp32 with dtype = EOE_F32), dgamma, dbeta;
+ * red_scratch EOE_BN_SCRATCH(C). */
 int eoe_bn_act_maxpool_fwd(const float* y, const float* stats, const float* gamma, const float* beta, float* out, void* out16,
                            uint8_t* idx, int n, int H, int W, int C, int k, int stride, int pad, float slope, int dtype,
                            void* stream);
 int eoe_bn_act_maxpool_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* dout,
                            const uint8_t* idx, float* red_scratch, void* dy, float* dgamma, float* dbeta, int n, int H, int W,
                            int C, int k, int stride, int pad, int training, float slope, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Parity mode (SURVEY.md section 7 "Hard parts", section 8d "Parity run"): the convolutions / linear layers of the BatchNorm
+ * encoders (cnn.py:73-86, resnet.py:85-149) in plain fp32 -- fp32 activations and fp32 master weights as operands, one fp32 FMA
+ * per product in a fixed order, no 16-bit rounding.  A correctness instrument (a register-tiled SGEMM on the vector ALUs), used
+ * by the trajectory parity tests to tell the fast path's 16-bit operand rounding from an implementation difference.
+ *   x: fp32 NHWC [n,H,W,C], or the fp32 NCHW image batch if x_nchw (then optional per-channel Normalize (x - mean) / std,
+ *   ad_trainer.py:413-425); w: [cout, C, kh, kw] (the nn.Conv2d parameter itself; a Linear layer is H = W = kh = kw = 1);
+ *   y / dy: fp32 [n*Ho*Wo, cout]; dx: fp32 NHWC (+= if accumulate); dw: [cout, C, kh, kw] overwritten (slab sums in fixed
+ *   order: bitwise reproducible).  geo.C = input channels; geo.Ho / geo.Wo must match the geometry.
+ * ---------------------------------------------------------------------------------------------------- */
+int eoe_conv_f32_fwd(const float* x, int x_nchw, const float* mean, const float* stdv, const float* w, const float* bias, float* y,
+                     const eoe_conv_geometry* geo, int cout, void* stream);
+int eoe_conv_f32_dgrad(const float* dy, const float* w, float* dx, const eoe_conv_geometry* geo, int cout, int accumulate,
+                       void* stream);
+size_t eoe_conv_f32_wgrad_workspace(const eoe_conv_geometry* geo, int cout);
+int eoe_conv_f32_wgrad(const float* x, int x_nchw, const float* mean, const float* stdv, const float* dy, float* dw,
+                       const eoe_conv_geometry* geo, int cout, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * WideResNet + CBAM (resnet.py:85-109,130-149; cbam.py:31-107).  All activations fp32 NHWC.  The 7x7/2 stem,

@@ -1,0 +1,51 @@
+"""Tolerances for the K-step trajectory parity tests (CPU and GPU tiers).
+
+The stated bar is 1e-3 on loss trajectories and scores (BASELINE.json north_star, SURVEY.md section 8d "Parity run").
+The `*_big` fixtures hold, next to the reference's fp32 trajectory, the trajectory of the SAME reference modules cast to
+fp64 on the same inputs (tests/golden/make_golden.py::run_trajectory_big).  Their difference is the reference's own
+rounding noise: on CNN32 at 128 + 128 images and Adam(lr 1e-3) it reaches 1.4e-3 on the loss and 1.5e-2 on single scores
+by step 5 -- Adam's g / (sqrt(v) + eps) turns the rounding noise of near-zero gradients into +-lr steps.  Where that
+noise is below the bar the bar applies unchanged; where it is above, no implementation (the reference on another BLAS
+included) can be held to 1e-3 against one particular fp32 run, and the allowance is K_NOISE x the measured noise.
+"""
+import numpy as np
+
+BAR = 1e-3
+
+
+def reference_noise(g, steps=None):
+    """per-step (loss, max score) distance between the reference's fp32 and fp64 trajectories"""
+    steps = steps or len(g["losses"])
+    if "losses64" not in g:                      # no fp64 twin in this fixture (the ViT: its LayerNorm is fp32-only): plain bar
+        return np.zeros(steps), np.zeros(steps)
+    l32, l64 = g["losses"][:steps], g["losses64"][:steps]
+    nl = np.abs(l32 - l64) / np.maximum(1.0, np.abs(l64))
+    ns = np.abs(g["scores"][:steps].astype(np.float64) - g["scores64"][:steps]).max(axis=1)
+    return nl, ns
+
+
+def trajectory_deviation(losses, scores, g, steps=None):
+    """per-step deviation of (losses, scores) from the reference's fp32 trajectory: loss relative to max(1, |ref|),
+    scores absolute (they live in [0, 1))"""
+    steps = steps or len(g["losses"])
+    ref = g["losses"][:steps]
+    dl = np.abs(np.asarray(losses[:steps], np.float64) - ref) / np.maximum(1.0, np.abs(ref))
+    ds = np.abs(np.stack([np.asarray(s, np.float64) for s in scores[:steps]]) - g["scores"][:steps]).max(axis=1)
+    return dl, ds
+
+
+def check_trajectory(losses, scores, g, k_noise, steps=None, what=""):
+    """assert the trajectory within max(1e-3, k_noise x reference noise) per step; returns a printable summary"""
+    dl, ds = trajectory_deviation(losses, scores, g, steps)
+    nl, ns = reference_noise(g, steps)
+    tl, ts = np.maximum(BAR, k_noise * nl), np.maximum(BAR, k_noise * ns)
+    fmt = lambda a: "[" + " ".join(f"{v:.1e}" for v in a) + "]"          # noqa: E731
+    msg = (f"[{what}] loss dev {fmt(dl)} (allowed {fmt(tl)}); score dev {fmt(ds)} (allowed {fmt(ts)}); "
+           f"steps at the plain 1e-3 bar: loss {int((tl <= BAR).sum())}/{len(tl)}, scores {int((ts <= BAR).sum())}/{len(ts)}")
+    assert (dl <= tl).all() and (ds <= ts).all(), msg
+    return msg
+
+
+def auc_of(labels, scores):
+    from oracle import metrics
+    return metrics.roc_auc(np.asarray(labels), np.asarray(scores))

@@ -291,3 +291,80 @@ def test_cnn28(golden):
     for n, gr in out["grads"].items():
         ref = float(g[f"gnorm/{n}"])
         assert abs(gr.double().norm().item() - ref) <= 5e-4 * ref + 2e-6, n
+
+
+# ------------------------------------------------------------------------------------------- step-batch layout vs the reference loader
+def _loader_batches(subset, set_id, label, bs):
+    """what a stock DataLoader(shuffle=False) over Subset(dataset, subset) yields for the fixture's indexed datasets"""
+    for s in range(0, len(subset), bs):
+        idx = np.asarray(subset[s:s + bs], np.int64)
+        imgs = np.stack([np.full(len(idx), float(set_id), np.float32), idx.astype(np.float32)], axis=1)
+        yield imgs, np.full(len(idx), label, np.int64), idx
+
+
+@pytest.mark.parametrize("case", ["ragged", "oe_larger", "oe_small_batches", "single_oe"])
+def test_batch_layout_vs_reference_loader(golden, case):
+    """oracle/batching.py against the batches the reference's own `BalancedConcatLoader` (bases.py:570-600) produced
+    over stock DataLoaders (fixture g12): images, labels and indices bit-exact, including the tiled OE index list"""
+    g = golden("g12_batching")
+    n_norm_ds, n_oe_ds, nb, ob = (int(v) for v in g[f"{case}/cfg"])
+    nsub, osub = g[f"{case}/normal_subset"], g[f"{case}/oe_subset"]
+    tiled = batching.tile_oe_indices(osub, len(nsub))
+    assert tiled.tolist() == g[f"{case}/oe_indices_tiled"].tolist()
+    oe_it = _loader_batches(tiled.tolist(), 1, 1, ob)
+    n_batches = int(g[f"{case}/n_batches"])
+    assert n_batches == int(g[f"{case}/len"]) == -(-len(nsub) // nb)           # len(loader) = len(normal loader) (:599-600)
+    for b, normal in enumerate(_loader_batches(nsub.tolist(), 0, 0, nb)):
+        imgs, lbls, idcs = batching.balanced_concat(normal, oe_it, n_norm_ds)
+        assert np.array_equal(imgs, g[f"{case}/b{b}/imgs"]), (case, b)
+        assert lbls.tolist() == g[f"{case}/b{b}/lbls"].tolist()
+        assert idcs.tolist() == g[f"{case}/b{b}/idcs"].tolist()
+        assert lbls.tolist() == batching.synthetic_labels(len(normal[1]), len(normal[1])).tolist()
+    assert b + 1 == n_batches
+
+
+# ------------------------------------------------------------------------------------------- well-conditioned K = 10 trajectories
+def _traj_check(out, g, steps=None, labels=None):
+    """the oracle (fp32) within max(1e-3, 1 x the reference's own fp32-vs-fp64 rounding noise) of the reference's fp32
+    trajectory (tests/parity_util.py), and the per-step AUC within 1e-3"""
+    import parity_util
+    print(parity_util.check_trajectory(out["loss"], out["scores"], g, k_noise=1.0, steps=steps, what="oracle"))
+    if labels is not None:
+        for k in range(steps or len(g["losses"])):
+            assert abs(parity_util.auc_of(labels, out["scores"][k]) - parity_util.auc_of(labels, g["scores"][k])) <= 1e-3
+
+
+@pytest.mark.parametrize("clf,obj", [(False, "hsc"), (True, "bce")])
+def test_cnn32_big(golden, clf, obj):
+    """the oracle's CNN32 against the reference's at the benchmark batch (128 + 128), K = 10 steps, at the stated 1e-3"""
+    g = golden(f"g2_cnn32_{obj}_big")
+    m = models.deterministic_init(models.CNN32(bias=True, clf=clf), tag="cnn32")
+    batches = [trainer.synthetic_batch(f"g2big/b{i}", 128, 128, 32) for i in range(10)]
+    out = trainer.train_steps(m, batches, obj, lr=1e-3, weight_decay=0.0, collect_grads=True)
+    _traj_check(out, g, labels=batches[0][1].numpy())
+    for n, gr in out["grads"].items():
+        ref = float(g[f"gnorm/{n}"])
+        assert abs(gr.double().norm().item() - ref) <= 1e-3 * ref + 2e-6, n
+
+
+def test_cnn28_big(golden):
+    g = golden("g11_cnn28_hsc_big")
+    m = models.deterministic_init(models.CNN28(bias=True, clf=False), tag="cnn28")
+    batches = []
+    for i in range(10):
+        imgs, lbls = trainer.synthetic_batch(f"g11big/b{i}", 128, 128, 28)
+        batches.append((imgs[:, :1].contiguous(), lbls))
+    _traj_check(trainer.train_steps(m, batches, "hsc", lr=1e-3, weight_decay=0.0), g, labels=batches[0][1].numpy())
+
+
+def test_wideresnet_big(golden):
+    """the oracle's WideResNet + CBAM against the reference's at 16 + 16 images of 224 x 224 (BatchNorm well conditioned);
+    the first 3 of the fixture's 10 steps here (CPU time), all 10 on the GPU tier"""
+    g = golden("g5_wideresnet_hsc_big")
+    m = models.deterministic_init(models.WideResNet(), tag="wrn")
+    batches = [trainer.synthetic_batch(f"g5big/b{i}", 16, 16, 224) for i in range(3)]
+    out = trainer.train_steps(m, batches, "hsc", lr=1e-3, weight_decay=0.0, collect_grads=True)
+    _traj_check(out, g, steps=3, labels=batches[0][1].numpy())
+    worst = max(abs(gr.double().norm().item() - float(g[f"gnorm/{n}"])) / max(float(g[f"gnorm/{n}"]), 1e-6)
+                for n, gr in out["grads"].items() if float(g[f"gnorm/{n}"]) > 1e-5)
+    assert worst < 5e-3, worst
