@@ -51,6 +51,10 @@ def parse():
                          "the ViT / WideResNet steps are GPU-bound and measure the same either way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--res", type=int, default=None, help="input resolution of --model wrn (224 default; 32 = BASELINE.json config 2)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --batch normal (+ as many OE) images per GPU; strong: that many per JOB, split over the ranks")
+    ap.add_argument("--no-torch-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=4)
     return ap.parse_args()
@@ -72,6 +76,49 @@ def cpu_baseline(args):
     return {"value": round(args.cpu_steps * 2 * nh / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(),
             "kind": "port",
             "sample": f"{args.cpu_steps} steps of {2 * nh} images (ViT-B/32 {args.layers} layers, {args.mode}, fp32 oracle)"}
+
+
+def torch_rocm_baseline(args, dev):
+    """context beside the CPU baseline, NOT a target: the same step (same architecture, batch, objective, Adam) written with
+    stock PyTorch-ROCm ops -- the oracle's modules moved to the GPU (GEMMs go to hipBLASLt / rocBLAS, everything else to eager
+    elementwise kernels) with torch.optim.Adam, in fp32 and under fp16 autocast.  It answers "what would plain PyTorch do on this
+    GPU"; the reference itself cannot travel to the GPU box."""
+    import torch
+    from oracle import models as omodels, objectives as oobj
+    out = {"kind": "stock PyTorch-ROCm ops (oracle modules on the GPU, torch.optim.Adam), same step", "unit": "images/sec"}
+    nb = args.batch
+    imgs = torch.randn((2 * nb, 3, 224, 224), device=dev)
+    lbls = torch.cat([torch.zeros(nb, dtype=torch.int64), torch.ones(nb, dtype=torch.int64)]).to(dev)
+    for name, cast in (("fp32", None), ("fp16_autocast", torch.float16)):
+        try:
+            m = omodels.ClipViTNet(layers=args.layers, freeze=(args.mode == "frozen"))
+            omodels.deterministic_init(m, tag="bench", layers=args.layers)
+            m = m.to(dev).train()
+            m.freeze_parts()
+            opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-4, weight_decay=1e-3)
+
+            def one():
+                opt.zero_grad()
+                with torch.autocast("cuda", dtype=cast, enabled=cast is not None):
+                    feats = m(imgs)
+                loss = oobj.hsc_loss(feats.float(), lbls, 0)
+                loss.backward()
+                opt.step()
+                return oobj.hsc_score(feats.detach().float())
+            for _ in range(3):
+                one()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                one()
+            torch.cuda.synchronize()
+            out[name] = round(5 * 2 * nb / (time.perf_counter() - t0), 1)
+            del m, opt
+            torch.cuda.empty_cache()
+        except Exception as e:                       # the baseline must never take the bench line down
+            out[name] = None
+            out[name + "_error"] = repr(e)[:200]
+    return out
 
 
 def pmc_traffic(kernel):
@@ -119,13 +166,17 @@ def main():
 
     torch.manual_seed(0)
     res = 224
+    if args.scaling == "strong":
+        assert args.batch % world == 0, "--scaling strong needs --batch divisible by the number of ranks"
+        args.batch //= world
     if args.model == "vit":
         model = ClipViTB32Custom(prediction_head=True, clf=False, freeze=(args.mode == "frozen"), layers=args.layers).to(dev).train()
         opt = eoe_amd.FusedAdam(model.parameters(), lr=1e-4, weight_decay=1e-3)     # train_clip_imagenet.py:13-14
         model.freeze_parts()
     elif args.model == "wrn":
         from eoe_amd.models import WideResNet
-        model = WideResNet().to(dev).train()                                         # train_imagenet.py backbone
+        res = args.res or 224
+        model = WideResNet(res=res).to(dev).train()                                  # train_imagenet.py backbone (224); 32: config 2
         opt = eoe_amd.FusedAdam(model.parameters(), lr=1e-3, weight_decay=0.0)
     else:
         from eoe_amd.models import CNN32
@@ -234,20 +285,20 @@ def main():
         if args.model == "cnn32":
             flop_per_img = 0.179
         if args.model == "wrn":
-            flop_per_img = 10.89                                                     # 3 x 3.63 GFLOP
+            flop_per_img = 10.89 * (res / 224.0) ** 2                                # 3 x 3.63 GFLOP at 224
         workload = {
             "vit": (f"CLIP ViT-B/32 ({args.layers} layers) + Linear(512,256) + HSC, "
                     f"{'full fine-tune' if args.mode == 'full' else 'frozen encoder'}, Adam lr 1e-4 wd 1e-3, "
                     f"224x224, {nb} normal + {nb} OE images per GPU per step"),
             "cnn32": f"CNN32(bias=True) + HSC, Adam lr 1e-3, 32x32, {nb} normal + {nb} OE images per GPU per step",
-            "wrn": f"WideResNet(ResNet-18 + CBAM) + HSC, Adam lr 1e-3, 224x224, {nb} normal + {nb} OE images per GPU per step",
+            "wrn": f"WideResNet(ResNet-18 + CBAM) + HSC, Adam lr 1e-3, {res}x{res}, {nb} normal + {nb} OE images per GPU per step",
         }[args.model]
         metric = {"vit": "train images/sec, CLIP ViT-B/32 + HSC, 224x224", "cnn32": "train images/sec, CNN32 + HSC, 32x32",
-                  "wrn": "train images/sec, WideResNet+CBAM + HSC, 224x224"}[args.model]
+                  "wrn": f"train images/sec, WideResNet+CBAM + HSC, {res}x{res}"}[args.model]
         out = {
             "metric": metric,
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload, "global_batch": n_global, "parallelism": f"dp{world}",
                        "launch": "hip graph replay" if use_graph else "eager"},
@@ -259,6 +310,10 @@ def main():
             out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline and args.model == "vit":
             out["cpu_baseline"] = cpu_baseline(args)
+        if world == 1 and not args.no_torch_baseline and args.model == "vit":
+            del model, opt, arena
+            torch.cuda.empty_cache()
+            out["torch_rocm_baseline"] = torch_rocm_baseline(args, dev)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

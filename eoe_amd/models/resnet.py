@@ -1,5 +1,8 @@
-"""Drop-in for `src/eoe/models/resnet.py:25-152` (WideResNet = ResNet-18 layout + CBAM in every BasicBlock, 224x224
-only): same constructor (rep_dim, clf), module tree, parameter / buffer names and initialisation (`resnet.py:50-66`).
+"""Drop-in for `src/eoe/models/resnet.py:25-152` (WideResNet = ResNet-18 layout + CBAM in every BasicBlock): same
+constructor (rep_dim, clf), module tree, parameter / buffer names and initialisation (`resnet.py:50-66`).  The reference
+accepts 224x224 inputs only (`view(-1, 3, 224, 224)`, `AvgPool2d(7)`; resnet.py:86,38); the extra `res` argument is this
+build's own generalisation for BASELINE.json's "WideResNet backbone, 32x32" configuration: the same layers on a res x res
+input, the final (res/32)^2 map averaged whole (at 224 that IS AvgPool2d(7)).
 The torch.nn modules are parameter/buffer CONTAINERS; the forward runs im2col + MFMA GEMM convolutions with fused
 BatchNorm/ReLU (`eoe_amd/csrc/conv.hip`) and the CBAM / pooling / residual kernels of `eoe_amd/csrc/cbam.hip`, on fp32
 NHWC activations.  `WideResNet50Pretrained` (`resnet.py:8-21`, torchvision) is out of scope (unused by any runner)."""
@@ -64,8 +67,11 @@ class BasicBlock(nn.Module):
 
 class WideResNet(nn.Module):
 
-    def __init__(self, rep_dim=256, clf=False):
+    def __init__(self, rep_dim=256, clf=False, res=224):
         super().__init__()
+        if res % 32 != 0 or res < 32:
+            raise ValueError(f"WideResNet: res = {res} must be a positive multiple of 32 (five stride-2 stages)")
+        self.res = res
         self.inplanes = 64
         self.clf = clf
         self.rep_dim = rep_dim
@@ -124,7 +130,7 @@ class WideResNet(nn.Module):
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("eoe_amd.WideResNet runs on the GPU only (no CPU fallback)")
-        x = x.view(-1, 3, 224, 224)
+        x = x.view(-1, 3, self.res, self.res)
         # all 16-bit weight copies that the optimiser step made stale, in one launch (the 19 block / down-sampling convolutions)
         ops.refresh_conv_weight_copies([m.weight for layer in (self.layer1, self.layer2, self.layer3, self.layer4)
                                         for m in layer.modules() if isinstance(m, nn.Conv2d) and m.weight.shape[1] % 8 == 0

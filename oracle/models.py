@@ -386,10 +386,13 @@ class BasicBlock(nn.Module):
 
 
 class WideResNet(nn.Module):
-    # resnet.py:25-109
-    def __init__(self, rep_dim=256, clf=False):
+    # resnet.py:25-109.  `res` != 224 is the build's own generalisation (BASELINE.json config 2 names a 32 x 32 WideResNet; the
+    # reference hard-codes view(-1, 3, 224, 224) and AvgPool2d(7), resnet.py:86,38): same layers, the input viewed as
+    # res x res, the final res/32 x res/32 map averaged whole.
+    def __init__(self, rep_dim=256, clf=False, res=224):
         super().__init__()
-        self.clf, self.rep_dim = clf, rep_dim
+        assert res % 32 == 0
+        self.clf, self.rep_dim, self.res = clf, rep_dim, res
         self.conv1 = _Conv(3, 64, 7, bias=False)
         self.bn1 = _BN(64, 1e-5, True)
         cfg = [(64, 64, 1), (64, 128, 2), (128, 256, 2), (256, 512, 2)]
@@ -401,11 +404,11 @@ class WideResNet(nn.Module):
             self.linear = _Lin(rep_dim, 1)
 
     def forward(self, x):
-        x = x.reshape(-1, 3, 224, 224)
+        x = x.reshape(-1, 3, self.res, self.res)
         x = torch.relu(self.bn1(F.conv2d(x, self.conv1.weight, None, stride=2, padding=3)))
         x = F.max_pool2d(x, 3, 2, 1)
         for i in range(1, 5):
             x = getattr(self, f"layer{i}")(x)
-        x = F.avg_pool2d(x, 7).reshape(x.shape[0], -1)
+        x = F.avg_pool2d(x, self.res // 32).reshape(x.shape[0], -1)
         x = self.fc(x)
         return self.linear(x) if self.clf else x

@@ -504,6 +504,27 @@ def g5big():
     save("g5_wideresnet_hsc_big", losses=losses, scores=scores, **first)
 
 
+def g13():
+    """BASELINE.json config 2, "WideResNet backbone, 32 x 32": the reference's WideResNet accepts 224 x 224 only (resnet.py:86,38),
+    so the fixture drives the reference's OWN layers (conv1 / bn1 / maxpool / layer1-4 with their BasicBlock + CBAM / fc,
+    resnet.py:33-48,112-149) in the reference's order (resnet.py:87-107) on 32 x 32 inputs; the only departure is the final
+    pooling, which averages the 1 x 1 map that is left instead of AvgPool2d(7).  128 + 128 images, K = 10 Adam steps."""
+    from eoe.models.resnet import WideResNet as RefWRN
+
+    class RefWRN32(RefWRN):
+        def forward(self, x):
+            x = self.maxpool(self.relu(self.bn1(self.conv1(x.view(-1, 3, 32, 32)))))
+            x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+            x = x.mean((2, 3))
+            x = self.fc(x)
+            return self.linear(x) if self.clf else x
+    m = RefWRN32()
+    omodels.deterministic_init(m, tag="wrn")
+    losses, scores, first = run_trajectory_big(m, lambda i: otrainer.synthetic_batch(f"g13/b{i}", 128, 128, 32), 10,
+                                               "hsc", lr=1e-3, wd=0.0)
+    save("g13_wideresnet32_hsc", losses=losses, scores=scores, **first)
+
+
 def g3big():
     """the 12-layer ViT-B/32 + head, ONE full fine-tune step at the benchmark batch (128 + 128 images = 12 800 token
     rows): features, loss, scores and per-tensor gradient summaries, plus the loss of a second step (which sees the
@@ -518,6 +539,6 @@ def g3big():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12",
-                             "g2big", "g11big", "g5big", "g3big"]
+                             "g2big", "g11big", "g5big", "g3big", "g13"]
     for w in which:
         globals()[w]()

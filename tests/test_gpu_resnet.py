@@ -258,64 +258,33 @@ def test_wideresnet_state_dict_and_param_count():
     assert float(sd["layer3.1.bn2.weight"].min()) == 1.0 and float(sd["fc.bias"].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("dtype", [torch.float16])
-def test_wideresnet_vs_golden(golden, dtype):
-    """WideResNet@224 with N=4 (2 normal + 2 OE): features, loss, per-tensor gradient norms and a 2-step Adam trajectory
-    against the vectors produced by the reference's own resnet.py"""
+@pytest.mark.parametrize("parity", [False, True])
+def test_wideresnet_small_batch_vs_golden(golden, parity):
+    """WideResNet@224 at N = 4 (2 normal + 2 OE) against the vectors of the reference's own resnet.py (fixture g5): features and
+    the first loss.  BatchNorm over 4 images is ill-conditioned by construction (the reference's own fp32 run is 1.2e-2 from
+    its fp64 run on the worst gradient tensor), so gradients and K-step trajectories are pinned on the well-conditioned
+    fixtures instead (tests/test_gpu_parity_big.py: 16 + 16 images, 10 steps, 1e-3 in parity mode)."""
     import eoe_amd
-    from eoe_amd import FusedAdam
     from eoe_amd.models import WideResNet
     from eoe_amd.ops import hsc_loss
-    eoe_amd.set_compute_dtype(dtype)
-    g = golden("g5_wideresnet_hsc")
-    ref = omodels.deterministic_init(omodels.WideResNet(), tag="wrn")
-    m = WideResNet()
-    m.load_state_dict(ref.state_dict())
-    m = m.cuda().train()
-    batches = [otrainer.synthetic_batch(f"g5/b{i}", 2, 2, 224) for i in range(2)]
-    # conditioning per tensor: the oracle's fp32 gradient norms against the golden ones (the reference in fp32 as well;
-    # both are ~1e-2 from fp64 on the worst tensors at this batch size)
-    ref.train()
-    objectives.hsc_loss(ref(batches[0][0]), batches[0][1], 0).backward()
-    sens = {n: abs(p.grad.double().norm().item() - float(g[f"gnorm/{n}"])) / (float(g[f"gnorm/{n}"]) + 1e-5)
-            for n, p in ref.named_parameters()}
-    x0, y0 = batches[0][0].cuda(), batches[0][1].cuda()
-    f0 = m(x0)
-    r = rel_rms(f0, torch.from_numpy(g["features0"]))
-    assert r < 2e-2, r               # 4-image BatchNorm amplifies the 16-bit operand rounding (fp32 vs fp64 of the reference: 1e-2)
-    loss = hsc_loss(f0, y0, 0)
-    loss.backward()
-    assert abs(loss.item() - float(g["losses"][0])) <= 1e-4 * abs(float(g["losses"][0]))
-    devs = {}
-    for name, p in m.named_parameters():
-        refn = float(g[f"gnorm/{name}"])
-        devs[name] = abs(p.grad.double().norm().item() - refn) / (refn + 1e-5)
-    # two fp32 evaluations of this network (reference vs oracle) already differ by `sens` per tensor (4-image BatchNorm,
-    # cancellation in the gate gradients); 16-bit conv operands perturb the same sums harder (gpu_util.conditioned_tol)
-    vals = sorted(devs.values())
-    assert vals[len(vals) // 2] < 1e-2 and vals[int(0.9 * len(vals))] < 6e-2, (vals[len(vals) // 2], vals[int(0.9 * len(vals))])
-    bad, pinned = {}, 0
-    for name, d in devs.items():
-        t = conditioned_tol(1e-1, sens[name], dtype)     # run-to-run atomics order alone moves single tensors by ~4e-2 here
-        if t is None:
-            continue
-        pinned += 1
-        if d > t:
-            bad[name] = (d, t, sens[name])
-    # run-to-run atomics order moves single ill-conditioned tensors by several 1e-2 at this batch size: allow two stragglers
-    assert len(bad) <= 2 and all(v[0] < 0.5 for v in bad.values()) and pinned >= 0.95 * len(devs), (bad, pinned)
-    # two Adam steps
-    m.load_state_dict(ref.state_dict())
-    m.zero_grad(set_to_none=True)
-    opt = FusedAdam(m.parameters(), lr=1e-3, weight_decay=0.0)
-    losses = []
-    for xb, yb in batches:
-        opt.zero_grad(set_to_none=True)
-        l = hsc_loss(m(xb.cuda()), yb.cuda(), 0)
-        l.backward()
-        opt.step()
-        losses.append(l.item())
-    np.testing.assert_allclose(losses, g["losses"], rtol=3e-2)
+    eoe_amd.set_compute_dtype(torch.float16)
+    eoe_amd.set_parity_mode(parity)
+    try:
+        g = golden("g5_wideresnet_hsc")
+        ref = omodels.deterministic_init(omodels.WideResNet(), tag="wrn")
+        m = WideResNet()
+        m.load_state_dict(ref.state_dict())
+        m = m.cuda().train()
+        x0, y0 = (t.cuda() for t in otrainer.synthetic_batch("g5/b0", 2, 2, 224))
+        f0 = m(x0)
+        r = rel_rms(f0, torch.from_numpy(g["features0"]))
+        assert r < (1e-3 if parity else 2e-2), r
+        loss = hsc_loss(f0, y0, 0)
+        loss.backward()
+        assert abs(loss.item() - float(g["losses"][0])) <= 1e-4 * abs(float(g["losses"][0]))
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    finally:
+        eoe_amd.set_parity_mode(False)
 
 
 def test_wideresnet_eval_mode_and_clf():

@@ -368,3 +368,14 @@ def test_wideresnet_big(golden):
     worst = max(abs(gr.double().norm().item() - float(g[f"gnorm/{n}"])) / max(float(g[f"gnorm/{n}"]), 1e-6)
                 for n, gr in out["grads"].items() if float(g[f"gnorm/{n}"]) > 1e-5)
     assert worst < 5e-3, worst
+
+
+def test_wideresnet32(golden):
+    """BASELINE.json config 2 ("WideResNet backbone, 32 x 32"): the oracle's `WideResNet(res=32)` against the trajectory the
+    reference's own layers produced on 32 x 32 inputs (fixture g13; the reference's forward itself is 224-only), 128 + 128
+    images, the first 4 of the fixture's 10 steps here"""
+    g = golden("g13_wideresnet32_hsc")
+    m = models.deterministic_init(models.WideResNet(res=32), tag="wrn")
+    batches = [trainer.synthetic_batch(f"g13/b{i}", 128, 128, 32) for i in range(4)]
+    out = trainer.train_steps(m, batches, "hsc", lr=1e-3, weight_decay=0.0)
+    _traj_check(out, g, steps=4, labels=batches[0][1].numpy())
