@@ -1,0 +1,261 @@
+// The one-wave-per-SIMD NT GEMM kernel (its own translation unit: 256 accumulator registers per lane make it slow to compile).
+#include "gemm_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ NT, (32*MI) x 256 tiles, one wave per SIMD
+// Fourth tile shape: (32*MI) x 256 x 64 tiles, FOUR wavefronts (2x2), each (16*MI) x 128 -- one wave per SIMD with the whole
+// 512-entry register file (up to 256 accumulator registers + the fragments), ONE persistent workgroup per CU.  Why: the 64x64
+// wave tiles of the kernels above read 16 KB of LDS per 32 MFMAs (0.5 ds_read_b128 per MFMA); with two waves per SIMD the LDS
+// array and the per-k-tile barrier skew, not the matrix pipe, set the k-tile time (~1800 cycles against 1024 of MFMA issue).  An
+// 80x128 wave tile reads 13 KB per 40 MFMAs (0.33 per MFMA), a 128x128 one 16 KB per 64 (0.25), halves the operand bytes that
+// cross L2 per flop, and a k-tile holds 1280 / 2048 cycles of back-to-back MFMAs behind ONE barrier.  MI = 5 (160 x 256) tiles
+// the ViT's M = 12800 without waste: N = 768 -> 240 tiles = one round over the 256 CUs, N = 2304 -> 720 = 3 rounds at 94 %,
+// N = 3072 -> 960 = 4 rounds at 94 %.  Persistent grid with cross-tile prefetch (the staging cursor runs two k-tiles ahead across
+// tile boundaries), 2-stage ring (2 x 52 / 64 KB) + 16 KB epilogue scratch.  Same LDS image / swizzle / fragment layout /
+// epilogues as the other kernels.
+constexpr int b256_bytes() { return 256 * BK * 2; }                               // 32 KiB
+constexpr int a256_bytes(int MI) { return 32 * MI * BK * 2; }                      // 20 / 32 KiB
+constexpr int stage256_bytes(int MI) { return a256_bytes(MI) + b256_bytes(); }     // 52 / 64 KiB
+// ring depth: 3 stages where they fit the 160 KiB (MI = 5: 156 KiB; the epilogue's transposition scratch then aliases the stage
+// that was consumed last), else 2 stages + 16 KiB of scratch (MI = 8: 144 KiB)
+constexpr int nstage256(int MI) { return 3 * stage256_bytes(MI) <= 160 * 1024 ? 3 : 2; }
+constexpr int smem256_bytes(int MI) { return nstage256(MI) == 3 ? 3 * stage256_bytes(MI) : 2 * stage256_bytes(MI) + 4 * 4096; }
+
+template <typename T> __device__ __forceinline__ void mfma_inplace(f32x4& c, typename T16<T>::v8 a, typename T16<T>::v8 b);
+template <> __device__ __forceinline__ void mfma_inplace<f16_t>(f32x4& c, f16x8 a, f16x8 b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+template <> __device__ __forceinline__ void mfma_inplace<bf16_t>(f32x4& c, bf16x8 a, bf16x8 b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
+template <typename T, int EPI, int MI>
+__global__ __launch_bounds__(256, 1) void gemm_nt256_kernel(GemmP p) {
+    constexpr int BMT = 32 * MI, A_B = a256_bytes(MI), STAGE = stage256_bytes(MI), NST = nstage256(MI), PER = MI + 8;
+    static_assert(NST == 2 || MI >= 4, "the aliased scratch is the wave's own MI KiB of A pieces (>= 4 KiB)");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = (p.N + 255) / 256;
+    const int total_tiles = tiles_n * ((p.M + BMT - 1) / BMT);
+    const int G = gridDim.x;
+    const int my_tiles = (total_tiles - (int)blockIdx.x + G - 1) / G;
+    const int nk = p.K / BK;
+    const int iters = my_tiles * nk;
+    if (iters <= 0) return;
+
+    __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.bytesA);
+    __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.bytesB);
+    unsigned offA[8], offB[8];
+    static_assert(MI <= 8, "offA");
+    int st_tile = 0, st_kt = 0, st_slot = 0;
+    auto tile_origin = [&](int seq, int& m0, int& n0) {
+        const int r = xcd_remap((int)blockIdx.x + seq * G, total_tiles);
+        m0 = (r / tiles_n) * BMT;
+        n0 = (r % tiles_n) * 256;
+    };
+    auto set_offsets = [&](int t) {
+        int m0, n0;
+        tile_origin(t, m0, n0);
+#pragma unroll
+        for (int j = 0; j < MI; ++j) {
+            const int row = (wave * MI + j) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            offA[j] = (m0 + row < p.M) ? (unsigned)(((size_t)(m0 + row) * p.lda + c * 8) * 2) : EOE_OOB;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = (wave * 8 + j) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            offB[j] = (n0 + row < p.N) ? (unsigned)(((size_t)(n0 + row) * p.ldb + c * 8) * 2) : EOE_OOB;
+        }
+    };
+    // LDS-DMA as inline asm (buffer_load_dwordx4 ... offen lds; M0 = the wave-uniform LDS byte address of the 1-KiB piece, written in
+    // the same statement that uses it): issued through the builtin, every LDS read the compiler can see -- and every asm
+    // statement -- is preceded by s_waitcnt vmcnt(0) while a piece is in flight (the waitcnt pass cannot prove that the read
+    // does not touch the slot being filled), which would shorten the DMA's lead from a whole k-tile to half of one.  The
+    // pieces are awaited by hand: EOE_WAIT_VM(0) in front of the barrier that precedes the first read of the slot.
+    const unsigned lds0 = (unsigned)(uintptr_t)((lds_void_t*)smem);
+    const unsigned wave_u = (unsigned)__builtin_amdgcn_readfirstlane(wave);
+#define EOE_DMA16(rsrc, lds_addr, voff)                                                                               \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"                            \
+                 :: "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory")
+    auto stage_next = [&]() {                      // MI + 8 LDS-DMA instructions per wave per k-tile
+        const unsigned sa = lds0 + (unsigned)st_slot * STAGE;
+        const unsigned sb = sa + A_B;
+        const unsigned k0 = (unsigned)st_kt * (BK * 2u);
+#pragma unroll
+        for (int j = 0; j < MI; ++j) {
+            const unsigned la = sa + (wave_u * MI + j) * 1024u, vo = offA[j] + k0;
+            EOE_DMA16(ra, la, vo);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned lb = sb + (wave_u * 8 + j) * 1024u, vo = offB[j] + k0;
+            EOE_DMA16(rb, lb, vo);
+        }
+        st_slot = (st_slot == NST - 1) ? 0 : st_slot + 1;
+        if (++st_kt == nk) {
+            st_kt = 0;
+            st_tile += 1;
+            if (st_tile < my_tiles) set_offsets(st_tile);
+        }
+    };
+
+    const int wm0 = (wave >> 1) * (16 * MI), wn0 = (wave & 1) * 128;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int sw = (lr >> 1) & 7;
+    const int fragA = (wm0 + lr) * 128, fragB = A_B + (wn0 + lr) * 128;
+    const int ch0 = ((0 + lg) ^ sw) * 16, ch1 = ((4 + lg) ^ sw) * 16;
+    typedef typename T16<T>::v8 V8;
+
+    // Fragment reads are inline asm too: hipcc's waitcnt pass cannot tell a compiler-issued ds_read from the ring slot an
+    // in-flight LDS-DMA is filling and puts s_waitcnt vmcnt(0) in front of the first read of every k-step, i.e. the k-tile
+    // requested half an iteration ago must land before the current one may be read.  Their completion is awaited by
+    // EOE_LANDED256: an lgkmcnt(0) that names every fragment register "+v", so that no use can be scheduled above it; each
+    // set is awaited before the loop's back edge / before its MFMAs, so the compiler never touches a register in flight.
+#define EOE_READ256(XA, WB, base, ks)                                                                            \
+    do {                                                                                                         \
+        const unsigned a_ = (unsigned)(size_t)((base) - smem) + fragA + ((ks) ? ch1 : ch0);                      \
+        const unsigned b_ = (unsigned)(size_t)((base) - smem) + fragB + ((ks) ? ch1 : ch0);                      \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                           \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(XA[i]) : "v"(a_), "i"(i * 2048));     \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                            \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(WB[i]) : "v"(b_), "i"(i * 2048));     \
+    } while (0)
+#define EOE_LANDED256(XA, WB)                                                                                    \
+    do {                                                                                                         \
+        if (MI == 5) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(XA[0]), "+v"(XA[1]), "+v"(XA[2]), "+v"(XA[3]), "+v"(XA[4]), \
+                                  "+v"(WB[0]), "+v"(WB[1]), "+v"(WB[2]), "+v"(WB[3]), "+v"(WB[4]), "+v"(WB[5]), "+v"(WB[6]), "+v"(WB[7]) :: "memory"); \
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(XA[0]), "+v"(XA[1]), "+v"(XA[2]), "+v"(XA[3]), "+v"(XA[4 < MI ? 4 : 0]), \
+                          "+v"(XA[5 < MI ? 5 : 0]), "+v"(XA[6 < MI ? 6 : 0]), "+v"(XA[7 < MI ? 7 : 0]),                      \
+                          "+v"(WB[0]), "+v"(WB[1]), "+v"(WB[2]), "+v"(WB[3]), "+v"(WB[4]), "+v"(WB[5]), "+v"(WB[6]), "+v"(WB[7]) :: "memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+    } while (0)
+    // The MFMAs are inline asm with the accumulator tied in place ("+a": an AGPR quad that is both C and D).  Through the
+    // builtin, with 160 accumulator registers carried around a loop that updates each of them twice, the register allocator
+    // gave the first update a different destination and moved accumulators between AGPRs with ~6 v_accvgpr_* copies per MFMA.
+    // Hazards: an MFMA taking the previous MFMA's D whole as its C needs no wait states; the fragments come from compiler-issued
+    // ds_reads (the compiler waits for them before the statement that names them); the only other reader of the accumulators
+    // is the epilogue, fenced by EOE_MFMA_DRAIN below.
+#define EOE_MFMA256(XA, WB)                                               \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                     \
+        _Pragma("unroll") for (int ni = 0; ni < 8; ++ni)                  \
+            mfma_inplace<T>(acc[ni >> 2][mi][ni & 3], WB[ni], XA[mi]);
+#define EOE_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
+
+    // counted waits: every k-tile is PER = MI + 8 LDS-DMA instructions per wave, nothing else is outstanding inside a tile's
+    // k-loop (the epilogue's stores are drained with everything else at the top of each tile)
+#define EOE_WAIT_GROUPS(g)                                                                             \
+    do {                                                                                               \
+        if ((g) <= 0) { EOE_WAIT_VM(0); }                                                              \
+        else if ((g) == 1) { if (PER == 13) { EOE_WAIT_VM(13); } else { EOE_WAIT_VM(16); } }           \
+        else { if (PER == 13) { EOE_WAIT_VM(26); } else { EOE_WAIT_VM(32); } }                         \
+    } while (0)
+    static_assert(PER == 13 || PER == 16, "EOE_WAIT_GROUPS knows MI = 5 and MI = 8");
+    V8 xa0[MI], wb0[8], xa1[MI], wb1[8];
+    set_offsets(0);
+    const int pre = iters < NST ? iters : NST;
+    for (int i = 0; i < pre; ++i) stage_next();
+    EOE_WAIT_GROUPS(pre - 1);                       // k-tile 0 landed; the later ones may stay in flight
+    __builtin_amdgcn_s_barrier();
+    EOE_READ256(xa0, wb0, smem, 0);
+    EOE_LANDED256(xa0, wb0);
+    int cur = 0, it = 0;
+    // two nested loops (tile, k-tile) over the flattened iteration space `it`: the accumulators live from their zero
+    // initialisation to the tile's epilogue and are not carried around the outer loop
+    for (int c_tile = 0; c_tile < my_tiles; ++c_tile) {
+        f32x4 acc[2][MI][4];                        // [64-column half][16-row tile][16-column tile]
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[h][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // every counter the COMPILER tracks is drained here, once per tile (the previous tile's epilogue stores and scratch
+        // reads): otherwise its waitcnt pass, merging that state into the loop header, opens every iteration with
+        // s_waitcnt vmcnt(0) lgkmcnt(0) -- and the hardware counter makes that a wait for the hand-issued LDS-DMA too
+        __builtin_amdgcn_s_waitcnt(0);
+        for (int kt = 0; kt < nk; ++kt, ++it) {
+            const int nxt = (cur == NST - 1) ? 0 : cur + 1;
+            const char* sc = smem + cur * STAGE;
+            const char* sn = smem + nxt * STAGE;
+            if (!(p.dbg & 4)) { EOE_READ256(xa1, wb1, sc, 1); }          // lands under MFMA(F0)
+            EOE_MFMA256(xa0, wb0);
+            {   // k-tile it+1 landed; the (up to NST - 2) k-tiles staged after it stay in flight
+                const int later = iters - 2 - it;   // k-tiles it+2 .. iters-1 that exist
+                const int g = later < NST - 2 ? later : NST - 2;
+                EOE_WAIT_GROUPS(g);
+            }
+            EOE_LANDED256(xa1, wb1);               // this wave's reads of slot `cur` are complete
+            __builtin_amdgcn_s_barrier();
+            // k-tile it+NST into the slot just consumed -- unless that slot is about to serve as the epilogue's scratch
+            const bool defer = (NST == 3) && (kt == nk - 1);
+            if (!defer && it + NST < iters && !(p.dbg & 2)) stage_next();
+            if (!(p.dbg & 4)) { EOE_READ256(xa0, wb0, sn, 0); }         // unconditional (the last one reads a stale slot and is discarded); lands under MFMA(F1)
+            EOE_MFMA256(xa1, wb1);
+            EOE_LANDED256(xa0, wb0);               // before the back edge: no fragment register is in flight across it
+            cur = nxt;
+        }
+        // epilogue while the next tile's first k-tiles are in flight (their fragments of k-step 0 are already in xa0 / wb0)
+        EOE_MFMA_DRAIN();                           // the last MFMAs' results must have landed before the accumulators are read
+        int m0, n0;
+        tile_origin(c_tile, m0, n0);
+        GemmP ep;
+        load_epilogue_args(ep, p);
+        // scratch (4 KiB per wave).  NST == 3: inside the slot consumed last (every wave's reads of it completed before the last
+        // barrier), in the MI KiB that THIS wave's own A pieces of the next k-tile will overwrite -- issued below, after this
+        // wave's epilogue, so no other wave's DMA can land in it
+        const int last = (cur == 0) ? NST - 1 : cur - 1;
+        char* scr = (NST == 3) ? smem + last * STAGE + wave * (MI * 1024) : smem + 2 * STAGE + wave * 4096;
+        epilogue<T, EPI, 4, MI, false>(ep, acc[0], m0 + wm0, n0 + wn0, lane, scr);
+        epilogue<T, EPI, 4, MI, false>(ep, acc[1], m0 + wm0, n0 + wn0 + 64, lane, scr);
+        if (NST == 3 && it - 1 + NST < iters) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);    // lgkmcnt(0): the scratch reads have returned before the DMA may overwrite them
+            stage_next();                           // the deferred k-tile (it-1)+NST
+        }
+    }
+#undef EOE_WAIT_GROUPS
+#undef EOE_DMA16
+#undef EOE_READ256
+#undef EOE_LANDED256
+#undef EOE_MFMA256
+#undef EOE_MFMA_DRAIN
+}
+
+
+extern int g_nt_flags;
+
+template <typename T, int MI>
+int launch_nt256(const GemmP& p, int epi, hipStream_t s) {
+    const int tiles = cdiv(p.M, 32 * MI) * cdiv(p.N, 256);
+    const int ncu = num_cus();
+    const int grid = tiles < ncu ? tiles : ncu;
+#define EOE_NT256_CASE(E)                                                                   \
+    case E:                                                                                 \
+        { static bool once = (hipFuncSetAttribute((const void*)gemm_nt256_kernel<T, E, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem256_bytes(MI)), true); (void)once; } \
+        hipLaunchKernelGGL((gemm_nt256_kernel<T, E, MI>), dim3(grid), dim3(256), smem256_bytes(MI), s, p); \
+        break;
+    switch (epi) {
+        EOE_NT256_CASE(EOE_EPI_NONE)
+        EOE_NT256_CASE(EOE_EPI_GELU)
+        EOE_NT256_CASE(EOE_EPI_RESIDUAL)
+        EOE_NT256_CASE(EOE_EPI_GELU_BWD)
+        default: return eoe_set_error(EOE_ERR_ARG, "gemm_nt: unknown epilogue %d", epi);
+    }
+#undef EOE_NT256_CASE
+    EOE_CHECK_LAUNCH("gemm_nt256");
+    return finish_colsum(p, epi, MI, s);
+}
+
+}  // namespace
+
+int eoe_launch_nt256(const void* gemm_p, int dtype, int epi, int mi, hipStream_t s) {
+    const GemmP& p = *(const GemmP*)gemm_p;
+#ifdef EOE_DEV256          // development builds: one instantiation family only (compile time)
+    return launch_nt256<f16_t, 5>(p, epi, s);
+#else
+    if (dtype == EOE_F16) return mi == 8 ? launch_nt256<f16_t, 8>(p, epi, s) : launch_nt256<f16_t, 5>(p, epi, s);
+    return mi == 8 ? launch_nt256<bf16_t, 8>(p, epi, s) : launch_nt256<bf16_t, 5>(p, epi, s);
+#endif
+}

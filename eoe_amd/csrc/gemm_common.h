@@ -1,0 +1,327 @@
+// Shared pieces of the NT GEMM kernels (gemm.hip, gemm256.hip): the kernel argument block, the two epilogues and the waits.
+#pragma once
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 256, BN = 128, BK = 64, NSTAGE = 3;
+#ifndef EOE_NT_DEFAULT_FLAGS
+#define EOE_NT_DEFAULT_FLAGS 1     // bit 0 (fast epilogue): 551 vs 669 us per ViT layer; bit 1 (asm fragment reads): no gain here (574 vs 573 us)
+#endif
+constexpr int A_BYTES = BM * BK * 2;              // 32 KiB
+constexpr int B_BYTES = BN * BK * 2;              // 16 KiB
+constexpr int STAGE_BYTES = A_BYTES + B_BYTES;    // 48 KiB
+constexpr int SMEM_BYTES = NSTAGE * STAGE_BYTES;  // 144 KiB: one 8-wave workgroup per CU
+
+struct GemmP {
+    const void* A; const void* B; void* C; const float* bias; const void* aux; void* aux_out; float* colsum;
+    float* colsum_part;            // column sums through per-wave partial rows (eoe_part_index layout) + a finish kernel (no atomics)
+    int colsum_blocked;            // layout of the partial rows: N % 64 == 0 -> blocked (BatchNorm statistics: always plain [R][2][N])
+    int colsum_sq;                 // partial rows are [.][2][N]: sums and sums of squares (BatchNorm statistics); no finish kernel
+    int M, N, K, lda, ldb, ldc, ldaux, out_f32, accumulate;
+    float alpha;
+    unsigned bytesA, bytesB;
+    unsigned long long* stamp;     // diagnostics (EOE_GEMM_STAMP=1): per-workgroup s_memtime stamps, else NULL
+    int dbg;                       // diagnostics (EOE_GEMM_DEBUG): bit 1 = no LDS-DMA inside the k-loop, bit 2 = no fragment reads there (gemm256.hip; results wrong)
+    // implicit patch matrix (GATHER kernels): A = 16-bit NHWC tensor [n, gH, gW, gC]; row m = output pixel (img, ho, wo) of
+    // a gHo x gWo grid, column k = (ky*gkw + kx)*gC + c -> element (img, ho*gstride - gpad + ky, wo*gstride - gpad + kx, c)
+    int gH, gW, gC, gWo, gHoWo, gkw, gstride, gpad;
+    // GATHER == 2 (3-channel first layer): A = physically zero-padded 16-bit [n, gH, gW, 4] image; a 128-B k-tile = 2 kernel
+    // rows x 8 pixels x 4 channels, i.e. 16-B piece q of k-tile kt = pixels (2*(q&3), +1) of kernel row 2*kt + (q>>2)
+    int gkstep;       // bytes between consecutive k-tiles = 2 * gW * 8
+    // GATHER == 3 (narrow layers, gC in {8, 16, 32}): a 64-deep k-tile spans 64/gC taps, so every 16-B piece decodes its
+    // own tap: k = kt*64 + 8*piece, tap = k >> glog2c, (ky, kx) = divmod(tap, gkw) by multiply-shift; taps >= gkh*gkw (the
+    // zero padding of K up to a multiple of 64) and taps in the image's zero padding read as zeros
+    int gkh, glog2c;
+    unsigned gmagic;  // ceil(65536 / gkw)
+};
+
+// General (slow) epilogue: straight from the MFMA accumulator layout (lane = output row within a 16-row band, 4
+// consecutive columns per 16x16 tile) -- 8/16-byte pieces, 16 rows per store instruction.  Handles any N / ldc.
+template <typename T, int EPI, int NI, int MI = 4>
+__device__ __forceinline__ void epilogue_generic(const GemmP& p, f32x4 (&acc)[MI][NI], int m_base, int n_base, int lane) {
+    const int lr = lane & 15, lg = lane >> 4;
+    const bool vec_ok = ((p.ldc & 3) == 0) && ((p.N & 3) == 0);
+    f32x4 cs[NI];                      // per-ni column sums of this lane's rows (bias gradient of the producer)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) cs[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = m_base + mi * 16 + lr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = n_base + ni * 16 + lg * 4;
+            if (n >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r] * p.alpha;
+            const int nvalid = (p.N - n) < 4 ? (p.N - n) : 4;
+            if (p.bias) {
+                if (vec_ok) {
+                    const f32x4 bv = *(const f32x4*)(p.bias + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += bv[r];
+                } else {
+                    for (int r = 0; r < nvalid; ++r) v[r] += p.bias[n + r];
+                }
+            }
+            const size_t off = (size_t)m * p.ldc + n;
+            if (EPI == EOE_EPI_GELU) {
+                // pre-activation (16-bit, saved for backward) and activation
+                T* pre = (T*)p.aux_out;
+                T* act = (T*)p.C;
+                if (vec_ok) {
+                    // the saved pre-activation is what backward differentiates: activate its ROUNDED value
+                    u32x2 pk = pack4<T>(v[0], v[1], v[2], v[3]);
+                    float pr[4];
+                    unpack4<T>(pk, pr);
+                    *(u32x2*)(pre + off) = pk;
+                    *(u32x2*)(act + off) = pack4<T>(quick_gelu_f(pr[0]), quick_gelu_f(pr[1]),
+                                                    quick_gelu_f(pr[2]), quick_gelu_f(pr[3]));
+                } else {
+                    for (int r = 0; r < nvalid; ++r) {
+                        T q = (T)v[r];
+                        pre[off + r] = q;
+                        act[off + r] = (T)quick_gelu_f((float)q);
+                    }
+                }
+                continue;
+            }
+            if (EPI == EOE_EPI_RESIDUAL) {
+                const float* res = (const float*)p.aux + (size_t)m * p.ldaux + n;
+                if (vec_ok && (p.ldaux & 3) == 0) {
+                    f32x4 rv = *(const f32x4*)res;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                } else {
+                    for (int r = 0; r < nvalid; ++r) v[r] += res[r];
+                }
+            }
+            if (EPI == EOE_EPI_GELU_BWD) {
+                const T* pre = (const T*)p.aux + (size_t)m * p.ldaux + n;
+                if (vec_ok && (p.ldaux & 3) == 0) {
+                    float pr[4];
+                    unpack4<T>(*(const u32x2*)pre, pr);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= quick_gelu_grad_f(pr[r]);
+                } else {
+                    for (int r = 0; r < nvalid; ++r) v[r] *= quick_gelu_grad_f((float)pre[r]);
+                }
+            }
+            if (EPI != EOE_EPI_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cs[ni][r] += v[r];
+            }
+            if (p.out_f32) {
+                float* c = (float*)p.C + off;
+                if (vec_ok) {
+                    f32x4 o = {v[0], v[1], v[2], v[3]};
+                    if (p.accumulate) {
+                        f32x4 old = *(f32x4*)c;
+                        o += old;
+                    }
+                    *(f32x4*)c = o;
+                } else {
+                    for (int r = 0; r < nvalid; ++r) c[r] = p.accumulate ? c[r] + v[r] : v[r];
+                }
+            } else {
+                T* c = (T*)p.C + off;
+                if (vec_ok) {
+                    *(u32x2*)c = pack4<T>(v[0], v[1], v[2], v[3]);
+                } else {
+                    for (int r = 0; r < nvalid; ++r) c[r] = (T)v[r];
+                }
+            }
+        }
+    }
+    if (EPI != EOE_EPI_GELU && p.colsum) {
+        // rows of this wave's 64x64 sub-tile live on the 16 lanes sharing lane>>4: xor-reduce over lane&15
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = cs[ni][r];
+                t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+                const int n = n_base + ni * 16 + lg * 4 + r;
+                if (lr != 0 || n >= p.N) continue;
+                if (p.colsum_part) {
+                    if (m_base < p.M)
+                        p.colsum_part[eoe_part_index(n, m_base / (16 * MI), (p.M + 16 * MI - 1) / (16 * MI), p.N, p.colsum_blocked)] = t;
+                }
+                else atomicAdd(p.colsum + n, t);
+            }
+        }
+    }
+}
+
+// Fast epilogue (N % 16 == 0, 16-byte aligned rows).  The generic form above is store-ISSUE-bound: one store
+// instruction writes 16 rows x 32 B, and it cost 15-21 k cycles per 256x128 tile -- as long as the 12 k-iterations of a
+// K = 768 GEMM.  Here every 16-row band of the wave's 64 x (16*NI) sub-tile is transposed through a 4-KiB LDS scratch
+// (the wave's OWN 4-KiB piece of the ring slot that was just consumed: only this wave's later LDS-DMA writes there, in
+// program order after these reads), so that a lane holds 16 consecutive columns of one row: bias / residual / saved
+// pre-activation are read, and the result is written, as 64-byte (fp32) or 32-byte (16-bit) contiguous pieces, 4 lanes
+// per row = whole 128/256-byte lines per row.
+// the fast form's precondition, checked by the host for kernels that have no generic fallback compiled in
+static inline bool epilogue_fast_ok(const GemmP& p) {
+    return ((p.N & 15) == 0) && ((p.ldc & 7) == 0) && ((p.ldaux & 7) == 0) && ((((uintptr_t)p.C) & 15) == 0);
+}
+
+template <typename T, int EPI, int NI, int MI = 4, bool GENERIC_FALLBACK = true>
+__device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][NI], int m_base, int n_base, int lane, char* scr) {
+    if (GENERIC_FALLBACK) {
+        const bool fast = ((p.N & 15) == 0) && ((p.ldc & 7) == 0) && ((p.ldaux & 7) == 0) && ((((uintptr_t)p.C) & 15) == 0);
+        if (!fast) {
+            epilogue_generic<T, EPI, NI, MI>(p, acc, m_base, n_base, lane);
+            return;
+        }
+    }
+    const int lr = lane & 15, lg = lane >> 4;
+    const int rrow = lane >> 2, rq = lane & 3;                 // read side: row of the band, 16-column group
+    const int n = n_base + rq * 16;
+    const bool col_ok = (rq < NI) && (n < p.N);
+    float cs[16], cs2[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { cs[c] = 0.f; cs2[c] = 0.f; }
+    float bias[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) bias[c] = 0.f;
+    if (p.bias && col_ok) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bv = *(const f32x4*)(p.bias + n + q * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bias[q * 4 + r] = bv[r];
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        // accumulator layout -> LDS [16 rows][64 cols] fp32, 16-B chunk index XOR row (bank spread)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) *(f32x4*)(scr + lr * 256 + (((ni * 4 + lg) ^ lr) << 4)) = acc[mi][ni];
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 t = *(const f32x4*)(scr + rrow * 256 + (((rq * 4 + q) ^ rrow) << 4));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[q * 4 + r] = t[r] * p.alpha + bias[q * 4 + r];
+        }
+        const int m = m_base + mi * 16 + rrow;
+        if (m >= p.M || !col_ok) continue;
+        const size_t off = (size_t)m * p.ldc + n;
+        if (EPI == EOE_EPI_GELU) {
+            T* pre = (T*)p.aux_out + off;
+            T* act = (T*)p.C + off;
+            float pr[16], ac[16];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const u32x4 pk = pack8<T>(v + 8 * h);          // the saved pre-activation is what backward differentiates:
+                unpack8<T>(pk, pr + 8 * h);                    // activate its ROUNDED value
+                *(u32x4*)(pre + 8 * h) = pk;
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) ac[c] = quick_gelu_f(pr[c]);
+            *(u32x4*)(act) = pack8<T>(ac);
+            *(u32x4*)(act + 8) = pack8<T>(ac + 8);
+            continue;
+        }
+        if (EPI == EOE_EPI_RESIDUAL) {
+            const float* res = (const float*)p.aux + (size_t)m * p.ldaux + n;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 rv = *(const f32x4*)(res + q * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[q * 4 + r] += rv[r];
+            }
+        }
+        if (EPI == EOE_EPI_GELU_BWD) {
+            const T* pre = (const T*)p.aux + (size_t)m * p.ldaux + n;
+            float pr[16];
+            unpack8<T>(*(const u32x4*)pre, pr);
+            unpack8<T>(*(const u32x4*)(pre + 8), pr + 8);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) v[c] *= quick_gelu_grad_f(pr[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) cs[c] += v[c];
+        if (p.colsum_sq) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) cs2[c] += v[c] * v[c];
+        }
+        if (p.out_f32) {
+            float* c = (float*)p.C + off;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 o = {v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]};
+                if (p.accumulate) o += *(const f32x4*)(c + q * 4);
+                *(f32x4*)(c + q * 4) = o;
+            }
+        } else {
+            T* c = (T*)p.C + off;
+            *(u32x4*)(c) = pack8<T>(v);
+            *(u32x4*)(c + 8) = pack8<T>(v + 8);
+        }
+    }
+    if (EPI != EOE_EPI_GELU && p.colsum_part) {
+        // partial-row form: the lanes' 16-column sums go through the wave's LDS scratch ([16 rows][64 cols], the band
+        // transposition's swizzle), lane j then adds column j over the 16 rows and stores ONE float of this wave's partial row
+        // (64 cross-lane shuffles + 64 scattered stores in the atomic form below cost more than a separate pass over C)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *(f32x4*)(scr + rrow * 256 + (((rq * 4 + q) ^ rrow) << 4)) = (f32x4){cs[q * 4], cs[q * 4 + 1], cs[q * 4 + 2], cs[q * 4 + 3]};
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += *(const float*)(scr + r * 256 + ((((lane >> 2) ^ r) << 4) | ((lane & 3) << 2)));
+        const int nn = n_base + lane;
+        const bool st_ok = lane < 16 * NI && nn < p.N && m_base < p.M;
+        if (!p.colsum_sq) {
+            if (st_ok) p.colsum_part[eoe_part_index(nn, m_base / (16 * MI), (p.M + 16 * MI - 1) / (16 * MI), p.N, p.colsum_blocked)] = t;
+        } else {
+            // BatchNorm statistics: row [2][N] = (sum, sum of squares) of this wave's 16*MI output rows
+            if (st_ok) p.colsum_part[((size_t)(m_base / (16 * MI)) * 2) * p.N + nn] = t;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *(f32x4*)(scr + rrow * 256 + (((rq * 4 + q) ^ rrow) << 4)) = (f32x4){cs2[q * 4], cs2[q * 4 + 1], cs2[q * 4 + 2], cs2[q * 4 + 3]};
+            float t2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t2 += *(const float*)(scr + r * 256 + ((((lane >> 2) ^ r) << 4) | ((lane & 3) << 2)));
+            if (st_ok) p.colsum_part[((size_t)(m_base / (16 * MI)) * 2 + 1) * p.N + nn] = t2;
+        }
+    } else if (EPI != EOE_EPI_GELU && p.colsum) {
+        // the 16 rows of a band sit on lanes with equal lane&3: xor-reduce over lane>>2, then 4 lanes x 16 atomics
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            float t = cs[c];
+            t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+            if (rrow == 0 && col_ok) atomicAdd(p.colsum + n + c, t);
+        }
+    }
+}
+
+// the epilogue-only arguments are re-read from the kernarg segment at the point of use (behind an opaque pointer), so
+// that they do not occupy ~40 SGPRs across the k-loop (the loop otherwise carries SGPR spills and extra waits)
+__device__ __forceinline__ void load_epilogue_args(GemmP& ep, const GemmP& p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __attribute__((address_space(4))) char* kp =
+        (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    __builtin_memcpy(&ep, (const void*)kp, sizeof(GemmP));
+#else
+    ep = p;
+#endif
+}
+
+#define EOE_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define EOE_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+static inline int num_cus() {
+    static const int ncu = [] { int d = 0, n = 256; hipDeviceProp_t pr; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) n = pr.multiProcessorCount; return n; }();
+    return ncu;
+}
+
+static int finish_colsum(const GemmP& p, int epi, int mi, hipStream_t s) {
+    if (!p.colsum_part || !p.colsum || p.colsum_sq || epi == EOE_EPI_GELU) return 0;
+    return eoe_finish_reduce(p.colsum_part, cdiv(p.M, 16 * mi), p.N, p.N, p.colsum, nullptr, nullptr, p.colsum_blocked, s);
+}
+
+}  // namespace

@@ -21,8 +21,10 @@ def ops():
 
 # tile shapes of the NT GEMM (nt_flags of gemm.hip; bit 0 = the shipped fast epilogue): the launcher's own choice (which includes
 # the 256x64 two-workgroup kernel for N <= 64), the persistent 256-row kernel (also for N <= 64: bit 6), and the two-workgroup
-# kernel with 128- and with 160-row tiles -- every test below must hold for each
-NT_VARIANTS = {"auto": 1, "persistent256": 1 | 4 | 64, "two_wg_128": 1 | 8 | 16, "two_wg_160": 1 | 8 | 32}
+# kernel with 128- and with 160-row tiles, and the one-wave-per-SIMD kernel (gemm256.hip) with 160x256 and 256x256 tiles -- every
+# test below must hold for each
+NT_VARIANTS = {"auto": 1, "persistent256": 1 | 4 | 64, "two_wg_128": 1 | 8 | 16, "two_wg_160": 1 | 8 | 32,
+               "one_wave_160x256": 1 | 128, "one_wave_256x256": 1 | 256}
 
 
 @pytest.fixture(params=list(NT_VARIANTS))
