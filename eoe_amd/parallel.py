@@ -43,6 +43,65 @@ def shard_rows(n_normal: int, n_oe: int, rank: int, world: int) -> torch.Tensor:
     return torch.cat([torch.arange(a, b), n_normal + torch.arange(c, d)])
 
 
+class NativeComm:
+    """the C-ABI communicator (`eoe_comm_*`, csrc/comm.cpp): RCCL behind libeoe_hip.so with its own side stream, for callers
+    that drive the hot path without torch.distributed collectives.  The 128-byte RCCL id is made on rank 0 and handed to the
+    other ranks through the torch.distributed process group that the launcher set up (any backend; world 1 needs none)."""
+
+    def __init__(self, rank: int = None, world: int = None, device: int = None, algo: int = None):
+        import ctypes as C
+        from . import _lib
+        self._lib, self._C = _lib, C
+        if world is None:
+            world = dist.get_world_size() if dist.is_initialized() else 1
+            rank = dist.get_rank() if dist.is_initialized() else 0
+        self.rank, self.world = rank, world
+        self.device = torch.cuda.current_device() if device is None else device
+        self.algo = _lib.EOE_COMM_ALGO_RING if algo is None else algo
+        ident = torch.zeros(_lib.EOE_COMM_ID_BYTES, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_char * _lib.EOE_COMM_ID_BYTES)()
+            _lib.check(_lib.lib.eoe_comm_unique_id(buf), "eoe_comm_unique_id")
+            ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        if world > 1:
+            dev = torch.device("cuda", self.device) if dist.get_backend() == "nccl" else torch.device("cpu")
+            ident = ident.to(dev)
+            dist.broadcast(ident, src=0)
+            ident = ident.cpu()
+        handle = C.c_void_p()
+        raw = bytes(ident.numpy().tobytes())
+        _lib.check(_lib.lib.eoe_comm_init(raw, rank, world, self.device, C.byref(handle)), "eoe_comm_init")
+        self.handle = handle
+
+    @staticmethod
+    def _code(t: torch.Tensor) -> int:
+        from . import _lib
+        return {torch.float32: _lib.EOE_F32, torch.float16: _lib.EOE_F16, torch.bfloat16: _lib.EOE_BF16,
+                torch.int64: _lib.EOE_COMM_I64}[t.dtype]
+
+    def all_reduce_async(self, t: torch.Tensor):
+        """SUM all-reduce of a contiguous device tensor, in place, on the communicator's side stream behind the current stream"""
+        assert t.is_cuda and t.is_contiguous()
+        self._lib.check(self._lib.lib.eoe_comm_allreduce_sum_async(self.handle, t.data_ptr(), t.numel(), self._code(t), self.algo,
+                                                                   torch.cuda.current_stream().cuda_stream), "eoe_comm_allreduce_sum_async")
+
+    def all_gather_async(self, t: torch.Tensor) -> torch.Tensor:
+        assert t.is_cuda and t.is_contiguous()
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        self._lib.check(self._lib.lib.eoe_comm_allgather_async(self.handle, t.data_ptr(), out.data_ptr(), t.numel(), self._code(t),
+                                                               torch.cuda.current_stream().cuda_stream), "eoe_comm_allgather_async")
+        return out
+
+    def join(self):
+        """the current stream waits for every collective issued so far"""
+        self._lib.check(self._lib.lib.eoe_comm_join(self.handle, torch.cuda.current_stream().cuda_stream), "eoe_comm_join")
+
+    def close(self):
+        if self.handle is not None:
+            self._lib.check(self._lib.lib.eoe_comm_destroy(self.handle), "eoe_comm_destroy")
+            self.handle = None
+
+
 class GradArena:
     """flat fp32 gradient arena over the trainable parameters of `model` + bucketed all-reduce overlapped with backward.
 
@@ -54,9 +113,10 @@ class GradArena:
     its own stream behind an event of the compute stream.  The sequence of collectives is the same on every rank (it depends
     only on the autograd graph), which is what RCCL needs."""
 
-    def __init__(self, model: torch.nn.Module, process_group=None, bucket_bytes: int = 8 << 20):
+    def __init__(self, model: torch.nn.Module, process_group=None, bucket_bytes: int = 8 << 20, comm: "NativeComm" = None):
         self.model = model
         self.group = process_group
+        self.comm = comm                                  # None: torch.distributed collectives; else the C-ABI communicator
         params = [p for p in model.parameters() if p.requires_grad]
         if not params:
             raise ValueError("no trainable parameters")
@@ -145,7 +205,9 @@ class GradArena:
 
     def _reduce_slice(self, lo, hi):
         self.issued.append((lo, hi))
-        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if self.comm is not None:
+            self.comm.all_reduce_async(self.flat[lo:hi])
+        elif dist.is_initialized() and dist.get_world_size(self.group) > 1:
             self.handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
@@ -166,6 +228,8 @@ class GradArena:
         for h in self.handles:
             h.wait()
         self.handles.clear()
+        if self.comm is not None:
+            self.comm.join()
         self.issued = []
 
 

@@ -363,6 +363,30 @@ int eoe_bn_act_maxpool_bwd(const float* y, const float* stats, const float* gamm
                            int C, int k, int stride, int pad, int training, float slope, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
+ * Data-parallel exchange (new -- the reference is single-device, main/__init__.py:110-114): gradient
+ * SUM all-reduce and score / label all-gather over RCCL on xGMI, one process per GPU.  RCCL is bound at run time (the librccl
+ * already in the process, else the system one); without it these return EOE_ERR_UNSUPPORTED and nothing else is affected.
+ * Rank 0 makes the id (eoe_comm_unique_id) and hands its EOE_COMM_ID_BYTES bytes to the other ranks by any out-of-band channel
+ * (the launcher's store); every rank then calls eoe_comm_init.  The `_async` calls run on the communicator's own side stream
+ * behind everything `after_stream` holds at the time of the call (overlap with the rest of backward); eoe_comm_join makes
+ * `stream` wait for all collectives issued so far.  Buffers are caller-owned device memory.
+ * dtype: EOE_F32 | EOE_F16 | EOE_BF16 | EOE_COMM_I64.  algo: EOE_COMM_ALGO_RING = RCCL's all-reduce; EOE_COMM_ALGO_RS_AG =
+ * in-place reduce-scatter + all-gather (count %% world == 0, else the former): on a fully connected xGMI node every rank
+ * exchanges 1/world of the buffer with every peer at once instead of walking a ring.
+ * ---------------------------------------------------------------------------------------------------- */
+#define EOE_COMM_ID_BYTES 128
+enum { EOE_COMM_I64 = 8 };
+enum { EOE_COMM_ALGO_RING = 0, EOE_COMM_ALGO_RS_AG = 1 };
+typedef struct eoe_comm* eoe_comm_t;
+int eoe_comm_unique_id(void* id_out);
+int eoe_comm_init(const void* id, int rank, int world, int device, eoe_comm_t* out);
+int eoe_comm_destroy(eoe_comm_t comm);
+int eoe_comm_info(eoe_comm_t comm, int* rank, int* world);
+int eoe_comm_allreduce_sum_async(eoe_comm_t comm, void* buf, int64_t count, int dtype, int algo, void* after_stream);
+int eoe_comm_allgather_async(eoe_comm_t comm, const void* send, void* recv, int64_t send_count, int dtype, void* after_stream);
+int eoe_comm_join(eoe_comm_t comm, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
  * Parity mode (SURVEY.md section 7 "Hard parts", section 8d "Parity run"): the convolutions / linear layers of the BatchNorm
  * encoders (cnn.py:73-86, resnet.py:85-149) in plain fp32 -- fp32 activations and fp32 master weights as operands, one fp32 FMA
  * per product in a fixed order, no 16-bit rounding.  A correctness instrument (a register-tiled SGEMM on the vector ALUs), used
