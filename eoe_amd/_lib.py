@@ -14,6 +14,7 @@ from . import _build
 
 ABI_VERSION = 1
 EOE_F16, EOE_BF16, EOE_F32 = 1, 2, 3
+EOE_RESIZE_BILINEAR, EOE_RESIZE_BICUBIC = 2, 3
 EOE_COMM_I64, EOE_COMM_ID_BYTES, EOE_COMM_ALGO_RING, EOE_COMM_ALGO_RS_AG = 8, 128, 0, 1
 EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_GELU_BWD = 0, 1, 2, 3
 ADAM_CHUNK, ADAM_GROUPS = 8192, 4
@@ -174,6 +175,9 @@ SIGNATURES = {
     "eoe_focal_fwd": [_vp, _vp, _i64, _vp, _vp, _vp, C.c_int, _f32, _f32, _f32, _vp],
     "eoe_focal_bwd": [_vp, _vp, _vp, _vp, C.c_int, _f32, _f32, _f32, _vp],
     "eoe_augment_batch": [_vp, _i64, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f32, C.c_uint64, _vp],
+    "eoe_resize_coeffs": [C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.POINTER(C.c_int)],
+    "eoe_resize_pass_u8": [_vp, _vp, _vp, _vp, C.c_int, _i64, C.c_int, C.c_int, C.c_int, _vp],
+    "eoe_color_jitter_u8": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
     "eoe_comm_unique_id": [_vp],
     "eoe_comm_init": [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)],
     "eoe_comm_destroy": [_vp],

@@ -126,6 +126,94 @@ def augment_batch(src_u8, params, out_hw, mean=None, std=None, flip_first=True, 
     return out
 
 
+def _resize_tables(in_size, out_size, filt, device):
+    """Pillow's filter taps for one axis from the library's host helper, uploaded once"""
+    import ctypes as C
+    from ._lib import check, lib
+    k = C.c_int(0)
+    check(lib.eoe_resize_coeffs(in_size, out_size, filt, None, None, 0, C.byref(k)), "eoe_resize_coeffs")
+    bounds = torch.empty((out_size, 2), dtype=torch.int32)
+    kk = torch.empty((out_size, k.value), dtype=torch.int32)
+    check(lib.eoe_resize_coeffs(in_size, out_size, filt, bounds.data_ptr(), kk.data_ptr(), k.value, None), "eoe_resize_coeffs")
+    return bounds.to(device), kk.to(device), k.value
+
+
+def resize_u8(src_u8, size, interpolation="bilinear"):
+    """`torchvision.transforms.Resize(size)` as the reference applies it to PIL images (`main/train_imagenet.py:31`,
+    `main/train_clip_imagenet.py:28`; bicubic for CLIP's preprocessing, `clip_official/clip/clip.py:60`), on a uint8 NHWC image
+    set in HBM and byte-exact with Pillow: `size` = (h, w), or an int = the shorter side (the other int(size * long / short)).
+    Deterministic, so a resident dataset is resized ONCE, not per step."""
+    from ._lib import check, lib, EOE_RESIZE_BILINEAR, EOE_RESIZE_BICUBIC
+    if not src_u8.is_cuda:
+        raise RuntimeError("resize_u8 needs a GPU tensor (there is no CPU fallback)")
+    assert src_u8.dtype == torch.uint8 and src_u8.dim() == 4 and src_u8.shape[3] == 3 and src_u8.is_contiguous()
+    filt = {"bilinear": EOE_RESIZE_BILINEAR, "bicubic": EOE_RESIZE_BICUBIC}[interpolation]
+    n, H, W, _ = src_u8.shape
+    if isinstance(size, int):
+        Ho, Wo = (int(size * H / W), size) if W <= H else (size, int(size * W / H))
+    else:
+        Ho, Wo = size
+    st = torch.cuda.current_stream().cuda_stream
+    cur = src_u8
+    if Wo != W:
+        b, k, ks = _resize_tables(W, Wo, filt, src_u8.device)
+        nxt = torch.empty((n, H, Wo, 3), dtype=torch.uint8, device=src_u8.device)
+        check(lib.eoe_resize_pass_u8(cur.data_ptr(), nxt.data_ptr(), b.data_ptr(), k.data_ptr(), ks, n * H, W, Wo, 3, st), "eoe_resize_pass_u8")
+        cur = nxt
+    if Ho != H:
+        b, k, ks = _resize_tables(H, Ho, filt, src_u8.device)
+        nxt = torch.empty((n, Ho, Wo, 3), dtype=torch.uint8, device=src_u8.device)
+        check(lib.eoe_resize_pass_u8(cur.data_ptr(), nxt.data_ptr(), b.data_ptr(), k.data_ptr(), ks, n, H, Ho, Wo * 3, st), "eoe_resize_pass_u8")
+        cur = nxt
+    return cur
+
+
+def color_jitter_u8(src_u8, idx, factors, order):
+    """`torchvision.transforms.ColorJitter` with its random draws made explicit (`main/train_cifar.py:32`,
+    `main/train_clip_imagenet.py:29`: brightness = contrast = saturation = hue = 0.01), byte-exact with Pillow: gathers
+    src_u8[idx] (uint8 NHWC) and applies, per image, the four ops in `order` (int32 [n, 4], a permutation of 0 brightness,
+    1 contrast, 2 saturation, 3 hue) with `factors` (fp32 [n, 4] = b, c, s around 1 and h around 0) -> uint8 [n, H, W, 3]"""
+    from ._lib import check, lib
+    if not src_u8.is_cuda:
+        raise RuntimeError("color_jitter_u8 needs GPU tensors (there is no CPU fallback)")
+    dev = src_u8.device
+    idx = idx.to(device=dev, dtype=torch.int32).contiguous()
+    factors = factors.to(device=dev, dtype=torch.float32).contiguous()
+    order = order.to(device=dev, dtype=torch.int32).contiguous()
+    n, (_, H, W, _) = idx.shape[0], src_u8.shape
+    assert factors.shape == (n, 4) and order.shape == (n, 4) and src_u8.dtype == torch.uint8 and src_u8.is_contiguous()
+    out = torch.empty((n, H, W, 3), dtype=torch.uint8, device=dev)
+    scratch = torch.empty(n, dtype=torch.int32, device=dev)
+    check(lib.eoe_color_jitter_u8(src_u8.data_ptr(), src_u8.shape[0], idx.data_ptr(), factors.data_ptr(), order.data_ptr(),
+                                  scratch.data_ptr(), out.data_ptr(), n, H, W, torch.cuda.current_stream().cuda_stream), "eoe_color_jitter_u8")
+    return out
+
+
+def sample_color_jitter(n, brightness, contrast, saturation, hue, generator=None):
+    """the draws of `ColorJitter.get_params`: a random permutation of the four ops and uniform factors in
+    [max(0, 1 - x), 1 + x] (hue: [-x, x]) per image"""
+    order = torch.stack([torch.randperm(4, generator=generator) for _ in range(n)]).to(torch.int32)
+    u = torch.rand((n, 4), generator=generator)
+    lo = torch.tensor([max(0.0, 1 - brightness), max(0.0, 1 - contrast), max(0.0, 1 - saturation), -hue])
+    hi = torch.tensor([1 + brightness, 1 + contrast, 1 + saturation, hue])
+    return (lo + u * (hi - lo)).to(torch.float32), order
+
+
+CLIP_MEAN, CLIP_STD = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)      # clip.py:64
+
+
+def clip_preprocess(src_u8, n_px=224):
+    """CLIP's `_transform` (`clip_official/clip/clip.py:58-65`): Resize(n_px, bicubic) -> CenterCrop(n_px) -> ToTensor ->
+    Normalize(CLIP mean / std), on a uint8 NHWC set in HBM -> fp32 NCHW"""
+    r = resize_u8(src_u8, n_px, "bicubic")
+    n, H, W, _ = r.shape
+    # torchvision's CenterCrop: top = int(round((H - n_px) / 2.0))
+    idx = torch.arange(n)
+    p = torch.stack([idx, torch.full_like(idx, int(round((H - n_px) / 2.0))), torch.full_like(idx, int(round((W - n_px) / 2.0))),
+                     torch.zeros_like(idx)], dim=1).to(torch.int32).to(r.device)
+    return augment_batch(r, p, (n_px, n_px), CLIP_MEAN, CLIP_STD, True, 0.0, 0)
+
+
 class ResidentImageSource:
     """one-vs-rest step-batch source whose uint8 images live in HBM: every step batch ([normal half | OE half], the
     BalancedConcatLoader contract of `datasets/bases.py:570-600`) is gathered, cropped, flipped, noised and normalised by one
@@ -135,9 +223,16 @@ class ResidentImageSource:
     nominal_label, anomalous_label = 0, 1
 
     def __init__(self, normal_u8, oe_u8, test_u8, test_labels, crop, padding=0, mean=None, std=None, flip_first=True,
-                 noise_std=0.001, seed=0, device="cuda"):
+                 noise_std=0.001, seed=0, device="cuda", resize=None, test_resize=None, color_jitter=None, interpolation="bilinear"):
+        """resize / test_resize: `transforms.Resize` argument applied once to the resident train / test sets (None: as given);
+        color_jitter: (brightness, contrast, saturation, hue) of `transforms.ColorJitter`, drawn per sample per step"""
         dev = torch.device(device)
         self.normal, self.oe, self.test = (t.to(dev).contiguous() for t in (normal_u8, oe_u8, test_u8))
+        if resize is not None:
+            self.normal, self.oe = resize_u8(self.normal, resize, interpolation), resize_u8(self.oe, resize, interpolation)
+        if test_resize is not None:
+            self.test = resize_u8(self.test, test_resize, interpolation)
+        self.color_jitter = color_jitter
         self.test_y = test_labels.clone()
         self.crop, self.padding, self.mean, self.std = int(crop), int(padding), mean, std
         self.flip_first, self.noise_std, self.seed = flip_first, noise_std, int(seed)
@@ -165,8 +260,17 @@ class ResidentImageSource:
             pn = self._params(ni, self.normal.shape[1], self.normal.shape[2]).to(dev)
             po = self._params(oi, self.oe.shape[1], self.oe.shape[2]).to(dev)
             seed = (self.seed * 65521 + self._step) % (1 << 23)
-            xn = augment_batch(self.normal, pn, (self.crop, self.crop), self.mean, self.std, self.flip_first, self.noise_std, 2 * seed)
-            xo = augment_batch(self.oe, po, (self.crop, self.crop), self.mean, self.std, self.flip_first, self.noise_std, 2 * seed + 1)
+            src_n, src_o = self.normal, self.oe
+            if self.color_jitter is not None:
+                # ColorJitter comes first in the reference's chains (train_cifar.py:32, train_clip_imagenet.py:29): the gathered,
+                # jittered uint8 images become the "set" the crop / flip kernel reads (slot i = image i)
+                fn, on = sample_color_jitter(len(ni), *self.color_jitter, generator=self._g)
+                fo, oo = sample_color_jitter(len(oi), *self.color_jitter, generator=self._g)
+                src_n, src_o = color_jitter_u8(self.normal, ni, fn, on), color_jitter_u8(self.oe, oi, fo, oo)
+                pn[:, 0] = torch.arange(len(ni), dtype=torch.int32, device=dev)
+                po[:, 0] = torch.arange(len(oi), dtype=torch.int32, device=dev)
+            xn = augment_batch(src_n, pn, (self.crop, self.crop), self.mean, self.std, self.flip_first, self.noise_std, 2 * seed)
+            xo = augment_batch(src_o, po, (self.crop, self.crop), self.mean, self.std, self.flip_first, self.noise_std, 2 * seed + 1)
             lbls = torch.cat([torch.zeros(len(ni), dtype=torch.int64), torch.ones(len(oi), dtype=torch.int64)])
             yield torch.cat([xn, xo]), lbls, torch.cat([ni, oi + n])          # OE indices offset by the normal set size (bases.py:597)
 

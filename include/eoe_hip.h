@@ -363,6 +363,28 @@ int eoe_bn_act_maxpool_bwd(const float* y, const float* stats, const float* gamm
                            int C, int k, int stride, int pad, int training, float slope, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
+ * Resize and ColorJitter of the input pipeline (N1; main/train_imagenet.py:30-31 Resize(256), main/train_clip_imagenet.py:28-29
+ * Resize((256,256)) + ColorJitter(0.01 x 4), main/train_cifar.py:32, CLIP's clip_official/clip/clip.py:58-65 bicubic Resize(224)).
+ * The reference runs them on PIL images (torchvision -> Pillow); these reproduce Pillow's 8-bit arithmetic byte for byte.
+ *   eoe_resize_coeffs   HOST helper: Pillow's antialiased filter taps for one axis (Resample.c), 22-bit fixed point.
+ *                       bounds int32 [out_size][2] = (first source index, taps); kk int32 [out_size][ksize_cap].
+ *                       bounds == NULL or kk == NULL: only *ksize_out (taps per output) is returned.
+ *   eoe_resize_pass_u8  one separable pass over uint8 data viewed as [outer, axis_in, inner] -> [outer, axis_out, inner]
+ *                       (bounds / kk on the DEVICE): horizontal pass outer = n*H, inner = 3; vertical pass outer = n,
+ *                       inner = Wo*3.  Image.resize = horizontal, then vertical, each skipped when the size is unchanged.
+ *   eoe_color_jitter_u8 dst[slot] = ColorJitter of src[idx[slot]] (uint8 NHWC [., H, W, 3]): factors fp32 [n][4] =
+ *                       (brightness, contrast, saturation around 1; hue around 0) as torchvision samples them, order int32
+ *                       [n][4] = the permutation in which the four ops (0..3) are applied; an entry outside 0..3 skips.
+ *                       gray_mean_scratch: n int32.
+ * ---------------------------------------------------------------------------------------------------- */
+enum { EOE_RESIZE_BILINEAR = 2, EOE_RESIZE_BICUBIC = 3 };   /* PIL.Image.BILINEAR / BICUBIC */
+int eoe_resize_coeffs(int in_size, int out_size, int filter, int32_t* bounds, int32_t* kk, int ksize_cap, int* ksize_out);
+int eoe_resize_pass_u8(const uint8_t* src, uint8_t* dst, const int32_t* bounds, const int32_t* kk, int ksize, int64_t outer,
+                       int axis_in, int axis_out, int inner, void* stream);
+int eoe_color_jitter_u8(const uint8_t* src, int64_t n_src, const int32_t* idx, const float* factors, const int32_t* order,
+                        int32_t* gray_mean_scratch, uint8_t* dst, int n, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
  * Data-parallel exchange (new -- the reference is single-device, main/__init__.py:110-114): gradient
  * SUM all-reduce and score / label all-gather over RCCL on xGMI, one process per GPU.  RCCL is bound at run time (the librccl
  * already in the process, else the system one); without it these return EOE_ERR_UNSUPPORTED and nothing else is affected.

@@ -525,6 +525,57 @@ def g13():
     save("g13_wideresnet32_hsc", losses=losses, scores=scores, **first)
 
 
+def g14():
+    """Resize / ColorJitter / CLIP preprocessing as the reference's runners apply them to PIL images (train_imagenet.py:31,
+    train_clip_imagenet.py:28-29, train_cifar.py:32, clip_official/clip/clip.py:58-65).  torchvision is absent here; its PIL code
+    path is a thin wrapper over Pillow (functional_pil: Image.resize, ImageEnhance.Brightness / Contrast / Color, HSV round
+    trip with `np_h += np.uint8(hue_factor * 255)`), so the fixture calls Pillow -- the third-party arithmetic -- directly."""
+    from PIL import Image, ImageEnhance
+    import PIL
+    out = {"pillow_version": np.array(PIL.__version__)}
+    rng_img = (fill.fill("g14/img", (3, 75, 100, 3), std=0.6, mean=0.0) * 128 + 128).clip(0, 255).astype(np.uint8)
+    rng_img[0, :20, :30] = 0
+    rng_img[0, 20:30, :10] = 255
+    rng_img[1, 40:50, 50:70] = rng_img[1, 40:50, 50:70, :1]                   # a gray patch (s = 0 in HSV)
+    out["images"] = rng_img
+    for name, size, filt in (("bilinear_64x48", (64, 48), Image.BILINEAR), ("bilinear_32x32", (32, 32), Image.BILINEAR),
+                             ("bilinear_150x200", (150, 200), Image.BILINEAR), ("bicubic_64x48", (64, 48), Image.BICUBIC),
+                             ("bicubic_150x200", (150, 200), Image.BICUBIC)):
+        out[f"resize/{name}"] = np.stack([np.asarray(Image.fromarray(im).resize((size[1], size[0]), filt)) for im in rng_img])
+    # torchvision Resize(int): shorter side -> size, longer side int(size * long / short)
+    out["resize/bicubic_short56"] = np.stack([np.asarray(Image.fromarray(im).resize((int(56 * 100 / 75), 56), Image.BICUBIC)) for im in rng_img])
+
+    def tv_hue(img, hue_factor):                          # torchvision.transforms.functional_pil.adjust_hue
+        h, s, v = img.convert("HSV").split()
+        np_h = np.array(h, dtype=np.uint8)
+        with np.errstate(over="ignore"):
+            np_h += np.uint8(int(hue_factor * 255) & 0xFF)
+        return Image.merge("HSV", (Image.fromarray(np_h, "L"), s, v)).convert("RGB")
+
+    ops = [lambda im, f: ImageEnhance.Brightness(im).enhance(f), lambda im, f: ImageEnhance.Contrast(im).enhance(f),
+           lambda im, f: ImageEnhance.Color(im).enhance(f), tv_hue]
+    factors = np.array([[0.993, 1.008, 0.991, 0.0071], [1.0095, 0.9902, 1.0049, -0.0093], [0.7, 1.6, 0.4, 0.31]], np.float32)
+    orders = np.array([[0, 1, 2, 3], [3, 1, 0, 2], [2, 3, 1, 0]], np.int32)
+    jit = []
+    for im, f, o in zip(rng_img, factors, orders):
+        pim = Image.fromarray(im)
+        for op in o:
+            pim = ops[int(op)](pim, float(f[int(op)]))
+        jit.append(np.asarray(pim))
+    out["jitter/factors"], out["jitter/orders"], out["jitter/out"] = factors, orders, np.stack(jit)
+    # CLIP _transform(32) on the 75 x 100 images: Resize(32, bicubic) -> CenterCrop(32) -> ToTensor -> Normalize
+    mean = np.array([0.48145466, 0.4578275, 0.40821073], np.float32).reshape(1, 3, 1, 1)
+    std = np.array([0.26862954, 0.26130258, 0.27577711], np.float32).reshape(1, 3, 1, 1)
+    res = []
+    for im in rng_img:
+        r = np.asarray(Image.fromarray(im).resize((int(32 * 100 / 75), 32), Image.BICUBIC))
+        top, left = int(round((r.shape[0] - 32) / 2.0)), int(round((r.shape[1] - 32) / 2.0))
+        res.append(r[top:top + 32, left:left + 32])
+    t = torch.from_numpy(np.stack(res)).permute(0, 3, 1, 2).float().div(255)           # ToTensor
+    out["clip/out"] = ((t.numpy() - mean) / std).astype(np.float32)
+    save("g14_pil_transforms", **out)
+
+
 def g3big():
     """the 12-layer ViT-B/32 + head, ONE full fine-tune step at the benchmark batch (128 + 128 images = 12 800 token
     rows): features, loss, scores and per-tensor gradient summaries, plus the loss of a second step (which sees the
@@ -539,6 +590,6 @@ def g3big():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12",
-                             "g2big", "g11big", "g5big", "g3big", "g13"]
+                             "g2big", "g11big", "g5big", "g3big", "g13", "g14"]
     for w in which:
         globals()[w]()

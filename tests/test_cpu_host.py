@@ -130,3 +130,23 @@ def test_header_is_plain_c():
     hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "eoe_hip.h")
     r = subprocess.run([gcc, "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Werror", hdr], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_resize_coefficient_tables_equal_the_oracle():
+    """the library's HOST helper eoe_resize_coeffs (Pillow's precompute_coeffs + 8 bpc normalisation) against the oracle's table,
+    which the fixture g14 pins to Pillow: identical integers for down- and up-scaling, both filters"""
+    import ctypes as C
+    import numpy as np
+    from eoe_amd import _lib
+    from oracle import augment
+    for in_size, out_size in ((100, 48), (75, 150), (256, 224), (500, 256), (32, 32), (7, 3)):
+        for name, code in (("bilinear", _lib.EOE_RESIZE_BILINEAR), ("bicubic", _lib.EOE_RESIZE_BICUBIC)):
+            k = C.c_int(0)
+            _lib.check(_lib.lib.eoe_resize_coeffs(in_size, out_size, code, None, None, 0, C.byref(k)), "size query")
+            bounds = np.zeros((out_size, 2), np.int32)
+            kk = np.full((out_size, k.value), -7, np.int32)
+            _lib.check(_lib.lib.eoe_resize_coeffs(in_size, out_size, code, bounds.ctypes.data, kk.ctypes.data, k.value, None), "tables")
+            rb, rk = augment.resize_coeffs(in_size, out_size, name)
+            assert rk.shape[1] == k.value and np.array_equal(bounds, rb), (in_size, out_size, name)
+            assert np.array_equal(kk, rk), (in_size, out_size, name)
+    assert _lib.lib.eoe_resize_coeffs(0, 4, _lib.EOE_RESIZE_BILINEAR, None, None, 0, None) != 0

@@ -379,3 +379,25 @@ def test_wideresnet32(golden):
     batches = [trainer.synthetic_batch(f"g13/b{i}", 128, 128, 32) for i in range(4)]
     out = trainer.train_steps(m, batches, "hsc", lr=1e-3, weight_decay=0.0)
     _traj_check(out, g, steps=4, labels=batches[0][1].numpy())
+
+
+# ------------------------------------------------------------------------------------------- Resize / ColorJitter / CLIP preprocessing vs Pillow
+def test_pil_transforms_oracle(golden):
+    """oracle/augment.py's integer restatement of Pillow's resize (bilinear / bicubic, antialiased), ImageEnhance blends and 8-bit HSV
+    hue shift against the bytes Pillow itself produced (fixture g14): bit-exact; CLIP's _transform within 1e-6"""
+    from oracle import augment
+    g = golden("g14_pil_transforms")
+    imgs = g["images"]
+    for name, size, filt in (("bilinear_64x48", (64, 48), "bilinear"), ("bilinear_32x32", (32, 32), "bilinear"),
+                             ("bilinear_150x200", (150, 200), "bilinear"), ("bicubic_64x48", (64, 48), "bicubic"),
+                             ("bicubic_150x200", (150, 200), "bicubic"), ("bicubic_short56", 56, "bicubic")):
+        got = np.stack([augment.resize(im, size, filt) for im in imgs])
+        assert np.array_equal(got, g[f"resize/{name}"]), name
+    jit = np.stack([augment.color_jitter(im, f, o) for im, f, o in zip(imgs, g["jitter/factors"], g["jitter/orders"])])
+    assert np.array_equal(jit, g["jitter/out"])
+    r = np.stack([augment.resize(im, 32, "bicubic") for im in imgs])
+    top, left = int(round((r.shape[1] - 32) / 2.0)), int(round((r.shape[2] - 32) / 2.0))
+    p = np.stack([np.arange(3), np.full(3, top), np.full(3, left), np.zeros(3, int)], axis=1)
+    clip = augment.augment_batch(r, p, 32, 32, mean=(0.48145466, 0.4578275, 0.40821073), std=(0.26862954, 0.26130258, 0.27577711),
+                                 noise_std=0.0)
+    np.testing.assert_allclose(clip, g["clip/out"], rtol=0, atol=1e-6)
