@@ -116,11 +116,22 @@ __global__ __launch_bounds__(256) void resize_pass_kernel(const uint8_t* __restr
     }
 }
 
+// Pillow's C code is compiled without fused multiply-adds; hipcc contracts a * b + c by default -- also through __fmul_rn /
+// __fadd_rn, which are plain operators in HIP's headers -- and a blend that lands within one ulp of an integer then truncates
+// to the neighbouring byte (saturation 0.99 on a gray level of 100: 100 - 99.00000095 = 0.99999905 -> 0 instead of 1)
+#pragma clang fp contract(off)
+// single IEEE operations compiled under the pragma above (HIP's __fmul_rn / __fadd_rn are header inlines that carry the default
+// `contract` flag and still fuse)
+__device__ __forceinline__ float add_(float a, float b) { return a + b; }
+__device__ __forceinline__ float sub_(float a, float b) { return a - b; }
+__device__ __forceinline__ float mul_(float a, float b) { return a * b; }
+__device__ __forceinline__ float div_(float a, float b) { return a / b; }
+
 __device__ __forceinline__ int gray_l(int r, int g, int b) { return (r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16; }
 
 // Blend.c: in1 + alpha * (in2 - in1) as separate float multiply and add (no fused multiply-add), truncated
 __device__ __forceinline__ int blend_u8(int deg, int v, float alpha) {
-    const float t = __fadd_rn((float)deg, __fmul_rn(alpha, (float)(v - deg)));
+    const float t = add_((float)deg, mul_(alpha, (float)(v - deg)));
     if (alpha >= 0.f && alpha <= 1.f) return (int)t & 255;
     return t <= 0.f ? 0 : (t >= 255.f ? 255 : (int)t);
 }
@@ -130,10 +141,10 @@ __device__ __forceinline__ void rgb2hsv_u8(int r, int g, int b, int& uh, int& us
     uv = maxc;
     if (minc == maxc) { uh = 0; us = 0; return; }
     const float cr = (float)(maxc - minc);
-    const float s = __fdiv_rn(cr, (float)maxc);
-    const float rc = __fdiv_rn((float)(maxc - r), cr), gc = __fdiv_rn((float)(maxc - g), cr), bc = __fdiv_rn((float)(maxc - b), cr);
+    const float s = div_(cr, (float)maxc);
+    const float rc = div_((float)(maxc - r), cr), gc = div_((float)(maxc - g), cr), bc = div_((float)(maxc - b), cr);
     float h;
-    if (r == maxc) h = __fsub_rn(bc, gc);
+    if (r == maxc) h = sub_(bc, gc);
     else if (g == maxc) h = (float)(2.0 + (double)rc - (double)bc);
     else h = (float)(4.0 + (double)gc - (double)rc);
     h = (float)fmod((double)h / 6.0 + 1.0, 1.0);
@@ -144,14 +155,14 @@ __device__ __forceinline__ void rgb2hsv_u8(int r, int g, int b, int& uh, int& us
 
 __device__ __forceinline__ void hsv2rgb_u8(int h, int s, int v, int& r, int& g, int& b) {
     if (s == 0) { r = g = b = v; return; }
-    const float hf = __fdiv_rn(__fmul_rn((float)h, 6.0f), 255.0f);
+    const float hf = div_(mul_((float)h, 6.0f), 255.0f);
     const int i = (int)floorf(hf);
-    const float f = __fsub_rn(hf, (float)i);
-    const float fs = __fdiv_rn((float)s, 255.0f);
+    const float f = sub_(hf, (float)i);
+    const float fs = div_((float)s, 255.0f);
     const float vf = (float)v;
-    const int p = (int)floor((double)__fmul_rn(vf, __fsub_rn(1.0f, fs)) + 0.5);
-    const int q = (int)floor((double)__fmul_rn(vf, __fsub_rn(1.0f, __fmul_rn(fs, f))) + 0.5);
-    const int t = (int)floor((double)__fmul_rn(vf, __fsub_rn(1.0f, __fmul_rn(fs, __fsub_rn(1.0f, f)))) + 0.5);
+    const int p = (int)floor((double)mul_(vf, sub_(1.0f, fs)) + 0.5);
+    const int q = (int)floor((double)mul_(vf, sub_(1.0f, mul_(fs, f))) + 0.5);
+    const int t = (int)floor((double)mul_(vf, sub_(1.0f, mul_(fs, sub_(1.0f, f)))) + 0.5);
     switch (i % 6) {
         case 0: r = v; g = t; b = p; break;
         case 1: r = q; g = v; b = p; break;

@@ -254,7 +254,8 @@ class ResidentImageSource:
         oe_order = oe_idx[torch.randperm(len(oe_idx), generator=self._g)]
         dev = self.normal.device
         for s in range(0, n, batch_size):
-            ni, oi = perm[s:s + batch_size], oe_order[s:s + batch_size]
+            ni = perm[s:s + batch_size]
+            oi = oe_order[s:s + batch_size][:len(ni)]            # the OE half is cut to the normal half's size (bases.py:597)
             self._step += 1
             # two launches (normal half from its image set, OE half from the other), written into one batch tensor
             pn = self._params(ni, self.normal.shape[1], self.normal.shape[2]).to(dev)
