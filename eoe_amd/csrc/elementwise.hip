@@ -320,12 +320,12 @@ __global__ __launch_bounds__(512) void layernorm_bwd_kernel(const void* __restri
 #pragma unroll
     for (int i = 0; i < NV; ++i)
         if (i < nv) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                red[0][wave][i * 256 + lane * 4 + r] = ag[i][r];
-                red[1][wave][i * 256 + lane * 4 + r] = ab[i][r];
-                red[2][wave][i * 256 + lane * 4 + r] = ax[i][r];
-            }
+            // 16-byte stores (four scalar stores per lane at a 16-B lane stride were a 4-way bank conflict each).
+            // (round 2: software-pipelining the wave's rows -- next row's loads ahead of this row's reductions -- raised the
+            //  kernel to 174 VGPRs = one workgroup per CU and measured the same 0.87 ms / step; reverted)
+            *(f32x4*)&red[0][wave][i * 256 + lane * 4] = ag[i];
+            *(f32x4*)&red[1][wave][i * 256 + lane * 4] = ab[i];
+            *(f32x4*)&red[2][wave][i * 256 + lane * 4] = ax[i];
         }
     __syncthreads();
     for (int c = threadIdx.x; c < D; c += blockDim.x) {
