@@ -202,6 +202,10 @@ __device__ __forceinline__ f32x4 token_sum(const f32x4 (&o)[4], int L, int lr) {
     }
     return t;
 }
+// (round 2, measured and rejected: TWO waves per (image, head) -- wave 0 = phase A / dQ, wave 1 = phase B / dK, dV, sharing the three
+//  LDS images, the row statistics handed over behind one workgroup barrier; bitwise identical results, but 256 VGPRs + 88 B of
+//  scratch per lane = four workgroups per CU, and 0.89 ms per step against 0.85: the kernel is not a per-wave latency chain that
+//  more waves would hide -- the fragment-shaped 8-byte stores of dQ / dK / dV and the row-strided loads bound it.)
 template <typename T>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                       T* __restrict__ dqkv, float* __restrict__ bias_part, int L, int heads,
