@@ -39,7 +39,7 @@ extern "C" int eoe_struct_size(int which) {
 extern "C" const char* eoe_last_error(void) { return g_eoe_err; }
 
 namespace {
-struct Rec { const char* name; hipEvent_t a, b; double flops, bytes; };
+struct Rec { char name[32]; hipEvent_t a, b; double flops, bytes; };      // the name is copied: callers may build it on their stack
 std::mutex g_mu;
 bool g_on = false;
 std::vector<Rec> g_recs;
@@ -49,7 +49,9 @@ bool eoe_prof_active() { return g_on; }
 
 int eoe_prof_begin(const char* name, double flops, double bytes, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_mu);
-    Rec r{name, nullptr, nullptr, flops, bytes};
+    Rec r{};
+    strncpy(r.name, name, sizeof(r.name) - 1);
+    r.flops = flops; r.bytes = bytes;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
     (void)hipEventRecord(r.a, s);
     g_recs.push_back(r);

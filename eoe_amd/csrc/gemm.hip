@@ -686,7 +686,28 @@ int launch_nt(const GemmP& p, int epi, int gather, hipStream_t s) {
     if (!p.colsum_sq && (g_nt_flags & (128 | 256)) && epilogue_fast_ok(p))
         return eoe_launch_nt256(&p, std::is_same<T, f16_t>::value ? EOE_F16 : EOE_BF16, epi, (g_nt_flags & 256) ? 8 : 5, s);
     const bool big = p.K >= 4096 && p.N >= 2048;
-    // large square problems: 256x256 tiles, one wave per SIMD (4096^3: 1100-1140 TF against 1040 of the persistent 256x128 kernel)
+    // The one-wave-per-SIMD kernel (gemm256.hip; 160x256 or 256x256 tiles by the cost model below) for every large NT GEMM: OPT-IN
+    // (nt_flags bit 9 = 512).  Stand-alone at M = 12800 (tools/gemm_bench.py, the same GEMM back to back, operands hot in the
+    // Infinity Cache) it wins on most shapes -- N=768 K=3072 59.8 us against 67-69 (1010 TF), + residual 74 / 81-91, N=3072 K=768
+    // GELU 91-93 / 99-103, N=2304 K=768 54.3 / 57.5, patch embedding 67.5 / 72-81, 4096^3 1312 TF / 1044 TF -- but INSIDE the training
+    // step, where every GEMM meets its weights cold (340 MB of 16-bit copies per step do not stay in the 256 MB cache), it loses on
+    // seven of the eight shapes (per-shape hipEvents in one process on one box, EOE_PROF_SHAPES=1: qkv 63.5 / 61.4 us, dX of fc
+    // 64.2 / 61.9, c_proj 86.5 / 81.7, GELU' x dY 114 / 103; only c_fc forward 102 / 105.6 wins; step 12.35 against 12.13 ms): one
+    // wave per SIMD behind a 2-k-tile LDS-DMA lead cannot hide an HBM miss the way two independent workgroups per CU do.
+    // Large square problems (below) keep it: there the 256x256 tile's halved operand traffic decides.
+    if (!p.colsum_sq && (g_nt_flags & 512) && !(g_nt_flags & (4 | 8)) && epilogue_fast_ok(p) && p.M >= 2048 && p.N >= 512) {
+        // time of a launch in units of one 16-row x 256-column x 64-deep slab of MFMAs: rounds over the CUs x (rows per tile x
+        // (k-tiles + 2 for the pipeline fill) + 30 for a tile's epilogue and hand-over)
+        const int nk = p.K / BK;
+        long best = 0;
+        int mi_best = 5;
+        for (int mi : {5, 8}) {
+            const long tiles = (long)cdiv(p.M, 32 * mi) * cdiv(p.N, 256);
+            const long cost = ((tiles + ncu - 1) / ncu) * ((long)mi * (nk + 2) + 30);
+            if (!best || cost < best) { best = cost; mi_best = mi; }
+        }
+        return eoe_launch_nt256(&p, std::is_same<T, f16_t>::value ? EOE_F16 : EOE_BF16, epi, mi_best, s);
+    }
     if (big && !p.colsum_sq && !(g_nt_flags & (4 | 8)) && epilogue_fast_ok(p) && p.M >= 2048)
         return eoe_launch_nt256(&p, std::is_same<T, f16_t>::value ? EOE_F16 : EOE_BF16, epi, 8, s);
     if (!p.colsum_sq && ((g_nt_flags & 8) || (!big && !(g_nt_flags & 4)))) return launch_nt128_auto<T>(p, epi, s);
@@ -774,7 +795,11 @@ extern "C" int eoe_gemm_nt(const eoe_gemm_args* a, void* stream) {
     GemmP p;
     EOE_TRY(fill_params(a, p));
     const int osz = a->out_f32 ? 4 : 2;
-    ProfScope ps("gemm_nt", 2.0 * a->M * a->N * a->K,
+    // diagnostics (EOE_PROF_SHAPES=1): one profile row per (shape, epilogue) instead of one for all NT GEMMs
+    static const bool by_shape = getenv("EOE_PROF_SHAPES") != nullptr;
+    char pname[32] = "gemm_nt";
+    if (by_shape) snprintf(pname, sizeof(pname), "nt_%dx%dx%d_e%d%s", a->M, a->N, a->K, a->epilogue, a->colsum ? "c" : "");
+    ProfScope ps(pname, 2.0 * a->M * a->N * a->K,
                  2.0 * ((a->gather ? (double)a->geo.n * a->geo.H * a->geo.W * a->geo.C : (double)a->M * a->K) + (double)a->N * a->K) +
                      (double)osz * a->M * a->N *
                      (a->epilogue == EOE_EPI_GELU ? 2 : 1) + (a->epilogue == EOE_EPI_RESIDUAL ? 4.0 * a->M * a->N : 0.0) +

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_kernel(GemmP p) {
 #define EOE_DMA16(rsrc, lds_addr, voff)                                                                               \
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"                            \
                  :: "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory")
-    auto stage_next = [&]() {                      // MI + 8 LDS-DMA instructions per wave per k-tile
+    auto stage_issue = [&]() {                     // MI + 8 LDS-DMA instructions per wave per k-tile
         const unsigned sa = lds0 + (unsigned)st_slot * STAGE;
         const unsigned sb = sa + A_B;
         const unsigned k0 = (unsigned)st_kt * (BK * 2u);
@@ -94,6 +94,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_kernel(GemmP p) {
             const unsigned lb = sb + (wave_u * 8 + j) * 1024u, vo = offB[j] + k0;
             EOE_DMA16(rb, lb, vo);
         }
+    };
+    auto stage_advance = [&]() {                   // the staging cursor moves on (every wave, after its pieces were issued)
         st_slot = (st_slot == NST - 1) ? 0 : st_slot + 1;
         if (++st_kt == nk) {
             st_kt = 0;
@@ -101,6 +103,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_kernel(GemmP p) {
             if (st_tile < my_tiles) set_offsets(st_tile);
         }
     };
+    auto stage_next = [&]() { stage_issue(); stage_advance(); };
 
     const int wm0 = (wave >> 1) * (16 * MI), wn0 = (wave & 1) * 128;
     const int lr = lane & 15, lg = lane >> 4;
@@ -142,6 +145,32 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_kernel(GemmP p) {
     _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                     \
         _Pragma("unroll") for (int ni = 0; ni < 8; ++ni)                  \
             mfma_inplace<T>(acc[ni >> 2][mi][ni & 3], WB[ni], XA[mi]);
+    // The cluster the k-loop uses: the MI * 8 MFMAs on (XA, WB) with, woven between them,
+    //   * the MI + 8 fragment reads of the OTHER register set (RA, RB) from `rbase`, one after every RSTEP-th MFMA: a read
+    //     issues in the shadow of the MFMA in front of it, and the four waves' LDS traffic is spread over the cluster instead
+    //     of arriving in one burst behind the barrier;
+    //   * (DMA = true) this wave's LDS-DMA pieces of the next k-tile behind the (wave_u + 1)-th quarter of the cluster.  The four
+    //     SIMDs of a CU share ONE address / LDS-DMA path (a 1 KiB piece ~ 16 cycles of it): when every wave issued its 13 pieces
+    //     right behind the barrier, the four of them queued for ~830 cycles with all matrix pipes idle (measured: 17 us of the
+    //     73 us of the K = 3072 GEMM went away when the pieces were not issued at all); staggered, one wave issues while the
+    //     other three SIMDs keep multiplying.
+    constexpr int NMF = MI * 8, RSTEP = NMF / (MI + 8), QUART = NMF / 4;
+#define EOE_CLUSTER256(XA, WB, RA, RB, rbase, rks, DMA)                                                          \
+    do {                                                                                                         \
+        const unsigned ra_ = (unsigned)(size_t)((rbase) - smem) + fragA + ((rks) ? ch1 : ch0);                   \
+        const unsigned rb_ = (unsigned)(size_t)((rbase) - smem) + fragB + ((rks) ? ch1 : ch0);                   \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                        \
+            _Pragma("unroll") for (int ni = 0; ni < 8; ++ni) {                                                   \
+                const int idx = mi * 8 + ni;                                                                     \
+                mfma_inplace<T>(acc[ni >> 2][mi][ni & 3], WB[ni], XA[mi]);                                       \
+                if (idx % RSTEP == 0 && idx / RSTEP < MI + 8) {                                                  \
+                    const int j = idx / RSTEP;                                                                   \
+                    if (j < MI) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(RA[j < MI ? j : 0]) : "v"(ra_), "i"((j < MI ? j : 0) * 2048)); \
+                    else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(RB[j >= MI ? j - MI : 0]) : "v"(rb_), "i"((j >= MI ? j - MI : 0) * 2048)); \
+                }                                                                                                \
+                if (idx % QUART == QUART - 1) { if ((DMA) && (int)wave_u == idx / QUART) stage_issue(); }       \
+            }                                                                                                    \
+    } while (0)
 #define EOE_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
 
     // counted waits: every k-tile is PER = MI + 8 LDS-DMA instructions per wave, nothing else is outstanding inside a tile's
@@ -180,8 +209,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_kernel(GemmP p) {
             const int nxt = (cur == NST - 1) ? 0 : cur + 1;
             const char* sc = smem + cur * STAGE;
             const char* sn = smem + nxt * STAGE;
-            if (!(p.dbg & 4)) { EOE_READ256(xa1, wb1, sc, 1); }          // lands under MFMA(F0)
-            EOE_MFMA256(xa0, wb0);
+            // first half: MFMA(F0) with the reads of F1 (k-step 1 of this k-tile) woven in
+            EOE_CLUSTER256(xa0, wb0, xa1, wb1, sc, 1, false);
             {   // k-tile it+1 landed; the (up to NST - 2) k-tiles staged after it stay in flight
                 const int later = iters - 2 - it;   // k-tiles it+2 .. iters-1 that exist
                 const int g = later < NST - 2 ? later : NST - 2;
@@ -189,11 +218,12 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_kernel(GemmP p) {
             }
             EOE_LANDED256(xa1, wb1);               // this wave's reads of slot `cur` are complete
             __builtin_amdgcn_s_barrier();
-            // k-tile it+NST into the slot just consumed -- unless that slot is about to serve as the epilogue's scratch
+            // second half: MFMA(F1) with the reads of the next k-tile's F0 and this wave's share of the LDS-DMA of k-tile it+NST
+            // (into the slot just consumed -- unless that slot is about to serve as the epilogue's scratch) woven in
             const bool defer = (NST == 3) && (kt == nk - 1);
-            if (!defer && it + NST < iters && !(p.dbg & 2)) stage_next();
-            if (!(p.dbg & 4)) { EOE_READ256(xa0, wb0, sn, 0); }         // unconditional (the last one reads a stale slot and is discarded); lands under MFMA(F1)
-            EOE_MFMA256(xa1, wb1);
+            const bool dma = !defer && it + NST < iters && !(p.dbg & 2);
+            EOE_CLUSTER256(xa1, wb1, xa0, wb0, sn, 0, dma);
+            if (dma) stage_advance();
             EOE_LANDED256(xa0, wb0);               // before the back edge: no fragment register is in flight across it
             cur = nxt;
         }
@@ -220,6 +250,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_kernel(GemmP p) {
 #undef EOE_READ256
 #undef EOE_LANDED256
 #undef EOE_MFMA256
+#undef EOE_CLUSTER256
 #undef EOE_MFMA_DRAIN
 }
 

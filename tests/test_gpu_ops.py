@@ -24,7 +24,7 @@ def ops():
 # kernel with 128- and with 160-row tiles, and the one-wave-per-SIMD kernel (gemm256.hip) with 160x256 and 256x256 tiles -- every
 # test below must hold for each
 NT_VARIANTS = {"auto": 1, "persistent256": 1 | 4 | 64, "two_wg_128": 1 | 8 | 16, "two_wg_160": 1 | 8 | 32,
-               "one_wave_160x256": 1 | 128, "one_wave_256x256": 1 | 256}
+               "one_wave_160x256": 1 | 128, "one_wave_256x256": 1 | 256, "one_wave_cost_model": 1 | 512}
 
 
 @pytest.fixture(params=list(NT_VARIANTS))
