@@ -596,6 +596,11 @@ int launch_nt128_auto(const GemmP& p, int epi, hipStream_t s) {
 // (round 2) Delaying the workgroup in the odd wave slot of each SIMD (HW_REG_HW_ID[3:0]) by half a k-tile at kernel entry, so that the
 // two workgroups of a CU would issue their LDS-DMA / fragment reads next to each other's MFMA clusters: null (layer total 592 / 601 us
 // against 605 us in the same process, within run-to-run spread).
+// (round 2) Weaving the LDS-DMA pieces of the next k-tile between the MFMAs of the second half (unconditional pieces, out-of-range offset
+// beyond the last k-tile, sched_group_barrier 2 MFMA : 1 piece : 1 fragment read) instead of issuing them in one burst behind the
+// barrier -- what gave the one-wave kernel of gemm256.hip 19 %: null here (layer total 476.9 against 477.4 us interleaved in one
+// process, bitwise identical results; in the step 11.70 against 11.65-11.79 ms).  With two workgroups per CU the burst of one is
+// already covered by the MFMAs of the other.
 // Measured on the two-workgroup kernel (tools/gemm128_timeline.py, s_memtime stamps + HW_ID per workgroup): the two workgroups of a CU
 // run in LOCKSTEP for the whole launch (they start, finish and are replaced together), so the MFMA loops of a CU cover only 72 % of its
 // time on the GELU GEMM (91 % on the plain K = 768 one).  De-phasing them (the second arrival of the first round sits out half a tile
