@@ -220,6 +220,12 @@ class AddReluFunction(torch.autograd.Function):
         dout = dout.contiguous().float()
         g = torch.empty_like(out)
         check(lib.eoe_relu_bwd(_p(dout), _p(out), _p(g), out.numel(), _stream()), "eoe_relu_bwd")
+        # Both operands receive the SAME buffer (the junction's gradient is identical for the branch and for the shortcut).  The
+        # shortcut's copy reaches ConvBnActPoolFunction.backward of the block's first convolution as `d_pass`, which ACCUMULATES
+        # its dgrad onto it in place.  That is safe by graph order, not by luck of stream order: that node also needs the gradient
+        # of its main output, which only exists after every consumer of the branch copy (conv2 / CBAM backward) has run, so the
+        # branch copy is dead by then.  A tensor hook or retain_grad() on the junction output that keeps `g` alive would see the
+        # accumulated values -- the modules of this package install none.
         return g, g.view_as(g)
 
 

@@ -54,10 +54,13 @@ class FusedAdam(torch.optim.Optimizer):
         hit = self._tables.get(gi)
         if hit is not None and hit[0] == sig:
             return hit[1:], distinct
-        pb = min(p.data_ptr() for p in active)
-        gb = min(p.grad.data_ptr() for p in active)
-        mb = min(self.state[p]["exp_avg"].data_ptr() for p in active)
-        vb = min(self.state[p]["exp_avg_sq"].data_ptr() for p in active)
+        # bases rounded DOWN to 16 bytes: the kernel takes its float4 path for a chunk iff all four element offsets are multiples
+        # of 4, which is a statement about the ADDRESS only if the bases themselves are 16-byte aligned (a parameter that is a
+        # 4-byte-aligned view of a user buffer may be the lowest address)
+        pb = min(p.data_ptr() for p in active) & ~15
+        gb = min(p.grad.data_ptr() for p in active) & ~15
+        mb = min(self.state[p]["exp_avg"].data_ptr() for p in active) & ~15
+        vb = min(self.state[p]["exp_avg_sq"].data_ptr() for p in active) & ~15
         rows = []
         for p, s in zip(active, steps):
             st = self.state[p]
@@ -138,9 +141,9 @@ class FusedSGD(torch.optim.Optimizer):
         hit = self._tables.get(gi)
         if hit is not None and hit[0] == sig:
             return hit[1:]
-        pb = min(p.data_ptr() for p in active)
-        gb = min(p.grad.data_ptr() for p in active)
-        mb = min(self.state[p]["momentum_buffer"].data_ptr() for p in active)
+        pb = min(p.data_ptr() for p in active) & ~15          # 16-byte aligned bases (see FusedAdam._table)
+        gb = min(p.grad.data_ptr() for p in active) & ~15
+        mb = min(self.state[p]["momentum_buffer"].data_ptr() for p in active) & ~15
         rows = []
         for p in active:
             po, go = (p.data_ptr() - pb) // 4, (p.grad.data_ptr() - gb) // 4
