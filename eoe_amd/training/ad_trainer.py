@@ -239,6 +239,10 @@ class ADTrainer(ABC):
             rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
             arena = parallel.GradArena(model)
             arena.install_hooks()
+            if rank == 0 and any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in model.modules()):
+                self.logger.warning("data parallel training of a BatchNorm encoder: batch statistics are per rank (no SyncBatchNorm), "
+                                    "i.e. DistributedDataParallel semantics, not the single-device full-batch ones; snapshots keep "
+                                    "rank 0's running statistics (eoe_amd/parallel.py)")
         nominal = getattr(ds, "nominal_label", 0)
         self.last_losses = []
         graphed = None                                      # (batch shape, GraphedStep) of the full-size step batch

@@ -182,3 +182,52 @@ def test_cnn32_run_buckets_two_ranks(tmp_path):
         err = (got["grads"][k].double() - ref).norm().item() / max(ref.norm().item(), 1e-9)
         # each rank's loss is scaled by 1 / world, which moves the fp16 rounding of the dY operands (4e-4 measured)
         assert err < 3e-3 or ref.norm().item() < 1e-6, (k, err)
+
+
+# ------------------------------------------------------------------------------------------------ the trainer itself under data parallelism
+def _trainer_batches():
+    from oracle import trainer as otrainer
+    # full batch (4 + 4), a ragged one whose halves split unevenly over 2 ranks (3 + 3), and one smaller than the ranks (1 + 1)
+    return [otrainer.synthetic_batch("ddp/t0", 4, 4, 224), otrainer.synthetic_batch("ddp/t1", 3, 3, 224),
+            otrainer.synthetic_batch("ddp/t2", 1, 1, 224)]
+
+
+def _trainer_run(data_parallel):
+    import eoe_amd
+    from eoe_amd.data import ListSource
+    from eoe_amd.training import HSCTrainer
+    eoe_amd.set_compute_dtype("fp16")
+    m = _make()
+    tr = HSCTrainer(m, dataset=ListSource(_trainer_batches()), epochs=2, lr=1e-4, wdk=1e-3, batch_size=4, data_parallel=data_parallel)
+    model = tr._fresh_model(m)            # a module preset: used as is (no weight reset), like `load` does
+    model, roc = tr.train_cls(model, tr.ds, 0, "0", 0)
+    return tr.last_losses, roc.auc, {k: v.detach().cpu() for k, v in model.state_dict().items()}
+
+
+def _trainer_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from eoe_amd import parallel
+    parallel.init_from_env("gloo")
+    torch.cuda.set_device(0)
+    losses, auc, sd = _trainer_run(True)
+    if rank == 0:
+        torch.save({"losses": losses, "auc": auc, "sd": sd}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainer_data_parallel_ragged_batches(tmp_path):
+    """`train_cls(data_parallel=True)` with 2 ranks over an epoch whose batches are full (4 + 4), uneven over the ranks (3 + 3: one
+    rank gets 1 + 1 rows, the other 2 + 2) and smaller than the world in each half (1 + 1: computed whole on every rank, weighted
+    1 / world): the per-step losses, the epoch AUC and the trained weights equal the single-process run (the reference keeps the
+    ragged last batch: no drop_last, bases.py:231-235)"""
+    out = str(tmp_path / "tr.pt")
+    mp.spawn(_trainer_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    losses, auc, sd = _trainer_run(False)
+    np.testing.assert_allclose(got["losses"], losses, rtol=2e-3, atol=1e-5)
+    assert abs(got["auc"] - auc) < 1e-6
+    for k in sd:
+        a, b = got["sd"][k].double(), sd[k].double()
+        assert (a - b).norm().item() <= 2e-3 * max(b.norm().item(), 1e-6), k
