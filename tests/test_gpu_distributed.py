@@ -181,7 +181,9 @@ def test_cnn32_run_buckets_two_ranks(tmp_path):
         ref = p.grad.cpu().double()
         err = (got["grads"][k].double() - ref).norm().item() / max(ref.norm().item(), 1e-9)
         # each rank's loss is scaled by 1 / world, which moves the fp16 rounding of the dY operands (4e-4 measured)
-        assert err < 3e-3 or ref.norm().item() < 1e-6, (k, err)
+        # (biases in front of a BatchNorm have a true gradient of 0: both sides hold rounding noise only)
+        noise_only = k in ("conv1.bias", "conv2.bias", "conv3.bias", "fc1.bias")
+        assert err < 3e-3 or noise_only, (k, err, ref.norm().item())
 
 
 # ------------------------------------------------------------------------------------------------ the trainer itself under data parallelism
