@@ -1,0 +1,34 @@
+# round-2 measurement pass (run through gpurun from the repo root): tests, bench lines of every configuration, rocprofv3
+# kernel tables (default and --side-stream 0) and PMC passes.  Outputs under gpurun_out/r2/.
+set -o pipefail
+O=gpurun_out/r2
+mkdir -p $O && cd /root/repo
+timeout -k 10 1000 python -m pytest tests -q -m gpu 2>&1 | tail -3 > $O/tests.log; cat $O/tests.log
+b() { name=$1; shift; timeout -k 10 300 python bench.py "$@" > $O/$name.json 2> $O/$name.err && cut -c1-200 $O/$name.json; }
+b bench --steps 20 --warmup 5
+b bench_ss0 --steps 20 --warmup 5 --side-stream 0 --no-cpu-baseline --no-torch-baseline
+b bench_frozen --mode frozen --no-cpu-baseline --no-torch-baseline
+b bench_bf16 --dtype bf16 --no-cpu-baseline --no-torch-baseline
+b bench_cnn32 --model cnn32 --steps 50 --warmup 10
+b bench_wrn --model wrn --steps 10 --warmup 3
+b bench_wrn32_bf16 --model wrn --res 32 --dtype bf16 --steps 20 --warmup 5
+b bench_wrn32_bf16_graph --model wrn --res 32 --dtype bf16 --graph on --steps 20 --warmup 5
+b bench_strong1 --scaling strong --steps 20 --warmup 5 --no-cpu-baseline --no-torch-baseline
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+cd /tmp
+p() { name=$1; shift; timeout -k 10 300 rocprofv3 "$@" > $R/$O/$name.log 2>&1; echo $name rc=$?; }
+p stats --kernel-trace --stats -d $R/$O/stats -o run -- python $R/bench.py --steps 8 --warmup 5 --no-cpu-baseline --no-torch-baseline
+p stats_ss0 --kernel-trace --stats -d $R/$O/stats_ss0 -o run -- python $R/bench.py --steps 8 --warmup 5 --side-stream 0 --no-cpu-baseline --no-torch-baseline
+p stats_wrn --kernel-trace --stats -d $R/$O/stats_wrn -o run -- python $R/bench.py --model wrn --steps 6 --warmup 3 --no-cpu-baseline
+p stats_wrn32 --kernel-trace --stats -d $R/$O/stats_wrn32 -o run -- python $R/bench.py --model wrn --res 32 --dtype bf16 --steps 8 --warmup 3 --no-cpu-baseline
+p pmc_fetch --kernel-trace --pmc FETCH_SIZE -d $R/$O/pmc_fetch -o run -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-torch-baseline --no-roofline
+p pmc_write --kernel-trace --pmc WRITE_SIZE -d $R/$O/pmc_write -o run -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-torch-baseline --no-roofline
+p pmc_sq --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $R/$O/pmc_sq -o run -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-torch-baseline --no-roofline
+cd $R
+for d in stats stats_ss0 stats_wrn stats_wrn32; do f=$(ls $O/$d/*/*results.db 2>/dev/null | head -1); [ -n "$f" ] && python tools/pmc_summary.py stats $f > $O/${d}_kernel_stats.csv; done
+ff=$(ls $O/pmc_fetch/*/*results.db | head -1); fw=$(ls $O/pmc_write/*/*results.db | head -1); fs=$(ls $O/pmc_sq/*/*results.db | head -1)
+python tools/pmc_summary.py hbm $ff $fw > $O/bench_pmc_hbm_bytes.csv
+python tools/pmc_summary.py sq $fs > $O/bench_pmc_sq.csv
+rm -rf $O/stats $O/stats_ss0 $O/stats_wrn $O/stats_wrn32 $O/pmc_fetch $O/pmc_write $O/pmc_sq
+ls -la $O
