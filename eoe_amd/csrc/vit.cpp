@@ -1,6 +1,7 @@
 // Fused launch chains for one ViT residual block (clip/model.py:167-188 and its backward): the host side only
 // enqueues kernels on the caller's stream; there is no host synchronisation and no allocation in here.
 #include "common.h"
+#include <mutex>
 
 #define TRY(expr)                   \
     do {                            \
@@ -20,8 +21,11 @@ struct SideStream {
     hipEvent_t fork = nullptr, join = nullptr;
     bool ok = false;
 };
+// per-device handle table (the only mutable state this file keeps), created once per device under a mutex
 SideStream* side_stream(hipStream_t main) {
     static SideStream per_dev[16];
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     SideStream& ss = per_dev[dev];

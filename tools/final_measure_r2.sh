@@ -26,8 +26,9 @@ p pmc_fetch --kernel-trace --pmc FETCH_SIZE -d $R/$O/pmc_fetch -o run -- python 
 p pmc_write --kernel-trace --pmc WRITE_SIZE -d $R/$O/pmc_write -o run -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-torch-baseline --no-roofline
 p pmc_sq --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $R/$O/pmc_sq -o run -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-torch-baseline --no-roofline
 cd $R
-for d in stats stats_ss0 stats_wrn stats_wrn32; do f=$(ls $O/$d/*/*results.db 2>/dev/null | head -1); [ -n "$f" ] && python tools/pmc_summary.py stats $f > $O/${d}_kernel_stats.csv; done
-ff=$(ls $O/pmc_fetch/*/*results.db | head -1); fw=$(ls $O/pmc_write/*/*results.db | head -1); fs=$(ls $O/pmc_sq/*/*results.db | head -1)
+db() { find $O/$1 -name "*results.db" 2>/dev/null | head -1; }
+for d in stats stats_ss0 stats_wrn stats_wrn32; do f=$(db $d); [ -n "$f" ] && python tools/pmc_summary.py stats $f > $O/${d}_kernel_stats.csv; done
+ff=$(db pmc_fetch); fw=$(db pmc_write); fs=$(db pmc_sq)
 python tools/pmc_summary.py hbm $ff $fw > $O/bench_pmc_hbm_bytes.csv
 python tools/pmc_summary.py sq $fs > $O/bench_pmc_sq.csv
 rm -rf $O/stats $O/stats_ss0 $O/stats_wrn $O/stats_wrn32 $O/pmc_fetch $O/pmc_write $O/pmc_sq
