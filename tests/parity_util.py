@@ -18,10 +18,14 @@ def reference_noise(g, steps=None):
     steps = steps or len(g["losses"])
     if "losses64" not in g:                      # no fp64 twin in this fixture (the ViT: its LayerNorm is fp32-only): plain bar
         return np.zeros(steps), np.zeros(steps)
-    l32, l64 = g["losses"][:steps], g["losses64"][:steps]
+    n_all = len(g["losses"])
+    l32, l64 = g["losses"], g["losses64"]
     nl = np.abs(l32 - l64) / np.maximum(1.0, np.abs(l64))
-    ns = np.abs(g["scores"][:steps].astype(np.float64) - g["scores64"][:steps]).max(axis=1)
-    return nl, ns
+    ns = np.abs(g["scores"].astype(np.float64) - g["scores64"]).max(axis=1)
+    # envelope: one fp32-vs-fp64 pair is a single draw of a noise whose amplitude grows with the step count (it can be small at
+    # one step by accident and three times larger at the next), so step k is given the largest value seen up to step k + 1
+    env = lambda a: np.array([a[:min(n_all, k + 2)].max() for k in range(n_all)])      # noqa: E731
+    return env(nl)[:steps], env(ns)[:steps]
 
 
 def trajectory_deviation(losses, scores, g, steps=None):
