@@ -44,6 +44,7 @@ def parse():
                          "wrn = secondary (WideResNet+CBAM, 224x224, config 3 backbone)")
     ap.add_argument("--nt-flags", type=int, default=None, help="tuning switch of the NT GEMM (A/B builds only)")
     ap.add_argument("--tn-flags", type=int, default=None, help="tuning switch of the wgrad GEMM")
+    ap.add_argument("--attn-flags", type=int, default=None, help="1: the one-wave attention backward kernel (A/B)")
     ap.add_argument("--side-stream", type=int, default=None, help="0: LayerNorm-1 backward after (not next to) the grouped wgrad")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="capture forward + loss + backward + scores of one step in a HIP graph and replay it (1 GPU only; "
@@ -163,6 +164,8 @@ def main():
         _lib.check(_lib.lib.eoe_set_option(b"vit_side_stream", args.side_stream), "eoe_set_option")
     if args.nt_flags is not None:
         _lib.check(_lib.lib.eoe_set_option(b"nt_flags", args.nt_flags), "eoe_set_option")
+    if args.attn_flags is not None:
+        _lib.check(_lib.lib.eoe_set_option(b"attn_flags", args.attn_flags), "eoe_set_option")
 
     torch.manual_seed(0)
     res = 224

@@ -11,6 +11,8 @@
 // lane = key (operands swapped) for dV and dK, so that every product sums over an accumulator-row index.
 #include "common.h"
 
+int g_attn_flags = 0;            // eoe_set_option("attn_flags", bit 0: the one-wave backward kernel)
+
 namespace {
 
 constexpr int ROWB = 160;            // LDS row pitch in bytes (64 x 16-bit + pad): conflict-free transposed reads
@@ -400,6 +402,210 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
 }
 
+
+// ---- four waves per (image, head) (round 2).  The one-wave kernel above keeps 5 waves on a CU (31 KB of LDS each), 1.25 per SIMD:
+// its ~14 k issue cycles per wave sit inside ~55 k cycles of exposed global / LDS / store latency.  Here the same seven products are
+// split by 16-row slabs: wave w owns queries 16w..16w+15 in phase A (S^T, dP^T columns of its queries, all keys -> row statistics, dS^T,
+// dQ) and keys 16w..16w+15 in phase B (S, dP rows of all queries x its keys -> dV, dK), the three LDS images are shared, the row
+// statistics cross between the phases behind one workgroup barrier.  A wave holds a quarter of the accumulators (<= 128 registers),
+// so 4 workgroups = 16 waves fit a CU and one workgroup's load / store latency is another's issue time.  Same arithmetic per element
+// as the one-wave kernel (same products, same k order); only the bias column sums associate differently (per-wave partials summed in
+// wave order).
+template <typename T>
+__device__ __forceinline__ void stage_slab(char* lds, const T* src, int ld, int L, int lane, int w) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int row = 16 * w + it * 8 + (lane >> 3), ch = lane & 7;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row < L) v = *(const u32x4*)(src + (size_t)row * ld + ch * 8);
+        *(u32x4*)(lds + row * ROWB + ch * 16) = v;
+    }
+}
+// column sums over the 16 tokens of one accumulator tile (token = lane & 15): the DPP row reduction of token_sum
+__device__ __forceinline__ f32x4 slab_sum(const f32x4& o, bool valid) {
+    f32x4 t = valid ? o : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float v = t[r];
+        v += dpp_mov<0xB1>(v);
+        v += dpp_mov<0x4E>(v);
+        v += dpp_mov<0x141>(v);
+        v += dpp_mov<0x140>(v);
+        t[r] = v;
+    }
+    return t;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd4_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, T* __restrict__ dqkv,
+                                                        float* __restrict__ bias_part, int L, int heads, float scale) {
+    __shared__ __attribute__((aligned(16))) char smem[3 * TILEB + 2 * 64 * 4 + 4 * 192 * 4];
+    char* qs = smem;
+    char* ks_ = smem + TILEB;
+    char* dos = smem + 2 * TILEB;
+    float* lse_s = (float*)(smem + 3 * TILEB);
+    float* dlt_s = lse_s + 64;
+    float* red = dlt_s + 64;                                  // [4 waves][dQ | dK | dV column sums, 64 each]
+
+    const int lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int img = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int D = heads * 64, ld = 3 * D;
+    const T* qp = qkv + (size_t)img * L * ld + h * 64;
+    const T* kp = qp + D;
+    const T* vp = qp + 2 * D;
+    const T* dop = dout + (size_t)img * L * D + h * 64;
+    T* dqp = dqkv + (size_t)img * L * ld + h * 64;
+    const int n_img = gridDim.x / heads;
+    float* bpart = bias_part ? bias_part + ((size_t)h * n_img + img) * 64 : nullptr;
+    const size_t bseg = (size_t)heads * n_img * 64;
+    const int mine = 16 * w + lr;                             // this lane's query (phase A) / key (phase B)
+    float* myred = red + w * 192;
+
+    // V only ever is a row-major MFMA operand: fragments straight from global memory (phase A: all keys; phase B: this wave's keys)
+    V8<T> vfr[2][4], vfw[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) vfr[ks][t] = gfrag<T>(vp, ld, L, t, ks, lane);
+        vfw[ks] = gfrag<T>(vp, ld, L, w, ks, lane);
+    }
+    stage_slab<T>(qs, qp, ld, L, lane, w);
+    stage_slab<T>(ks_, kp, ld, L, lane, w);
+    stage_slab<T>(dos, dop, D, L, lane, w);
+    __syncthreads();
+
+    // ---- phase A: lane = query of this wave's slab.  S^T = K Q^T, dP^T = V dO^T
+    {
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dp[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const V8<T> qf = lfrag<T>(qs, w, ks, lane), df = lfrag<T>(dos, w, ks, lane);
+#pragma unroll
+            for (int tk = 0; tk < 4; ++tk) {
+                s[tk] = T16<T>::mfma16(lfrag<T>(ks_, tk, ks, lane), qf, s[tk]);
+                dp[tk] = T16<T>::mfma16(vfr[ks][tk], df, dp[tk]);
+            }
+        }
+        // softmax over the keys of this lane's query: 16 in-lane values + the 4 lanes sharing lane & 15 (softmax_T, one query tile)
+        float m = -INFINITY;
+#pragma unroll
+        for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * tk + 4 * lg + r;
+                const float v = (key < L) ? s[tk][r] * scale : -INFINITY;
+                s[tk][r] = v;
+                m = fmaxf(m, v);
+            }
+        m = group_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(s[tk][r] - m);
+                s[tk][r] = e;
+                sum += e;
+            }
+        sum = group_sum(sum);
+        const float inv = 1.0f / sum;
+        float dl = 0.f;
+#pragma unroll
+        for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[tk][r] *= inv;
+                dl += s[tk][r] * dp[tk][r];
+            }
+        dl = group_sum(dl);
+#pragma unroll
+        for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dp[tk][r] = s[tk][r] * (dp[tk][r] - dl) * scale;
+        if (lg == 0) {
+            lse_s[mine] = m + __logf(sum);
+            dlt_s[mine] = dl;
+        }
+        // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]
+#pragma unroll
+        for (int td = 0; td < 4; ++td) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+                o = T16<T>::mfma16(tfrag<T>(ks_, td, st, lane), acc_as_operand<T>(dp[2 * st], dp[2 * st + 1]), o);
+            if (mine < L) *(u32x2*)(dqp + (size_t)mine * ld + 16 * td + 4 * lg) = pack4<T>(o[0], o[1], o[2], o[3]);
+            if (bpart) {
+                const f32x4 cs = slab_sum(o, mine < L);
+                if (lr == 0) *(f32x4*)(myred + 16 * td + 4 * lg) = cs;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B: lane = key of this wave's slab (operands swapped).  S = Q K^T, dP = dO V^T; rows (registers) = queries
+    {
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dp[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const V8<T> kf = lfrag<T>(ks_, w, ks, lane);
+#pragma unroll
+            for (int tq = 0; tq < 4; ++tq) {
+                s[tq] = T16<T>::mfma16(lfrag<T>(qs, tq, ks, lane), kf, s[tq]);
+                dp[tq] = T16<T>::mfma16(lfrag<T>(dos, tq, ks, lane), vfw[ks], dp[tq]);
+            }
+        }
+        // P = exp(S*scale - lse[q]);  dS = P (dP - delta[q]) * scale
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq) {
+            const f32x4 lse = *(const f32x4*)(lse_s + 16 * tq + 4 * lg);
+            const f32x4 dl = *(const f32x4*)(dlt_s + 16 * tq + 4 * lg);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(s[tq][r] * scale - lse[r]);
+                s[tq][r] = p;
+                dp[tq][r] = p * (dp[tq][r] - dl[r]) * scale;
+            }
+        }
+        // dV^T[d][key] = sum_q dO^T[d][q] P[q][key] ;  dK^T[d][key] = sum_q Q^T[d][q] dS[q][key]
+#pragma unroll
+        for (int td = 0; td < 4; ++td) {
+            f32x4 ov = {0.f, 0.f, 0.f, 0.f}, ok = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                ov = T16<T>::mfma16(tfrag<T>(dos, td, st, lane), acc_as_operand<T>(s[2 * st], s[2 * st + 1]), ov);
+                ok = T16<T>::mfma16(tfrag<T>(qs, td, st, lane), acc_as_operand<T>(dp[2 * st], dp[2 * st + 1]), ok);
+            }
+            if (mine < L) {
+                *(u32x2*)(dqp + (size_t)mine * ld + 2 * D + 16 * td + 4 * lg) = pack4<T>(ov[0], ov[1], ov[2], ov[3]);
+                *(u32x2*)(dqp + (size_t)mine * ld + D + 16 * td + 4 * lg) = pack4<T>(ok[0], ok[1], ok[2], ok[3]);
+            }
+            if (bpart) {
+                const f32x4 cv = slab_sum(ov, mine < L), ck = slab_sum(ok, mine < L);
+                if (lr == 0) {
+                    *(f32x4*)(myred + 128 + 16 * td + 4 * lg) = cv;
+                    *(f32x4*)(myred + 64 + 16 * td + 4 * lg) = ck;
+                }
+            }
+        }
+    }
+    if (bpart) {
+        __syncthreads();
+        const int t = threadIdx.x;
+        if (t < 192) bpart[(size_t)(t >> 6) * bseg + (t & 63)] = (red[t] + red[192 + t]) + (red[384 + t] + red[576 + t]);
+    }
+}
+
 }  // namespace
 
 extern "C" int eoe_attn_fwd(const void* qkv, void* out, int n, int L, int heads, int dtype, void* stream) {
@@ -426,11 +632,18 @@ extern "C" int eoe_attn_bwd(const void* qkv, const void* dout, void* dqkv, float
     EOE_CHECK_ARG(L >= 1 && L <= 64, "attn: sequence length %d not in [1, 64]", L);
     const float scale = 0.125f;
     ProfScope ps("attn_bwd", 14.0 * n * heads * (double)L * L * 64, 2.0 * (double)n * L * heads * 64 * 7, stream);
-    if (dtype == EOE_F16)
+    const bool one_wave = g_attn_flags & 1;     // A/B switch: the round-1 kernel
+    if (dtype == EOE_F16 && one_wave)
         hipLaunchKernelGGL((attn_bwd_kernel<f16_t>), dim3(n * heads), dim3(64), 0, (hipStream_t)stream,
                            (const f16_t*)qkv, (const f16_t*)dout, (f16_t*)dqkv, bias_scratch, L, heads, scale);
-    else if (dtype == EOE_BF16)
+    else if (dtype == EOE_BF16 && one_wave)
         hipLaunchKernelGGL((attn_bwd_kernel<bf16_t>), dim3(n * heads), dim3(64), 0, (hipStream_t)stream,
+                           (const bf16_t*)qkv, (const bf16_t*)dout, (bf16_t*)dqkv, bias_scratch, L, heads, scale);
+    else if (dtype == EOE_F16)
+        hipLaunchKernelGGL((attn_bwd4_kernel<f16_t>), dim3(n * heads), dim3(256), 0, (hipStream_t)stream,
+                           (const f16_t*)qkv, (const f16_t*)dout, (f16_t*)dqkv, bias_scratch, L, heads, scale);
+    else if (dtype == EOE_BF16)
+        hipLaunchKernelGGL((attn_bwd4_kernel<bf16_t>), dim3(n * heads), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_t*)qkv, (const bf16_t*)dout, (bf16_t*)dqkv, bias_scratch, L, heads, scale);
     else
         return eoe_set_error(EOE_ERR_ARG, "attn_bwd: bad dtype %d", dtype);

@@ -26,6 +26,7 @@
 unsigned long long* g_stamp_buf = nullptr;
 extern int g_tn_flags;     // gemm_tn.hip
 extern int g_vit_side_stream;   // vit.cpp
+extern int g_attn_flags;        // attention.hip
 int eoe_launch_nt256(const void* gemm_p, int dtype, int epi, int mi, hipStream_t s);   // gemm256.hip
 
 namespace {
@@ -843,5 +844,6 @@ extern "C" int eoe_set_option(const char* name, int value) {
     if (name && !strcmp(name, "nt_flags")) { g_nt_flags = value; return 0; }
     if (name && !strcmp(name, "tn_flags")) { g_tn_flags = value; return 0; }
     if (name && !strcmp(name, "vit_side_stream")) { g_vit_side_stream = value; return 0; }
+    if (name && !strcmp(name, "attn_flags")) { g_attn_flags = value; return 0; }
     return eoe_set_error(EOE_ERR_ARG, "unknown option");
 }
