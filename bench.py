@@ -189,6 +189,8 @@ def main():
     arena = parallel.GradArena(model)
     if world > 1:
         arena.install_hooks()
+        if any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in model.modules()):
+            parallel.enable_sync_bn()          # global-batch BatchNorm statistics, as the single-device reference computes them
 
     nb = args.batch
     n_local = 2 * nb

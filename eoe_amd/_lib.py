@@ -100,6 +100,9 @@ class VitBlockBwdArgs(C.Structure):
 
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); must match include/eoe_hip.h
+# eoe_allreduce_fn of include/eoe_hip.h (synchronised BatchNorm hook)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
+
 SIGNATURES = {
     "eoe_abi_version": [],
     "eoe_struct_size": [C.c_int],
@@ -185,6 +188,7 @@ SIGNATURES = {
     "eoe_comm_allreduce_sum_async": [_vp, _vp, _i64, C.c_int, C.c_int, _vp],
     "eoe_comm_allgather_async": [_vp, _vp, _vp, _i64, C.c_int, _vp],
     "eoe_comm_join": [_vp, _vp],
+    "eoe_set_bn_sync": [_vp, _vp],
     "eoe_prof_enable": [C.c_int],
     "eoe_set_option": [C.c_char_p, C.c_int],
     "eoe_debug_gemm_stamps": [_vp, C.c_int],

@@ -435,12 +435,32 @@ __global__ __launch_bounds__(256) void sgate_bn_bwd_apply_kernel(const float* __
     for (int sft = 32; sft >= 1; sft >>= 1) { t0 += __shfl_xor(t0, sft, 64); t1 += __shfl_xor(t1, sft, 64); }
     if ((threadIdx.x & 63) == 0) { l0[threadIdx.x >> 6] = t0; l1[threadIdx.x >> 6] = t1; }
     __syncthreads();
-    const float r0 = (l0[0] + l0[1]) + (l0[2] + l0[3]), r1 = (l1[0] + l1[1]) + (l1[2] + l1[3]);
-    const float m0 = r0 / (float)P, m1 = r1 / (float)P;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && dgamma) { dgamma[0] = r1; dbeta[0] = r0; }
+    float r0 = (l0[0] + l0[1]) + (l0[2] + l0[3]), r1 = (l1[0] + l1[1]) + (l1[2] + l1[3]);
+    float cnt = (float)P;
+    // nparts < 0: synchronised BatchNorm -- red[0..2] = (sum g, sum g*xhat, pixels) already totalled over the ranks, this rank's own
+    // sums (the parameter gradients) in red[3..4] (sgate_bn_bwd_total_kernel)
+    if (nparts < 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0 && dgamma) { dgamma[0] = red[4]; dbeta[0] = red[3]; }
+        r0 = red[0]; r1 = red[1]; cnt = red[2];
+    } else if (blockIdx.x == 0 && threadIdx.x == 0 && dgamma) { dgamma[0] = r1; dbeta[0] = r0; }
+    const float m0 = r0 / cnt, m1 = r1 / cnt;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (size_t)gridDim.x * blockDim.x) {
         const float xh = (z[p] - mu) * rs;
         g[p] = training ? ga * rs * (g[p] - m0 - xh * m1) : ga * rs * g[p];
+    }
+}
+// synchronised BatchNorm: the partial pairs -> red[0..2] = (sum g, sum g*xhat, P) for the all-reduce, red[3..4] = a copy that stays local
+__global__ __launch_bounds__(256) void sgate_bn_bwd_total_kernel(float* __restrict__ red, int nparts, float P) {
+    __shared__ float l0[4], l1[4];
+    float t0 = 0.f, t1 = 0.f;
+    for (int k = threadIdx.x; k < nparts; k += blockDim.x) { t0 += red[2 + 2 * k]; t1 += red[3 + 2 * k]; }
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) { t0 += __shfl_xor(t0, sft, 64); t1 += __shfl_xor(t1, sft, 64); }
+    if ((threadIdx.x & 63) == 0) { l0[threadIdx.x >> 6] = t0; l1[threadIdx.x >> 6] = t1; }
+    __syncthreads();                 // every partial pair has been read: the head of red may be overwritten
+    if (threadIdx.x == 0) {
+        const float r0 = (l0[0] + l0[1]) + (l0[2] + l0[3]), r1 = (l1[0] + l1[1]) + (l1[2] + l1[3]);
+        red[0] = r0; red[1] = r1; red[2] = P; red[3] = r0; red[4] = r1;
     }
 }
 // dcomp[p, ch] = sum_taps dz[y-ky+3, x-kx+3] * w[ch, ky, kx]
@@ -727,6 +747,12 @@ extern "C" int eoe_sgate_bwd(const eoe_sgate_bwd_args* b, void* stream) {
     int g = grid_for(P, EOE_SGATE_PARTIALS);
     hipLaunchKernelGGL(sgate_bn_bwd_reduce_kernel, dim3(g), dim3(256), 0, s, a->z, a->stats, a->scale, b->dscale, b->red, P);
     EOE_CHECK_LAUNCH("sgate_bn_bwd_reduce");
+    if (a->training && eoe_bn_sync_active()) {
+        hipLaunchKernelGGL(sgate_bn_bwd_total_kernel, dim3(1), dim3(256), 0, s, b->red, g, (float)P);
+        EOE_CHECK_LAUNCH("sgate_bn_bwd_total");
+        EOE_TRY(eoe_bn_sync_allreduce(b->red, 3, 0, stream));
+        g = -1;
+    }
     hipLaunchKernelGGL(sgate_bn_bwd_apply_kernel, dim3(grid_for(P)), dim3(256), 0, s, a->z, a->stats, a->gamma, (const float*)b->red, g,
                        b->dscale, b->dgamma, b->dbeta, P, a->training);
     EOE_CHECK_LAUNCH("sgate_bn_bwd_apply");

@@ -363,6 +363,46 @@ __global__ __launch_bounds__(256) void bn_running_stats_kernel(const float* __re
     stats[C + c] = 1.0f / sqrtf(rv[c] + eps);
 }
 
+// synchronised BatchNorm, forward: partial rows -> sums[0..C) = sum y, sums[C..2C) = sum y^2, sums[2C] = M as doubles (the
+// all-reduce hook then adds the ranks up), and statistics from such sums
+__global__ __launch_bounds__(1024) void bn_sums_kernel(const float* __restrict__ part, int P, double* __restrict__ sums, int M, int C) {
+    __shared__ double l[2][64][17];
+    const int col = threadIdx.x & 15, lane = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + col;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int p = lane; p < P; p += 64) {
+            s += part[(size_t)p * 2 * C + c];
+            q += part[(size_t)p * 2 * C + C + c];
+        }
+    l[0][lane][col] = s;
+    l[1][lane][col] = q;
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) sums[2 * C] = (double)M;
+    if (lane != 0 || c >= C) return;
+    for (int k = 1; k < 64; ++k) { s += l[0][k][col]; q += l[1][k][col]; }
+    sums[c] = s;
+    sums[C + c] = q;
+}
+__global__ __launch_bounds__(256) void bn_finalize_sums_kernel(const double* __restrict__ sums, float* __restrict__ stats,
+                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                               int64_t* __restrict__ nbt, int C, float eps, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) nbt[0] += 1;
+    if (c >= C) return;
+    const double M = sums[2 * C];
+    const double mean = sums[c] / M;
+    double var = sums[C + c] / M - mean * mean;
+    if (var < 0) var = 0;
+    stats[c] = (float)mean;
+    stats[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * M / (M > 1 ? M - 1 : 1));
+    }
+}
+__global__ void set_float_kernel(float* p, float v) { *p = v; }
+
 __device__ __forceinline__ float lrelu(float z, float slope) { return z > 0.f ? z : slope * z; }
 
 // out = maxpool_P(leaky_relu(bn(y))); y fp32 [n,H,W,C] ; out 16-bit [n,H/P,W/P,C], or (nchw_flat) [n, C*(H/P)*(W/P)] in the
@@ -452,7 +492,8 @@ __global__ __launch_bounds__(256) void bn_act_pool_bwd_kernel(const float* __res
     extern __shared__ float lds[];                // MODE 0: [2][C] partial sums
     const int Ho = H / P, Wo = W / P, cc = C / 4;
     const unsigned total = (unsigned)n * Ho * Wo * cc;
-    const float invM = 1.0f / ((float)n * H * W);
+    // use_batch_stats == 2: synchronised BatchNorm, the all-reduced row count sits behind the sums
+    const float invM = (MODE == 1 && use_batch_stats == 2) ? 1.0f / red[2 * C] : 1.0f / ((float)n * H * W);
     if (MODE == 0) {
         for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lds[i] = 0.f;
         __syncthreads();
@@ -572,7 +613,7 @@ __global__ __launch_bounds__(256) void bn_act_maxpool_bwd_kernel(const float* __
     extern __shared__ float lds[];
     const int cc = C / 4;
     const unsigned total = (unsigned)n * H * W * cc;
-    const float invM = 1.0f / ((float)n * H * W);
+    const float invM = (MODE == 1 && use_batch_stats == 2) ? 1.0f / red[2 * C] : 1.0f / ((float)n * H * W);
     if (MODE == 0) {
         for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lds[i] = 0.f;
         __syncthreads();
@@ -769,6 +810,40 @@ extern "C" int eoe_stem_unpack_wgrad(const float* g, float* dw, int cout, int kh
     return 0;
 }
 
+// ---- synchronised BatchNorm: a registered all-reduce is called at every training-mode reduction point (include/eoe_hip.h)
+static eoe_allreduce_fn g_bn_sync_fn = nullptr;
+static void* g_bn_sync_user = nullptr;
+extern "C" int eoe_set_bn_sync(eoe_allreduce_fn fn, void* user) {
+    g_bn_sync_fn = fn;
+    g_bn_sync_user = fn ? user : nullptr;
+    return 0;
+}
+bool eoe_bn_sync_active() { return g_bn_sync_fn != nullptr; }
+int eoe_bn_sync_allreduce(void* buf, int64_t count, int is_f64, void* stream) {
+    if (!g_bn_sync_fn) return eoe_set_error(EOE_ERR_ARG, "bn sync: no hook registered");
+    if (g_bn_sync_fn(g_bn_sync_user, buf, count, is_f64, stream) != 0) return eoe_set_error(EOE_ERR_LAUNCH, "bn sync: the all-reduce hook failed");
+    return 0;
+}
+
+// partial rows [P][2C] -> stats (+ running buffers); with the hook: -> double sums behind the rows -> all-reduce -> stats
+static int bn_finalize_rows(const float* rows, int P, float* sums_scratch, float* stats, float* running_mean, float* running_var,
+                            int64_t* nbt, int M, int C, float eps, float momentum, hipStream_t s) {
+    if (!g_bn_sync_fn) {
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(1024), 0, s, rows, P, stats, running_mean, running_var, nbt, M, C,
+                           eps, momentum);
+        EOE_CHECK_LAUNCH("bn_finalize");
+        return 0;
+    }
+    double* dsum = (double*)(sums_scratch + (size_t)EOE_BN_PARTIALS * 2 * C);        // the 3 spare rows of EOE_BN_SCRATCH: 3C doubles
+    hipLaunchKernelGGL(bn_sums_kernel, dim3(cdiv(C, 16)), dim3(1024), 0, s, rows, P, dsum, M, C);
+    EOE_CHECK_LAUNCH("bn_sums");
+    EOE_TRY(eoe_bn_sync_allreduce(dsum, 2 * (int64_t)C + 1, 1, (void*)s));
+    hipLaunchKernelGGL(bn_finalize_sums_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)dsum, stats, running_mean, running_var,
+                       nbt, C, eps, momentum);
+    EOE_CHECK_LAUNCH("bn_finalize_sums");
+    return 0;
+}
+
 extern "C" int eoe_bn_stats(const float* y, float* sums_scratch, float* stats, float* running_mean, float* running_var,
                             int64_t* num_batches_tracked, int M, int C, float eps, float momentum, int training, void* stream) {
     EOE_CHECK_ARG(stats && M > 0 && C > 0, "bn_stats: bad args");
@@ -794,10 +869,7 @@ extern "C" int eoe_bn_stats(const float* y, float* sums_scratch, float* stats, f
     if (vec == 4) hipLaunchKernelGGL(bn_stats_kernel<4>, dim3(gx, gy), dim3(256), 0, s, y, sums_scratch, M, C, cpb);
     else hipLaunchKernelGGL(bn_stats_kernel<1>, dim3(gx, gy), dim3(256), 0, s, y, sums_scratch, M, C, cpb);
     EOE_CHECK_LAUNCH("bn_stats");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(1024), 0, s, (const float*)sums_scratch, gy, stats, running_mean,
-                       running_var, num_batches_tracked, M, C, eps, momentum);
-    EOE_CHECK_LAUNCH("bn_finalize");
-    return 0;
+    return bn_finalize_rows(sums_scratch, gy, sums_scratch, stats, running_mean, running_var, num_batches_tracked, M, C, eps, momentum, s);
 }
 
 extern "C" int eoe_bn_stats_partials(const float* part, int R, float* sums_scratch, float* stats, float* running_mean,
@@ -813,10 +885,7 @@ extern "C" int eoe_bn_stats_partials(const float* part, int R, float* sums_scrat
         EOE_CHECK_LAUNCH("bn_fold_partials");
         rows = sums_scratch;
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(1024), 0, s, rows, P, stats, running_mean, running_var,
-                       num_batches_tracked, M, C, eps, momentum);
-    EOE_CHECK_LAUNCH("bn_finalize");
-    return 0;
+    return bn_finalize_rows(rows, P, sums_scratch, stats, running_mean, running_var, num_batches_tracked, M, C, eps, momentum, s);
 }
 
 extern "C" int eoe_bn_act_pool_fwd(const float* y, const float* stats, const float* gamma, const float* beta, void* out,
@@ -867,6 +936,11 @@ extern "C" int eoe_bn_act_pool_bwd(const float* y, const float* stats, const flo
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * C, 16)), dim3(1024), 0, s, (const float*)(red_scratch + 2 * C), red_scratch, g0,
                        2 * C, dbeta, dgamma, C, accumulate);
     EOE_CHECK_LAUNCH("bn_act_pool_bwd_reduce2");
+    if (training && g_bn_sync_fn) {      // (sum g, sum g*xhat, rows) summed over the ranks; dgamma / dbeta above stay this rank's
+        hipLaunchKernelGGL(set_float_kernel, dim3(1), dim3(1), 0, s, red_scratch + 2 * C, (float)n * H * W);
+        EOE_TRY(eoe_bn_sync_allreduce(red_scratch, 2 * (int64_t)C + 1, 0, stream));
+        training = 2;
+    }
     if (pool == 1) { EOE_BNB(1, 1, grid, 0); } else { EOE_BNB(1, 2, grid, 0); }
     EOE_CHECK_LAUNCH("bn_act_pool_bwd_apply");
 #undef EOE_BNB
@@ -926,6 +1000,11 @@ extern "C" int eoe_bn_act_maxpool_bwd(const float* y, const float* stats, const 
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * C, 16)), dim3(1024), 0, s, (const float*)(red_scratch + 2 * C), red_scratch, g0,
                        2 * C, dbeta, dgamma, C, 0);
     EOE_CHECK_LAUNCH("bn_act_maxpool_bwd_reduce2");
+    if (training && g_bn_sync_fn) {
+        hipLaunchKernelGGL(set_float_kernel, dim3(1), dim3(1), 0, s, red_scratch + 2 * C, (float)n * H * W);
+        EOE_TRY(eoe_bn_sync_allreduce(red_scratch, 2 * (int64_t)C + 1, 0, stream));
+        training = 2;
+    }
     if (stride == 2) { EOE_BMP(1, 2, grid, 0); } else if (stride == 1) { EOE_BMP(1, 1, grid, 0); } else { EOE_BMP(1, 0, grid, 0); }
 #undef EOE_BMP
 #undef EOE_BMP_T

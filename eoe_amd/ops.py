@@ -759,7 +759,7 @@ def focal_loss(feats, labels, inv_count=None, gamma=2.0, eps=1e-7):
 
 
 # ------------------------------------------------------------------------------------------------ autograd: CNN backbone
-BN_SCRATCH = (1024 + 1) * 2         # EOE_BN_SCRATCH(C) / C of include/eoe_hip.h: per-workgroup partial sums + the total
+BN_SCRATCH = (1024 + 3) * 2         # EOE_BN_SCRATCH(C) / C of include/eoe_hip.h: per-workgroup partial sums + totals (+ the sync-BN doubles)
 
 
 def _conv_kp(cin: int, taps: int = 25) -> int:

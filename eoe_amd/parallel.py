@@ -8,11 +8,14 @@ each ViT block's slice (28 MB for ViT-B/32) is one bucket whose all-reduce is is
 backward (RCCL runs it on its own stream, overlapped with the remaining backward kernels); all other parameters
 (and every layer of the conv nets) go out in ~8 MB runs as their gradients arrive (`GradArena`).
 
-BatchNorm encoders (CNN32 / CNN28 / WideResNet + CBAM) under data parallelism use PER-RANK batch statistics, exactly as
-`torch.nn.parallel.DistributedDataParallel` without SyncBatchNorm does: their activations and gradients are those of R
-independent half-batches, not of the single-device full batch, and each rank's running statistics follow its own shard
-(snapshots take rank 0's).  The ViT headline model has no BatchNorm and is exact.
+BatchNorm encoders (CNN32 / CNN28 / WideResNet + CBAM): the reference is single-device, its BatchNorm layers see the whole
+step batch.  `enable_sync_bn()` keeps that meaning under data parallelism: every training-mode BatchNorm reduction of the HIP
+library -- forward (sum, sum of squares, rows), backward (sum g, sum g*xhat, rows) -- is summed over the ranks before it is used
+(C ABI hook `eoe_set_bn_sync`), so activations, gradients and running statistics are those of the global batch whatever the
+sharding (ragged shards included: the row count travels with the sums).  Without it the statistics are per rank
+(`DistributedDataParallel`-without-SyncBatchNorm semantics).  The ViT headline model has no BatchNorm.
 """
+import ctypes as C
 import os
 import weakref
 from typing import List, Optional
@@ -231,6 +234,48 @@ class GradArena:
         if self.comm is not None:
             self.comm.join()
         self.issued = []
+
+
+_bn_sync_cb = None            # the ctypes callback object must outlive its registration
+
+
+class _DevPtr:
+    """a raw device buffer as a `__cuda_array_interface__` object (what torch.as_tensor wraps without a copy)"""
+
+    def __init__(self, ptr: int, count: int, f64: bool):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8" if f64 else "<f4", "data": (ptr, False), "version": 2}
+
+
+def enable_sync_bn(process_group=None) -> bool:
+    """synchronised BatchNorm over `process_group` (module docstring); returns False (and clears the hook) when there is
+    nothing to synchronise (no process group, or one rank)"""
+    global _bn_sync_cb
+    from . import _lib
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+        disable_sync_bn()
+        return False
+
+    def _hook(user, buf, count, is_f64, stream):
+        try:
+            # the library passes the stream the ops were given = torch's current stream, the one all_reduce orders itself after
+            t = torch.as_tensor(_DevPtr(buf, count, bool(is_f64)), device=torch.device("cuda", torch.cuda.current_device()))
+            dist.all_reduce(t, group=process_group)
+            return 0
+        except Exception as e:          # an exception must not unwind through the C frame
+            print(f"eoe_amd.parallel: BatchNorm all-reduce failed: {e!r}", flush=True)
+            return 1
+
+    cb = _lib.ALLREDUCE_FN(_hook)
+    _lib.check(_lib.lib.eoe_set_bn_sync(C.cast(cb, C.c_void_p), None), "eoe_set_bn_sync")
+    _bn_sync_cb = cb
+    return True
+
+
+def disable_sync_bn():
+    global _bn_sync_cb
+    from . import _lib
+    _lib.check(_lib.lib.eoe_set_bn_sync(None, None), "eoe_set_bn_sync")
+    _bn_sync_cb = None
 
 
 def all_gather_1d(t: torch.Tensor, group=None) -> torch.Tensor:

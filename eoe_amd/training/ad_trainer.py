@@ -84,7 +84,7 @@ class ADTrainer(ABC):
                  wdk: float = 0.0, milestones: List[int] = (), batch_size: int = 128, ad_mode: str = "one_vs_rest",
                  device: Union[str, torch.device] = "cuda", oe_limit_samples=np.inf, oe_limit_classes=np.inf,
                  msms=(), workers: int = 2, classes: List[str] = None, data_parallel: bool = False,
-                 graph_steps: bool = False):
+                 graph_steps: bool = False, sync_bn: bool = True):
         """same parameters as the reference (`ad_trainer.py:98-164`).  `dataset` is either a step-batch source
         (eoe_amd.data: an object with `.loaders(batch_size)`, `.nominal_label`, `.normalize`) or a callable
         `(cls, seed) -> source`; `classes` names the classes to iterate (default: one class "0")."""
@@ -103,6 +103,7 @@ class ADTrainer(ABC):
         self.ds = dataset if hasattr(dataset, "loaders") else None
         self.classes = classes if classes is not None else ["0"]
         self.data_parallel = data_parallel
+        self.sync_bn = sync_bn      # data parallel only: BatchNorm statistics of the GLOBAL step batch (eoe_amd.parallel.enable_sync_bn)
         if msms:
             raise NotImplementedError("multi-scale modes (MSM) are out of scope")
 
@@ -239,10 +240,13 @@ class ADTrainer(ABC):
             rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
             arena = parallel.GradArena(model)
             arena.install_hooks()
-            if rank == 0 and any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in model.modules()):
-                self.logger.warning("data parallel training of a BatchNorm encoder: batch statistics are per rank (no SyncBatchNorm), "
-                                    "i.e. DistributedDataParallel semantics, not the single-device full-batch ones; snapshots keep "
-                                    "rank 0's running statistics (eoe_amd/parallel.py)")
+            if any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in model.modules()):
+                # the reference's BatchNorm layers see the whole step batch: keep that meaning across the ranks
+                if self.sync_bn:
+                    parallel.enable_sync_bn()
+                elif rank == 0:
+                    self.logger.warning("data parallel training of a BatchNorm encoder with sync_bn=False: batch statistics are per "
+                                        "rank, not those of the single-device full batch (eoe_amd/parallel.py)")
         nominal = getattr(ds, "nominal_label", 0)
         self.last_losses = []
         graphed = None                                      # (batch shape, GraphedStep) of the full-size step batch
@@ -306,6 +310,7 @@ class ADTrainer(ABC):
                 sched.step()                                                                            # :468
         finally:
             if arena is not None:
+                parallel.disable_sync_bn()
                 arena.remove_hooks()
                 for p in model.parameters():
                     if hasattr(p, "_eoe_grad_buf"):

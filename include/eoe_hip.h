@@ -333,7 +333,15 @@ int eoe_stem_unpack_wgrad(const float* g, float* dw, int cout, int kh, int kw, v
  * running_mean/var (momentum, unbiased var) and num_batches_tracked as nn.BatchNorm does (cnn.py:57-66); eval reads
  * the running buffers.  sums_scratch: EOE_BN_SCRATCH(C) floats (per-workgroup partial sums: no atomics). */
 #define EOE_BN_PARTIALS 1024
-#define EOE_BN_SCRATCH(C) ((EOE_BN_PARTIALS + 1) * 2 * (C))
+#define EOE_BN_SCRATCH(C) ((EOE_BN_PARTIALS + 3) * 2 * (C))
+/* Synchronised BatchNorm for data-parallel training (the reference is single-device: its BatchNorm sees the whole batch,
+ * cnn.py:57-66, resnet.py:37-41, cbam.py:74).  With a hook registered, every training-mode BatchNorm reduction point of this
+ * library -- (sum, sum of squares, row count) of the forward statistics as 2C+1 doubles, (sum g, sum g*xhat, row count) of the
+ * backward as 2C+1 floats -- is handed to `fn` for an in-place SUM over the ranks, on `stream`, before it is used; the row count
+ * travels with the sums, so ranks may hold different numbers of rows.  fn == NULL switches back to per-rank statistics.
+ * Process-wide, like eoe_set_option; not capturable in a HIP graph.  Returns 0 / the hook returns 0 on success. */
+typedef int (*eoe_allreduce_fn)(void* user, void* buf, int64_t count, int is_f64, void* stream);
+int eoe_set_bn_sync(eoe_allreduce_fn fn, void* user);
 /* the same statistics from the partial rows [R][2][C] an eoe_gemm_nt call with `colstats` left in its workspace (R = ceil(M/64)) */
 int eoe_bn_stats_partials(const float* part, int R, float* sums_scratch, float* stats, float* running_mean, float* running_var,
                           int64_t* num_batches_tracked, int M, int C, float eps, float momentum, void* stream);

@@ -233,3 +233,83 @@ def test_trainer_data_parallel_ragged_batches(tmp_path):
     for k in sd:
         a, b = got["sd"][k].double(), sd[k].double()
         assert (a - b).norm().item() <= 2e-3 * max(b.norm().item(), 1e-6), k
+
+
+# ------------------------------------------------------------------------------------------------ synchronised BatchNorm
+def _bn_model(kind):
+    from eoe_amd.models import CNN32, WideResNet
+    from oracle import models as omodels
+    if kind == "cnn32":
+        return omodels.deterministic_init(CNN32(bias=True), tag="cnn32").cuda().train(), (15, 15, 32)
+    return omodels.deterministic_init(WideResNet(res=32), tag="wrn32sync").cuda().train(), (7, 7, 32)
+
+
+def _bn_buffers(m):
+    return {k: v.detach().cpu() for k, v in m.state_dict().items() if "running_" in k or "num_batches" in k}
+
+
+def _syncbn_worker(rank, world, port, out, kind):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    import eoe_amd
+    from eoe_amd import parallel
+    from oracle import trainer as otrainer
+    parallel.init_from_env("gloo")
+    torch.cuda.set_device(0)
+    eoe_amd.set_compute_dtype("fp16")
+    eoe_amd.set_parity_mode(kind == "wrn32")
+    m, (nn_, no_, res) = _bn_model(kind)
+    arena = parallel.GradArena(m, bucket_bytes=256 << 10)
+    arena.install_hooks()
+    assert parallel.enable_sync_bn()
+    x, y = otrainer.synthetic_batch("ddp/syncbn", nn_, no_, res)
+    rows = parallel.shard_rows(nn_, no_, rank, world)              # odd halves: the ranks hold 7 + 7 and 8 + 8 rows (3 + 3 / 4 + 4)
+    loss = eoe_amd.hsc_loss(m(x[rows].cuda()), y[rows].cuda(), 0, 1.0 / (nn_ + no_))
+    loss.backward()
+    arena.finish()
+    parallel.disable_sync_bn()
+    tot = loss.detach().clone()
+    dist.all_reduce(tot)
+    if rank == 0:
+        torch.save({"grads": {k: p.grad.cpu() for k, p in m.named_parameters()}, "loss": tot.cpu(), "buffers": _bn_buffers(m),
+                    "rows": len(rows)}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["cnn32", "wrn32"])
+def test_sync_batchnorm_two_ranks_equal_the_full_batch(tmp_path, kind):
+    """2 ranks with UNEVEN shards and `enable_sync_bn()`: every BatchNorm (2-d, 1-d, the spatial gate's one-channel one) normalises
+    with the statistics of the global batch, so loss, summed gradients and the running buffers equal the single-process full-batch
+    step -- the meaning the single-device reference gives its BatchNorm layers (cnn.py:57-66, resnet.py:37-41, cbam.py:74)"""
+    import eoe_amd
+    from oracle import trainer as otrainer
+    out = str(tmp_path / "sbn.pt")
+    mp.spawn(_syncbn_worker, args=(2, _free_port(), out, kind), nprocs=2, join=True)
+    got = torch.load(out)
+    eoe_amd.set_compute_dtype("fp16")
+    # the 14-image WideResNet (1x1 maps in layer4: BatchNorm over 14 values) amplifies 16-bit operand rounding to percents of the
+    # stem gradient whichever way the batch is split; its fp32 parity mode isolates the BatchNorm logic under test
+    eoe_amd.set_parity_mode(kind == "wrn32")
+    try:
+        m, (nn_, no_, res) = _bn_model(kind)
+        assert got["rows"] < nn_ + no_
+        x, y = otrainer.synthetic_batch("ddp/syncbn", nn_, no_, res)
+        loss = eoe_amd.hsc_loss(m(x.cuda()), y.cuda(), 0)
+        loss.backward()
+    finally:
+        eoe_amd.set_parity_mode(False)
+    assert abs(got["loss"].item() - loss.item()) < 1e-4 * max(1.0, abs(loss.item()))
+    for k, v in _bn_buffers(m).items():
+        # (deep layers: the 16-bit activation copies upstream may round differently when a statistic moves by one ulp)
+        np.testing.assert_allclose(got["buffers"][k].double().numpy(), v.double().numpy(), rtol=1e-3, atol=2e-5, err_msg=k)
+    worst = 0.0
+    for k, p in m.named_parameters():
+        ref = p.grad.cpu().double()
+        err = (got["grads"][k].double() - ref).norm().item() / max(ref.norm().item(), 1e-9)
+        # (a bias in front of a BatchNorm has a true gradient of 0: both sides hold rounding noise only)
+        noise_only = ref.norm().item() < 1e-6 * max(p.detach().norm().item(), 1.0) or (k.endswith("bias") and ("conv" in k or k == "fc1.bias") and kind == "cnn32")
+        if not noise_only:
+            worst = max(worst, err)
+            assert err < (3e-3 if kind == "cnn32" else 1e-3), (k, err, ref.norm().item())
+    print(f"[sync bn {kind}] worst relative gradient deviation {worst:.2e}")
