@@ -48,8 +48,9 @@ def parse():
     ap.add_argument("--side-stream", type=int, default=None, help="0: LayerNorm-1 backward after (not next to) the grouped wgrad")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="capture forward + loss + backward + scores of one step in a HIP graph and replay it (1 GPU only; "
-                         "the optimiser step stays outside the graph).  auto = on for the launch-bound cnn32 configuration; "
-                         "the ViT / WideResNet steps are GPU-bound and measure the same either way")
+                         "the optimiser step stays outside the graph).  auto = on for the launch-bound 32x32 configurations (cnn32, "
+                         "wrn --res <= 64: ~400 launches of a few us each); the ViT / WideResNet-224 steps are GPU-bound and "
+                         "measure the same either way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--res", type=int, default=None, help="input resolution of --model wrn (224 default; 32 = BASELINE.json config 2)")
@@ -217,7 +218,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = args.graph == "on" or (args.graph == "auto" and args.model == "cnn32" and world == 1)
+    launch_bound = args.model == "cnn32" or (args.model == "wrn" and res <= 64)
+    use_graph = args.graph == "on" or (args.graph == "auto" and launch_bound and world == 1)
     eager_step = step
     if use_graph:
         assert world == 1, "--graph on is a single-GPU option"

@@ -75,7 +75,9 @@ def test_conv_bn_general_vs_oracle(dtype, n, cin, cout, H, k, s, p, slope, is_im
 
 @pytest.mark.parametrize("n,cin,cout,H,k,s,p", [(5, 64, 64, 13, 3, 1, 1), (3, 128, 256, 14, 3, 2, 1), (2, 64, 128, 9, 1, 2, 0),
                                                (2, 256, 64, 7, 3, 1, 1), (1, 64, 192, 30, 5, 1, 2), (3, 32, 64, 16, 5, 1, 2),
-                                               (2, 16, 64, 11, 3, 1, 1), (2, 8, 64, 10, 3, 2, 1)])
+                                               (2, 16, 64, 11, 3, 1, 1), (2, 8, 64, 10, 3, 2, 1),
+                                               # 1x1 maps under a padded kernel: the one-tap plain-GEMM shortcut (ops._single_pixel)
+                                               (37, 128, 192, 1, 3, 1, 1), (70, 64, 64, 1, 5, 1, 2), (256, 512, 512, 1, 3, 1, 1)])
 def test_implicit_conv_equals_materialised(n, cin, cout, H, k, s, p):
     """the implicit-GEMM path (patches fetched inside the GEMM's LDS stage: forward, wgrad, stride-1 dgrad) against the
     materialised im2col / col2im path on the same 16-bit operands: same products, different summation order only"""
