@@ -418,3 +418,46 @@ def test_conv_weight_pack_batched(dtype):
             assert torch.equal(w16d, refd), (co, ci, k, cp)
     finally:
         eoe_amd.set_compute_dtype("fp16")
+
+
+@pytest.mark.parametrize("dtype", ["bf16"])
+def test_wideresnet32_graph_replay_equals_eager(dtype):
+    """the HIP-graph replay `bench.py --model wrn --res 32` uses by default (a launch-bound ~400-kernel step): 20 replayed Adam steps
+    against the eager run at the benchmark batch.  The WideResNet step holds no atomics, so the trajectories have identical bits."""
+    import eoe_amd
+    from eoe_amd import parallel
+    from eoe_amd.models import WideResNet
+    eoe_amd.set_compute_dtype(dtype)
+    dev, nb = torch.device("cuda"), 128
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+    imgs = torch.randn((2 * nb, 3, 32, 32), generator=gen, device=dev)
+    imgs[nb:] += 0.5
+    lbls = torch.cat([torch.zeros(nb, dtype=torch.int64), torch.ones(nb, dtype=torch.int64)]).to(dev)
+
+    def run(graph):
+        torch.manual_seed(0)
+        model = WideResNet(res=32).to(dev).train()
+        opt = eoe_amd.FusedAdam(model.parameters(), lr=1e-3, weight_decay=0.0)
+        arena = parallel.GradArena(model)
+        gs = eoe_amd.GraphedStep(model, lambda f, y: eoe_amd.hsc_loss(f, y, 0, 1.0 / (2 * nb)), eoe_amd.hsc_score, imgs, lbls) if graph else None
+        losses = []
+        for _ in range(20):
+            opt.zero_grad()
+            if graph:
+                loss, _ = gs(imgs, lbls)
+            else:
+                loss = eoe_amd.hsc_loss(model(imgs), lbls, 0, 1.0 / (2 * nb))
+                loss.backward()
+            opt.step()
+            losses.append(loss.detach().clone())
+        del arena
+        return torch.stack(losses).cpu()
+    try:
+        ref = run(False)
+        assert torch.isfinite(ref).all()
+        for rep in range(2):
+            got = run(True)
+            assert torch.equal(got, ref), (rep, (got != ref).nonzero().flatten()[:4].tolist(), (got - ref).abs().max().item())
+    finally:
+        eoe_amd.set_compute_dtype("fp16")
