@@ -96,7 +96,8 @@ class VitBlockBwdArgs(C.Structure):
                 ("g_b_in", _vp), ("g_b_out", _vp), ("g_b_fc", _vp), ("g_b_proj", _vp),
                 ("g_w_in", _vp), ("g_w_out", _vp), ("g_w_fc", _vp), ("g_w_proj", _vp),
                 ("accumulate", _i32),
-                ("d16_a", _vp), ("d16_b", _vp), ("d16_c", _vp), ("dh", _vp), ("dqkv", _vp), ("dx_mid", _vp), ("red_scratch", _vp)]
+                ("d16_a", _vp), ("d16_b", _vp), ("d16_c", _vp), ("dh", _vp), ("dqkv", _vp), ("dx_mid", _vp), ("red_scratch", _vp),
+                ("tn_workspace", _vp), ("tn_workspace_bytes", _i64)]
 
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); must match include/eoe_hip.h

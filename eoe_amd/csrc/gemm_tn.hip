@@ -15,6 +15,9 @@
 // address: LDS-DMA writes linearly), conflict-free for both 4-row halves of a k-step.
 // Workgroup ids are remapped so that each XCD (private L2) gets a contiguous run of tiles, which share A/B panels.
 #include "common.h"
+#include <map>
+#include <mutex>
+#include <utility>
 #include <stdlib.h>
 
 int g_tn_flags = 0;     // option "tn_flags": reserved for A/B experiments (none active)
@@ -43,6 +46,10 @@ struct TnGroup {
     unsigned long long mHoWo, mWo;
     float* part;      // split reduction without atomics (optional workspace): split s of problem i writes a dense [M][N] block
     long long part_stride[EOE_TN_MAX_GROUP];   // element offset of problem i's partial block in `part`
+    // stream-K (sk_wgs > 0): see gemm_tn_grouped_kernel
+    int sk_wgs;
+    float* sk_part;   // [sk_wgs][BM*BN] partial accumulators of the ranges that do not end their tile
+    int* sk_flags;    // [sk_wgs] = 1 once that workgroup's partial is visible; reset to 0 by the workgroup that consumes it
 };
 
 __device__ __forceinline__ int swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
@@ -85,8 +92,44 @@ template <typename T, int GATHER, int RD = 1>
 __global__ __launch_bounds__(512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int split = blockIdx.x / g.total_tiles;
-    const int gt = xcd_remap(blockIdx.x % g.total_tiles, g.total_tiles);
+    // Stream-K (g.sk_wgs > 0; round 2).  A group of 216 equal tiles on 256 CUs leaves 16 % of the chip idle whatever the tile shape (one
+    // round, the largest tile sets the time).  Instead the (tile, k-tile) space of the whole group is cut into gridDim.x = #CUs equal
+    // ranges, one per workgroup.  A range is shorter than a tile's reduction, so it is at most the END of one tile followed by the START
+    // of the next: up to two segments.  A segment that does not end its tile stores its accumulators as a partial (128 KiB, fragment
+    // order) and publishes a flag; the workgroup whose segment ends the tile adds the one or two partials in a fixed order and runs the
+    // epilogue.  No atomics on data, no second kernel, bitwise reproducible; extra traffic 2 x 128 KiB per split point.  The grid is
+    // exactly one workgroup per CU (144 KiB of LDS each), so every range is resident while its successor waits for it; the wait is
+    // bounded all the same and a time-out poisons the tile with NaN instead of hanging the GPU or passing silently.
+    const int split = g.sk_wgs ? 0 : (int)blockIdx.x / g.total_tiles;
+    const int nk_tile = (g.T + BK - 1) / BK;
+    const long long sk_total = (long long)g.total_tiles * nk_tile;
+    int seg_gt[2], seg_tb[2], seg_te[2], nseg = 1;
+    // range index: XCD-remapped like the tiles of the plain launch, so the 32 workgroups of an XCD walk neighbouring tiles (shared A / B
+    // slabs stay in its L2: without this every CU streams its own 10 MB of operands, 2.5 GB per launch) and a range's predecessor sits
+    // on the same XCD (its partial is read at the same-XCD rate) except at the 7 chunk starts
+    const int rid = g.sk_wgs ? xcd_remap((int)blockIdx.x, g.sk_wgs) : 0;
+    if (g.sk_wgs) {
+        const long long u0 = sk_total * (long long)rid / g.sk_wgs, u1 = sk_total * ((long long)rid + 1) / g.sk_wgs;
+        const int t0 = (int)(u0 / nk_tile);
+        const long long e0 = (long long)(t0 + 1) * nk_tile;
+        seg_gt[0] = t0;
+        seg_tb[0] = (int)(u0 - (long long)t0 * nk_tile) * BK;
+        seg_te[0] = (u1 < e0) ? (int)(u1 - (long long)t0 * nk_tile) * BK : g.T;
+        seg_gt[1] = t0 + 1; seg_tb[1] = 0; seg_te[1] = 0;
+        if (u1 > e0) { nseg = 2; seg_te[1] = min(g.T, (int)(u1 - e0) * BK); }
+    } else {
+        seg_gt[0] = xcd_remap((int)blockIdx.x % g.total_tiles, g.total_tiles);
+        seg_tb[0] = split * g.t_per_split;
+        seg_te[0] = min(g.T, seg_tb[0] + g.t_per_split);
+        seg_gt[1] = 0; seg_tb[1] = 0; seg_te[1] = 0;
+    }
+    // the segment that STARTS a tile goes first: its partial is what the next workgroup's fix-up waits for (the other order chains every
+    // workgroup behind its predecessor: 7 ms instead of 0.2)
+#pragma nounroll
+  for (int si = 0; si < nseg; ++si) {
+    const int seg = nseg - 1 - si;
+    if (si) __syncthreads();                     // the previous segment's last ring reads are behind every wave
+    const int gt = seg_gt[seg];
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < EOE_TN_MAX_GROUP; ++i)
@@ -94,8 +137,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
     const TnProblem& P = g.p[pi];
     const int lt = gt - P.tile_start;
     const int m0 = (lt / P.tiles_n) * BM, n0 = (lt % P.tiles_n) * BN;
-    const int t_begin = split * g.t_per_split;
-    const int t_end = min(g.T, t_begin + g.t_per_split);
+    const int t_begin = seg_tb[seg];
+    const int t_end = seg_te[seg];
 
     __amdgpu_buffer_rsrc_t ra = make_rsrc(P.A, P.bytesA);
     __amdgpu_buffer_rsrc_t rb = make_rsrc(P.B, P.bytesB);
@@ -257,6 +300,65 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
 #undef EOE_MFMA
 #undef EOE_LANDED
 
+    if (g.sk_wgs) {
+        const long long W = g.sk_wgs;
+        // (no second __shared__ object: the asm fragment reads assume the ring at LDS address 0; the time-out word borrows the first
+        //  bytes of the ring, idle by now -- every DMA piece and fragment read of this workgroup's last segment has landed)
+        volatile int* sk_timeout = (volatile int*)smem;
+        if (t_end < g.T) {                       // contributor: partial accumulators in fragment order (16 B per lane, coalesced)
+            float* mine = g.sk_part + (size_t)rid * (BM * BN);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    *(f32x4*)(mine + ((size_t)((wave * 16 + mi * 4 + ni) * 64 + lane)) * 4) = acc[mi][ni];
+            // publish (cdna_hip_programming.md, Guideline 16): every storing wave drains its stores, the workgroup meets, ONE lane
+            // releases at agent scope and raises the flag with a relaxed agent-scope store (a __threadfence() per thread here
+            // writes the XCD's L2 back 512 times per workgroup: 360 us instead of 180)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(g.sk_flags + rid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            continue;
+        }
+        if (t_begin > 0) {                       // owner of a split tile: add the earlier ranges' partials, nearest first
+            const long long tile_u0 = (long long)gt * nk_tile;
+            for (int cc = rid - 1; cc >= 0; --cc) {
+                const long long cu0 = sk_total * cc / W, cu1 = sk_total * (cc + 1) / W;
+                if (cu1 <= tile_u0) break;
+                if (tid == 0) {
+                    // relaxed polls of the one word (an acquiring poll would invalidate the caches on every iteration), bounded: a
+                    // protocol error must not hang the GPU (the result is then wrong and the tests say so); ONE acquire after the match
+                    int spins = 0;
+                    while (__hip_atomic_load(g.sk_flags + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1 && ++spins < (1 << 22))
+                        __builtin_amdgcn_s_sleep(8);
+                    *sk_timeout = spins >= (1 << 22) ? 1 : 0;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    // self-cleaning: each flag has exactly one reader; the next launch finds the words zero again
+                    __hip_atomic_store(g.sk_flags + cc, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+                if (*sk_timeout) {               // loud, not silent: the tile becomes NaN
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){NAN, NAN, NAN, NAN};
+                    break;
+                }
+                const float* theirs = g.sk_part + (size_t)cc * (BM * BN);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+                        acc[mi][ni] += *(const f32x4*)(theirs + ((size_t)((wave * 16 + mi * 4 + ni) * 64 + lane)) * 4);
+                if (cu0 <= tile_u0) break;
+            }
+        }
+    }
     if (g.splits > 1 && g.part) {
         // per-split partial result [M][N] (dense), summed by tn_reduce_kernel
         float* base = g.part + g.part_stride[pi] + (size_t)split * P.M * P.N;
@@ -271,7 +373,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
                 *(f32x4*)(base + (size_t)m * P.N + n) = acc[mi][ni];
             }
         }
-        return;
+        continue;
     }
     const bool atomic = g.splits > 1;
     const bool vec = ((P.ldc & 3) == 0) && ((P.N & 3) == 0) && !atomic;
@@ -298,6 +400,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
             }
         }
     }
+  }   // segments
 }
 
 // C[m][n] = alpha * sum_s part[s][m][n] (+ C if accumulate).  A workgroup owns 64 column quads; its 4 wavefronts take the
@@ -350,6 +453,26 @@ int check_problem(const eoe_gemm_args* a, int T, int dtype) {
 }
 
 }  // namespace
+
+// stream-K flag words: one zeroed block per (device, stream), owned by the library and self-cleaning (every flag is reset by its one
+// reader), so a launch -- or the replay of a captured one -- always starts from zeros whatever the caller does with its workspace.
+// Not created while the stream is being captured (that launch then runs without stream-K).
+static int* streamk_flags(hipStream_t s, int n) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, int*> table;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = table.find({dev, s});
+    if (it != table.end()) return it->second;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
+    int* p = nullptr;
+    if (hipMalloc(&p, (size_t)n * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, (size_t)n * sizeof(int)) != hipSuccess) { (void)hipFree(p); return nullptr; }
+    table[{dev, s}] = p;
+    return p;
+}
 
 extern "C" int eoe_gemm_tn_grouped(const eoe_gemm_args* args, int count, void* stream) {
     EOE_CHECK_ARG(args && count >= 1 && count <= EOE_TN_MAX_GROUP, "gemm_tn_grouped: count %d not in [1, %d]", count,
@@ -431,12 +554,30 @@ extern "C" int eoe_gemm_tn_grouped(const eoe_gemm_args* args, int count, void* s
         }
     }
     const int gather = args[0].gather;
+    // stream-K: a plain group that fills between 5/8 and all of the CUs with one tile each (the ViT block's four wgrads: 216 tiles)
+    // runs as #CUs equal k-ranges instead (kernel comment); needs the caller's workspace: EOE_TN_STREAMK_WORKSPACE_BYTES(#CUs).
+    // "tn_flags" bit 1 switches it off (A/B)
+    int grid = tiles * splits;
+    {
+        const int nk_tile = cdiv(T, BK);
+        const size_t need = (size_t)ncu * (BM * BN * sizeof(float));
+        if (!(g_tn_flags & 2) && gather == 0 && splits == 1 && tiles < ncu && nk_tile >= 32 && args[0].workspace &&
+            (size_t)args[0].workspace_bytes >= need && (((uintptr_t)args[0].workspace) & 15) == 0) {
+            int* flags = streamk_flags(s, ncu);
+            if (flags) {
+                g.sk_wgs = ncu;
+                g.sk_part = (float*)args[0].workspace;
+                g.sk_flags = flags;
+                grid = ncu;
+            }
+        }
+    }
 #define EOE_TN_LAUNCH_RD(TT, GG, RR)                                                                                       \
     do {                                                                                                                   \
         static bool once = (hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel<TT, GG, RR>,                           \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES), true);            \
         (void)once;                                                                                                        \
-        hipLaunchKernelGGL((gemm_tn_grouped_kernel<TT, GG, RR>), dim3(tiles * splits), dim3(512), SMEM_BYTES, s, g);       \
+        hipLaunchKernelGGL((gemm_tn_grouped_kernel<TT, GG, RR>), dim3(grid), dim3(512), SMEM_BYTES, s, g);       \
     } while (0)
     // option "tn_flags" bit 0 = 1 selects the intrinsic fragment reads (A/B of tr_frag_asm, plain kernel only)
 #define EOE_TN_LAUNCH(TT, GG)                                                                                              \

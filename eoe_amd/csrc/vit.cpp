@@ -9,6 +9,7 @@
         if (rc__ != 0) return rc__; \
     } while (0)
 
+extern int g_tn_flags;          // gemm_tn.hip
 int g_vit_side_stream = 1;      // eoe_set_option("vit_side_stream", 0|1)
 
 namespace {
@@ -152,7 +153,12 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
     w[2] = gemm(b->dqkv, a->xn1, b->g_w_in, nullptr, 3 * D, D, M, 3 * D, D, D, dt);         // dW_in[3D,D]   = dqkv^T xn1
     w[3] = gemm(b->d16_c, a->att, b->g_w_out, nullptr, D, D, M, D, D, D, dt);               // dW_out[D,D]   = dmid^T att
     for (int i = 0; i < 4; ++i) { w[i].out_f32 = 1; w[i].accumulate = acc; }
-    SideStream* ss = (g_vit_side_stream && b->red_scratch) ? side_stream(s) : nullptr;
+    w[0].workspace = b->tn_workspace; w[0].workspace_bytes = b->tn_workspace ? b->tn_workspace_bytes : 0;     // stream-K partials
+    // LayerNorm-1 backward next to the wgrad launch on a second stream pays only while that launch leaves CUs idle (216 tiles on 256
+    // CUs); with the stream-K workspace the launch fills every CU itself and the side stream is left out (same step time, one
+    // stream, capturable)
+    const bool streamk = b->tn_workspace != nullptr && !(g_tn_flags & 2);
+    SideStream* ss = (g_vit_side_stream == 2 || (g_vit_side_stream && !streamk)) && b->red_scratch ? side_stream(s) : nullptr;
     if (ss) {
         // fork before the wgrad launch (LayerNorm-1 backward depends on d xn1 and dx_mid only), join before the finish kernel
         if (hipEventRecord(ss->fork, s) != hipSuccess) return eoe_set_error(EOE_ERR_LAUNCH, "vit_block_bwd: event record failed");

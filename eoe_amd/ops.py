@@ -474,6 +474,8 @@ class VitBlockFunction(torch.autograd.Function):
         b.dx_mid = _p(scratch("dx_mid", (M, D), torch.float32, dev))
         nred = (M + 63) // 64 * 4 * D + 2 * LN_SCRATCH_ROWS * 3 * D + ctx.args.n * 3 * D + 256 * D          # EOE_VIT_RED_SCRATCH(n, L, D)
         b.red_scratch = _p(scratch("vit_red", (nred,), torch.float32, dev))
+        sk_bytes = torch.cuda.get_device_properties(dev).multi_processor_count * (256 * 128 * 4)      # EOE_TN_STREAMK_WORKSPACE_BYTES
+        b.tn_workspace, b.tn_workspace_bytes = _p(scratch("tn_streamk", (sk_bytes,), torch.uint8, dev)), sk_bytes
         check(lib.eoe_vit_block_bwd(C.byref(b), _stream()), "eoe_vit_block_bwd")
         hook = grad_ready_hooks.get(id(params["ln1_g"]))
         if hook is not None and hook[0]() is params["ln1_g"]:      # (weakref to the parameter, callable)

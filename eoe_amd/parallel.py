@@ -184,8 +184,22 @@ class GradArena:
             for p in ps:
                 self._hook_handles.append(p.register_post_accumulate_grad_hook(lambda p, b=b: self._arrived(p, b)))
         self._installed = True
+        # With collectives in flight RCCL's workgroups occupy CUs for the length of a bucket, and the stream-K wgrad launch wants every CU
+        # at once (one k-range per CU, each waiting for its predecessor's partial): ranges that find no CU would start a second round.
+        # Data parallel runs keep the one-tile-per-workgroup launch (216 of 256 CUs) with LayerNorm-1 backward beside it instead.
+        if self._world() > 1:
+            from . import _lib
+            _lib.check(_lib.lib.eoe_set_option(b"tn_flags", 2), "eoe_set_option")
+
+    def _world(self) -> int:
+        if self.comm is not None:
+            return self.comm.world
+        return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
 
     def remove_hooks(self):
+        if self._installed and self._world() > 1:
+            from . import _lib
+            _lib.check(_lib.lib.eoe_set_option(b"tn_flags", 0), "eoe_set_option")
         for first, _, _ in self.block_buckets:
             ops.grad_ready_hooks.pop(id(first), None)
         for h in self._hook_handles:

@@ -77,7 +77,9 @@ typedef struct {
     float alpha;        /* result scale applied to acc before bias/epilogue (1.0 = none) */
     void* workspace;    /* optional (TN): scratch for the per-split partial results of a split reduction; with
                          * workspace_bytes >= EOE_TN_WORKSPACE_BYTES the splits are summed by a second kernel instead of fp32
-                         * atomics (faster, and bitwise reproducible) */
+                         * atomics (faster, and bitwise reproducible).  With >= EOE_TN_STREAMK_WORKSPACE_BYTES(#CUs) a group
+                         * whose tiles fill most but not all of the CUs once (216 of 256) runs as #CUs equal k-ranges (stream-K;
+                         * the first problem's workspace is the one used) */
     int64_t workspace_bytes;
     int32_t gather;     /* 1: A is the NHWC tensor of `geo` and stands for its patch matrix (lda ignored).
                          *    NT: [M = n*Ho*Wo, K = kh*kw*C], C % 64 == 0 (one tap per 64-deep k-tile), or C in {8,16,32} with K
@@ -99,6 +101,7 @@ int eoe_gemm_tn(const eoe_gemm_args* args, void* stream);
  * ONE launch (the four weight gradients of a transformer block fill the chip together: no split-K, no atomics) */
 #define EOE_TN_MAX_GROUP 4
 #define EOE_TN_WORKSPACE_BYTES (512ll * 256 * 128 * 4)   /* (#CUs rounded up) x one 256x128 fp32 tile */
+#define EOE_TN_STREAMK_WORKSPACE_BYTES(cus) ((size_t)(cus) * (256 * 128 * 4))   /* one partial fp32 tile per CU */
 int eoe_gemm_tn_grouped(const eoe_gemm_args* args, int count, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
@@ -281,6 +284,9 @@ typedef struct {
     float* dx_mid;    /* fp32 [M,D] */
     float* red_scratch; /* optional: EOE_VIT_RED_SCRATCH(n, L, D) floats -> LayerNorm-parameter and bias column sums through
                          * partial rows and fixed-order reduce kernels instead of fp32 atomics / separate passes */
+    void* tn_workspace; /* optional: EOE_TN_STREAMK_WORKSPACE_BYTES(#CUs) bytes -> the grouped wgrad launch balances its 216 tiles
+                         * over all CUs (eoe_gemm_args.workspace) */
+    int64_t tn_workspace_bytes;
 } eoe_vit_block_bwd_args;
 
 /* floats: partial rows of the fc dgrad GEMM's fused column sums [ceil(n*L/64)][4D] + of the two LayerNorm backwards + the attention

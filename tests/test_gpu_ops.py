@@ -170,6 +170,52 @@ def test_gemm_tn_grouped(ops, dtype):
         assert_close(out, 2 * ref, 4e-6, 6e-5 * math.sqrt(T), "gemm_tn_grouped accumulate")
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_tn_grouped_stream_k(ops, dtype):
+    """the ViT block's wgrad group (216 tiles of 256x128 on 256 CUs) with a workspace: the launch runs as #CUs equal k-ranges (stream-K:
+    partial tiles handed between workgroups inside the launch).  Ragged T; against fp64, against the one-tile-per-workgroup launch
+    (`tn_flags` bit 1), accumulate, and twice over for bitwise repeatability"""
+    from eoe_amd import _lib
+    T = 64 * 45 + 24
+    shapes = [(3072, 768), (768, 3072), (2304, 768), (768, 768)]
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    ws = torch.empty(cus * 256 * 128 * 4, dtype=torch.uint8, device="cuda")
+    args = (_lib.GemmArgs * 4)()
+    keep, outs, refs = [], [], []
+    for i, (m, n) in enumerate(shapes):
+        a, ar = t16(f"tnsk/a{i}", (T, m), 1.0, dtype)
+        b, br = t16(f"tnsk/b{i}", (T, n), 1.0, dtype)
+        out = torch.full((m, n), 3.0, dtype=torch.float32, device="cuda")
+        keep += [a, b]
+        outs.append(out)
+        refs.append((ar.cuda().double().t() @ br.cuda().double()).cpu())
+        args[i] = _lib.GemmArgs(a.data_ptr(), b.data_ptr(), out.data_ptr(), None, None, None, None, m, n, T, m, n, n, 0,
+                                ops.dtype_code(dtype), 0, 1, 0, 1.0, ws.data_ptr(), ws.numel())
+    st = torch.cuda.current_stream().cuda_stream
+    ws.fill_(0xFF)                                   # stale partials (NaN patterns) must never be read
+    _lib.check(_lib.lib.eoe_gemm_tn_grouped(args, 4, st), "grouped stream-K")
+    first = [o.clone() for o in outs]
+    for out, ref in zip(outs, refs):
+        assert_close(out, ref, 2e-6, 3e-5 * math.sqrt(T), "gemm_tn_grouped stream-K")
+    for rep in range(3):
+        for o in outs:
+            o.fill_(-1.0)
+        _lib.check(_lib.lib.eoe_gemm_tn_grouped(args, 4, st), "grouped stream-K again")
+        assert all(torch.equal(o, f) for o, f in zip(outs, first)), "stream-K is not bitwise repeatable"
+    try:
+        _lib.check(_lib.lib.eoe_set_option(b"tn_flags", 2), "opt")
+        _lib.check(_lib.lib.eoe_gemm_tn_grouped(args, 4, st), "grouped plain")
+    finally:
+        _lib.check(_lib.lib.eoe_set_option(b"tn_flags", 0), "opt")
+    for o, f in zip(outs, first):                   # same products, the split tiles add three partial sums instead of one
+        assert (o - f).abs().max().item() <= 1e-5 * math.sqrt(T) * 4
+    for i in range(4):
+        args[i].accumulate = 1
+    _lib.check(_lib.lib.eoe_gemm_tn_grouped(args, 4, st), "grouped stream-K acc")
+    for out, ref in zip(outs, refs):
+        assert_close(out, 2 * ref, 4e-6, 6e-5 * math.sqrt(T), "gemm_tn_grouped stream-K accumulate")
+
+
 def test_gemm_rejects_bad_shapes(ops):
     a = torch.zeros((8, 40), dtype=torch.bfloat16, device="cuda")
     b = torch.zeros((8, 40), dtype=torch.bfloat16, device="cuda")

@@ -7,10 +7,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import eoe_amd.ops as ops
 from eoe_amd import _lib
 
-variants = [int(v) for v in sys.argv[1:]] or [0, 1]
+variants = [int(v) for v in sys.argv[1:]] or [0, 2]
 dt = torch.float16
 M = 12800
 args = (_lib.GemmArgs * 4)()
+ws = torch.empty(ops.TN_WORKSPACE_BYTES, dtype=torch.uint8, device="cuda")      # tn_flags bit 1 = 2 switches stream-K off
 keep, fl, outs = [], 0, []
 for i, (m, n, t) in enumerate([(3072, 768, M), (768, 3072, M), (2304, 768, M), (768, 768, M)]):
     a = torch.randn(t, m, device="cuda").to(dt)
@@ -18,7 +19,7 @@ for i, (m, n, t) in enumerate([(3072, 768, M), (768, 3072, M), (2304, 768, M), (
     out = torch.empty(m, n, device="cuda", dtype=torch.float32)
     keep += [a, b]; outs.append(out)
     args[i] = _lib.GemmArgs(a.data_ptr(), b.data_ptr(), out.data_ptr(), None, None, None, None, m, n, t, m, n, n, 0,
-                            ops.dtype_code(dt), 0, 1, 0, 1.0)
+                            ops.dtype_code(dt), 0, 1, 0, 1.0, ws.data_ptr(), ws.numel())
     fl += 2.0 * m * n * t
 st = torch.cuda.current_stream().cuda_stream
 fn = lambda: _lib.check(_lib.lib.eoe_gemm_tn_grouped(args, 4, st), "g")
