@@ -789,7 +789,7 @@ int fill_params(const eoe_gemm_args* a, GemmP& p) {
         p.stamp = buf;
         g_stamp_buf = buf;
     }
-    if (a->epilogue == EOE_EPI_GELU) EOE_CHECK_ARG(a->aux_out && !a->out_f32, "gemm: GELU epilogue needs aux_out, 16-bit C");
+    if (a->epilogue == EOE_EPI_GELU) EOE_CHECK_ARG(!a->out_f32, "gemm: the GELU epilogue needs a 16-bit C");      // aux_out optional
     if (a->epilogue == EOE_EPI_RESIDUAL) EOE_CHECK_ARG(a->aux && a->out_f32, "gemm: RESIDUAL epilogue needs aux, fp32 C");
     if (a->epilogue == EOE_EPI_GELU_BWD) EOE_CHECK_ARG(a->aux, "gemm: GELU_BWD epilogue needs aux");
     return 0;

@@ -76,13 +76,13 @@ __device__ __forceinline__ void epilogue_generic(const GemmP& p, f32x4 (&acc)[MI
                     u32x2 pk = pack4<T>(v[0], v[1], v[2], v[3]);
                     float pr[4];
                     unpack4<T>(pk, pr);
-                    *(u32x2*)(pre + off) = pk;
+                    if (p.aux_out) *(u32x2*)(pre + off) = pk;
                     *(u32x2*)(act + off) = pack4<T>(quick_gelu_f(pr[0]), quick_gelu_f(pr[1]),
                                                     quick_gelu_f(pr[2]), quick_gelu_f(pr[3]));
                 } else {
                     for (int r = 0; r < nvalid; ++r) {
                         T q = (T)v[r];
-                        pre[off + r] = q;
+                        if (p.aux_out) pre[off + r] = q;
                         act[off + r] = (T)quick_gelu_f((float)q);
                     }
                 }
@@ -217,7 +217,7 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][NI], i
             for (int h = 0; h < 2; ++h) {
                 const u32x4 pk = pack8<T>(v + 8 * h);          // the saved pre-activation is what backward differentiates:
                 unpack8<T>(pk, pr + 8 * h);                    // activate its ROUNDED value
-                *(u32x4*)(pre + 8 * h) = pk;
+                if (p.aux_out) *(u32x4*)(pre + 8 * h) = pk;    // (forward-only callers do not keep it: same activation either way)
             }
 #pragma unroll
             for (int c = 0; c < 16; ++c) ac[c] = quick_gelu_f(pr[c]);

@@ -61,7 +61,7 @@ int check_fwd(const eoe_vit_block_fwd_args* a) {
                              a->n, a->L, a->D, a->heads);
     if (!a->ln1_g || !a->ln1_b || !a->ln2_g || !a->ln2_b || !a->b_in || !a->b_out || !a->b_fc || !a->b_proj || !a->w_in ||
         !a->w_out || !a->w_fc || !a->w_proj || !a->x_in || !a->x_mid || !a->x_out || !a->xn1 || !a->qkv || !a->att ||
-        !a->xn2 || !a->hpre || !a->hact || !a->stats1 || !a->stats2)
+        !a->xn2 || !a->hact || !a->stats1 || !a->stats2)      // hpre is optional: forward-only callers pass NULL
         return eoe_set_error(EOE_ERR_ARG, "vit_block: null pointer in arguments");
     return 0;
 }
@@ -94,7 +94,7 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
     if (!b) return eoe_set_error(EOE_ERR_ARG, "vit_block_bwd: null args");
     const eoe_vit_block_fwd_args* a = &b->f;
     TRY(check_fwd(a));
-    if (!a->w_in_t || !a->w_out_t || !a->w_fc_t || !a->w_proj_t || !b->dx_out || !b->dx_in || !b->g_ln1_g || !b->g_ln1_b ||
+    if (!a->hpre || !a->w_in_t || !a->w_out_t || !a->w_fc_t || !a->w_proj_t || !b->dx_out || !b->dx_in || !b->g_ln1_g || !b->g_ln1_b ||
         !b->g_ln2_g || !b->g_ln2_b || !b->g_b_in || !b->g_b_out || !b->g_b_fc || !b->g_b_proj || !b->g_w_in || !b->g_w_out ||
         !b->g_w_fc || !b->g_w_proj || !b->d16_a || !b->d16_b || !b->d16_c || !b->dh || !b->dqkv || !b->dx_mid)
         return eoe_set_error(EOE_ERR_ARG, "vit_block_bwd: null pointer in arguments");

@@ -442,6 +442,9 @@ class VitBlockFunction(torch.autograd.Function):
         a.x_in, a.x_mid, a.x_out = _p(x), ptr["x_mid"], _p(x_out)
         a.xn1, a.qkv, a.att, a.xn2, a.hpre, a.hact = (ptr[k] for k in ("xn1", "qkv", "att", "xn2", "hpre", "hact"))
         a.stats1, a.stats2 = ptr["stats1"], ptr["stats2"]
+        keep = any(ctx.needs_input_grad)            # (grad mode itself is always off inside a Function's forward)
+        if not keep:
+            a.hpre = None          # forward only (frozen encoder, scoring): the MLP's pre-activation is not kept (79 MB per block)
         check(lib.eoe_vit_block_fwd(C.byref(a), _stream()), "eoe_vit_block_fwd")
         ctx.save_for_backward(x, ws, ln1_g, ln1_b, w_in, b_in, w_out, b_out, ln2_g, ln2_b, w_fc, b_fc, w_proj, b_proj)
         ctx.args = a

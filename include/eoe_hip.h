@@ -43,7 +43,7 @@ const char* eoe_last_error(void);
  * ---------------------------------------------------------------------------------------------------- */
 enum {
     EOE_EPI_NONE = 0,      /* C = acc (+ bias)                                                         */
-    EOE_EPI_GELU = 1,      /* pre = acc + bias -> aux_out (16-bit);  C = pre * sigmoid(1.702 pre)      */
+    EOE_EPI_GELU = 1,      /* pre = acc + bias -> aux_out (16-bit; NULL: not kept);  C = pre * sigmoid(1.702 pre) of the ROUNDED pre */
     EOE_EPI_RESIDUAL = 2,  /* C(fp32) = acc + bias + aux(fp32 [M,N], leading dim ldaux)                */
     EOE_EPI_GELU_BWD = 3   /* C = acc * d/dpre[pre sigmoid(1.702 pre)],  pre = aux (16-bit [M,N])      */
 };
