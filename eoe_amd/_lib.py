@@ -189,6 +189,7 @@ SIGNATURES = {
     "eoe_comm_allreduce_sum_async": [_vp, _vp, _i64, C.c_int, C.c_int, _vp],
     "eoe_comm_allgather_async": [_vp, _vp, _vp, _i64, C.c_int, _vp],
     "eoe_comm_join": [_vp, _vp],
+    "eoe_comm_sync_bn": [_vp, C.c_int],
     "eoe_set_bn_sync": [_vp, _vp],
     "eoe_prof_enable": [C.c_int],
     "eoe_set_option": [C.c_char_p, C.c_int],

@@ -180,6 +180,18 @@ extern "C" int eoe_comm_join(eoe_comm_t c, void* stream) {
     return 0;
 }
 
+static int comm_bn_hook(void* user, void* buf, int64_t count, int is_f64, void* stream) {
+    eoe_comm_t c = (eoe_comm_t)user;
+    Rccl* r = rccl();
+    if (!c || !r) return 1;
+    return r->AllReduce(buf, buf, (size_t)count, is_f64 ? ncclFloat64 : ncclFloat32, ncclSum, c->comm, (hipStream_t)stream) == ncclSuccess ? 0 : 1;
+}
+
+extern "C" int eoe_comm_sync_bn(eoe_comm_t c, int enable) {
+    EOE_CHECK_ARG(c != nullptr || !enable, "eoe_comm_sync_bn: null communicator");
+    return eoe_set_bn_sync(enable ? comm_bn_hook : nullptr, enable ? (void*)c : nullptr);
+}
+
 extern "C" int eoe_comm_info(eoe_comm_t c, int* rank, int* world) {
     EOE_CHECK_ARG(c && rank && world, "eoe_comm_info: null pointer");
     *rank = c->rank; *world = c->world;

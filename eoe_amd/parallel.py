@@ -260,11 +260,16 @@ class _DevPtr:
         self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8" if f64 else "<f4", "data": (ptr, False), "version": 2}
 
 
-def enable_sync_bn(process_group=None) -> bool:
+def enable_sync_bn(process_group=None, comm: "NativeComm" = None) -> bool:
     """synchronised BatchNorm over `process_group` (module docstring); returns False (and clears the hook) when there is
-    nothing to synchronise (no process group, or one rank)"""
+    nothing to synchronise (no process group, or one rank).  With a `NativeComm` the sums are added by RCCL inside the library
+    (`eoe_comm_sync_bn`: no Python in the path, same stream as the BatchNorm kernels)"""
     global _bn_sync_cb
     from . import _lib
+    if comm is not None:
+        _lib.check(_lib.lib.eoe_comm_sync_bn(comm.handle, 1), "eoe_comm_sync_bn")
+        _bn_sync_cb = comm                    # keeps the communicator alive while registered
+        return True
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
         disable_sync_bn()
         return False

@@ -421,6 +421,10 @@ int eoe_comm_info(eoe_comm_t comm, int* rank, int* world);
 int eoe_comm_allreduce_sum_async(eoe_comm_t comm, void* buf, int64_t count, int dtype, int algo, void* after_stream);
 int eoe_comm_allgather_async(eoe_comm_t comm, const void* send, void* recv, int64_t send_count, int dtype, void* after_stream);
 int eoe_comm_join(eoe_comm_t comm, void* stream);
+/* synchronised BatchNorm over this communicator without leaving the library: registers (enable != 0) or clears an eoe_set_bn_sync
+ * hook that sums the BatchNorm reduction buffers with ncclAllReduce IN the stream the BatchNorm kernels run on (no side stream: the
+ * very next kernel consumes the sums).  The communicator must outlive the registration. */
+int eoe_comm_sync_bn(eoe_comm_t comm, int enable);
 
 /* ------------------------------------------------------------------------------------------------------
  * Parity mode (SURVEY.md section 7 "Hard parts", section 8d "Parity run"): the convolutions / linear layers of the BatchNorm

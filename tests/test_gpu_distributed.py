@@ -117,6 +117,23 @@ def _rccl_worker(rank, world, port, out):
             res[mode]["gather"] = g.cpu()
             comm.close()
     res["ragged"] = parallel.all_gather_1d(torch.arange(3, device="cuda", dtype=torch.float32)).cpu()
+    # (c) synchronised BatchNorm with RCCL called from inside the library (eoe_comm_sync_bn) and through the torch.distributed hook
+    # (world 1 is "nothing to synchronise" for the latter: forced on by binding the hook by hand)
+    from eoe_amd.models import CNN32
+    from oracle import models as omodels, trainer as otrainer
+    xb, yb = otrainer.synthetic_batch("ddp/syncbn1", 8, 8, 32)
+    for mode in ("plain", "native"):
+        m = omodels.deterministic_init(CNN32(bias=True), tag="cnn32").cuda().train()
+        comm = parallel.NativeComm() if mode == "native" else None
+        if comm is not None:
+            assert parallel.enable_sync_bn(comm=comm)
+        eoe_amd.hsc_loss(m(xb.cuda()), yb.cuda(), 0).backward()
+        torch.cuda.synchronize()
+        res["bn_" + mode] = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}
+        res["bn_" + mode].update({k: v.detach().cpu().clone() for k, v in m.state_dict().items() if "running" in k})
+        if comm is not None:
+            parallel.disable_sync_bn()
+            comm.close()
     torch.save(res, out)
     dist.barrier()
     dist.destroy_process_group()
@@ -136,6 +153,10 @@ def test_rccl_world1_buckets_and_native_comm(tmp_path):
             assert torch.equal(got[mode]["grads"][k], p.grad.cpu()), (mode, k)   # the step is bitwise reproducible
     assert got["native_ring"]["gather"].tolist() == [[0.0, 1.0, 2.0, 3.0, 4.0]]
     assert got["ragged"].tolist() == [0.0, 1.0, 2.0]
+    # one rank: the all-reduced BatchNorm sums are the local ones (forward sums pass through double precision on the way)
+    for k, v in got["bn_plain"].items():
+        a, b = got["bn_native"][k].double(), v.double()
+        assert (a - b).norm().item() <= 1e-5 * max(b.norm().item(), 1e-6), k
 
 
 def _cnn_worker(rank, world, port, out):
