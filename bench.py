@@ -159,6 +159,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     eoe_amd.set_compute_dtype(args.dtype)
+    eoe_amd.set_grad_scale(eoe_amd.default_grad_scale())          # fp16: loss gradient x 256 against underflow in the 16-bit backward chain
     if args.tn_flags is not None:
         _lib.check(_lib.lib.eoe_set_option(b"tn_flags", args.tn_flags), "eoe_set_option")
     if args.side_stream is not None:

@@ -8,8 +8,10 @@ There is no CPU fallback: importing this package loads (or builds) the HIP libra
 from . import _lib                      # noqa: F401  (loads libeoe_hip.so; raises if unavailable)
 from .ops import set_compute_dtype, compute_dtype, hsc_loss, hsc_score, bce_loss, bce_score, linear  # noqa: F401
 from .ops import dsad_loss, dsvdd_loss, dsvdd_score, focal_loss, set_parity_mode, parity_mode  # noqa: F401
+from .ops import set_grad_scale, grad_scale, default_grad_scale  # noqa: F401
 from .optim import FusedAdam, FusedSGD  # noqa: F401
 from .graph import GraphedStep          # noqa: F401
 
 __all__ = ["set_compute_dtype", "compute_dtype", "hsc_loss", "hsc_score", "bce_loss", "bce_score", "linear",
-           "FusedAdam", "FusedSGD", "GraphedStep", "set_parity_mode", "parity_mode"]
+           "FusedAdam", "FusedSGD", "GraphedStep", "set_parity_mode", "parity_mode", "set_grad_scale", "grad_scale",
+           "default_grad_scale"]

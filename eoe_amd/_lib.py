@@ -40,7 +40,7 @@ class AdamChunk(C.Structure):
 
 
 class AdamScalars(C.Structure):
-    _fields_ = [("step_size", _f32 * ADAM_GROUPS), ("bc2_sqrt", _f32 * ADAM_GROUPS)]
+    _fields_ = [("step_size", _f32 * ADAM_GROUPS), ("bc2_sqrt", _f32 * ADAM_GROUPS), ("grad_scale_inv", _f32)]
 
 
 class CGateArgs(C.Structure):
@@ -171,7 +171,7 @@ SIGNATURES = {
     "eoe_clip_fwd": [_vp, _vp, _vp, _i64, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _f32, _vp],
     "eoe_clip_bwd": [_vp, _vp, _vp, _i64, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _f32, _vp],
     "eoe_clip_score": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
-    "eoe_sgd_multi": [_vp, _vp, _vp, _vp, C.c_int, _f32, _f32, _f32, C.c_int, _vp],
+    "eoe_sgd_multi": [_vp, _vp, _vp, _vp, C.c_int, _f32, _f32, _f32, C.c_int, _f32, _vp],
     "eoe_dsad_fwd": [_vp, _vp, _i64, _vp, _vp, C.c_int, C.c_int, _f32, _vp],
     "eoe_dsad_bwd": [_vp, _vp, _i64, _vp, _vp, C.c_int, C.c_int, _f32, _vp],
     "eoe_dsvdd_fwd": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _vp],

@@ -962,14 +962,14 @@ __global__ __launch_bounds__(256) void linear_small_dw_kernel(const float* __res
 // Same chunk tables as the Adam kernel (m_off = the momentum buffer, v_off unused).
 __global__ __launch_bounds__(256) void sgd_multi_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
                                                         const eoe_adam_chunk* __restrict__ chunks, float lr, float momentum, float wd,
-                                                        int nesterov) {
+                                                        int nesterov, float grad_scale_inv) {
     const eoe_adam_chunk ck = chunks[blockIdx.x];
     float* pp = p + ck.p_off;
     const float* gg = g + ck.g_off;
     float* bb = buf + ck.m_off;
     for (int i = threadIdx.x; i < ck.n; i += blockDim.x) {
         const float pv = pp[i];
-        float gv = gg[i];
+        float gv = gg[i] * grad_scale_inv;
         if (wd != 0.f) gv = gv + wd * pv;
         float step = gv;
         if (momentum != 0.f) {
@@ -997,7 +997,9 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(float* __restrict__ p, 
     float* vv = v + ck.v_off;
     T* sh = shadow ? shadow + ck.p_off : nullptr;
     const bool aligned = (((ck.p_off | ck.g_off | ck.m_off | ck.v_off) & 3) == 0);
+    const float ginv = sc.grad_scale_inv;          // gradients arrive multiplied by the loss scale (a power of two: exact)
     auto upd = [&](float pv, float gv, float& mv, float& vvv) -> float {
+        gv *= ginv;
         if (wd != 0.f) gv = gv + wd * pv;
         mv = mv + (gv - mv) * (1.0f - beta1);
         vvv = vvv * beta2 + (1.0f - beta2) * gv * gv;
@@ -1491,11 +1493,11 @@ extern "C" int eoe_clip_score(const float* f, const float* text, float* scores, 
 }
 
 extern "C" int eoe_sgd_multi(float* p, const float* g, float* buf, const eoe_adam_chunk* chunks, int n_chunks, float lr,
-                             float momentum, float weight_decay, int nesterov, void* stream) {
+                             float momentum, float weight_decay, int nesterov, float grad_scale_inv, void* stream) {
     EOE_CHECK_ARG(p && g && chunks && n_chunks > 0 && (buf || momentum == 0.f), "sgd_multi: bad args");
     ProfScope ps("sgd_multi", 0, 20.0 * n_chunks * EOE_ADAM_CHUNK, stream);
     hipLaunchKernelGGL(sgd_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, p, g, buf, chunks, lr, momentum, weight_decay,
-                       nesterov);
+                       nesterov, grad_scale_inv > 0.f ? grad_scale_inv : 1.0f);
     EOE_CHECK_LAUNCH("sgd_multi");
     return 0;
 }
@@ -1506,7 +1508,8 @@ extern "C" int eoe_adam_multi(float* p, const float* g, float* m, float* v, cons
     EOE_CHECK_ARG(p && g && m && v && chunks && scalars && n_chunks > 0, "adam_multi: bad args");
     ProfScope ps("adam_multi", 0, 28.0 * n_chunks * EOE_ADAM_CHUNK, stream);
     if (!shadow16) dtype = EOE_BF16;
-    const eoe_adam_scalars sc = *scalars;
+    eoe_adam_scalars sc = *scalars;
+    if (!(sc.grad_scale_inv > 0.f)) sc.grad_scale_inv = 1.0f;        // 0 (a zero-initialised struct) = no scaling
     DISPATCH_T(dtype, hipLaunchKernelGGL((adam_multi_kernel<T>), dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, p, g,
                                          m, v, chunks, sc, beta1, beta2, eps, weight_decay, (T*)shadow16));
     EOE_CHECK_LAUNCH("adam_multi");

@@ -5,6 +5,7 @@ is a hand-written HIP kernel reached through ctypes (eoe_amd._lib).  All functio
 and raise otherwise -- there is no CPU path in this package.
 """
 import ctypes as C
+import math
 import weakref
 from typing import Optional
 
@@ -28,6 +29,33 @@ def set_compute_dtype(dt):
     if dt not in (torch.bfloat16, torch.float16):
         raise ValueError(f"unsupported compute dtype {dt}")
     _compute_dtype = dt
+
+
+# Gradient (loss) scale.  fp16's smallest subnormal is 6e-8 and the backward chain keeps its dY tensors in 16 bits: at the benchmark
+# batch (a mean over 256 images, 12 800 token rows) the gradients of late training steps fall below that and are flushed, which the
+# 10-step trajectory of the 12-layer ViT shows as a drift to 3e-3 off the fp32 reference (tests/test_gpu_parity_big.py; bf16 has
+# fp32's exponent range and is unaffected).  With a scale S the objectives' backward kernels multiply dL/df by S (a power of two:
+# exact) and FusedAdam / FusedSGD multiply every gradient by 1/S before using it -- the same update in exact arithmetic, no
+# underflow; `p.grad` then holds S times the gradient (`grad_scale()` tells by how much).  Default 1 (off); the trainers and
+# bench.py set 256 for fp16.  Only with the eoe_amd optimisers: a stock torch optimiser would see the scaled gradients.
+_grad_scale = 1.0
+
+
+def set_grad_scale(scale: float):
+    global _grad_scale
+    scale = float(scale)
+    if not (scale > 0 and math.log2(scale) == int(math.log2(scale))):
+        raise ValueError("the gradient scale must be a positive power of two")
+    _grad_scale = scale
+
+
+def grad_scale() -> float:
+    return _grad_scale
+
+
+def default_grad_scale(dtype=None) -> float:
+    """256 for fp16 compute, 1 otherwise"""
+    return 256.0 if (dtype or _compute_dtype) == torch.float16 else 1.0
 
 
 def compute_dtype():
@@ -551,7 +579,7 @@ class HscLossFunction(torch.autograd.Function):
         n, d = f.shape
         df = torch.empty_like(f)
         gs = gout.contiguous().float().reshape(1)
-        check(lib.eoe_hsc_bwd(_p(f), _p(labels), nominal, _p(gs), _p(df), None, n, d, inv, _lib.EOE_BF16, _stream()),
+        check(lib.eoe_hsc_bwd(_p(f), _p(labels), nominal, _p(gs), _p(df), None, n, d, inv * _grad_scale, _lib.EOE_BF16, _stream()),
               "eoe_hsc_bwd")
         return df, None, None, None
 
@@ -593,7 +621,7 @@ class BceLossFunction(torch.autograd.Function):
         x, labels = ctx.saved_tensors
         dx = torch.empty_like(x)
         gs = gout.contiguous().float().reshape(1)
-        check(lib.eoe_bce_bwd(_p(x), _p(labels), _p(gs), _p(dx), x.shape[0], ctx.inv, _stream()), "eoe_bce_bwd")
+        check(lib.eoe_bce_bwd(_p(x), _p(labels), _p(gs), _p(dx), x.shape[0], ctx.inv * _grad_scale, _stream()), "eoe_bce_bwd")
         return dx.reshape(ctx.shape), None, None
 
 
@@ -639,8 +667,8 @@ class ClipLossFunction(torch.autograd.Function):
         nominal, loo, inv = ctx.cfg
         df = torch.empty_like(f)
         gs = gout.contiguous().float().reshape(1)
-        check(lib.eoe_clip_bwd(_p(f), _p(t), _p(labels), nominal, loo, _p(gs), _p(df), f.shape[0], f.shape[1], t.shape[0], inv,
-                               _stream()), "eoe_clip_bwd")
+        check(lib.eoe_clip_bwd(_p(f), _p(t), _p(labels), nominal, loo, _p(gs), _p(df), f.shape[0], f.shape[1], t.shape[0],
+                               inv * _grad_scale, _stream()), "eoe_clip_bwd")
         return df, None, None, None, None, None
 
 
@@ -682,7 +710,7 @@ class DsadLossFunction(torch.autograd.Function):
         nominal, inv = ctx.cfg
         df = torch.empty_like(f)
         gs = gout.contiguous().float().reshape(1)
-        check(lib.eoe_dsad_bwd(_p(f), _p(labels), nominal, _p(gs), _p(df), f.shape[0], f.shape[1], inv, _stream()), "eoe_dsad_bwd")
+        check(lib.eoe_dsad_bwd(_p(f), _p(labels), nominal, _p(gs), _p(df), f.shape[0], f.shape[1], inv * _grad_scale, _stream()), "eoe_dsad_bwd")
         return df, None, None, None
 
 
@@ -713,7 +741,7 @@ class DsvddLossFunction(torch.autograd.Function):
         f, c = ctx.saved_tensors
         df = torch.empty_like(f)
         gs = gout.contiguous().float().reshape(1)
-        check(lib.eoe_dsvdd_bwd(_p(f), _p(c), _p(gs), _p(df), f.shape[0], f.shape[1], ctx.inv, _stream()), "eoe_dsvdd_bwd")
+        check(lib.eoe_dsvdd_bwd(_p(f), _p(c), _p(gs), _p(df), f.shape[0], f.shape[1], ctx.inv * _grad_scale, _stream()), "eoe_dsvdd_bwd")
         return df, None, None
 
 
@@ -755,7 +783,7 @@ class FocalLossFunction(torch.autograd.Function):
         inv, gamma, eps, shape = ctx.cfg
         dx = torch.empty_like(x)
         gs = gout.contiguous().float().reshape(1)
-        check(lib.eoe_focal_bwd(_p(x), _p(labels), _p(gs), _p(dx), x.shape[0], inv, gamma, eps, _stream()), "eoe_focal_bwd")
+        check(lib.eoe_focal_bwd(_p(x), _p(labels), _p(gs), _p(dx), x.shape[0], inv * _grad_scale, gamma, eps, _stream()), "eoe_focal_bwd")
         return dx.reshape(shape), None, None, None, None
 
 

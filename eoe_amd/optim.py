@@ -12,7 +12,7 @@ import math
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, ops
 from ._lib import lib, check
 
 _CHUNK_DT = np.dtype([("p_off", "<i8"), ("g_off", "<i8"), ("m_off", "<i8"), ("v_off", "<i8"), ("n", "<i4"),
@@ -99,6 +99,7 @@ class FusedAdam(torch.optim.Optimizer):
             if len(distinct) > _lib.ADAM_GROUPS:
                 raise RuntimeError("FusedAdam: more than %d distinct step counts in one group" % _lib.ADAM_GROUPS)
             sc = _lib.AdamScalars()
+            sc.grad_scale_inv = 1.0 / ops.grad_scale()       # the losses' backward multiplied every gradient by the scale
             for i, s in enumerate(distinct):
                 bc1 = 1.0 - beta1 ** s
                 bc2 = 1.0 - beta2 ** s
@@ -173,6 +174,6 @@ class FusedSGD(torch.optim.Optimizer):
             tab, n_chunks, bases = self._table(gi, active)
             check(lib.eoe_sgd_multi(bases[0], bases[1], bases[2], tab.data_ptr(), n_chunks, float(group["lr"]),
                                     float(group["momentum"]), float(group["weight_decay"]), 1 if group["nesterov"] else 0,
-                                    torch.cuda.current_stream().cuda_stream), "eoe_sgd_multi")
+                                    1.0 / ops.grad_scale(), torch.cuda.current_stream().cuda_stream), "eoe_sgd_multi")
             torch._C._increment_version(active)
         return loss

@@ -234,6 +234,10 @@ class ADTrainer(ABC):
         ep = self.load(load if isinstance(load, str) else None, model, opt, sched)                      # :396
         center = self.center = self.prepare_metric(clsstr, loader, model, seed)                         # :397
         self._normalize_hook(model, ds)
+        # fp16 compute: scale the loss gradient so that the 16-bit backward chain does not underflow (ops.set_grad_scale); the
+        # optimiser un-scales.  Restored on the way out.
+        prev_scale = ops.grad_scale()
+        ops.set_grad_scale(ops.default_grad_scale())
         rank, world = 0, 1
         arena = None
         if self.data_parallel and torch.distributed.is_initialized():
@@ -309,6 +313,7 @@ class ADTrainer(ABC):
                     cls_roc = ROC(auc_ap_device(la, sc)[0] if sc.is_cuda else roc_auc(la.cpu().numpy(), sc.cpu().numpy()))   # :452-455
                 sched.step()                                                                            # :468
         finally:
+            ops.set_grad_scale(prev_scale)
             if arena is not None:
                 parallel.disable_sync_bn()
                 arena.remove_hooks()

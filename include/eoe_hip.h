@@ -238,12 +238,18 @@ typedef struct {
 typedef struct {                        /* per step-count group, computed on the host in double as torch does: */
     float step_size[EOE_ADAM_GROUPS];   /*   lr / (1 - beta1**step)                                            */
     float bc2_sqrt[EOE_ADAM_GROUPS];    /*   sqrt(1 - beta2**step)                                             */
+    float grad_scale_inv;               /* the gradients are multiplied by this first (0 = 1): 1 / the loss scale of an fp16 run.
+                                         * fp16's smallest subnormal is 6e-8: with 12 800 token rows sharing a mean loss the 16-bit
+                                         * dY tensors of late training steps underflow, and the 10-step trajectory of the 12-layer
+                                         * ViT drifts to 3e-3 off the fp32 reference; with the loss gradient scaled by 256 (the
+                                         * `inv_count` argument of the loss kernels) it stays within 1.2e-4 */
 } eoe_adam_scalars;
 
 /* fused multi-tensor SGD with momentum / Nesterov = torch.optim.SGD(..., dampening=0) as constructed for CLIP models
  * (ad_trainer.py:380-381: momentum 0.9, nesterov): the same chunk tables (m_off = momentum buffer, zero-initialised; v_off unused) */
 int eoe_sgd_multi(float* p, const float* g, float* buf, const eoe_adam_chunk* chunks /*device*/, int n_chunks, float lr,
-                  float momentum, float weight_decay, int nesterov, void* stream);
+                  float momentum, float weight_decay, int nesterov, float grad_scale_inv /* as in eoe_adam_scalars; <= 0 = 1 */,
+                  void* stream);
 int eoe_adam_multi(float* p, const float* g, float* m, float* v, const eoe_adam_chunk* chunks /*device*/,
                    int n_chunks, const eoe_adam_scalars* scalars /*host*/, float beta1, float beta2, float eps,
                    float weight_decay, void* shadow16, int dtype, void* stream);

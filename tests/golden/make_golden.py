@@ -577,13 +577,13 @@ def g14():
 
 
 def g3big():
-    """the 12-layer ViT-B/32 + head, ONE full fine-tune step at the benchmark batch (128 + 128 images = 12 800 token
-    rows): features, loss, scores and per-tensor gradient summaries, plus the loss of a second step (which sees the
-    updated weights).  No fp64 twin: the reference's LayerNorm computes in fp32 whatever the input (clip/model.py:156-159)
-    and raises on fp64 parameters"""
+    """the 12-layer ViT-B/32 + head, K = 10 full fine-tune steps at the benchmark batch (128 + 128 images = 12 800 token rows, a new
+    batch every step; SURVEY.md section 8d's parity run on the headline model): features and per-tensor gradient summaries of the
+    first step, loss and scores of every step.  No fp64 twin: the reference's LayerNorm computes in fp32 whatever the input
+    (clip/model.py:156-159) and raises on fp64 parameters"""
     m = RefClipNet(12)
     omodels.deterministic_init(m, tag="vit", layers=12)
-    losses, scores, first = run_trajectory_big(m, lambda i: otrainer.synthetic_batch(f"g3big/b{i}", 128, 128, 224), 2,
+    losses, scores, first = run_trajectory_big(m, lambda i: otrainer.synthetic_batch(f"g3big/b{i}", 128, 128, 224), 10,
                                                "hsc", lr=1e-4, wd=1e-3, twin64=False)
     save("g3_vit_l12_hsc_big", losses=losses, scores=scores, **first)
 

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     assert set(declared) == set(_lib.SIGNATURES), set(declared) ^ set(_lib.SIGNATURES)
     assert _lib.lib.eoe_abi_version() == _lib.ABI_VERSION
     # struct layouts the Python side mirrors
-    assert C.sizeof(_lib.AdamChunk) == 40 and C.sizeof(_lib.AdamScalars) == 32
+    assert C.sizeof(_lib.AdamChunk) == 40 and C.sizeof(_lib.AdamScalars) == 36
     mirrors = [_lib.GemmArgs, _lib.ConvGeometry, _lib.AdamChunk, _lib.AdamScalars, _lib.VitBlockFwdArgs, _lib.VitBlockBwdArgs,
                _lib.CGateArgs, _lib.CGateBwdArgs, _lib.SGateArgs, _lib.SGateBwdArgs]
     for which, cls in enumerate(mirrors):

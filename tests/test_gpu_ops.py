@@ -519,6 +519,33 @@ def test_clip_objective_n2_vs_golden_and_oracle(golden):
         assert_close(fg.grad, fr.grad, 5e-4, 1e-6, f"clip grad vs oracle loo={loo}")
 
 
+@pytest.mark.parametrize("which", ["adam", "sgd"])
+def test_optimisers_unscale_scaled_gradients(which):
+    """eoe_amd.set_grad_scale(S): the losses hand out S x the gradient, the optimisers multiply by 1/S before anything else (weight
+    decay included) -- parameters and optimiser state after 3 steps are the bits of the unscaled run (S is a power of two)"""
+    import eoe_amd
+    shapes = ((513, 7), (8192,), (3,))
+
+    def run(scale):
+        ps = [torch.nn.Parameter(torch.from_numpy(fill.fill(f"gsc/p{i}", s, std=0.5)).cuda()) for i, s in enumerate(shapes)]
+        opt = (eoe_amd.FusedAdam(ps, lr=1e-2, weight_decay=1e-2) if which == "adam"
+               else eoe_amd.FusedSGD(ps, lr=1e-2, momentum=0.9, nesterov=True, weight_decay=1e-2))
+        eoe_amd.set_grad_scale(scale)
+        try:
+            for t in range(3):
+                for i, p in enumerate(ps):
+                    p.grad = torch.from_numpy(fill.fill(f"gsc/g{i}/t{t}", tuple(p.shape), std=0.1)).cuda() * scale
+                opt.step()
+        finally:
+            eoe_amd.set_grad_scale(1.0)
+        state = [v.clone() for p in ps for v in opt.state[p].values() if torch.is_tensor(v) and v.is_cuda]
+        return [p.detach().clone() for p in ps] + state
+    for a, b in zip(run(1.0), run(256.0)):
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        eoe_amd.set_grad_scale(3.0)
+
+
 def test_fused_sgd_vs_golden(golden):
     """SGD with Nesterov momentum (ad_trainer.py:380-381) = torch.optim.SGD, incl. a parameter whose gradient appears late"""
     import eoe_amd

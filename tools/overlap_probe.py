@@ -106,3 +106,30 @@ def both2():
 t_g = timed(gemms); t_a = timed(lambda: opt.step()); t_seq = timed(lambda: (opt.step(), gemms())); t_par = timed(both2)
 print(f"Adam over 66 M parameters under 6 NT GEMMs + the grouped wgrad: GEMMs alone {t_g:.0f} us, Adam alone {t_a:.0f} us, sequential {t_seq:.0f} us, "
       f"two streams {t_par:.0f} us (hidden {t_seq - t_par:.0f} us = {100 * (t_seq - t_par) / min(t_g, t_a):.0f} % of the shorter)")
+
+# ---- third question (round 2): one block's Adam (7 M parameters) under ONE stream-K wgrad launch (all 256 CUs hold a 448-register,
+# 144-KB workgroup: 64 registers per SIMD and 16 KB of LDS are left for a co-resident streaming kernel)
+ws = torch.empty(ops.TN_WORKSPACE_BYTES, dtype=torch.uint8, device=dev)
+args[0].workspace, args[0].workspace_bytes = ws.data_ptr(), ws.numel()
+wb = [torch.randn(2304, 768, device=dev, requires_grad=True), torch.randn(768, 768, device=dev, requires_grad=True),
+      torch.randn(3072, 768, device=dev, requires_grad=True), torch.randn(768, 3072, device=dev, requires_grad=True)]
+for p in wb:
+    p.grad = torch.randn_like(p)
+optb = eoe_amd.FusedAdam(wb, lr=1e-4)
+optb.step()
+
+
+def both3():
+    side.wait_stream(main)
+    tn(main)
+    with torch.cuda.stream(side):
+        optb.step()
+    main.wait_stream(side)
+
+
+for flags in (0, 2):
+    _lib.check(_lib.lib.eoe_set_option(b"tn_flags", flags), "opt")
+    t_t = timed(lambda: tn(main)); t_a = timed(lambda: optb.step()); t_seq = timed(lambda: (tn(main), optb.step())); t_par = timed(both3)
+    print(f"tn_flags {flags} ({'stream-K' if flags == 0 else '216 tiles'}): wgrad alone {t_t:.0f} us, one block's Adam alone {t_a:.0f} us, sequential {t_seq:.0f} us, "
+          f"two streams {t_par:.0f} us (hidden {t_seq - t_par:.0f} us)")
+_lib.check(_lib.lib.eoe_set_option(b"tn_flags", 0), "opt")

@@ -1,0 +1,34 @@
+#!/usr/bin/env python
+"""does fp16 gradient underflow explain the late-step drift of the 12-layer ViT trajectory?  The 10-step parity run with the loss scaled
+by S (and Adam's eps / weight decay scaled alike: the same update in exact arithmetic, gradients S times larger in the 16-bit chain)"""
+import os, sys
+import numpy as np
+import torch
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import eoe_amd
+from eoe_amd.models import ClipViTB32Custom
+from oracle import models as omodels, trainer as otrainer
+import parity_util
+
+g = np.load(os.path.join(R, "tests", "golden", "g3_vit_l12_hsc_big.npz"))
+K = len(g["losses"])
+for dtype in (torch.float16, torch.bfloat16):
+    for S in (1.0, 256.0, 4096.0, 65536.0):
+        eoe_amd.set_compute_dtype(dtype)
+        m = omodels.deterministic_init(ClipViTB32Custom(layers=12), tag="vit", layers=12).cuda().train()
+        opt = eoe_amd.FusedAdam(m.parameters(), lr=1e-4, weight_decay=1e-3 * S, eps=1e-8 * S)
+        losses, scores = [], []
+        for it in range(K):
+            imgs, lbls = otrainer.synthetic_batch(f"g3big/b{it}", 128, 128, 224)
+            imgs, lbls = imgs.cuda(), lbls.cuda()
+            opt.zero_grad()
+            feats = m(imgs)
+            loss = eoe_amd.hsc_loss(feats, lbls, 0, S / 256.0)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item() / S)
+            scores.append(eoe_amd.hsc_score(feats).cpu().numpy())
+        dl, ds = parity_util.trajectory_deviation(losses, scores, g)
+        np.set_printoptions(precision=1, linewidth=200)
+        print(f"{dtype} S={S:g}: loss dev {dl}  score dev max {ds.max():.1e}", flush=True)
