@@ -588,8 +588,18 @@ def g3big():
     save("g3_vit_l12_hsc_big", losses=losses, scores=scores, **first)
 
 
+def g3bigbce():
+    """BASELINE config 5 ("CLIP ViT-B/32 full fine-tune, BCE"): the 12-layer ViT with the 1-logit head (clf=True) and the BCE objective,
+    K = 10 steps at the benchmark batch, same batches as g3big"""
+    m = RefClipNet(12, clf=True)
+    omodels.deterministic_init(m, tag="vit", layers=12)
+    losses, scores, first = run_trajectory_big(m, lambda i: otrainer.synthetic_batch(f"g3big/b{i}", 128, 128, 224), 10,
+                                               "bce", lr=1e-4, wd=1e-3, twin64=False)
+    save("g3_vit_l12_bce_big", losses=losses, scores=scores, **first)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12",
-                             "g2big", "g11big", "g5big", "g3big", "g13", "g14"]
+                             "g2big", "g11big", "g5big", "g3big", "g3bigbce", "g13", "g14"]
     for w in which:
         globals()[w]()

@@ -45,6 +45,12 @@ BAR = parity_util.BAR          # the stated 1e-3
 #     steps (single-batch AUC: rank swaps between near-tied scores), then growing with the training dynamics to 2e-3 at step 9.
 VIT_BARS = {torch.float16: dict(loss0=1e-3, loss=1e-3, score=1e-3, auc=1e-3, grad=1e-3),
             torch.bfloat16: dict(loss0=1e-3, loss=5e-3, score=5e-3, auc=1e-2, grad=4e-3, strict=5, strict_auc=3)}
+# BCE on one logit (config 5): the trajectory starts with a loss spike (0.73 -> 9.7 -> 6.0 -> 2.0) and every gradient is proportional to
+# the per-sample sigmoid(z) - y, so the forward's logit error (8e-4 relative in fp16: 16-bit operands through 12 layers) passes straight
+# into the gradients (median gradient-norm deviation 5e-4 against 1e-5 with the HSC objective).  fp16: scores / AUC / gradient norms inside
+# 1e-3 on every step, the loss at 1.0e-3 on the two steps after the spike; bf16 eight times that.
+VIT_BCE_BARS = {torch.float16: dict(loss0=1e-3, loss=2e-3, score=1e-3, auc=1e-3, grad=1e-3, strict=3, strict_auc=10),
+                torch.bfloat16: dict(loss0=1e-3, loss=2e-2, score=5e-3, auc=1e-3, grad=8e-3)}
 
 
 @pytest.fixture(autouse=True)
@@ -234,6 +240,19 @@ def test_vit12_big(golden, dtype):
     m = omodels.deterministic_init(ClipViTB32Custom(layers=12), tag="vit", layers=12)
     out = run_hip(m, lambda i: otrainer.synthetic_batch(f"g3big/b{i}", 128, 128, 224), len(g["losses"]), "hsc", 1e-4, 1e-3)
     check("vit12 hsc", dtype, g, *out, feat_tol=30 * 2.0 ** (-11 if dtype == torch.float16 else -8), bars=VIT_BARS[dtype])
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_vit12_big_bce(golden, dtype):
+    """BASELINE config 5 (CLIP ViT-B/32 full fine-tune, BCE): the same model with the 1-logit head and the BCE objective, K = 10 steps
+    at the benchmark batch"""
+    import eoe_amd
+    from eoe_amd.models import ClipViTB32Custom
+    eoe_amd.set_compute_dtype(dtype)
+    g = golden("g3_vit_l12_bce_big")
+    m = omodels.deterministic_init(ClipViTB32Custom(layers=12, clf=True), tag="vit", layers=12)
+    out = run_hip(m, lambda i: otrainer.synthetic_batch(f"g3big/b{i}", 128, 128, 224), len(g["losses"]), "bce", 1e-4, 1e-3)
+    check("vit12 bce", dtype, g, *out, feat_tol=30 * 2.0 ** (-11 if dtype == torch.float16 else -8), bars=VIT_BCE_BARS[dtype])
 
 
 # ---------------------------------------------------------------------------------------------- parity mode (fp32 conv / linear)
