@@ -504,6 +504,17 @@ def g5big():
     save("g5_wideresnet_hsc_big", losses=losses, scores=scores, **first)
 
 
+def g5full():
+    """WideResNet + CBAM at the FULL benchmark batch (128 + 128 images of 224 x 224: every convolution at its benchmark geometry,
+    M = 802 816 rows in layer1), K = 3 Adam steps, with the fp64 twin"""
+    from eoe.models.resnet import WideResNet as RefWRN
+    m = RefWRN()
+    omodels.deterministic_init(m, tag="wrn")
+    losses, scores, first = run_trajectory_big(m, lambda i: otrainer.synthetic_batch(f"g5full/b{i}", 128, 128, 224), 3,
+                                               "hsc", lr=1e-3, wd=0.0)
+    save("g5_wideresnet_hsc_full", losses=losses, scores=scores, **first)
+
+
 def g13():
     """BASELINE.json config 2, "WideResNet backbone, 32 x 32": the reference's WideResNet accepts 224 x 224 only (resnet.py:86,38),
     so the fixture drives the reference's OWN layers (conv1 / bn1 / maxpool / layer1-4 with their BasicBlock + CBAM / fc,
@@ -600,6 +611,6 @@ def g3bigbce():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12",
-                             "g2big", "g11big", "g5big", "g3big", "g3bigbce", "g13", "g14"]
+                             "g2big", "g11big", "g5big", "g5full", "g3big", "g3bigbce", "g13", "g14"]
     for w in which:
         globals()[w]()
