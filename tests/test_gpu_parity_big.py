@@ -251,6 +251,26 @@ def test_vit12_big(golden, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_vit12_big_frozen(golden, dtype):
+    """BASELINE config 4 (frozen CLIP ViT-B/32 encoder + HSC head): `freeze_parts()`, forward-only encoder (no saved pre-activations), the
+    head alone trains; K = 10 steps at the benchmark batch.  The encoder output is the same on every step, so the deviation is that of
+    one 16-bit forward pass"""
+    import eoe_amd
+    from eoe_amd.models import ClipViTB32Custom
+    eoe_amd.set_compute_dtype(dtype)
+    g = golden("g3_vit_l12_hsc_frozen_big")
+    m = omodels.deterministic_init(ClipViTB32Custom(layers=12, freeze=True), tag="vit", layers=12)
+    m.freeze_parts()
+    out = run_hip(m, lambda i: otrainer.synthetic_batch(f"g3big/b{i}", 128, 128, 224), len(g["losses"]), "hsc", 1e-4, 1e-3)
+    assert set(out[2]["grads"]) == {"final_linear.weight", "final_linear.bias"}
+    # (with lr 1e-4 the head hardly moves in ten steps: d = sqrt(|f|^2 + 1) - 1 stays near 6-8, every score sits within 1e-3 of 1.0 in
+    #  fp32, and the single-batch AUC ranks differences of a few float32 ulps -- it is reported, not held to 1e-3)
+    bars = dict(loss0=1e-3, loss=1e-3, score=1e-3, auc=2e-2, grad=1e-3) if dtype == torch.float16 else \
+        dict(loss0=1e-3, loss=1e-3, score=1e-3, auc=2e-2, grad=1e-3)
+    check("vit12 frozen", dtype, g, *out, feat_tol=30 * 2.0 ** (-11 if dtype == torch.float16 else -8), bars=bars)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_vit12_big_bce(golden, dtype):
     """BASELINE config 5 (CLIP ViT-B/32 full fine-tune, BCE): the same model with the 1-logit head and the BCE objective, K = 10 steps
     at the benchmark batch"""
