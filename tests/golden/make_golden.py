@@ -506,11 +506,11 @@ def g5big():
 
 def g5full():
     """WideResNet + CBAM at the FULL benchmark batch (128 + 128 images of 224 x 224: every convolution at its benchmark geometry,
-    M = 802 816 rows in layer1), K = 3 Adam steps, with the fp64 twin"""
+    M = 802 816 rows in layer1), K = 10 Adam steps, with the fp64 twin"""
     from eoe.models.resnet import WideResNet as RefWRN
     m = RefWRN()
     omodels.deterministic_init(m, tag="wrn")
-    losses, scores, first = run_trajectory_big(m, lambda i: otrainer.synthetic_batch(f"g5full/b{i}", 128, 128, 224), 3,
+    losses, scores, first = run_trajectory_big(m, lambda i: otrainer.synthetic_batch(f"g5full/b{i}", 128, 128, 224), 10,
                                                "hsc", lr=1e-3, wd=0.0)
     save("g5_wideresnet_hsc_full", losses=losses, scores=scores, **first)
 
