@@ -325,7 +325,7 @@ def test_wideresnet_big_parity_mode(golden):
 
 @pytest.mark.parametrize("mode", ["fast", "parity"])
 def test_wideresnet_full_batch(golden, mode):
-    """WideResNet + CBAM at the FULL benchmark batch (128 + 128 images of 224 x 224; every convolution at its benchmark geometry), K = 3
+    """WideResNet + CBAM at the FULL benchmark batch (128 + 128 images of 224 x 224; every convolution at its benchmark geometry), K = 10
     steps, against the reference's own modules: fp16 fast mode at the fast-mode bars, parity mode (fp32 convolutions) at the stated bar
     scaled by the reference's own fp32-vs-fp64 noise"""
     import eoe_amd
