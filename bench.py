@@ -44,6 +44,7 @@ def parse():
                          "wrn = secondary (WideResNet+CBAM, 224x224, config 3 backbone)")
     ap.add_argument("--nt-flags", type=int, default=None, help="tuning switch of the NT GEMM (A/B builds only)")
     ap.add_argument("--tn-flags", type=int, default=None, help="tuning switch of the wgrad GEMM")
+    ap.add_argument("--grad-scale", type=float, default=None, help="loss-gradient scale (default: 256 for fp16, 1 otherwise)")
     ap.add_argument("--attn-flags", type=int, default=None, help="1: the one-wave attention backward kernel (A/B)")
     ap.add_argument("--side-stream", type=int, default=None, help="0: LayerNorm-1 backward after (not next to) the grouped wgrad")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
@@ -159,7 +160,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     eoe_amd.set_compute_dtype(args.dtype)
-    eoe_amd.set_grad_scale(eoe_amd.default_grad_scale())          # fp16: loss gradient x 256 against underflow in the 16-bit backward chain
+    # fp16: loss gradient x 256 against underflow in the 16-bit backward chain (FusedAdam divides it out)
+    eoe_amd.set_grad_scale(args.grad_scale if args.grad_scale else eoe_amd.default_grad_scale())
     if args.tn_flags is not None:
         _lib.check(_lib.lib.eoe_set_option(b"tn_flags", args.tn_flags), "eoe_set_option")
     if args.side_stream is not None:
