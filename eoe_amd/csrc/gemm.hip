@@ -291,6 +291,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmP p) {
 // each SIMD holds one wave of each, so one workgroup's stalls are the other's issue slots.  Non-persistent on purpose: one tile
 // per workgroup, dispatched as slots free up, which de-synchronises the two workgroups of a CU (a persistent tile loop with
 // cross-tile prefetch kept them in lockstep and measured 5-13 % slower on the heavy-epilogue shapes).  Tiles XCD-remapped.  Same LDS image / swizzle / fragment layout / epilogues as gemm_nt_kernel.
+// (round 2, measured and rejected: s_setprio 2 for the MFMA loop and 0 for the epilogue, or the reverse -- the co-resident workgroup's
+//  epilogue VALU against this one's MFMA issue: layer total 473.2 / 475.3 vs 474.4 us, i.e. nothing)
 // MI = 16-row MFMA tiles per wave along M: the workgroup tile is (32*MI) x 128.  MI = 4 (128x128) is the default; MI = 5
 // (160x128) is chosen when it quantises better over the 2 x #CU workgroup slots (N = 768, M = 12800: 480 tiles in one round
 // instead of 600 in two).
