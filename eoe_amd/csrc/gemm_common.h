@@ -162,6 +162,8 @@ __device__ __forceinline__ void epilogue_generic(const GemmP& p, f32x4 (&acc)[MI
 // program order after these reads), so that a lane holds 16 consecutive columns of one row: bias / residual / saved
 // pre-activation are read, and the result is written, as 64-byte (fp32) or 32-byte (16-bit) contiguous pieces, 4 lanes
 // per row = whole 128/256-byte lines per row.
+// (round 2, measured and rejected: alternating the bands between two 4-KiB halves so that a band's LDS writes need not wait for the
+//  previous band's reads -- layer total 494.0 / 491.2 vs 490.9 / 492.2 us on one box: the band round trips are not the epilogue's cost)
 // the fast form's precondition, checked by the host for kernels that have no generic fallback compiled in
 static inline bool epilogue_fast_ok(const GemmP& p) {
     return ((p.N & 15) == 0) && ((p.ldc & 7) == 0) && ((p.ldaux & 7) == 0) && ((((uintptr_t)p.C) & 15) == 0);
