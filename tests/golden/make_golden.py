@@ -599,6 +599,15 @@ def g3big():
     save("g3_vit_l12_hsc_big", losses=losses, scores=scores, **first)
 
 
+def g3long():
+    """how far does the 1e-3 bar hold?  the 12-layer ViT at the benchmark batch for K = 40 steps (losses and scores only)"""
+    m = RefClipNet(12)
+    omodels.deterministic_init(m, tag="vit", layers=12)
+    losses, scores, first = run_trajectory_big(m, lambda i: otrainer.synthetic_batch(f"g3big/b{i}", 128, 128, 224), 40,
+                                               "hsc", lr=1e-4, wd=1e-3, twin64=False)
+    save("g3_vit_l12_hsc_long", losses=losses, scores=scores)
+
+
 def g3bigfrozen():
     """BASELINE config 4 ("CLIP ViT-B/32 frozen encoder + HSC head"): freeze_parts() on the 12-layer encoder, only the head trains;
     K = 10 steps at the benchmark batch, same batches as g3big, the CLIP runner's lr / wd (train_clip_imagenet.py:13-17)"""
@@ -624,6 +633,6 @@ def g3bigbce():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12",
-                             "g2big", "g11big", "g5big", "g5full", "g3big", "g3bigfrozen", "g3bigbce", "g13", "g14"]
+                             "g2big", "g11big", "g5big", "g5full", "g3big", "g3long", "g3bigfrozen", "g3bigbce", "g13", "g14"]
     for w in which:
         globals()[w]()

@@ -11,10 +11,11 @@ from eoe_amd.models import ClipViTB32Custom
 from oracle import models as omodels, trainer as otrainer
 import parity_util
 
-g = np.load(os.path.join(R, "tests", "golden", "g3_vit_l12_hsc_big.npz"))
+g = np.load(os.path.join(R, "tests", "golden", os.environ.get("EOE_PROBE_FIXTURE", "g3_vit_l12_hsc_big") + ".npz"))
 K = len(g["losses"])
-for dtype in (torch.float16, torch.bfloat16):
-    for S in (1.0, 256.0, 4096.0, 65536.0):
+SCALES = [float(x) for x in os.environ.get("EOE_PROBE_SCALES", "1,256,4096,65536").split(",")]
+for dtype in ((torch.float16,) if os.environ.get("EOE_PROBE_FP16_ONLY") else (torch.float16, torch.bfloat16)):
+    for S in SCALES:
         eoe_amd.set_compute_dtype(dtype)
         m = omodels.deterministic_init(ClipViTB32Custom(layers=12), tag="vit", layers=12).cuda().train()
         opt = eoe_amd.FusedAdam(m.parameters(), lr=1e-4, weight_decay=1e-3 * S, eps=1e-8 * S)
@@ -31,4 +32,6 @@ for dtype in (torch.float16, torch.bfloat16):
             scores.append(eoe_amd.hsc_score(feats).cpu().numpy())
         dl, ds = parity_util.trajectory_deviation(losses, scores, g)
         np.set_printoptions(precision=1, linewidth=200)
-        print(f"{dtype} S={S:g}: loss dev {dl}  score dev max {ds.max():.1e}", flush=True)
+        dec = lambda a: np.array([a[i:i + 10].max() for i in range(0, K, 10)])
+        fm = lambda a: "[" + " ".join(f"{x:.1e}" for x in a) + "]"
+        print(f"{dtype} S={S:g}: loss dev per 10 steps {fm(dec(dl))}  score dev per 10 steps {fm(dec(ds))}", flush=True)
