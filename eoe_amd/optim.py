@@ -20,6 +20,20 @@ _CHUNK_DT = np.dtype([("p_off", "<i8"), ("g_off", "<i8"), ("m_off", "<i8"), ("v_
 assert _CHUNK_DT.itemsize == C.sizeof(_lib.AdamChunk)
 
 
+_warned_unscaled = False
+
+
+def _warn_if_unscaled_fp16():
+    """once per process: fp16 compute with the gradient scale left at 1 (ops.set_grad_scale)"""
+    global _warned_unscaled
+    if not _warned_unscaled and ops.compute_dtype() == torch.float16 and ops.grad_scale() == 1.0:
+        _warned_unscaled = True
+        import warnings
+        warnings.warn("eoe_amd: fp16 compute without a gradient scale -- the 16-bit backward chain underflows once gradients get small "
+                      "(the 12-layer ViT leaves the fp32 trajectory within 20 steps); call eoe_amd.set_grad_scale("
+                      "eoe_amd.default_grad_scale()) before training, as eoe_amd.training and bench.py do", stacklevel=3)
+
+
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False):
         if amsgrad:
@@ -99,6 +113,7 @@ class FusedAdam(torch.optim.Optimizer):
             if len(distinct) > _lib.ADAM_GROUPS:
                 raise RuntimeError("FusedAdam: more than %d distinct step counts in one group" % _lib.ADAM_GROUPS)
             sc = _lib.AdamScalars()
+            _warn_if_unscaled_fp16()
             sc.grad_scale_inv = 1.0 / ops.grad_scale()       # the losses' backward multiplied every gradient by the scale
             for i, s in enumerate(distinct):
                 bc1 = 1.0 - beta1 ** s
@@ -172,6 +187,7 @@ class FusedSGD(torch.optim.Optimizer):
                     raise RuntimeError("FusedSGD needs contiguous fp32 parameters and gradients on the GPU")
             self._init_state(group)
             tab, n_chunks, bases = self._table(gi, active)
+            _warn_if_unscaled_fp16()
             check(lib.eoe_sgd_multi(bases[0], bases[1], bases[2], tab.data_ptr(), n_chunks, float(group["lr"]),
                                     float(group["momentum"]), float(group["weight_decay"]), 1 if group["nesterov"] else 0,
                                     1.0 / ops.grad_scale(), torch.cuda.current_stream().cuda_stream), "eoe_sgd_multi")
