@@ -126,6 +126,8 @@ def run_hip(m, batch_fn, steps, obj, lr, wd):
     losses, scores, first = [], [], {}
     # as the trainers run it: fp16 compute scales the loss gradient by 256 (underflow of the 16-bit dY chain), FusedAdam un-scales
     scale = eoe_amd.default_grad_scale() if os.environ.get("EOE_TEST_NO_GRAD_SCALE") != "1" else 1.0
+    if os.environ.get("EOE_TEST_GRAD_SCALE") and scale != 1.0:          # tuning runs: another power of two for the fp16 cases
+        scale = float(os.environ["EOE_TEST_GRAD_SCALE"])
     eoe_amd.set_grad_scale(scale)
     for it in range(steps):
         imgs, lbls = batch_fn(it)
