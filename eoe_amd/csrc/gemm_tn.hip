@@ -359,7 +359,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
             }
         }
     }
-    if (g.splits > 1 && g.part) {
+    if (g.part) {
         // per-split partial result [M][N] (dense), summed by tn_reduce_kernel
         float* base = g.part + g.part_stride[pi] + (size_t)split * P.M * P.N;
 #pragma unroll
@@ -406,8 +406,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
 // C[m][n] = alpha * sum_s part[s][m][n] (+ C if accumulate).  A workgroup owns 64 column quads; its 4 wavefronts take the
 // splits s = w, w+4, ... with four independent 16-B loads in flight each and are combined through LDS in a fixed order (one
 // thread walking all the splits serially was a chain of up to 85 dependent loads: 18 us average, 62 us worst case).
+// unpack_cin > 0: the [M = taps * cin][N = cout] matrix is a convolution's transposed weight gradient and C is that weight's own
+// [cout][cin][taps] layout -- written here directly (the former separate eoe_conv_unpack_wgrad pass: 20 launches per WideResNet step)
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, int M, int N, int ldc,
-                                                        int splits, float alpha, int accumulate) {
+                                                        int splits, float alpha, int accumulate, int unpack_cin, int unpack_taps) {
     __shared__ f32x4 red[4][64];
     const int q = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + q;
@@ -430,6 +432,15 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
     __syncthreads();
     if (w != 0 || !valid) return;
     s = ((red[0][q] + red[1][q]) + (red[2][q] + red[3][q])) * alpha;
+    if (unpack_cin) {
+        const int tap = m / unpack_cin, ch = m - tap * unpack_cin;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float* d = C + ((size_t)(n + r) * unpack_cin + ch) * unpack_taps + tap;
+            *d = accumulate ? *d + s[r] : s[r];
+        }
+        return;
+    }
     float* c = C + (size_t)m * ldc + n;
     if ((ldc & 3) == 0) {
         if (accumulate) s += *(const f32x4*)c;
@@ -537,7 +548,14 @@ extern "C" int eoe_gemm_tn_grouped(const eoe_gemm_args* args, int count, void* s
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps("gemm_tn", flops, bytes, stream);
     g.part = nullptr;
-    if (splits > 1 && args[0].workspace) {
+    const bool unpack = args[0].unpack_dw != 0;
+    if (unpack) {
+        EOE_CHECK_ARG(count == 1 && args[0].gather == 1 && args[0].workspace && args[0].M == args[0].geo.kh * args[0].geo.kw * args[0].geo.C,
+                      "gemm_tn: unpack_dw needs a single implicit-convolution problem and a workspace");
+        EOE_CHECK_ARG((size_t)splits * args[0].M * args[0].N * sizeof(float) <= (size_t)args[0].workspace_bytes &&
+                      (((uintptr_t)args[0].workspace) & 15) == 0, "gemm_tn: unpack_dw: workspace too small");
+    }
+    if ((splits > 1 || unpack) && args[0].workspace) {
         size_t need = 0;
         for (int i = 0; i < count; ++i) {
             g.part_stride[i] = (long long)need;
@@ -596,7 +614,7 @@ extern "C" int eoe_gemm_tn_grouped(const eoe_gemm_args* args, int count, void* s
         for (int i = 0; i < count; ++i) {
             hipLaunchKernelGGL(tn_reduce_kernel, dim3(cdiv(args[i].M * (args[i].N / 4), 64)), dim3(256), 0, s,
                                (const float*)(g.part + g.part_stride[i]), (float*)args[i].C, args[i].M, args[i].N, args[i].ldc, splits,
-                               g.alpha, g.accumulate);
+                               g.alpha, g.accumulate, unpack ? args[i].geo.C : 0, unpack ? args[i].geo.kh * args[i].geo.kw : 0);
         }
         EOE_CHECK_LAUNCH("gemm_tn_reduce");
     }

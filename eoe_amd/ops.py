@@ -925,10 +925,19 @@ def conv_gemm_fwd(x16, w16, y, geo, bias=None, mode=1, colstats_ws=None, accumul
     return y
 
 
-def conv_gemm_wgrad(x16, dy16, gT, geo, mode=1):
-    """gT[kh*kw*C, cout] (fp32) = patches(x16)^T @ dy16 without materialising the patches"""
+def conv_gemm_wgrad(x16, dy16, gT, geo, mode=1, dw=None):
+    """gT[kh*kw*C, cout] (fp32) = patches(x16)^T @ dy16 without materialising the patches.  With `dw` (the weight gradient
+    [cout, C, kh, kw] itself, mode 1) the launch's reduce kernel writes that layout directly and gT is not needed (`unpack_dw`)"""
     n, H, W, Cc, kh, kw, stride, pad, Ho, Wo = geo
     T, M, N = n * Ho * Wo, (kh * kw * Cc if mode == 1 else (kh + 1) // 2 * 64), dy16.shape[1]
+    if dw is not None and mode == 1 and not _single_pixel(geo):
+        assert x16.is_contiguous() and dy16.shape[0] == T and dy16.stride(1) == 1 and dw.shape == (N, Cc, kh, kw) and dw.is_contiguous()
+        ws = scratch("tn_ws", (TN_WORKSPACE_BYTES,), torch.uint8, x16.device)
+        g = GemmArgs(_p(x16), _p(dy16), _p(dw), None, None, None, None, M, N, T, 0, dy16.stride(0), N, 0, dtype_code(x16.dtype),
+                     EPI_NONE, 1, 0, 1.0, _p(ws), TN_WORKSPACE_BYTES, mode, _lib.ConvGeometry(*geo))
+        g.unpack_dw = 1
+        check(lib.eoe_gemm_tn(C.byref(g), _stream()), "eoe_gemm_tn")
+        return dw
     assert x16.is_contiguous() and dy16.shape[0] == T and dy16.stride(1) == 1 and gT.shape == (M, N) and gT.is_contiguous()
     if mode == 1 and _single_pixel(geo):
         # (see conv_gemm_fwd) the taps that only ever see padding have a zero gradient; the one on the pixel is a plain x^T dy
@@ -1249,10 +1258,14 @@ class ConvBnActPoolFunction(torch.autograd.Function):
             check(lib.eoe_stem_unpack_wgrad(_p(gT), _p(dw), cout, kh, kw, _stream()), "eoe_stem_unpack_wgrad")
         elif implicit:
             cg = 8 if implicit == 3 else cin          # channels per tap of the gathered tensor (NHWC8 image: 8)
-            gT = torch.empty((kh * kw * cg, cout), dtype=torch.float32, device=dev)
-            conv_gemm_wgrad(operand, dy16, gT, (n, Hi, Wi, cg, kh, kw, stride, pad, H, W))
-            check(lib.eoe_conv_unpack_wgrad(_p(gT), _p(dw), cout, cin, cg, kh, kw, kh * kw * cg, 1, 0, _stream()),
-                  "eoe_conv_unpack_wgrad")
+            geo_w = (n, Hi, Wi, cg, kh, kw, stride, pad, H, W)
+            if cg == cin and dw.is_contiguous() and not _single_pixel(geo_w):
+                conv_gemm_wgrad(operand, dy16, None, geo_w, dw=dw)            # the reduce kernel writes dw's own layout
+            else:
+                gT = torch.empty((kh * kw * cg, cout), dtype=torch.float32, device=dev)
+                conv_gemm_wgrad(operand, dy16, gT, geo_w)
+                check(lib.eoe_conv_unpack_wgrad(_p(gT), _p(dw), cout, cin, cg, kh, kw, kh * kw * cg, 1, 0, _stream()),
+                      "eoe_conv_unpack_wgrad")
         else:
             g = torch.empty((cout, kp), dtype=torch.float32, device=dev)
             gemm_tn(dy16, operand, g)

@@ -92,6 +92,10 @@ typedef struct {
     int32_t colstats;   /* NT only: the workspace (>= 2 * EOE_NT_COLSUM_WORKSPACE_BYTES(M, N)) receives, per 64 output rows, the column
                          * sums and sums of squares of the fp32 epilogue result: [ceil(M/64)][2][N] floats -- BatchNorm batch
                          * statistics without a pass over C (eoe_bn_stats_partials reduces them); N % 16 == 0 */
+    int32_t unpack_dw;  /* TN with gather == 1 only: C is the convolution's weight gradient in the reference's own layout
+                         * [cout][cin][kh][kw] (not the [kh*kw*cin][cout] matrix): the launch goes through the workspace's partial
+                         * tiles and the reduce kernel writes that order directly -- no eoe_conv_unpack_wgrad pass.  Needs the
+                         * workspace (>= splits * M * N * 4 bytes, EOE_TN_WORKSPACE_BYTES always suffices for the shapes here) */
 } eoe_gemm_args;
 #define EOE_NT_COLSUM_WORKSPACE_BYTES(M, N) ((size_t)(((M) + 63) / 64) * (size_t)(N) * 4)
 
