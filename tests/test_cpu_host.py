@@ -150,3 +150,24 @@ def test_resize_coefficient_tables_equal_the_oracle():
             assert rk.shape[1] == k.value and np.array_equal(bounds, rb), (in_size, out_size, name)
             assert np.array_equal(kk, rk), (in_size, out_size, name)
     assert _lib.lib.eoe_resize_coeffs(0, 4, _lib.EOE_RESIZE_BILINEAR, None, None, 0, None) != 0
+
+
+def test_grad_scale_api():
+    """the fp16 gradient scale is a power of two, 256 by default for fp16 compute and 1 for bf16; the 1x1-map shortcut only fires on
+    its own geometry (host logic, no GPU)"""
+    import torch
+    import eoe_amd
+    from eoe_amd import ops
+    assert eoe_amd.grad_scale() == 1.0
+    assert eoe_amd.default_grad_scale(torch.float16) == 256.0 and eoe_amd.default_grad_scale(torch.bfloat16) == 1.0
+    eoe_amd.set_grad_scale(4096)
+    assert eoe_amd.grad_scale() == 4096.0
+    eoe_amd.set_grad_scale(1.0)
+    for bad in (0, -2, 3, 0.3):
+        with pytest.raises(ValueError):
+            eoe_amd.set_grad_scale(bad)
+    # (n, H, W, C, kh, kw, stride, pad, Ho, Wo)
+    assert ops._single_pixel((256, 1, 1, 512, 3, 3, 1, 1, 1, 1))
+    assert not ops._single_pixel((256, 2, 2, 512, 3, 3, 1, 1, 2, 2))
+    assert not ops._single_pixel((256, 1, 1, 512, 3, 3, 2, 1, 1, 1))
+    assert not ops._single_pixel((256, 1, 1, 48, 3, 3, 1, 1, 1, 1))
