@@ -14,7 +14,8 @@ import parity_util
 g = np.load(os.path.join(R, "tests", "golden", os.environ.get("EOE_PROBE_FIXTURE", "g3_vit_l12_hsc_big") + ".npz"))
 K = len(g["losses"])
 SCALES = [float(x) for x in os.environ.get("EOE_PROBE_SCALES", "1,256,4096,65536").split(",")]
-for dtype in ((torch.float16,) if os.environ.get("EOE_PROBE_FP16_ONLY") else (torch.float16, torch.bfloat16)):
+DT = {"fp16": (torch.float16,), "bf16": (torch.bfloat16,)}.get(os.environ.get("EOE_PROBE_DTYPE", ""), (torch.float16, torch.bfloat16))
+for dtype in ((torch.float16,) if os.environ.get("EOE_PROBE_FP16_ONLY") else DT):
     for S in SCALES:
         eoe_amd.set_compute_dtype(dtype)
         m = omodels.deterministic_init(ClipViTB32Custom(layers=12), tag="vit", layers=12).cuda().train()
