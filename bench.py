@@ -35,8 +35,15 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=128, help="normal images per GPU per step (an equal OE half is added)")
-    ap.add_argument("--mode", choices=["full", "frozen"], default="full",
-                    help="full fine-tune (config 5 style) or frozen encoder + trained head (config 4)")
+    ap.add_argument("--mode", choices=["full", "frozen", "eval"], default="full",
+                    help="full fine-tune (config 5 style), frozen encoder + trained head (config 4), or eval = the forward-only "
+                         "scoring loop of eval_cls (ad_trainer.py:473-550): encoder forward + anomaly scores, no backward / optimiser")
+    ap.add_argument("--comm", choices=["auto", "native", "torch"], default="auto",
+                    help="gradient transport under --gpus N: native = the C-ABI communicator (eoe_comm_*: RCCL on its own side HIP "
+                         "stream, BatchNorm sums inside the library), torch = torch.distributed collectives; auto = native on the "
+                         "nccl (RCCL) backend, torch otherwise (gloo rehearsals)")
+    ap.add_argument("--comm-algo", choices=["rs_ag", "ring"], default="rs_ag",
+                    help="native transport: reduce-scatter + all-gather per bucket (every xGMI link busy in both phases) or one all-reduce")
     ap.add_argument("--dtype", choices=["fp16", "bf16"], default="fp16")
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--model", choices=["vit", "cnn32", "wrn"], default="vit",
@@ -72,10 +79,16 @@ def cpu_baseline(args):
     omodels.deterministic_init(m, tag="bench", layers=args.layers)
     nh = args.cpu_batch // 2
     batch = otrainer.synthetic_batch("bench/cpu", nh, nh, 224)
-    otrainer.train_steps(m, [batch], "hsc", lr=1e-4, weight_decay=1e-3)          # warm-up
-    t0 = time.perf_counter()
-    otrainer.train_steps(m, [batch] * args.cpu_steps, "hsc", lr=1e-4, weight_decay=1e-3)
-    dt = time.perf_counter() - t0
+    if args.mode == "eval":
+        otrainer.eval_scores(m, [batch], "hsc")                                  # warm-up
+        t0 = time.perf_counter()
+        otrainer.eval_scores(m, [batch] * args.cpu_steps, "hsc")
+        dt = time.perf_counter() - t0
+    else:
+        otrainer.train_steps(m, [batch], "hsc", lr=1e-4, weight_decay=1e-3)          # warm-up
+        t0 = time.perf_counter()
+        otrainer.train_steps(m, [batch] * args.cpu_steps, "hsc", lr=1e-4, weight_decay=1e-3)
+        dt = time.perf_counter() - t0
     return {"value": round(args.cpu_steps * 2 * nh / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(),
             "kind": "port",
             "sample": f"{args.cpu_steps} steps of {2 * nh} images (ViT-B/32 {args.layers} layers, {args.mode}, fp32 oracle)"}
@@ -190,11 +203,15 @@ def main():
         res = 32
         model = CNN32(bias=True).to(dev).train()                                     # train_cifar.py:44
         opt = eoe_amd.FusedAdam(model.parameters(), lr=1e-3, weight_decay=0.0)       # train_cifar.py:17-18
-    arena = parallel.GradArena(model)
-    if world > 1:
+    # ---- the exchange step.  Default on RCCL: the library's own communicator -- gradient buckets reduce-scattered
+    # and all-gathered on a side HIP stream from inside backward, BatchNorm sums added inside the library (no Python in that path).
+    comm, comm_kind = parallel.make_comm(args.comm, args.comm_algo) if world > 1 else (None, "none")
+    training = args.mode != "eval"
+    arena = parallel.GradArena(model, comm=comm) if training else None
+    if world > 1 and training:
         arena.install_hooks()
         if any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in model.modules()):
-            parallel.enable_sync_bn()          # global-batch BatchNorm statistics, as the single-device reference computes them
+            parallel.enable_sync_bn(comm=comm)   # global-batch BatchNorm statistics, as the single-device reference computes them
 
     nb = args.batch
     n_local = 2 * nb
@@ -206,15 +223,33 @@ def main():
     lbls = torch.cat([torch.zeros(nb, dtype=torch.int64), torch.ones(nb, dtype=torch.int64)]).to(dev)
     score_buf = torch.empty((args.steps + args.warmup + 8, n_local), dtype=torch.float32, device=dev)
 
+    wait_events = []                 # (before, after) events around the wait for the step's collectives: the EXPOSED communication
+
     def step(i):
         opt.zero_grad()
         feats = model(imgs)
         loss = eoe_amd.hsc_loss(feats, lbls, 0, 1.0 / n_global)
         loss.backward()
-        arena.finish()
+        if world > 1:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            arena.finish()
+            b.record()
+            wait_events.append((a, b))
+        else:
+            arena.finish()
         opt.step()
         score_buf[i % score_buf.shape[0]] = eoe_amd.hsc_score(feats)
         return loss
+
+    if not training:
+        model.eval()
+
+        def step(i):                                       # noqa: F811  (eval_cls: forward-only scoring, ad_trainer.py:498-512)
+            with torch.no_grad():
+                feats = model(imgs)
+            score_buf[i % score_buf.shape[0]] = eoe_amd.hsc_score(feats)
+            return score_buf[i % score_buf.shape[0]][0]
 
     def sync():
         if world > 1:
@@ -222,7 +257,7 @@ def main():
         torch.cuda.synchronize()
 
     launch_bound = args.model == "cnn32" or (args.model == "wrn" and res <= 64)
-    use_graph = args.graph == "on" or (args.graph == "auto" and launch_bound and world == 1)
+    use_graph = training and (args.graph == "on" or (args.graph == "auto" and launch_bound and world == 1))
     eager_step = step
     if use_graph:
         assert world == 1, "--graph on is a single-GPU option"
@@ -238,6 +273,7 @@ def main():
     for i in range(args.warmup):
         loss = step(i)
     sync()
+    wait_events.clear()
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
@@ -247,6 +283,9 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+    comm_exposed_ms = None
+    if wait_events:
+        comm_exposed_ms = sum(a.elapsed_time(b) for a, b in wait_events) / len(wait_events)
     final_loss = loss.item()
     if final_loss != final_loss:                         # diagnose before failing: which tensors went non-finite
         import sys as _sys
@@ -292,19 +331,23 @@ def main():
         ms = elapsed / args.steps * 1e3
         value = n_global * args.steps / elapsed
         flop_per_img = FWD_GFLOP_PER_IMG * (3.0 if args.mode == "full" else 1.0) * args.layers / 12.0
+        mode_txt = {"full": "full fine-tune", "frozen": "frozen encoder", "eval": "forward-only scoring (eval_cls)"}[args.mode]
         if args.model == "cnn32":
             flop_per_img = 0.179
         if args.model == "wrn":
             flop_per_img = 10.89 * (res / 224.0) ** 2                                # 3 x 3.63 GFLOP at 224
         workload = {
             "vit": (f"CLIP ViT-B/32 ({args.layers} layers) + Linear(512,256) + HSC, "
-                    f"{'full fine-tune' if args.mode == 'full' else 'frozen encoder'}, Adam lr 1e-4 wd 1e-3, "
+                    f"{mode_txt}, Adam lr 1e-4 wd 1e-3, "
                     f"224x224, {nb} normal + {nb} OE images per GPU per step"),
             "cnn32": f"CNN32(bias=True) + HSC, Adam lr 1e-3, 32x32, {nb} normal + {nb} OE images per GPU per step",
             "wrn": f"WideResNet(ResNet-18 + CBAM) + HSC, Adam lr 1e-3, {res}x{res}, {nb} normal + {nb} OE images per GPU per step",
         }[args.model]
-        metric = {"vit": "train images/sec, CLIP ViT-B/32 + HSC, 224x224", "cnn32": "train images/sec, CNN32 + HSC, 32x32",
-                  "wrn": f"train images/sec, WideResNet+CBAM + HSC, {res}x{res}"}[args.model]
+        verb = "train" if training else "eval"
+        metric = {"vit": f"{verb} images/sec, CLIP ViT-B/32 + HSC, 224x224", "cnn32": f"{verb} images/sec, CNN32 + HSC, 32x32",
+                  "wrn": f"{verb} images/sec, WideResNet+CBAM + HSC, {res}x{res}"}[args.model]
+        if not training:
+            flop_per_img = {"vit": FWD_GFLOP_PER_IMG * args.layers / 12.0, "cnn32": 0.0597, "wrn": 3.63 * (res / 224.0) ** 2}[args.model]
         out = {
             "metric": metric,
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -314,19 +357,31 @@ def main():
                        "launch": "hip graph replay" if use_graph else "eager"},
             "model_tflops": round(value * flop_per_img / 1e3, 1),
             "mfma_roofline_frac_end_to_end": round(value * flop_per_img / 1e3 / (MFMA_PEAK_TFLOPS * world), 4),
-            "final_loss": round(final_loss, 5), "auc_last_step": round(auc, 4),
+            "final_loss": round(final_loss, 5) if training else None, "auc_last_step": round(auc, 4),
         }
+        if world > 1 and training:
+            # what the first hardware scaling run needs to be read: how much was sent, in how many collectives, and how long the
+            # compute stream stood waiting for them at the end of backward (hipEvents around the join; everything else overlapped)
+            sent = [hi - lo for _, lo, hi in arena.block_buckets] + [hi - lo for _, lo, hi in arena.run_buckets]
+            out["comm"] = {"transport": comm_kind, "buckets": len(sent), "allreduce_bytes_per_step": int(4 * sum(sent)),
+                           "largest_bucket_bytes": int(4 * max(sent)), "comm_exposed_ms": round(comm_exposed_ms, 3),
+                           "sync_bn": bool(parallel._bn_sync_cb is not None)}
         if roof is not None:
             out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline and args.model == "vit":
             out["cpu_baseline"] = cpu_baseline(args)
-        if world == 1 and not args.no_torch_baseline and args.model == "vit":
+        if world == 1 and not args.no_torch_baseline and args.model == "vit" and training:
             del model, opt, arena
             torch.cuda.empty_cache()
             out["torch_rocm_baseline"] = torch_rocm_baseline(args, dev)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        if training:
+            parallel.disable_sync_bn()
+            arena.remove_hooks()
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
 
 

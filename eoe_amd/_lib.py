@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must precede the CDLL below)
 
 from . import _build
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 EOE_F16, EOE_BF16, EOE_F32 = 1, 2, 3
 EOE_RESIZE_BILINEAR, EOE_RESIZE_BICUBIC = 2, 3
 EOE_COMM_I64, EOE_COMM_ID_BYTES, EOE_COMM_ALGO_RING, EOE_COMM_ALGO_RS_AG = 8, 128, 0, 1
@@ -136,7 +136,8 @@ SIGNATURES = {
     "eoe_bce_fwd": [_vp, _vp, _i64, _vp, _vp, _vp, C.c_int, _f32, _vp],
     "eoe_bce_bwd": [_vp, _vp, _vp, _vp, C.c_int, _f32, _vp],
     "eoe_adam_multi": [_vp, _vp, _vp, _vp, _vp, C.c_int, C.POINTER(AdamScalars), _f32, _f32, _f32, _f32, _vp, C.c_int,
-                       _vp],
+                       _vp, _vp],
+    "eoe_grads_nonfinite": [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp],
     "eoe_vit_block_fwd": [C.POINTER(VitBlockFwdArgs), _vp],
     "eoe_vit_block_bwd": [C.POINTER(VitBlockBwdArgs), _vp],
     "eoe_im2col": [_vp, C.c_int, _vp, _vp, _vp] + [C.c_int] * 10 + [_vp],
@@ -172,7 +173,7 @@ SIGNATURES = {
     "eoe_clip_fwd": [_vp, _vp, _vp, _i64, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _f32, _vp],
     "eoe_clip_bwd": [_vp, _vp, _vp, _i64, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _f32, _vp],
     "eoe_clip_score": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
-    "eoe_sgd_multi": [_vp, _vp, _vp, _vp, C.c_int, _f32, _f32, _f32, C.c_int, _f32, _vp],
+    "eoe_sgd_multi": [_vp, _vp, _vp, _vp, C.c_int, _f32, _f32, _f32, C.c_int, _f32, _vp, _vp],
     "eoe_dsad_fwd": [_vp, _vp, _i64, _vp, _vp, C.c_int, C.c_int, _f32, _vp],
     "eoe_dsad_bwd": [_vp, _vp, _i64, _vp, _vp, C.c_int, C.c_int, _f32, _vp],
     "eoe_dsvdd_fwd": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _vp],
@@ -194,6 +195,7 @@ SIGNATURES = {
     "eoe_set_bn_sync": [_vp, _vp],
     "eoe_prof_enable": [C.c_int],
     "eoe_set_option": [C.c_char_p, C.c_int],
+    "eoe_get_option": [C.c_char_p, C.POINTER(C.c_int)],
     "eoe_debug_gemm_stamps": [_vp, C.c_int],
     "eoe_prof_collect": [C.POINTER(ProfEntry), C.c_int, C.POINTER(C.c_int)],
 }
@@ -208,13 +210,19 @@ def header_symbols():
     return sorted(set(re.findall(r"\b(eoe_[a-z0-9_]+)\s*\(", txt)))
 
 
+# the argument structs mirrored above, by their eoe_struct_size index (include/eoe_hip.h)
+_STRUCTS = {0: GemmArgs, 1: ConvGeometry, 2: AdamChunk, 3: AdamScalars, 4: VitBlockFwdArgs, 5: VitBlockBwdArgs, 6: CGateArgs,
+            7: CGateBwdArgs, 8: SGateArgs, 9: SGateBwdArgs}
+
+
 def _load():
     if _build.needs_build():
-        if _build.hipcc_path() is None and not os.path.exists(_build.LIB):
-            raise ImportError("eoe_amd: libeoe_hip.so is missing and hipcc is not available to build it; "
-                              "there is no CPU fallback")
-        if _build.hipcc_path() is not None:
-            _build.build(verbose=False)
+        if _build.hipcc_path() is None:
+            # a library that does not match the sources must not be loaded silently: a struct-only change of the C ABI would
+            # corrupt memory without any symbol going missing
+            what = "is missing" if not os.path.exists(_build.LIB) else "does not match the sources (content stamp)"
+            raise ImportError(f"eoe_amd: libeoe_hip.so {what} and hipcc is not available to build it; there is no CPU fallback")
+        _build.build(verbose=False)
     lib = C.CDLL(_build.LIB)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)            # AttributeError here = the library does not export the ABI
@@ -223,7 +231,24 @@ def _load():
     v = lib.eoe_abi_version()
     if v != ABI_VERSION:
         raise ImportError(f"eoe_amd: libeoe_hip.so has ABI version {v}, expected {ABI_VERSION}")
+    for idx, cls in _STRUCTS.items():
+        if lib.eoe_struct_size(idx) != C.sizeof(cls):
+            raise ImportError(f"eoe_amd: {cls.__name__} is {C.sizeof(cls)} bytes here but {lib.eoe_struct_size(idx)} in libeoe_hip.so "
+                              "(the ctypes mirror and include/eoe_hip.h disagree)")
     return lib
+
+
+def get_option(name: str) -> int:
+    v = C.c_int(0)
+    check(lib.eoe_get_option(name.encode(), C.byref(v)), "eoe_get_option")
+    return v.value
+
+
+def set_option(name: str, value: int) -> int:
+    """sets a tuning switch and returns the value it had"""
+    old = get_option(name)
+    check(lib.eoe_set_option(name.encode(), int(value)), "eoe_set_option")
+    return old
 
 
 lib = _load()

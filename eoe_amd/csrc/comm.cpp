@@ -23,12 +23,14 @@ struct Rccl {
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     char why[256] = {0};
 };
 
+Rccl g_rccl;
 Rccl* rccl() {
-    static Rccl r;
+    static Rccl& r = g_rccl;
     static std::once_flag once;
     std::call_once(once, [] {
         // the copy already in the process first (torch's), so that there is ONE RCCL and one set of its global state
@@ -51,6 +53,7 @@ Rccl* rccl() {
         EOE_SYM(AllReduce, "ncclAllReduce")
         EOE_SYM(ReduceScatter, "ncclReduceScatter")
         EOE_SYM(AllGather, "ncclAllGather")
+        EOE_SYM(Broadcast, "ncclBroadcast")
         EOE_SYM(GetErrorString, "ncclGetErrorString")
 #undef EOE_SYM
     });
@@ -59,7 +62,7 @@ Rccl* rccl() {
 
 int need_rccl(Rccl*& r) {
     r = rccl();
-    if (!r) return eoe_set_error(EOE_ERR_UNSUPPORTED, "RCCL is not available: %s", rccl() ? "" : "dlopen / dlsym failed");
+    if (!r) return eoe_set_error(EOE_ERR_UNSUPPORTED, "RCCL is not available: %s", g_rccl.why[0] ? g_rccl.why : "dlopen / dlsym failed");
     return 0;
 }
 
@@ -88,6 +91,9 @@ int dtype_of(int dtype, ncclDataType_t& t, int& size) {
 
 struct eoe_comm {
     ncclComm_t comm;
+    ncclComm_t bn_comm;      // a SECOND communicator for the BatchNorm sums (eoe_comm_sync_bn): they run on the caller's compute stream
+                             // while gradient buckets are in flight on the side stream, and one ncclComm must not be driven from two
+                             // streams at once.  Created on first use (a collective call: every rank enables together).
     int rank, world, device;
     hipStream_t side;
     hipEvent_t ready, done;
@@ -108,7 +114,7 @@ extern "C" int eoe_comm_init(const void* id, int rank, int world, int device, eo
     EOE_TRY(need_rccl(r));
     EOE_HIP(hipSetDevice(device), "hipSetDevice");
     eoe_comm* c = new eoe_comm();
-    c->rank = rank; c->world = world; c->device = device;
+    c->rank = rank; c->world = world; c->device = device; c->bn_comm = nullptr;
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof(uid));
     ncclResult_t rc = r->CommInitRank(&c->comm, world, uid, rank);
@@ -127,7 +133,11 @@ extern "C" int eoe_comm_init(const void* id, int rank, int world, int device, eo
 extern "C" int eoe_comm_destroy(eoe_comm_t c) {
     if (!c) return 0;
     Rccl* r = rccl();
+    // a BatchNorm hook that points at this communicator must not outlive it (the next training-mode BatchNorm would call into freed memory)
+    if (eoe_bn_sync_user() == (void*)c) (void)eoe_set_bn_sync(nullptr, nullptr);
     (void)hipStreamSynchronize(c->side);
+    (void)hipDeviceSynchronize();                 // BatchNorm sums run on the caller's streams
+    if (r && c->bn_comm) r->CommDestroy(c->bn_comm);
     if (r) r->CommDestroy(c->comm);
     (void)hipEventDestroy(c->ready);
     (void)hipEventDestroy(c->done);
@@ -183,13 +193,42 @@ extern "C" int eoe_comm_join(eoe_comm_t c, void* stream) {
 static int comm_bn_hook(void* user, void* buf, int64_t count, int is_f64, void* stream) {
     eoe_comm_t c = (eoe_comm_t)user;
     Rccl* r = rccl();
-    if (!c || !r) return 1;
-    return r->AllReduce(buf, buf, (size_t)count, is_f64 ? ncclFloat64 : ncclFloat32, ncclSum, c->comm, (hipStream_t)stream) == ncclSuccess ? 0 : 1;
+    if (!c || !r || !c->bn_comm) return 1;
+    return r->AllReduce(buf, buf, (size_t)count, is_f64 ? ncclFloat64 : ncclFloat32, ncclSum, c->bn_comm, (hipStream_t)stream) == ncclSuccess ? 0 : 1;
+}
+
+// the second communicator: rank 0 draws a fresh id and hands it to the others through the first one (side stream, then a host wait)
+static int make_bn_comm(eoe_comm_t c) {
+    Rccl* r;
+    EOE_TRY(need_rccl(r));
+    ncclUniqueId uid;
+    memset(&uid, 0, sizeof(uid));
+    if (c->rank == 0) EOE_NCCL(r, r->GetUniqueId(&uid), "ncclGetUniqueId");
+    if (c->world > 1) {
+        void* dbuf = nullptr;
+        EOE_HIP(hipMalloc(&dbuf, sizeof(uid)), "hipMalloc");
+        hipError_t e = hipMemcpy(dbuf, &uid, sizeof(uid), hipMemcpyHostToDevice);
+        ncclResult_t rc = ncclSuccess;
+        if (e == hipSuccess) rc = r->Broadcast(dbuf, dbuf, sizeof(uid), ncclChar, 0, c->comm, c->side);
+        if (e == hipSuccess && rc == ncclSuccess) e = hipStreamSynchronize(c->side);
+        if (e == hipSuccess && rc == ncclSuccess) e = hipMemcpy(&uid, dbuf, sizeof(uid), hipMemcpyDeviceToHost);
+        (void)hipFree(dbuf);
+        if (rc != ncclSuccess) return eoe_set_error(EOE_ERR_LAUNCH, "eoe_comm_sync_bn: ncclBroadcast: %s", r->GetErrorString(rc));
+        if (e != hipSuccess) return eoe_set_error(EOE_ERR_LAUNCH, "eoe_comm_sync_bn: %s", hipGetErrorString(e));
+    }
+    EOE_NCCL(r, r->CommInitRank(&c->bn_comm, c->world, uid, c->rank), "ncclCommInitRank (BatchNorm communicator)");
+    return 0;
 }
 
 extern "C" int eoe_comm_sync_bn(eoe_comm_t c, int enable) {
     EOE_CHECK_ARG(c != nullptr || !enable, "eoe_comm_sync_bn: null communicator");
-    return eoe_set_bn_sync(enable ? comm_bn_hook : nullptr, enable ? (void*)c : nullptr);
+    if (enable && !c->bn_comm) EOE_TRY(make_bn_comm(c));
+    if (!enable) {
+        // clears the hook only if it is this communicator's (or none was given): another live communicator keeps its registration
+        if (c && eoe_bn_sync_user() != (void*)c) return 0;
+        return eoe_set_bn_sync(nullptr, nullptr);
+    }
+    return eoe_set_bn_sync(comm_bn_hook, (void*)c);
 }
 
 extern "C" int eoe_comm_info(eoe_comm_t c, int* rank, int* world) {

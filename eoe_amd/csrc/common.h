@@ -63,6 +63,7 @@ bool eoe_defer_reduce(const float* part, int R, int N, int seg, float* o0, float
 int eoe_flush_reduce(EoeRedJobs* jobs, void* stream);      // elementwise.hip
 bool eoe_bn_sync_active();                                  // conv.hip: synchronised BatchNorm hook (eoe_set_bn_sync)
 int eoe_bn_sync_allreduce(void* buf, int64_t count, int is_f64, void* stream);
+void* eoe_bn_sync_user();                                    // the registered hook's user pointer (NULL when none)
 // appends to the open batch, or (none open) finishes this one job right away with `out += sum`
 int eoe_finish_reduce(const float* part, int R, int N, int seg, float* o0, float* o1, float* o2, int blocked, void* stream);
 

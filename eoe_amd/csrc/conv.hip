@@ -903,6 +903,7 @@ extern "C" int eoe_set_bn_sync(eoe_allreduce_fn fn, void* user) {
     return 0;
 }
 bool eoe_bn_sync_active() { return g_bn_sync_fn != nullptr; }
+void* eoe_bn_sync_user() { return g_bn_sync_fn ? g_bn_sync_user : nullptr; }
 int eoe_bn_sync_allreduce(void* buf, int64_t count, int is_f64, void* stream) {
     if (!g_bn_sync_fn) return eoe_set_error(EOE_ERR_ARG, "bn sync: no hook registered");
     if (g_bn_sync_fn(g_bn_sync_user, buf, count, is_f64, stream) != 0) return eoe_set_error(EOE_ERR_LAUNCH, "bn sync: the all-reduce hook failed");

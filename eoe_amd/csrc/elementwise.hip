@@ -962,7 +962,8 @@ __global__ __launch_bounds__(256) void linear_small_dw_kernel(const float* __res
 // Same chunk tables as the Adam kernel (m_off = the momentum buffer, v_off unused).
 __global__ __launch_bounds__(256) void sgd_multi_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
                                                         const eoe_adam_chunk* __restrict__ chunks, float lr, float momentum, float wd,
-                                                        int nesterov, float grad_scale_inv) {
+                                                        int nesterov, float grad_scale_inv, const int* __restrict__ skip) {
+    if (skip && *skip) return;                      // a non-finite gradient was found this step (eoe_grads_nonfinite): no update at all
     const eoe_adam_chunk ck = chunks[blockIdx.x];
     float* pp = p + ck.p_off;
     const float* gg = g + ck.g_off;
@@ -987,7 +988,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void adam_multi_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                   float* __restrict__ v, const eoe_adam_chunk* __restrict__ chunks,
                                   eoe_adam_scalars sc, float beta1, float beta2, float eps, float wd,
-                                  T* __restrict__ shadow) {
+                                  T* __restrict__ shadow, const int* __restrict__ skip) {
+    if (skip && *skip) return;                      // a non-finite gradient was found this step (eoe_grads_nonfinite): no update at all
     const eoe_adam_chunk ck = chunks[blockIdx.x];
     const float step_size = sc.step_size[ck.group & (EOE_ADAM_GROUPS - 1)];
     const float bc2_sqrt = sc.bc2_sqrt[ck.group & (EOE_ADAM_GROUPS - 1)];
@@ -1037,6 +1039,36 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(float* __restrict__ p, 
             if (sh) sh[i] = (T)np;
         }
     }
+}
+
+// Non-finite guard of a scaled fp16 step (the reference's numerical-failure policy is the per-epoch NaN check of ad_trainer.py:448-449;
+// the gradient scale this build adds for fp16 needs its own): one streaming pass over the gradients the optimiser is about to apply,
+// through the SAME chunk table.  state = {flag of even steps, flag of odd steps, steps skipped so far, steps checked so far}: a chunk
+// with an inf / NaN raises flag[parity]; eoe_adam_multi / eoe_sgd_multi given &state[parity] then leave p, m, v untouched.  Block 0 also
+// retires the OTHER flag (the previous step's, final since that step's optimiser launch has completed in stream order) into the
+// skipped-steps count, so nothing is ever reset from the host and nothing needs a host synchronisation.
+__global__ __launch_bounds__(256) void grads_nonfinite_kernel(const float* __restrict__ g, const eoe_adam_chunk* __restrict__ chunks,
+                                                              int* __restrict__ state, int parity, int first) {
+    if (first && blockIdx.x == 0 && threadIdx.x == 0) {
+        if (state[1 - parity]) state[2] += 1;
+        state[1 - parity] = 0;
+        state[3] += 1;
+    }
+    const eoe_adam_chunk ck = chunks[blockIdx.x];
+    const float* gg = g + ck.g_off;
+    unsigned bad = 0;
+    auto test = [&](float x) { bad |= ((__float_as_uint(x) & 0x7f800000u) == 0x7f800000u) ? 1u : 0u; };
+    if ((ck.g_off & 3) == 0) {
+        const int n4 = ck.n >> 2;
+        for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+            const f32x4 v = *(const f32x4*)(gg + i * 4);
+            test(v[0]); test(v[1]); test(v[2]); test(v[3]);
+        }
+        for (int i = (n4 << 2) + threadIdx.x; i < ck.n; i += blockDim.x) test(gg[i]);
+    } else {
+        for (int i = threadIdx.x; i < ck.n; i += blockDim.x) test(gg[i]);
+    }
+    if (__any(bad != 0) && (threadIdx.x & 63) == 0) state[parity] = 1;       // same value from every writer: plain stores
 }
 
 }  // namespace
@@ -1492,26 +1524,35 @@ extern "C" int eoe_clip_score(const float* f, const float* text, float* scores, 
     return 0;
 }
 
+extern "C" int eoe_grads_nonfinite(const float* g, const eoe_adam_chunk* chunks, int n_chunks, int32_t* state, int parity, int first,
+                                  void* stream) {
+    EOE_CHECK_ARG(g && chunks && state && n_chunks > 0 && (parity == 0 || parity == 1), "grads_nonfinite: bad args");
+    ProfScope ps("grads_nonfinite", 0, 4.0 * n_chunks * EOE_ADAM_CHUNK, stream);
+    hipLaunchKernelGGL(grads_nonfinite_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, g, chunks, (int*)state, parity, first);
+    EOE_CHECK_LAUNCH("grads_nonfinite");
+    return 0;
+}
+
 extern "C" int eoe_sgd_multi(float* p, const float* g, float* buf, const eoe_adam_chunk* chunks, int n_chunks, float lr,
-                             float momentum, float weight_decay, int nesterov, float grad_scale_inv, void* stream) {
+                             float momentum, float weight_decay, int nesterov, float grad_scale_inv, const int32_t* skip_flag, void* stream) {
     EOE_CHECK_ARG(p && g && chunks && n_chunks > 0 && (buf || momentum == 0.f), "sgd_multi: bad args");
     ProfScope ps("sgd_multi", 0, 20.0 * n_chunks * EOE_ADAM_CHUNK, stream);
     hipLaunchKernelGGL(sgd_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, p, g, buf, chunks, lr, momentum, weight_decay,
-                       nesterov, grad_scale_inv > 0.f ? grad_scale_inv : 1.0f);
+                       nesterov, grad_scale_inv > 0.f ? grad_scale_inv : 1.0f, (const int*)skip_flag);
     EOE_CHECK_LAUNCH("sgd_multi");
     return 0;
 }
 
 extern "C" int eoe_adam_multi(float* p, const float* g, float* m, float* v, const eoe_adam_chunk* chunks,
                               int n_chunks, const eoe_adam_scalars* scalars, float beta1, float beta2, float eps,
-                              float weight_decay, void* shadow16, int dtype, void* stream) {
+                              float weight_decay, void* shadow16, int dtype, const int32_t* skip_flag, void* stream) {
     EOE_CHECK_ARG(p && g && m && v && chunks && scalars && n_chunks > 0, "adam_multi: bad args");
     ProfScope ps("adam_multi", 0, 28.0 * n_chunks * EOE_ADAM_CHUNK, stream);
     if (!shadow16) dtype = EOE_BF16;
     eoe_adam_scalars sc = *scalars;
     if (!(sc.grad_scale_inv > 0.f)) sc.grad_scale_inv = 1.0f;        // 0 (a zero-initialised struct) = no scaling
     DISPATCH_T(dtype, hipLaunchKernelGGL((adam_multi_kernel<T>), dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, p, g,
-                                         m, v, chunks, sc, beta1, beta2, eps, weight_decay, (T*)shadow16));
+                                         m, v, chunks, sc, beta1, beta2, eps, weight_decay, (T*)shadow16, (const int*)skip_flag));
     EOE_CHECK_LAUNCH("adam_multi");
     return 0;
 }

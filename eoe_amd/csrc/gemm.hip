@@ -849,3 +849,12 @@ extern "C" int eoe_set_option(const char* name, int value) {
     if (name && !strcmp(name, "attn_flags")) { g_attn_flags = value; return 0; }
     return eoe_set_error(EOE_ERR_ARG, "unknown option");
 }
+
+extern "C" int eoe_get_option(const char* name, int* value) {
+    EOE_CHECK_ARG(name && value, "eoe_get_option: null pointer");
+    if (!strcmp(name, "nt_flags")) { *value = g_nt_flags; return 0; }
+    if (!strcmp(name, "tn_flags")) { *value = g_tn_flags; return 0; }
+    if (!strcmp(name, "vit_side_stream")) { *value = g_vit_side_stream; return 0; }
+    if (!strcmp(name, "attn_flags")) { *value = g_attn_flags; return 0; }
+    return eoe_set_error(EOE_ERR_ARG, "unknown option");
+}

@@ -49,7 +49,9 @@ struct TnGroup {
     // stream-K (sk_wgs > 0): see gemm_tn_grouped_kernel
     int sk_wgs;
     float* sk_part;   // [sk_wgs][BM*BN] partial accumulators of the ranges that do not end their tile
-    int* sk_flags;    // [sk_wgs] = 1 once that workgroup's partial is visible; reset to 0 by the workgroup that consumes it
+    int* sk_flags;    // [sk_wgs] = sk_epoch once that workgroup's partial of THIS launch is visible (never reset: the next launch waits
+                      // for its own epoch, so a time-out or an aborted launch cannot leave a flag that a later launch would trust)
+    int sk_epoch;     // per-(device, stream) launch counter, never 0
 };
 
 __device__ __forceinline__ int swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
@@ -99,7 +101,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
     // order) and publishes a flag; the workgroup whose segment ends the tile adds the one or two partials in a fixed order and runs the
     // epilogue.  No atomics on data, no second kernel, bitwise reproducible; extra traffic 2 x 128 KiB per split point.  The grid is
     // exactly one workgroup per CU (144 KiB of LDS each), so every range is resident while its successor waits for it; the wait is
-    // bounded all the same and a time-out poisons the tile with NaN instead of hanging the GPU or passing silently.
+    // bounded all the same and a time-out poisons the tile with NaN instead of hanging the GPU or passing silently.  Flags carry the
+    // launch's epoch (TnGroup::sk_epoch), so they are never reset and nothing an earlier launch left behind can be mistaken for a
+    // partial of this one.
     const int split = g.sk_wgs ? 0 : (int)blockIdx.x / g.total_tiles;
     const int nk_tile = (g.T + BK - 1) / BK;
     const long long sk_total = (long long)g.total_tiles * nk_tile;
@@ -320,7 +324,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
             if (tid == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(g.sk_flags + rid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(g.sk_flags + rid, g.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             continue;
         }
@@ -331,18 +335,20 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_grouped_kernel(TnGroup g) {
                 if (cu1 <= tile_u0) break;
                 if (tid == 0) {
                     // relaxed polls of the one word (an acquiring poll would invalidate the caches on every iteration), bounded: a
-                    // protocol error must not hang the GPU (the result is then wrong and the tests say so); ONE acquire after the match
+                    // protocol error must not hang the GPU (the result is then wrong and the tests say so); ONE acquire after the match.
+                    // The flag carries this launch's epoch: whatever an earlier launch left there (a contributor that arrived after
+                    // its consumer had timed out, a launch that was aborted) is not mistaken for this launch's partial.
                     int spins = 0;
-                    while (__hip_atomic_load(g.sk_flags + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1 && ++spins < (1 << 22))
+                    while (__hip_atomic_load(g.sk_flags + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g.sk_epoch && ++spins < (1 << 22))
                         __builtin_amdgcn_s_sleep(8);
                     *sk_timeout = spins >= (1 << 22) ? 1 : 0;
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    // self-cleaning: each flag has exactly one reader; the next launch finds the words zero again
-                    __hip_atomic_store(g.sk_flags + cc, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 __syncthreads();
-                if (*sk_timeout) {               // loud, not silent: the tile becomes NaN
+                const bool timed_out = *sk_timeout != 0;
+                __syncthreads();                 // every thread has read the word before thread 0 may rewrite it for the next partial
+                if (timed_out) {                 // loud, not silent: the tile becomes NaN (no flag to clean up: epochs)
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -465,24 +471,61 @@ int check_problem(const eoe_gemm_args* a, int T, int dtype) {
 
 }  // namespace
 
-// stream-K flag words: one zeroed block per (device, stream), owned by the library and self-cleaning (every flag is reset by its one
-// reader), so a launch -- or the replay of a captured one -- always starts from zeros whatever the caller does with its workspace.
-// Not created while the stream is being captured (that launch then runs without stream-K).
-static int* streamk_flags(hipStream_t s, int n) {
+// stream-K flag words: one block per (device, stream), owned by the library, zeroed once.  A launch publishes and waits for its own
+// EPOCH (a per-block launch counter, never 0), so the words need no cleaning: a launch -- whatever happened to the ones before it --
+// never trusts a flag it did not write itself.  Not used while the stream is being captured: a replayed launch would reuse its
+// captured epoch and find the previous replay's flags (that launch then runs without stream-K).
+struct SkFlags { int* flags; int epoch; };
+static bool streamk_flags(hipStream_t s, int n, int** flags, int* epoch) {
     static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, int*> table;
+    static std::map<std::pair<int, hipStream_t>, SkFlags> table;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return false;
     std::lock_guard<std::mutex> lk(mu);
     auto it = table.find({dev, s});
-    if (it != table.end()) return it->second;
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
-    int* p = nullptr;
-    if (hipMalloc(&p, (size_t)n * sizeof(int)) != hipSuccess) return nullptr;
-    if (hipMemset(p, 0, (size_t)n * sizeof(int)) != hipSuccess) { (void)hipFree(p); return nullptr; }
-    table[{dev, s}] = p;
-    return p;
+    if (it == table.end()) {
+        int* p = nullptr;
+        if (hipMalloc(&p, (size_t)n * sizeof(int)) != hipSuccess) return false;
+        if (hipMemset(p, 0, (size_t)n * sizeof(int)) != hipSuccess) { (void)hipFree(p); return false; }
+        it = table.insert({{dev, s}, SkFlags{p, 0}}).first;
+    }
+    if (flags) {                                   // a launch: take the next epoch
+        it->second.epoch = it->second.epoch >= 0x7ffffff0 ? 1 : it->second.epoch + 1;
+        *flags = it->second.flags;
+        *epoch = it->second.epoch;
+    }
+    return true;
+}
+
+static int tn_num_cus() {
+    static const int ncu = [] { int d = 0, n = 256; hipDeviceProp_t pr; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) n = pr.multiProcessorCount; return n; }();
+    return ncu;
+}
+
+// Stream-K precondition, in one place (the launch below and vit.cpp's choice of the LayerNorm-1 side stream both ask): a plain
+// group (no implicit patch matrix, no split) whose tiles fill between 5/8 and all of the CUs -- every one of the #CUs ranges must be
+// RESIDENT at once (one 144-KiB workgroup per CU), because a range waits for its predecessor's partial inside the launch --, a
+// reduction of at least 32 k-tiles, a 16-byte aligned workspace of EOE_TN_STREAMK_WORKSPACE_BYTES(#CUs), an eager (not captured)
+// stream, and "tn_flags" bit 1 clear.
+static bool streamk_applies(int tiles, int splits, int gather, int T, const void* ws, int64_t ws_bytes, hipStream_t s) {
+    const int ncu = tn_num_cus();
+    const size_t need = (size_t)ncu * (BM * BN * sizeof(float));
+    if ((g_tn_flags & 2) || gather != 0 || splits != 1 || tiles >= ncu || tiles * 8 < ncu * 5 || cdiv(T, BK) < 32) return false;
+    if (!ws || (size_t)ws_bytes < need || (((uintptr_t)ws) & 15) != 0) return false;
+    return streamk_flags(s, ncu, nullptr, nullptr);
+}
+
+// for vit.cpp: will eoe_gemm_tn_grouped(args, count, stream) run as stream-K?
+bool eoe_tn_streamk_would_run(const eoe_gemm_args* args, int count, void* stream) {
+    if (!args || count < 1) return false;
+    int tiles = 0;
+    for (int i = 0; i < count; ++i) tiles += cdiv(args[i].M, BM) * cdiv(args[i].N, BN);
+    const int ncu = tn_num_cus();
+    const int T = args[0].K;
+    const bool would_split = tiles * 8 < ncu * 5;
+    return streamk_applies(tiles, would_split ? 2 : 1, args[0].gather, T, args[0].workspace, args[0].workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int eoe_gemm_tn_grouped(const eoe_gemm_args* args, int count, void* stream) {
@@ -572,22 +615,17 @@ extern "C" int eoe_gemm_tn_grouped(const eoe_gemm_args* args, int count, void* s
         }
     }
     const int gather = args[0].gather;
-    // stream-K: a plain group that fills between 5/8 and all of the CUs with one tile each (the ViT block's four wgrads: 216 tiles)
-    // runs as #CUs equal k-ranges instead (kernel comment); needs the caller's workspace: EOE_TN_STREAMK_WORKSPACE_BYTES(#CUs).
-    // "tn_flags" bit 1 switches it off (A/B)
+    // stream-K (streamk_applies): the ViT block's four wgrads (216 tiles) run as #CUs equal k-ranges instead (kernel comment)
     int grid = tiles * splits;
-    {
-        const int nk_tile = cdiv(T, BK);
-        const size_t need = (size_t)ncu * (BM * BN * sizeof(float));
-        if (!(g_tn_flags & 2) && gather == 0 && splits == 1 && tiles < ncu && nk_tile >= 32 && args[0].workspace &&
-            (size_t)args[0].workspace_bytes >= need && (((uintptr_t)args[0].workspace) & 15) == 0) {
-            int* flags = streamk_flags(s, ncu);
-            if (flags) {
-                g.sk_wgs = ncu;
-                g.sk_part = (float*)args[0].workspace;
-                g.sk_flags = flags;
-                grid = ncu;
-            }
+    if (streamk_applies(tiles, splits, gather, T, args[0].workspace, args[0].workspace_bytes, s)) {
+        int* flags = nullptr;
+        int epoch = 0;
+        if (streamk_flags(s, ncu, &flags, &epoch)) {
+            g.sk_wgs = ncu;
+            g.sk_part = (float*)args[0].workspace;
+            g.sk_flags = flags;
+            g.sk_epoch = epoch;
+            grid = ncu;
         }
     }
 #define EOE_TN_LAUNCH_RD(TT, GG, RR)                                                                                       \

@@ -10,6 +10,7 @@
     } while (0)
 
 extern int g_tn_flags;          // gemm_tn.hip
+bool eoe_tn_streamk_would_run(const eoe_gemm_args* args, int count, void* stream);   // gemm_tn.hip: the stream-K precondition
 int g_vit_side_stream = 1;      // eoe_set_option("vit_side_stream", 0|1)
 
 namespace {
@@ -157,7 +158,8 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
     // LayerNorm-1 backward next to the wgrad launch on a second stream pays only while that launch leaves CUs idle (216 tiles on 256
     // CUs); with the stream-K workspace the launch fills every CU itself and the side stream is left out (same step time, one
     // stream, capturable)
-    const bool streamk = b->tn_workspace != nullptr && !(g_tn_flags & 2);
+    // (asked of the launch itself: small or ragged batches, captured streams and "tn_flags" bit 1 all run the plain 216-tile form)
+    const bool streamk = eoe_tn_streamk_would_run(w, 4, stream);
     SideStream* ss = (g_vit_side_stream == 2 || (g_vit_side_stream && !streamk)) && b->red_scratch ? side_stream(s) : nullptr;
     if (ss) {
         // fork before the wgrad launch (LayerNorm-1 backward depends on d xn1 and dx_mid only), join before the finish kernel

@@ -215,15 +215,20 @@ def clip_preprocess(src_u8, n_px=224):
 
 
 class ResidentImageSource:
-    """one-vs-rest step-batch source whose uint8 images live in HBM: every step batch ([normal half | OE half], the
-    BalancedConcatLoader contract of `datasets/bases.py:570-600`) is gathered, cropped, flipped, noised and normalised by one
-    kernel; the host only draws (index, crop origin, flip) per sample.  Batches come out already normalised, so
-    `.normalize` is None (the trainer then installs no second Normalize)."""
+    """step-batch source whose uint8 images live in HBM: every step batch ([normal half | OE half], the BalancedConcatLoader
+    contract of `datasets/bases.py:570-600`) is gathered, cropped, flipped, noised and normalised by one kernel; the host only
+    draws (index, crop origin, flip) per sample.  Batches come out already normalised, so `.normalize` is None (the trainer
+    then installs no second Normalize).
+
+    `normal_index` (optional): the rows of `normal_u8` that ARE the normal training set -- the reference's `Subset` over the
+    samples of the normal classes (`bases.py:169-203`); batches report those rows' indices in the full set, as the reference's
+    datasets do (`cifar.py:106-121`), and OE indices are offset by the length of the FULL normal set (`bases.py:596`)."""
 
     nominal_label, anomalous_label = 0, 1
 
     def __init__(self, normal_u8, oe_u8, test_u8, test_labels, crop, padding=0, mean=None, std=None, flip_first=True,
-                 noise_std=0.001, seed=0, device="cuda", resize=None, test_resize=None, color_jitter=None, interpolation="bilinear"):
+                 noise_std=0.001, seed=0, device="cuda", resize=None, test_resize=None, color_jitter=None, interpolation="bilinear",
+                 normal_index=None):
         """resize / test_resize: `transforms.Resize` argument applied once to the resident train / test sets (None: as given);
         color_jitter: (brightness, contrast, saturation, hue) of `transforms.ColorJitter`, drawn per sample per step"""
         dev = torch.device(device)
@@ -237,6 +242,8 @@ class ResidentImageSource:
         self.crop, self.padding, self.mean, self.std = int(crop), int(padding), mean, std
         self.flip_first, self.noise_std, self.seed = flip_first, noise_std, int(seed)
         self.normalize = None
+        self.ds_statistics = None
+        self.normal_index = None if normal_index is None else torch.as_tensor(normal_index, dtype=torch.int64).clone()
         self._g = torch.Generator().manual_seed(seed)
         self._step = 0
 
@@ -248,10 +255,14 @@ class ResidentImageSource:
         return torch.stack([idx.to(torch.int64), top, left, flip], dim=1).to(torch.int32)
 
     def _epoch(self, batch_size):
-        n, m = self.normal.shape[0], self.oe.shape[0]
-        perm = torch.randperm(n, generator=self._g)
+        subset = self.normal_index if self.normal_index is not None else torch.arange(self.normal.shape[0])
+        n, n_full, m = len(subset), self.normal.shape[0], self.oe.shape[0]
+        perm = subset[torch.randperm(n, generator=self._g)]
         oe_idx = tile_oe_indices(torch.arange(m), n)
-        oe_order = oe_idx[torch.randperm(len(oe_idx), generator=self._g)]
+        if m >= 10000:                                   # bases.py:561: OE sets of >= 10 000 samples are drawn with replacement
+            oe_order = oe_idx[torch.randint(len(oe_idx), (len(oe_idx),), generator=self._g)]
+        else:
+            oe_order = oe_idx[torch.randperm(len(oe_idx), generator=self._g)]
         dev = self.normal.device
         for s in range(0, n, batch_size):
             ni = perm[s:s + batch_size]
@@ -272,8 +283,9 @@ class ResidentImageSource:
                 po[:, 0] = torch.arange(len(oi), dtype=torch.int32, device=dev)
             xn = augment_batch(src_n, pn, (self.crop, self.crop), self.mean, self.std, self.flip_first, self.noise_std, 2 * seed)
             xo = augment_batch(src_o, po, (self.crop, self.crop), self.mean, self.std, self.flip_first, self.noise_std, 2 * seed + 1)
-            lbls = torch.cat([torch.zeros(len(ni), dtype=torch.int64), torch.ones(len(oi), dtype=torch.int64)])
-            yield torch.cat([xn, xo]), lbls, torch.cat([ni, oi + n])          # OE indices offset by the normal set size (bases.py:597)
+            lbls = torch.cat([torch.full((len(ni),), self.nominal_label, dtype=torch.int64),
+                              torch.full((len(oi),), self.anomalous_label, dtype=torch.int64)])
+            yield torch.cat([xn, xo]), lbls, torch.cat([ni, oi + n_full])      # OE indices offset by the FULL normal set (bases.py:596)
 
     def loaders(self, batch_size, **kw):
         outer = self
@@ -283,7 +295,8 @@ class ResidentImageSource:
                 return outer._epoch(batch_size)
 
             def __len__(s):
-                return math.ceil(outer.normal.shape[0] / batch_size)
+                n = outer.normal.shape[0] if outer.normal_index is None else len(outer.normal_index)
+                return math.ceil(n / batch_size)
 
         # test split: centre crop, no flip, no noise (val_transform: ToTensor + normalize, train_cifar.py:39-42)
         Hs, Ws = self.test.shape[1], self.test.shape[2]
@@ -294,3 +307,52 @@ class ResidentImageSource:
                              torch.zeros_like(idx)], dim=1).to(torch.int32).to(self.test.device)
             test.append((augment_batch(self.test, p, (self.crop, self.crop), self.mean, self.std, True, 0.0, 0), self.test_y[idx], idx))
         return _Train(), test
+
+
+def normal_subset(class_labels, normal_classes) -> torch.Tensor:
+    """rows of a labelled set that belong to the normal classes, ascending: `TorchvisionDataset.create_subset`
+    (`datasets/bases.py:192-195`: np.argwhere(np.isin(labels, normal_classes)))"""
+    lab = torch.as_tensor(class_labels, dtype=torch.int64)
+    keep = torch.zeros(len(lab), dtype=torch.bool)
+    for c in normal_classes:
+        keep |= lab == int(c)
+    return torch.nonzero(keep).flatten()
+
+
+def ad_targets(class_labels, normal_classes, nominal_label: int = 0) -> torch.Tensor:
+    """the reference's `target_transform` (`datasets/bases.py:137-139`): anomalous iff the sample's class is not a normal class"""
+    lab = torch.as_tensor(class_labels, dtype=torch.int64)
+    normal = torch.zeros(len(lab), dtype=torch.bool)
+    for c in normal_classes:
+        normal |= lab == int(c)
+    return torch.where(normal, torch.tensor(nominal_label), torch.tensor(1 - nominal_label)).to(torch.int64)
+
+
+class LabelledImageSet:
+    """A multi-class image set resident in HBM (uint8 NHWC + integer class labels) from which the class x seed loop of
+    `ADTrainer.run` draws one anomaly-detection task per call, as the reference's `load_dataset(dsstr, datapath,
+    self.get_nominal_classes(c), 0, ...)` does (`training/ad_trainer.py:248-253`, `datasets/__init__.py:237-340`):
+      * normal training samples = the training rows whose class is one of `normal_classes` (`bases.py:169-203`);
+      * the test split is the WHOLE test set, labelled nominal (0) for the normal classes and anomalous (1) for the rest
+        (`bases.py:130-139`) -- under `leave_one_out` the anomalies are the one held-out class, under `one_vs_rest` all others;
+      * outlier exposure comes from a separate image set (`oe_u8`), every sample labelled anomalous (`datasets/__init__.py:300`).
+    The images are uploaded once; a task is an index list over them (`ResidentImageSource(normal_index=...)`), so iterating 30
+    classes x 2 seeds does not copy the set 60 times."""
+
+    def __init__(self, train_u8, train_classes, test_u8, test_classes, oe_u8, classes, crop, device="cuda", **source_kw):
+        dev = torch.device(device)
+        self.train, self.test, self.oe = (t.to(dev).contiguous() for t in (train_u8, test_u8, oe_u8))
+        self.train_classes = torch.as_tensor(train_classes, dtype=torch.int64).clone()
+        self.test_classes = torch.as_tensor(test_classes, dtype=torch.int64).clone()
+        self.classes = list(classes)
+        self.crop, self.source_kw, self.device = crop, dict(source_kw), dev
+
+    def no_classes(self) -> int:
+        return len(self.classes)
+
+    def source(self, normal_classes, seed: int = 0) -> ResidentImageSource:
+        src = ResidentImageSource(self.train, self.oe, self.test, ad_targets(self.test_classes, normal_classes), self.crop,
+                                  seed=seed, device=self.device, normal_index=normal_subset(self.train_classes, normal_classes),
+                                  **self.source_kw)
+        src.normal_classes = tuple(int(c) for c in normal_classes)
+        return src

@@ -33,7 +33,9 @@ class GraphedStep:
         for p in params:
             p.grad = None
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # captured on the stream the warm-up ran on: ops.scratch buffers (keyed by stream) exist before the capture and are not
+        # allocated inside the graph's private pool
+        with torch.cuda.graph(self.graph, stream=side):
             feats = model(self.imgs)
             self.loss = loss_fn(feats, self.lbls)
             self.loss.backward()

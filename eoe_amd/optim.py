@@ -34,13 +34,60 @@ def _warn_if_unscaled_fp16():
                       "eoe_amd.default_grad_scale()) before training, as eoe_amd.training and bench.py do", stacklevel=3)
 
 
-class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False):
+class _NonFiniteGuard:
+    """Skip-on-overflow for the scaled fp16 step, without a host synchronisation (C ABI `eoe_grads_nonfinite`).
+
+    The reference's numerical-failure policy is the per-epoch NaN check with retry (`ad_trainer.py:257-280, 448-449`).  This build
+    multiplies the loss gradient by a scale so that the 16-bit backward chain does not underflow (ops.set_grad_scale); a scale can
+    also overflow that chain.  With the guard on (default whenever the gradient scale is not 1) the optimiser first streams over the
+    gradients it is about to apply; if any is inf / NaN the update kernels of that step leave parameters and moments untouched (a
+    device flag: the host is not asked).  `skipped_steps()` reads the device counter (one small copy) and takes the skipped steps out
+    of the per-parameter step counts again, so later bias corrections are those of the steps actually applied; trainers poll it
+    every few steps to halve the scale after an overflow and to grow it back after a run of clean steps (training/ad_trainer.py)."""
+
+    def _guard_init(self, guard):
+        self.guard = guard                    # None: on iff the gradient scale is not 1; True / False: forced
+        self._guard_state = None              # device int32[4]: flag even, flag odd, skipped, checked
+        self._guard_parity = 0
+        self._guard_seen = 0                  # skipped steps already reported / taken out of the step counts
+        self._guard_counted = {}              # id -> parameter whose step count advanced on the steps not yet polled
+
+    def _guard_active(self) -> bool:
+        return (ops.grad_scale() != 1.0) if self.guard is None else bool(self.guard)
+
+    def _guard_begin(self, device):
+        """one call per optimiser step, before the first group: returns (state tensor, parity)"""
+        if self._guard_state is None or self._guard_state.device != device:
+            self._guard_state = torch.zeros(4, dtype=torch.int32, device=device)
+        self._guard_parity ^= 1
+        return self._guard_state, self._guard_parity
+
+    def skipped_steps(self) -> int:
+        """number of optimiser steps dropped for non-finite gradients since the last call (synchronises with the device once).
+        The step counts that advanced on those steps are taken back."""
+        if self._guard_state is None:
+            return 0
+        st = self._guard_state.cpu().tolist()
+        total = st[2] + (1 if st[self._guard_parity] else 0)      # the newest step's flag has not been retired into the count yet
+        new = total - self._guard_seen
+        self._guard_seen = total
+        if new > 0:
+            for p in self._guard_counted.values():
+                st_p = self.state.get(p)
+                if st_p is not None and "step" in st_p:
+                    st_p["step"] -= float(new)
+        self._guard_counted = {}
+        return new
+
+
+class FusedAdam(_NonFiniteGuard, torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, guard=None):
         if amsgrad:
             raise NotImplementedError("amsgrad is not used by the reference trainer (ad_trainer.py:383)")
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False)
         super().__init__(params, defaults)
         self._tables = {}
+        self._guard_init(guard)
 
     def _init_state(self, group):
         """exp_avg / exp_avg_sq of a whole group live in two flat arenas (one allocation each)"""
@@ -94,6 +141,7 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        work = []
         for gi, group in enumerate(self.param_groups):
             active = [p for p in group["params"] if p.grad is not None]
             if not active:
@@ -106,14 +154,28 @@ class FusedAdam(torch.optim.Optimizer):
             for p in active:
                 st = self.state[p]
                 st["step"] += 1
-                steps.append(int(st["step"].item()))
-            beta1, beta2 = group["betas"]
-            lr = float(group["lr"])
+                steps.append(int(round(st["step"].item())))
             (tab, n_chunks, bases), distinct = self._table(gi, active, steps)
             if len(distinct) > _lib.ADAM_GROUPS:
                 raise RuntimeError("FusedAdam: more than %d distinct step counts in one group" % _lib.ADAM_GROUPS)
+            work.append((group, active, tab, n_chunks, bases, distinct))
+        if not work:
+            return loss
+        stream = torch.cuda.current_stream().cuda_stream
+        skip = None
+        if self._guard_active():
+            # every group is checked before any group is updated: a step is dropped whole or applied whole
+            state, parity = self._guard_begin(work[0][1][0].device)
+            for k, (group, active, tab, n_chunks, bases, distinct) in enumerate(work):
+                check(lib.eoe_grads_nonfinite(bases[1], tab.data_ptr(), n_chunks, state.data_ptr(), parity, 1 if k == 0 else 0, stream),
+                      "eoe_grads_nonfinite")
+                self._guard_counted.update((id(p), p) for p in active)
+            skip = state.data_ptr() + 4 * parity
+        _warn_if_unscaled_fp16()
+        for group, active, tab, n_chunks, bases, distinct in work:
+            beta1, beta2 = group["betas"]
+            lr = float(group["lr"])
             sc = _lib.AdamScalars()
-            _warn_if_unscaled_fp16()
             sc.grad_scale_inv = 1.0 / ops.grad_scale()       # the losses' backward multiplied every gradient by the scale
             for i, s in enumerate(distinct):
                 bc1 = 1.0 - beta1 ** s
@@ -122,23 +184,29 @@ class FusedAdam(torch.optim.Optimizer):
                 sc.bc2_sqrt[i] = math.sqrt(bc2)
             check(lib.eoe_adam_multi(bases[0], bases[1], bases[2], bases[3], tab.data_ptr(), n_chunks, C.byref(sc),
                                      float(beta1), float(beta2), float(group["eps"]), float(group["weight_decay"]),
-                                     None, _lib.EOE_BF16, torch.cuda.current_stream().cuda_stream), "eoe_adam_multi")
+                                     None, _lib.EOE_BF16, skip, stream), "eoe_adam_multi")
             torch._C._increment_version(active)     # the kernel wrote in place: invalidate 16-bit weight copies
         return loss
 
 
-class FusedSGD(torch.optim.Optimizer):
+class FusedSGD(_NonFiniteGuard, torch.optim.Optimizer):
     """`torch.optim.SGD(params, lr, momentum=0.9, nesterov=True, weight_decay=wdk)` as the reference constructs it for CLIP models
     (`ad_trainer.py:380-381`), one kernel per step (`eoe_sgd_multi`): same Optimizer API, dampening 0, L2-in-gradient weight decay,
     momentum buffers created at the first step (zero-initialised arena: `buf = momentum * 0 + g` is torch's first-step `buf = g`)."""
 
-    def __init__(self, params, lr=1e-3, momentum=0.0, weight_decay=0.0, nesterov=False, dampening=0.0):
+    def __init__(self, params, lr=1e-3, momentum=0.0, weight_decay=0.0, nesterov=False, dampening=0.0, guard=None):
         if dampening != 0.0:
             raise NotImplementedError("dampening is not used by the reference trainer (ad_trainer.py:381)")
         if nesterov and momentum <= 0:
             raise ValueError("Nesterov momentum requires a momentum")
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=nesterov, dampening=0.0))
         self._tables = {}
+        self._guard_init(guard)
+
+    def skipped_steps(self) -> int:
+        """SGD keeps no step counts: only the counter is read"""
+        self._guard_counted = {}
+        return super().skipped_steps()
 
     def _init_state(self, group):
         need = [p for p in group["params"] if p.grad is not None and "momentum_buffer" not in self.state[p]]
@@ -178,6 +246,7 @@ class FusedSGD(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        work = []
         for gi, group in enumerate(self.param_groups):
             active = [p for p in group["params"] if p.grad is not None]
             if not active:
@@ -186,10 +255,21 @@ class FusedSGD(torch.optim.Optimizer):
                 if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
                     raise RuntimeError("FusedSGD needs contiguous fp32 parameters and gradients on the GPU")
             self._init_state(group)
-            tab, n_chunks, bases = self._table(gi, active)
-            _warn_if_unscaled_fp16()
+            work.append((group, active) + tuple(self._table(gi, active)))
+        if not work:
+            return loss
+        stream = torch.cuda.current_stream().cuda_stream
+        skip = None
+        if self._guard_active():
+            state, parity = self._guard_begin(work[0][1][0].device)
+            for k, (group, active, tab, n_chunks, bases) in enumerate(work):
+                check(lib.eoe_grads_nonfinite(bases[1], tab.data_ptr(), n_chunks, state.data_ptr(), parity, 1 if k == 0 else 0, stream),
+                      "eoe_grads_nonfinite")
+            skip = state.data_ptr() + 4 * parity
+        _warn_if_unscaled_fp16()
+        for group, active, tab, n_chunks, bases in work:
             check(lib.eoe_sgd_multi(bases[0], bases[1], bases[2], tab.data_ptr(), n_chunks, float(group["lr"]),
                                     float(group["momentum"]), float(group["weight_decay"]), 1 if group["nesterov"] else 0,
-                                    1.0 / ops.grad_scale(), torch.cuda.current_stream().cuda_stream), "eoe_sgd_multi")
+                                    1.0 / ops.grad_scale(), skip, stream), "eoe_sgd_multi")
             torch._C._increment_version(active)
         return loss

@@ -100,9 +100,40 @@ class NativeComm:
         self._lib.check(self._lib.lib.eoe_comm_join(self.handle, torch.cuda.current_stream().cuda_stream), "eoe_comm_join")
 
     def close(self):
+        global _bn_sync_cb
         if self.handle is not None:
+            if _bn_sync_cb is self:                       # the library clears its hook in eoe_comm_destroy; drop our reference too
+                _bn_sync_cb = None
             self._lib.check(self._lib.lib.eoe_comm_destroy(self.handle), "eoe_comm_destroy")
             self.handle = None
+
+
+def make_comm(prefer: str = "auto", algo: str = "rs_ag"):
+    """the gradient transport of a data-parallel run: (NativeComm or None, description).  "auto" (or the environment's EOE_COMM)
+    takes the C-ABI communicator -- RCCL on its own side HIP stream, reduce-scatter + all-gather per bucket, BatchNorm sums inside the
+    library -- whenever the process group runs on RCCL ("nccl"); gloo groups (the CPU / one-GPU rehearsals: RCCL refuses two ranks on
+    one device) keep torch.distributed collectives.  Every rank must end up on the same transport, so the outcome of the communicator's
+    construction is agreed on with one MIN all-reduce."""
+    from . import _lib
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return None, "none"
+    prefer = os.environ.get("EOE_COMM", prefer)
+    kind = f"torch.distributed ({dist.get_backend()})"
+    if not (prefer == "native" or (prefer == "auto" and dist.get_backend() == "nccl")):
+        return None, kind
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    ok, err, comm = torch.ones(1, device=dev), "", None
+    try:
+        comm = NativeComm(algo=_lib.EOE_COMM_ALGO_RS_AG if algo == "rs_ag" else _lib.EOE_COMM_ALGO_RING)
+    except Exception as e:
+        ok.zero_()
+        err = repr(e)[:160]
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if ok.item() < 1:
+        if comm is not None:
+            comm.close()
+        return None, kind + f" [native communicator failed on some rank: {err}]"
+    return comm, f"eoe_comm (RCCL, side stream, {algo})"
 
 
 class GradArena:
@@ -187,9 +218,13 @@ class GradArena:
         # With collectives in flight RCCL's workgroups occupy CUs for the length of a bucket, and the stream-K wgrad launch wants every CU
         # at once (one k-range per CU, each waiting for its predecessor's partial): ranges that find no CU would start a second round.
         # Data parallel runs keep the one-tile-per-workgroup launch (216 of 256 CUs) with LayerNorm-1 backward beside it instead.
+        # (bit 1 is OR-ed into whatever the switch holds -- a user's A/B bits, another arena's request -- and remove_hooks puts back
+        #  exactly what this arena found)
+        self._tn_flags_before = None
         if self._world() > 1:
             from . import _lib
-            _lib.check(_lib.lib.eoe_set_option(b"tn_flags", 2), "eoe_set_option")
+            self._tn_flags_before = _lib.get_option("tn_flags")
+            _lib.set_option("tn_flags", self._tn_flags_before | 2)
 
     def _world(self) -> int:
         if self.comm is not None:
@@ -197,9 +232,11 @@ class GradArena:
         return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
 
     def remove_hooks(self):
-        if self._installed and self._world() > 1:
+        if self._installed and getattr(self, "_tn_flags_before", None) is not None:
             from . import _lib
-            _lib.check(_lib.lib.eoe_set_option(b"tn_flags", 0), "eoe_set_option")
+            if not (self._tn_flags_before & 2):          # clear only the bit this arena set; leave bits others changed meanwhile
+                _lib.set_option("tn_flags", _lib.get_option("tn_flags") & ~2)
+            self._tn_flags_before = None
         for first, _, _ in self.block_buckets:
             ops.grad_ready_hooks.pop(id(first), None)
         for h in self._hook_handles:

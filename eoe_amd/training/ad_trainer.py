@@ -76,7 +76,7 @@ class JsonLogger:
 
 
 class ADTrainer(ABC):
-    AD_MODES = ("one_vs_rest", "leave_one_out")
+    AD_MODES = ("one_vs_rest", "leave_one_out", "fifty_fifty")
     KEEP_SNAPSHOT_IN_RAM = False
 
     def __init__(self, model: torch.nn.Module, train_transform=None, test_transform=None, dataset=None,
@@ -101,7 +101,11 @@ class ADTrainer(ABC):
         self.center = None
         self.workers = workers
         self.ds = dataset if hasattr(dataset, "loaders") else None
-        self.classes = classes if classes is not None else ["0"]
+        if classes is None:
+            # a labelled multi-class set (eoe_amd.data.LabelledImageSet) names its own classes, as `str_labels(dsstr)` does
+            # in the reference (ad_trainer.py:226); a single pre-built task is one class "0"
+            classes = list(dataset.classes) if hasattr(dataset, "source") and hasattr(dataset, "classes") else ["0"]
+        self.classes = classes
         self.data_parallel = data_parallel
         self.sync_bn = sync_bn      # data parallel only: BatchNorm statistics of the GLOBAL step batch (eoe_amd.parallel.enable_sync_bn)
         if msms:
@@ -109,19 +113,28 @@ class ADTrainer(ABC):
 
     # ------------------------------------------------------------------------------------------- run
     def get_nominal_classes(self, cur_class: int):
-        # ad_trainer.py:166-175
+        """the normal classes of the task "class `cur_class`" under the AD mode (ad_trainer.py:166-175)"""
+        n = len(self.classes)
         if self.ad_mode == "one_vs_rest":
             return [cur_class]
         elif self.ad_mode == "leave_one_out":
-            return [c for c in range(len(self.classes)) if c != cur_class]
+            return [c for c in range(n) if c != cur_class]
+        elif self.ad_mode == "fifty_fifty":
+            return [c % n for c in range(cur_class, n // 2 + cur_class)]
         raise NotImplementedError(f"AD mode {self.ad_mode} unknown. Known modes are {ADTrainer.AD_MODES}.")
 
     def _dataset(self, c: int, seed: int):
+        """the task of one (class, seed) run.  The reference builds it with `load_dataset(dsstr, datapath,
+        self.get_nominal_classes(c), 0, ...)` unless `trainer.ds` was pre-set (ad_trainer.py:248-253): here a pre-built
+        step-batch source is used as is, a labelled image set (`.source(normal_classes, seed)`) is asked for the task of the
+        current AD mode, and a callable (cls, seed) -> source decides for itself."""
         if self.ds is not None:
             return self.ds
+        if hasattr(self.dsstr, "source"):
+            return self.dsstr.source(self.get_nominal_classes(c), seed)
         if callable(self.dsstr):
             return self.dsstr(c, seed)
-        raise ValueError("dataset must be a step-batch source or a callable (cls, seed) -> source")
+        raise ValueError("dataset must be a step-batch source, a labelled image set or a callable (cls, seed) -> source")
 
     NAN_ATTEMPTS, NAN_GIVE_UP_AT = 5, 3      # ad_trainer.py:257-280: up to five tries; the third failure clears the result
 
@@ -162,6 +175,8 @@ class ADTrainer(ABC):
         Returns (models[class][seed], {'mean_auc', 'mean_avg_prec', 'std_auc', 'cls_aucs'})"""
         n_cls = len(self.classes)
         wanted = set(range(n_cls)) if run_classes is None else set(run_classes)
+        # ad_trainer.py:231-232: a pre-loaded dataset is ONE task; iterating classes over it would train the same task again
+        assert self.ds is None or len(wanted) == 1, "pre-loading DS (setting trainer.ds to something) only allowed for one class"
         models, train_rocs = [[] for _ in range(n_cls)], [[] for _ in range(n_cls)]
         eval_rocs, eval_prcs = [[] for _ in range(n_cls)], [[] for _ in range(n_cls)]
         for c, cstr in enumerate(self.classes):
@@ -212,11 +227,32 @@ class ADTrainer(ABC):
         if hasattr(enc, "set_normalize"):
             enc.set_normalize(*(norm if norm is not None else (None, None)))
             return None
-        if norm is None:
-            return None
-        mean = torch.as_tensor(norm[0], dtype=torch.float32, device=self.device).view(1, -1, 1, 1)
-        std = torch.as_tensor(norm[1], dtype=torch.float32, device=self.device).view(1, -1, 1, 1)
-        raise NotImplementedError("this encoder has no fused normalise; add one to its first kernel")
+        if norm is not None:
+            raise NotImplementedError("this encoder has no fused normalise; add one to its first kernel")
+        return None
+
+    # the fp16 gradient scale (ops.set_grad_scale) follows the usual dynamic rule: halved when a step was dropped for non-finite
+    # gradients, doubled again after SCALE_GROWTH_INTERVAL clean steps (never above SCALE_MAX or below 1).  The optimiser's device
+    # counter is read every SCALE_POLL_EVERY steps and at the end of an epoch -- between an overflow and the next poll the steps
+    # keep being dropped on the device, nothing non-finite reaches the weights or the moments.
+    SCALE_POLL_EVERY, SCALE_GROWTH_INTERVAL, SCALE_MAX = 16, 2000, 65536.0
+
+    def _move_grad_scale(self, opt, clean_steps: int, gstep: int, graphed):
+        skipped = opt.skipped_steps() if hasattr(opt, "skipped_steps") else 0
+        scale = ops.grad_scale()
+        if skipped > 0:
+            new = max(1.0, scale / 2.0)
+            clean_steps = 0
+        elif clean_steps >= self.SCALE_GROWTH_INTERVAL and 1.0 < scale < self.SCALE_MAX:
+            new, clean_steps = scale * 2.0, 0
+        else:
+            return clean_steps, graphed
+        if new != scale:
+            ops.set_grad_scale(new)
+            self.scale_events.append((gstep, new))
+            self.logger.print(f"fp16 gradient scale {scale:g} -> {new:g} at step {gstep}" + (f" ({skipped} step(s) dropped)" if skipped else ""))
+            graphed = None                   # a captured step has the old scale baked into its loss kernel: capture again
+        return clean_steps, graphed
 
     def make_optimizer(self, model: torch.nn.Module):
         """Adam for every encoder (ad_trainer.py:383); the CLIP objective overrides this with SGD-Nesterov (:380-381)"""
@@ -234,27 +270,33 @@ class ADTrainer(ABC):
         ep = self.load(load if isinstance(load, str) else None, model, opt, sched)                      # :396
         center = self.center = self.prepare_metric(clsstr, loader, model, seed)                         # :397
         self._normalize_hook(model, ds)
-        # fp16 compute: scale the loss gradient so that the 16-bit backward chain does not underflow (ops.set_grad_scale); the
-        # optimiser un-scales.  Restored on the way out.
-        prev_scale = ops.grad_scale()
-        ops.set_grad_scale(ops.default_grad_scale())
         rank, world = 0, 1
-        arena = None
-        if self.data_parallel and torch.distributed.is_initialized():
-            rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
-            arena = parallel.GradArena(model)
-            arena.install_hooks()
-            if any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in model.modules()):
-                # the reference's BatchNorm layers see the whole step batch: keep that meaning across the ranks
-                if self.sync_bn:
-                    parallel.enable_sync_bn()
-                elif rank == 0:
-                    self.logger.warning("data parallel training of a BatchNorm encoder with sync_bn=False: batch statistics are per "
-                                        "rank, not those of the single-device full batch (eoe_amd/parallel.py)")
+        arena = comm = None
         nominal = getattr(ds, "nominal_label", 0)
         self.last_losses = []
+        self.scale_events = []                              # (global step, new scale) whenever the fp16 gradient scale moved
         graphed = None                                      # (batch shape, GraphedStep) of the full-size step batch
+        # process-wide state this loop changes (gradient scale, wgrad launch form, BatchNorm hook) is restored on every way out
+        prev_scale = ops.grad_scale()
         try:
+            # fp16 compute: scale the loss gradient so that the 16-bit backward chain does not underflow (ops.set_grad_scale); the
+            # optimiser un-scales, drops a step whose gradients overflowed (optim._NonFiniteGuard) and this loop moves the scale
+            ops.set_grad_scale(ops.default_grad_scale())
+            clean_steps, gstep = 0, 0
+            if self.data_parallel and torch.distributed.is_initialized():
+                rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
+                # on RCCL: the library's own communicator (side HIP stream, reduce-scatter + all-gather, BatchNorm sums inside the
+                # library); gloo rehearsals: torch.distributed collectives (parallel.make_comm)
+                comm, _ = parallel.make_comm()
+                arena = parallel.GradArena(model, comm=comm)
+                arena.install_hooks()
+                if any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in model.modules()):
+                    # the reference's BatchNorm layers see the whole step batch: keep that meaning across the ranks
+                    if self.sync_bn:
+                        parallel.enable_sync_bn(comm=comm)
+                    elif rank == 0:
+                        self.logger.warning("data parallel training of a BatchNorm encoder with sync_bn=False: batch statistics are per "
+                                            "rank, not those of the single-device full batch (eoe_amd/parallel.py)")
             for ep in range(ep, epochs):
                 ep_labels, ep_scores, ep_losses = [], [], []
                 for batch in loader:                                                                    # :410
@@ -298,6 +340,11 @@ class ADTrainer(ABC):
                         ep_labels.append(lbls)
                         ep_scores.append(scores.detach().reshape(-1))
                     ep_losses.append(loss.detach())
+                    gstep += 1
+                    clean_steps += 1
+                    if gstep % self.SCALE_POLL_EVERY == 0:
+                        clean_steps, graphed = self._move_grad_scale(opt, clean_steps, gstep, graphed)
+                clean_steps, graphed = self._move_grad_scale(opt, clean_steps, gstep, graphed)
                 # ---- epoch tail (:447-469): one host copy per epoch
                 la = torch.cat(ep_labels) if ep_labels else torch.zeros(0, dtype=torch.int64, device=self.device)
                 sc = torch.cat(ep_scores) if ep_scores else torch.zeros(0, dtype=torch.float32, device=self.device)
@@ -320,6 +367,8 @@ class ADTrainer(ABC):
                 for p in model.parameters():
                     if hasattr(p, "_eoe_grad_buf"):
                         del p._eoe_grad_buf
+            if comm is not None:
+                comm.close()
         return model.cpu().eval(), cls_roc                                                              # :471
 
     def eval_cls(self, model: torch.nn.Module, ds, cls: int, clsstr: str, seed: int):

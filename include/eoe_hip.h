@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define EOE_ABI_VERSION 1
+#define EOE_ABI_VERSION 2
 
 enum { EOE_OK = 0, EOE_ERR_ARG = 1, EOE_ERR_LAUNCH = 2, EOE_ERR_UNSUPPORTED = 3 };
 enum { EOE_F16 = 1, EOE_BF16 = 2, EOE_F32 = 3 /* only where an entry point says so */ };
@@ -253,10 +253,20 @@ typedef struct {                        /* per step-count group, computed on the
  * (ad_trainer.py:380-381: momentum 0.9, nesterov): the same chunk tables (m_off = momentum buffer, zero-initialised; v_off unused) */
 int eoe_sgd_multi(float* p, const float* g, float* buf, const eoe_adam_chunk* chunks /*device*/, int n_chunks, float lr,
                   float momentum, float weight_decay, int nesterov, float grad_scale_inv /* as in eoe_adam_scalars; <= 0 = 1 */,
-                  void* stream);
+                  const int32_t* skip_flag /* device, may be NULL: see eoe_grads_nonfinite */, void* stream);
 int eoe_adam_multi(float* p, const float* g, float* m, float* v, const eoe_adam_chunk* chunks /*device*/,
                    int n_chunks, const eoe_adam_scalars* scalars /*host*/, float beta1, float beta2, float eps,
-                   float weight_decay, void* shadow16, int dtype, void* stream);
+                   float weight_decay, void* shadow16, int dtype, const int32_t* skip_flag /* device, may be NULL */, void* stream);
+/* Non-finite guard for the scaled fp16 step.  The reference's numerical-failure policy is the per-epoch NaN check with retry
+ * (ad_trainer.py:257-280, 448-449); the loss-gradient scale this build adds for fp16 can overflow the 16-bit backward chain, so the
+ * optimisers can be told to drop such a step whole.  One streaming pass over the gradients of the chunk table the optimiser is about to
+ * apply.  `state` = 4 device ints {flag of even steps, flag of odd steps, steps skipped so far, steps checked so far}, zero-initialised
+ * by the caller once; `parity` alternates 0 / 1 from step to step; `first` != 0 on the first chunk table of a step (several parameter
+ * groups = several calls with the same parity): that call retires the previous step's flag into the skipped count.  An inf / NaN raises
+ * state[parity]; pass &state[parity] as `skip_flag` to eoe_adam_multi / eoe_sgd_multi of the same step: with the flag up they touch
+ * nothing (parameters, moments, 16-bit shadows).  No host synchronisation anywhere; the host reads state[2] when it cares to. */
+int eoe_grads_nonfinite(const float* g, const eoe_adam_chunk* chunks /*device*/, int n_chunks, int32_t* state /*device*/, int parity,
+                        int first, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * fused ViT residual block (clip/model.py:167-188 ResidualAttentionBlock.forward and its backward):
@@ -607,6 +617,7 @@ typedef struct {
 int eoe_prof_enable(int on);
 /* tuning switches for A/B measurements inside one process ("nt_flags": see gemm.hip) */
 int eoe_set_option(const char* name, int value);
+int eoe_get_option(const char* name, int* value);    /* the current value (callers that change a switch restore what they found) */
 /* diagnostics only (EOE_GEMM_STAMP=1): in-kernel s_memtime stamps of the last eoe_gemm_nt launch, 16 words per workgroup */
 int eoe_debug_gemm_stamps(unsigned long long* out, int n_words);
 int eoe_prof_collect(eoe_prof_entry* out, int max_entries, int* n_out);

@@ -53,3 +53,28 @@ def shard_rows(n_normal: int, n_oe: int, rank: int, world: int):
     a, b = part(n_normal)
     c, d = part(n_oe)
     return np.concatenate([np.arange(a, b), n_normal + np.arange(c, d)]).astype(np.int64)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the class x seed loop's task definition (reference `training/ad_trainer.py:166-175`, `datasets/bases.py:129-139,169-203`)
+# ---------------------------------------------------------------------------------------------------------------------
+def nominal_classes(ad_mode: str, cur_class: int, n_classes: int):
+    """ADTrainer.get_nominal_classes (ad_trainer.py:166-175): the normal classes of the task "class cur_class" """
+    if ad_mode == "one_vs_rest":
+        return [cur_class]
+    if ad_mode == "leave_one_out":
+        return [c for c in range(n_classes) if c != cur_class]
+    if ad_mode == "fifty_fifty":
+        return [c % n_classes for c in range(cur_class, n_classes // 2 + cur_class)]
+    raise NotImplementedError(ad_mode)
+
+
+def normal_subset(class_labels, normal_classes) -> np.ndarray:
+    """TorchvisionDataset.create_subset without a sample limit (bases.py:192-203): ascending rows whose class is normal"""
+    return np.argwhere(np.isin(np.asarray(class_labels), list(normal_classes))).flatten().astype(np.int64)
+
+
+def ad_targets(class_labels, normal_classes, nominal_label: int = 0) -> np.ndarray:
+    """the target_transform of bases.py:129-139: anomalous iff the class is not one of the normal classes"""
+    normal = np.isin(np.asarray(class_labels), list(normal_classes))
+    return np.where(normal, nominal_label, 1 - nominal_label).astype(np.int64)

@@ -449,6 +449,41 @@ def g12():
     save("g12_batching", **out)
 
 
+def g15():
+    """the class x seed loop's task definition: `ADTrainer.get_nominal_classes` (training/ad_trainer.py:166-175; the module cannot
+    be imported -- torchvision / kornia / cv2 --, so the method's own definition is taken out of the file with `ast` and executed)
+    for every class of 3-, 10- and 30-class sets under the three AD modes, and `TorchvisionDataset.create_subset`
+    (datasets/bases.py:169-203) = the rows of a labelled split that form the normal training set"""
+    import ast
+    import types as _types
+    src = open(f"{REF}/training/ad_trainer.py").read()
+    cls = next(n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == "ADTrainer")
+    fn = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "get_nominal_classes")
+    ns = {"no_classes": lambda ds: ds, "ADTrainer": _types.SimpleNamespace(AD_MODES=("one_vs_rest", "leave_one_out", "fifty_fifty"))}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), f"{REF}/training/ad_trainer.py", "exec"), ns)
+    out = {}
+    for n in (3, 10, 30):
+        for mode in ("one_vs_rest", "leave_one_out", "fifty_fifty"):
+            for c in range(n):
+                me = _types.SimpleNamespace(ad_mode=mode, dsstr=n)
+                out[f"nominal/{n}/{mode}/{c}"] = np.array(ns["get_nominal_classes"](me, c), np.int64)
+    from torch.utils.data import Dataset
+
+    class _Split(Dataset):
+        def __len__(self):
+            return 0
+    rng = np.random.RandomState(3)
+    for name, (n_cls, n_rows) in {"small": (3, 17), "cifar_like": (10, 200), "in30_like": (30, 390)}.items():
+        labels = rng.randint(0, n_cls, n_rows).astype(np.int64)
+        out[f"subset/{name}/labels"] = labels
+        for mode, normal in (("ovr", [1]), ("loo", [c for c in range(n_cls) if c != 1]), ("ff", list(range(1, n_cls // 2 + 1)))):
+            me = _types.SimpleNamespace(normal_classes=tuple(normal), limit_samples=np.inf)
+            sub = ref_bases.TorchvisionDataset.create_subset(me, _Split(), labels.tolist())
+            out[f"subset/{name}/{mode}/normal_classes"] = np.array(normal, np.int64)
+            out[f"subset/{name}/{mode}/indices"] = np.array(sub.indices, np.int64)
+    save("g15_tasks", **out)
+
+
 # ----------------------------------------------------------------------------------------------- big, well-conditioned parity cases
 def run_trajectory_big(model, batches_fn, n_steps, objective, lr, wd, twin64=True):
     """as run_trajectory with batches produced one at a time (memory), run twice: the reference modules in fp32 (the
@@ -633,6 +668,6 @@ def g3bigbce():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12",
-                             "g2big", "g11big", "g5big", "g5full", "g3big", "g3long", "g3bigfrozen", "g3bigbce", "g13", "g14"]
+                             "g2big", "g11big", "g5big", "g5full", "g3big", "g3long", "g3bigfrozen", "g3bigbce", "g13", "g14", "g15"]
     for w in which:
         globals()[w]()

@@ -171,3 +171,23 @@ def test_grad_scale_api():
     assert not ops._single_pixel((256, 2, 2, 512, 3, 3, 1, 1, 2, 2))
     assert not ops._single_pixel((256, 1, 1, 512, 3, 3, 2, 1, 1, 1))
     assert not ops._single_pixel((256, 1, 1, 48, 3, 3, 1, 1, 1, 1))
+
+
+def test_task_definition_matches_oracle_and_golden(golden):
+    """host logic of the class x seed loop (ADTrainer.get_nominal_classes, data.normal_subset / ad_targets) against the oracle and
+    the fixture made by the reference's own functions (g15): bit-exact"""
+    from eoe_amd import data
+    from eoe_amd.training import TRAINER
+    g = golden("g15_tasks")
+    for n in (3, 10, 30):
+        for mode in ("one_vs_rest", "leave_one_out", "fifty_fifty"):
+            tr = TRAINER["hsc"](None, dataset=None, classes=[str(i) for i in range(n)], ad_mode=mode)
+            for c in range(n):
+                got = tr.get_nominal_classes(c)
+                assert got == batching.nominal_classes(mode, c, n) == g[f"nominal/{n}/{mode}/{c}"].tolist()
+    for name in ("small", "cifar_like", "in30_like"):
+        labels = g[f"subset/{name}/labels"]
+        for mode in ("ovr", "loo", "ff"):
+            normal = g[f"subset/{name}/{mode}/normal_classes"].tolist()
+            assert data.normal_subset(labels, normal).tolist() == g[f"subset/{name}/{mode}/indices"].tolist()
+            assert data.ad_targets(labels, normal).tolist() == batching.ad_targets(labels, normal).tolist()

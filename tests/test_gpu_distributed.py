@@ -334,3 +334,46 @@ def test_sync_batchnorm_two_ranks_equal_the_full_batch(tmp_path, kind):
             worst = max(worst, err)
             assert err < (3e-3 if kind == "cnn32" else 1e-3), (k, err, ref.norm().item())
     print(f"[sync bn {kind}] worst relative gradient deviation {worst:.2e}")
+
+
+def _run_bench(args, env_extra=None, nproc=1, timeout=900):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    if nproc > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(root, "bench.py")] + args
+    else:
+        cmd = [sys.executable, os.path.join(root, "bench.py")] + args
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_itself_with_two_ranks():
+    """bench.py as the driver launches it for N > 1 (torchrun, one rank per process), rehearsed with two gloo ranks on the one GPU:
+    ONE JSON line from rank 0, whole-job throughput, the exchange step described (transport, buckets, bytes, exposed wait)"""
+    out = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--layers", "1", "--batch", "4", "--no-roofline"],
+                     {"EOE_DIST_BACKEND": "gloo"}, nproc=2)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 16
+    c = out["comm"]
+    assert c["transport"].startswith("torch.distributed (gloo") and c["buckets"] >= 2 and c["comm_exposed_ms"] >= 0.0
+    # ViT-B/32 with one block: every trainable parameter is sent exactly once (slices are padded to 256 B)
+    from eoe_amd.models import ClipViTB32Custom
+    n_par = sum(p.numel() for p in ClipViTB32Custom(layers=1).parameters())
+    assert 4 * n_par <= c["allreduce_bytes_per_step"] <= 4 * n_par * 1.01 + 65536
+    assert out["value"] > 0 and np.isfinite(out["final_loss"])
+
+
+def test_bench_eval_mode_line():
+    """`bench.py --mode eval`: the forward-only scoring loop of eval_cls (ad_trainer.py:473-550) as a throughput line"""
+    out = _run_bench(["--mode", "eval", "--steps", "3", "--warmup", "1", "--layers", "2", "--batch", "8", "--no-cpu-baseline"])
+    assert out["metric"].startswith("eval images/sec") and out["value"] > 0 and out["final_loss"] is None
+    assert "eval_cls" in out["config"]["workload"]
+    r = out["roofline"]
+    assert r["kernel"].startswith("gemm") and set(k for k in r["kernels_ms_per_step"] if k.startswith("gemm")) == {"gemm_nt"}   # no wgrad

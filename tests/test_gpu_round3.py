@@ -1,0 +1,238 @@
+"""GPU tier (round 3): the non-finite guard of the scaled fp16 step, the dynamic gradient scale of the trainer, and the class x seed
+loop over a labelled image set in the reference's AD modes (leave-one-out, one-vs-rest; `training/ad_trainer.py:166-175, 248-253`)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import batching, models as omodels, trainer as otrainer   # noqa: E402
+
+
+@pytest.fixture(autouse=True)
+def _restore_state():
+    import eoe_amd
+    old_dt, old_scale = eoe_amd.compute_dtype(), eoe_amd.grad_scale()
+    yield
+    eoe_amd.set_compute_dtype(old_dt)
+    eoe_amd.set_grad_scale(old_scale)
+
+
+def _params(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(5,), (2 * 8192 + 3,), (33, 100), (8192,)]
+    return [torch.nn.Parameter(torch.randn(s, generator=g).cuda()) for s in shapes]
+
+
+def _set_grads(ps, seed):
+    g = torch.Generator().manual_seed(1000 + seed)
+    for p in ps:
+        p.grad = torch.randn(p.shape, generator=g).cuda()
+
+
+@pytest.mark.parametrize("bad", [float("inf"), float("-inf"), float("nan")])
+@pytest.mark.parametrize("groups", [1, 2])
+def test_adam_drops_a_step_with_a_non_finite_gradient(bad, groups):
+    """an injected inf / NaN anywhere (any parameter group) leaves EVERY parameter and moment untouched; the clean steps around
+    it are `torch.optim.Adam`'s (the dropped step does not count towards the bias corrections once `skipped_steps()` was read)"""
+    import eoe_amd
+    ps = _params()
+    ref_ps = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    split = [{"params": ps[:2]}, {"params": ps[2:], "lr": 3e-3}] if groups == 2 else ps
+    ref_split = [{"params": ref_ps[:2]}, {"params": ref_ps[2:], "lr": 3e-3}] if groups == 2 else ref_ps
+    opt = eoe_amd.FusedAdam(split, lr=1e-2, weight_decay=1e-3, guard=True)
+    ref = torch.optim.Adam(ref_split, lr=1e-2, weight_decay=1e-3)
+    _set_grads(ps, 0)
+    for p, q in zip(ps, ref_ps):
+        q.grad = p.grad.clone()
+    opt.step()
+    ref.step()
+    before = [(p.detach().clone(), opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone()) for p in ps]
+    _set_grads(ps, 1)
+    ps[3].grad.view(-1)[4321] = bad                       # last tensor of the LAST group
+    opt.step()
+    torch.cuda.synchronize()
+    for p, (w, m, v) in zip(ps, before):
+        assert torch.equal(p.detach(), w) and torch.equal(opt.state[p]["exp_avg"], m) and torch.equal(opt.state[p]["exp_avg_sq"], v)
+    assert opt.skipped_steps() == 1 and opt.skipped_steps() == 0
+    assert all(int(opt.state[p]["step"].item()) == 1 for p in ps)
+    _set_grads(ps, 2)
+    for p, q in zip(ps, ref_ps):
+        q.grad = p.grad.clone()
+    opt.step()
+    ref.step()
+    for p, q in zip(ps, ref_ps):
+        assert torch.isfinite(p).all()
+        torch.testing.assert_close(p.detach(), q.detach(), rtol=2e-6, atol=2e-7)
+    assert opt.skipped_steps() == 0
+
+
+def test_sgd_drops_a_step_with_a_non_finite_gradient():
+    import eoe_amd
+    ps = _params(3)
+    opt = eoe_amd.FusedSGD(ps, lr=1e-2, momentum=0.9, nesterov=True, weight_decay=1e-3, guard=True)
+    _set_grads(ps, 0)
+    opt.step()
+    before = [(p.detach().clone(), opt.state[p]["momentum_buffer"].clone()) for p in ps]
+    _set_grads(ps, 1)
+    ps[0].grad[2] = float("inf")
+    opt.step()
+    for p, (w, b) in zip(ps, before):
+        assert torch.equal(p.detach(), w) and torch.equal(opt.state[p]["momentum_buffer"], b)
+    assert opt.skipped_steps() == 1
+    _set_grads(ps, 2)
+    opt.step()
+    assert all(not torch.equal(p.detach(), w) for p, (w, _) in zip(ps, before)) and opt.skipped_steps() == 0
+
+
+def test_guard_is_off_without_a_scale_and_costs_nothing_then():
+    """bf16 / unscaled runs do not pay for the gradient pass: no state is created, inf goes through as in torch.optim.Adam"""
+    import eoe_amd
+    eoe_amd.set_grad_scale(1.0)
+    ps = _params(5)
+    opt = eoe_amd.FusedAdam(ps, lr=1e-2)
+    _set_grads(ps, 0)
+    opt.step()
+    assert opt._guard_state is None and opt.skipped_steps() == 0
+
+
+def test_trainer_halves_an_overflowing_scale(monkeypatch):
+    """fp16 with an absurd starting scale: the 16-bit backward chain overflows, the steps are dropped on the device (weights and
+    moments stay finite), the trainer halves the scale until steps go through again, and training then proceeds"""
+    import eoe_amd
+    from eoe_amd import ops
+    from eoe_amd.data import SyntheticAD
+    from eoe_amd.models import CNN32
+    from eoe_amd.training import TRAINER
+    eoe_amd.set_compute_dtype("fp16")
+    monkeypatch.setattr(ops, "default_grad_scale", lambda dtype=None: 2.0 ** 36)
+    torch.manual_seed(3)
+    ds = SyntheticAD(n_train_normal=64, n_oe=64, n_test=32, res=32, shift=1.0, seed=2)
+    m0 = CNN32(bias=True)
+    tr = TRAINER["hsc"](copy.deepcopy(m0), dataset=ds, epochs=8, lr=1e-3, wdk=0.0, milestones=[], batch_size=16, classes=["only"])
+    tr.SCALE_POLL_EVERY = 1
+    model, roc = tr.train_cls(copy.deepcopy(m0), ds, 0, "only", 0)
+    assert len(tr.scale_events) >= 4, tr.scale_events                 # several halvings
+    assert all(b[1] == a[1] / 2 for a, b in zip(tr.scale_events, tr.scale_events[1:]))
+    final = tr.scale_events[-1][1]
+    assert 1.0 <= final < 2.0 ** 36
+    assert all(torch.isfinite(p).all() for p in model.parameters())
+    assert all(np.isfinite(tr.last_losses))
+    assert tr.last_losses[-1] < tr.last_losses[0]                     # the steps after the scale settled did train
+    assert roc is not None and 0.0 <= roc.auc <= 1.0
+
+
+# ----------------------------------------------------------------------------------------------- class x seed loop, AD modes
+class _Recorder:
+    """a step-batch source that remembers what it handed out (for the oracle's run on the SAME splits)"""
+
+    def __init__(self, inner):
+        self.inner, self.train_batches, self.test_batches = inner, [], None
+        self.nominal_label, self.normalize, self.ds_statistics = inner.nominal_label, inner.normalize, None
+
+    def loaders(self, batch_size, **kw):
+        train, test = self.inner.loaders(batch_size, **kw)
+        outer = self
+
+        class _T:
+            def __iter__(s):
+                for b in train:
+                    outer.train_batches.append(tuple(t.detach().cpu().clone() for t in b))
+                    yield b
+
+            def __len__(s):
+                return len(train)
+        self.test_batches = [tuple(t.detach().cpu().clone() for t in b) for b in test]
+        return _T(), test
+
+
+def _labelled_set(n_cls=3, per_cls_train=12, per_cls_test=8, n_oe=10, res=224):
+    """uint8 images with a class-dependent low-frequency pattern (so that held-out classes ARE anomalous) + noise"""
+    g = torch.Generator().manual_seed(11)
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, res), torch.linspace(0, 1, res), indexing="ij")
+    pats = [torch.stack([torch.sin(6.28 * (k + 1) * xx + k), torch.cos(6.28 * (k + 1) * yy - k), torch.sin(6.28 * (xx + yy) * (k + 1))], -1)
+            for k in range(n_cls + 1)]
+
+    def make(k, n):
+        x = 128 + 60 * pats[k].unsqueeze(0) + 25 * torch.randn((n, res, res, 3), generator=g)
+        return x.clamp(0, 255).to(torch.uint8)
+    train = torch.cat([make(k, per_cls_train) for k in range(n_cls)])
+    train_y = torch.arange(n_cls).repeat_interleave(per_cls_train)
+    perm = torch.randperm(len(train_y), generator=g)                  # classes interleaved, as in a real set
+    train, train_y = train[perm], train_y[perm]
+    test = torch.cat([make(k, per_cls_test) for k in range(n_cls)])
+    test_y = torch.arange(n_cls).repeat_interleave(per_cls_test)
+    oe = make(n_cls, n_oe)
+    return train, train_y, test, test_y, oe
+
+
+@pytest.mark.parametrize("ad_mode", ["leave_one_out", "one_vs_rest"])
+def test_class_seed_loop_over_a_labelled_set(ad_mode):
+    """3 classes x 2 seeds through `ADTrainer.run` on a labelled resident image set: which rows are normal / anomalous is bit-exact
+    with the reference's rule (oracle.batching, pinned by fixture g15), and the per-(class, seed) test scores and AUC equal the CPU
+    oracle's run on the same splits and initial weights to 1e-3"""
+    import eoe_amd
+    from eoe_amd.data import LabelledImageSet
+    from eoe_amd.models import ClipViTB32Custom
+    from eoe_amd.training import TRAINER, ADTrainer
+    eoe_amd.set_compute_dtype("fp16")
+    n_cls, seeds, bs, epochs = 3, 2, 8, 2
+    train, train_y, test, test_y, oe = _labelled_set(n_cls)
+    mean, std = (0.5, 0.5, 0.5), (0.25, 0.25, 0.25)
+    lset = LabelledImageSet(train, train_y, test, test_y, oe, classes=[f"c{k}" for k in range(n_cls)], crop=224, mean=mean, std=std,
+                            noise_std=0.0)
+    recorders = {}
+
+    def dataset(c, seed):
+        tr_ = trainer_ref[0]
+        rec = _Recorder(lset.source(tr_.get_nominal_classes(c), seed))
+        recorders[(c, seed)] = rec
+        return rec
+    presets = [[omodels.deterministic_init(ClipViTB32Custom(layers=1), tag=f"loo/{c}/{s}", layers=1) for s in range(seeds)]
+               for c in range(n_cls)]
+    tr = TRAINER["hsc"](ClipViTB32Custom(layers=1), dataset=dataset, epochs=epochs, lr=1e-4, wdk=1e-3, milestones=[1], batch_size=bs,
+                        ad_mode=ad_mode, classes=lset.classes)
+    trainer_ref = [tr]
+    ADTrainer.KEEP_SNAPSHOT_IN_RAM = True
+    try:
+        models, res = tr.run(run_seeds=seeds, load=presets)
+    finally:
+        ADTrainer.KEEP_SNAPSHOT_IN_RAM = False
+    assert len(res["cls_aucs"]) == n_cls and all(len(a) == seeds for a in res["cls_aucs"])
+    worst_auc = worst_score = 0.0
+    for c in range(n_cls):
+        normal = batching.nominal_classes(ad_mode, c, n_cls)
+        want_rows = batching.normal_subset(train_y.numpy(), normal)
+        want_test = batching.ad_targets(test_y.numpy(), normal)
+        for s in range(seeds):
+            rec = recorders[(c, s)]
+            # ---- membership, bit-exact: every epoch walks exactly the normal rows once; labels; OE offset; test labels
+            per_epoch = len(rec.train_batches) // epochs
+            for e in range(epochs):
+                bt = rec.train_batches[e * per_epoch:(e + 1) * per_epoch]
+                rows = np.concatenate([b[2][: len(b[2]) // 2].numpy() for b in bt])
+                assert np.array_equal(np.sort(rows), want_rows), (ad_mode, c, s, e)
+                for b in bt:
+                    h = len(b[1]) // 2
+                    assert b[1].tolist() == [0] * h + [1] * h
+                    assert (b[2][h:] >= len(train_y)).all() and (b[2][h:] < len(train_y) + len(oe)).all()
+            assert np.array_equal(torch.cat([b[1] for b in rec.test_batches]).numpy(), want_test)
+            # ---- the oracle on the same splits and weights
+            ref = omodels.deterministic_init(omodels.ClipViTNet(layers=1), tag=f"loo/{c}/{s}", layers=1)
+            otrainer.train_steps(ref, [(b[0], b[1]) for b in rec.train_batches], "hsc", lr=1e-4, weight_decay=1e-3, milestones=[1],
+                                 steps_per_epoch=per_epoch)
+            ev = otrainer.eval_scores(ref, [(b[0], b[1]) for b in rec.test_batches], "hsc")
+            with torch.no_grad():
+                mm = models[c][s].cuda().eval()
+                got = torch.cat([eoe_amd.hsc_score(mm(b[0].cuda())).cpu() for b in rec.test_batches]).numpy()
+            worst_score = max(worst_score, float(np.abs(got - ev["scores"]).max()))
+            n0, n1 = int((want_test == 0).sum()), int((want_test == 1).sum())
+            d = abs(res["cls_aucs"][c][s] - ev["auc"])
+            worst_auc = max(worst_auc, d)
+            # 1e-3 on the AUC; with n0 x n1 test pairs one swapped near-tie moves it by 1 / (n0 n1), which is allowed for
+            assert d <= max(1e-3, 1.0 / (n0 * n1) + 1e-12), (ad_mode, c, s, res["cls_aucs"][c][s], ev["auc"])
+    print(f"[{ad_mode}] worst |score - oracle| {worst_score:.2e}, worst |AUC - oracle| {worst_auc:.2e}, mean AUC {res['mean_auc']:.4f}")
+    assert worst_score < 1e-3
+    assert 0.0 <= res["mean_auc"] <= 1.0

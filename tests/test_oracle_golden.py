@@ -401,3 +401,20 @@ def test_pil_transforms_oracle(golden):
     clip = augment.augment_batch(r, p, 32, 32, mean=(0.48145466, 0.4578275, 0.40821073), std=(0.26862954, 0.26130258, 0.27577711),
                                  noise_std=0.0)
     np.testing.assert_allclose(clip, g["clip/out"], rtol=0, atol=1e-6)
+
+
+def test_tasks_match_reference_functions(golden):
+    """the class x seed loop's task definition against the reference's OWN `get_nominal_classes` and `create_subset`
+    (fixture g15, generated by executing those functions): integer paths, bit-exact"""
+    g = golden("g15_tasks")
+    for n in (3, 10, 30):
+        for mode in ("one_vs_rest", "leave_one_out", "fifty_fifty"):
+            for c in range(n):
+                assert batching.nominal_classes(mode, c, n) == g[f"nominal/{n}/{mode}/{c}"].tolist(), (n, mode, c)
+    for name in ("small", "cifar_like", "in30_like"):
+        labels = g[f"subset/{name}/labels"]
+        for mode in ("ovr", "loo", "ff"):
+            normal = g[f"subset/{name}/{mode}/normal_classes"].tolist()
+            assert np.array_equal(batching.normal_subset(labels, normal), g[f"subset/{name}/{mode}/indices"])
+            t = batching.ad_targets(labels, normal)
+            assert np.array_equal(np.nonzero(t == 0)[0], g[f"subset/{name}/{mode}/indices"])      # nominal <=> in the subset
