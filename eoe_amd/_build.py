@@ -20,7 +20,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libeoe_hip.so")
 OBJDIR = os.path.join(HERE, "build")
 SOURCES = ["api.cpp", "gemm.hip", "gemm_tn.hip", "elementwise.hip", "attention.hip", "conv.hip", "cbam.hip", "augment.hip",
-           "vit.cpp", "parity.hip", "gemm256.hip", "comm.cpp"]
+           "vit.cpp", "parity.hip", "gemm256.hip", "comm.cpp", "gemm_tn256.hip"]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--no-undefined"]
 

@@ -27,6 +27,7 @@ unsigned long long* g_stamp_buf = nullptr;
 extern int g_tn_flags;     // gemm_tn.hip
 extern int g_vit_side_stream;   // vit.cpp
 extern int g_attn_flags;        // attention.hip
+extern int g_tn256_launches;    // gemm_tn256.hip
 int eoe_launch_nt256(const void* gemm_p, int dtype, int epi, int mi, hipStream_t s);   // gemm256.hip
 
 namespace {
@@ -856,5 +857,6 @@ extern "C" int eoe_get_option(const char* name, int* value) {
     if (!strcmp(name, "tn_flags")) { *value = g_tn_flags; return 0; }
     if (!strcmp(name, "vit_side_stream")) { *value = g_vit_side_stream; return 0; }
     if (!strcmp(name, "attn_flags")) { *value = g_attn_flags; return 0; }
+    if (!strcmp(name, "tn256_launches")) { *value = g_tn256_launches; return 0; }       // read-only diagnostics
     return eoe_set_error(EOE_ERR_ARG, "unknown option");
 }

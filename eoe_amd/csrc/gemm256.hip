@@ -20,7 +20,11 @@ constexpr int stage256_bytes(int MI) { return a256_bytes(MI) + b256_bytes(); }  
 // ring depth: 3 stages where they fit the 160 KiB (MI = 5: 156 KiB; the epilogue's transposition scratch then aliases the stage
 // that was consumed last), else 2 stages + 16 KiB of scratch (MI = 8: 144 KiB)
 constexpr int nstage256(int MI) { return 3 * stage256_bytes(MI) <= 160 * 1024 ? 3 : 2; }
-constexpr int smem256_bytes(int MI) { return nstage256(MI) == 3 ? 3 * stage256_bytes(MI) : 2 * stage256_bytes(MI) + 4 * 4096; }
+// + 4 KiB behind the ring (and scratch): the target of LDS-DMA pieces that are issued unconditionally but have nothing to fetch
+// (out-of-range offset -> zero fill), one KiB per wave -- cheaper than a branch around every piece
+constexpr int spare256_off(int MI) { return nstage256(MI) == 3 ? 3 * stage256_bytes(MI) : 2 * stage256_bytes(MI) + 4 * 4096; }
+constexpr int smem256_bytes(int MI) { return spare256_off(MI) + 4096; }
+static_assert(smem256_bytes(5) <= 160 * 1024 && smem256_bytes(8) <= 160 * 1024, "LDS");
 
 template <typename T> __device__ __forceinline__ void mfma_inplace(f32x4& c, typename T16<T>::v8 a, typename T16<T>::v8 b);
 template <> __device__ __forceinline__ void mfma_inplace<f16_t>(f32x4& c, f16x8 a, f16x8 b) {
@@ -80,20 +84,24 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_kernel(GemmP p) {
 #define EOE_DMA16(rsrc, lds_addr, voff)                                                                               \
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"                            \
                  :: "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory")
-    auto stage_issue = [&]() {                     // MI + 8 LDS-DMA instructions per wave per k-tile
+    // piece j of the staging cursor's k-tile (j < MI: the A image, else the B image).  `live` (wave-uniform): a piece with nothing to
+    // fetch keeps its place in the instruction stream and in the vmcnt count -- out-of-range offset (zero fill), written to this wave's
+    // KiB of the spare area
+    const unsigned spare = lds0 + (unsigned)spare256_off(MI) + wave_u * 1024u;
+    auto stage_piece = [&](int j, bool live) {
         const unsigned sa = lds0 + (unsigned)st_slot * STAGE;
-        const unsigned sb = sa + A_B;
-        const unsigned k0 = (unsigned)st_kt * (BK * 2u);
-#pragma unroll
-        for (int j = 0; j < MI; ++j) {
-            const unsigned la = sa + (wave_u * MI + j) * 1024u, vo = offA[j] + k0;
+        const unsigned k0 = live ? (unsigned)st_kt * (BK * 2u) : EOE_OOB;
+        if (j < MI) {
+            const unsigned la = live ? sa + (wave_u * MI + j) * 1024u : spare, vo = offA[j < MI ? j : 0] + k0;
             EOE_DMA16(ra, la, vo);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const unsigned lb = sb + (wave_u * 8 + j) * 1024u, vo = offB[j] + k0;
+        } else {
+            const unsigned lb = live ? sa + A_B + (wave_u * 8 + (j - MI)) * 1024u : spare, vo = offB[j >= MI ? j - MI : 0] + k0;
             EOE_DMA16(rb, lb, vo);
         }
+    };
+    auto stage_issue = [&]() {                     // the whole k-tile in one burst (prologue, and the k-tile deferred past an epilogue)
+#pragma unroll
+        for (int j = 0; j < PER; ++j) stage_piece(j, true);
     };
     auto stage_advance = [&]() {                   // the staging cursor moves on (every wave, after its pieces were issued)
         st_slot = (st_slot == NST - 1) ? 0 : st_slot + 1;
@@ -154,8 +162,16 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_kernel(GemmP p) {
     //     right behind the barrier, the four of them queued for ~830 cycles with all matrix pipes idle (measured: 17 us of the
     //     73 us of the K = 3072 GEMM went away when the pieces were not issued at all); staggered, one wave issues while the
     //     other three SIMDs keep multiplying.
-    constexpr int NMF = MI * 8, RSTEP = NMF / (MI + 8), QUART = NMF / 4;
-#define EOE_CLUSTER256(XA, WB, RA, RB, rbase, rks, DMA)                                                          \
+    //   * (round 3) the LDS-DMA pieces [P_LO, P_HI) of the staging cursor's k-tile, SPREAD evenly over the cluster, the four waves one
+    //     MFMA apart (s_nop behind the barrier).  The four SIMDs of a CU share ONE LDS-DMA path (a 1 KiB piece ~ 16 cycles of it) and a
+    //     wave sits at a piece until the path takes it: issued as bursts of 13 / 16 (round 2: one wave's burst per quarter of the
+    //     cluster) the bursts of the four waves ran into each other and a piece cost its wave ~97 cycles -- 1550 cycles per k-tile with
+    //     the matrix pipe idle (in-kernel stamps of the same scheme in gemm_tn256.hip: second half 2577 -> 1524 cycles); one piece per
+    //     wave per 4-6 MFMAs costs ~30.  With the 3-stage ring the pieces of k-tile it+3 are spread over the second half of iteration
+    //     it AND the first half of iteration it+1; with 2 stages over the second half only.
+    constexpr int NMF = MI * 8, RSTEP = NMF / (MI + 8);
+    constexpr int P1 = (NST == 3) ? (PER + 1) / 2 : PER;          // pieces issued in the second half; the rest in the next first half
+#define EOE_CLUSTER256(XA, WB, RA, RB, rbase, rks, P_LO, P_HI, LIVE)                                            \
     do {                                                                                                         \
         const unsigned ra_ = (unsigned)(size_t)((rbase) - smem) + fragA + ((rks) ? ch1 : ch0);                   \
         const unsigned rb_ = (unsigned)(size_t)((rbase) - smem) + fragB + ((rks) ? ch1 : ch0);                   \
@@ -168,7 +184,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_kernel(GemmP p) {
                     if (j < MI) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(RA[j < MI ? j : 0]) : "v"(ra_), "i"((j < MI ? j : 0) * 2048)); \
                     else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(RB[j >= MI ? j - MI : 0]) : "v"(rb_), "i"((j >= MI ? j - MI : 0) * 2048)); \
                 }                                                                                                \
-                if (idx % QUART == QUART - 1) { if ((DMA) && (int)wave_u == idx / QUART) stage_issue(); }       \
+                _Pragma("unroll") for (int sl = 0; sl < (P_HI) - (P_LO); ++sl)                                   \
+                    if (idx == ((sl + 1) * NMF) / ((P_HI) - (P_LO)) - 1) stage_piece((P_LO) + sl, (LIVE));       \
             }                                                                                                    \
     } while (0)
 #define EOE_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
@@ -191,6 +208,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_kernel(GemmP p) {
     EOE_READ256(xa0, wb0, smem, 0);
     EOE_LANDED256(xa0, wb0);
     int cur = 0, it = 0;
+    bool part = false;                             // the staging cursor's k-tile has its first P1 pieces issued, the rest are due
     // two nested loops (tile, k-tile) over the flattened iteration space `it`: the accumulators live from their zero
     // initialisation to the tile's epilogue and are not carried around the outer loop
     for (int c_tile = 0; c_tile < my_tiles; ++c_tile) {
@@ -209,21 +227,25 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_kernel(GemmP p) {
             const int nxt = (cur == NST - 1) ? 0 : cur + 1;
             const char* sc = smem + cur * STAGE;
             const char* sn = smem + nxt * STAGE;
-            // first half: MFMA(F0) with the reads of F1 (k-step 1 of this k-tile) woven in
-            EOE_CLUSTER256(xa0, wb0, xa1, wb1, sc, 1, false);
-            {   // k-tile it+1 landed; the (up to NST - 2) k-tiles staged after it stay in flight
-                const int later = iters - 2 - it;   // k-tiles it+2 .. iters-1 that exist
-                const int g = later < NST - 2 ? later : NST - 2;
-                EOE_WAIT_GROUPS(g);
-            }
+            // first half: MFMA(F0) with the reads of F1 (k-step 1 of this k-tile) and -- 3-stage ring -- the second part of the pieces
+            // the previous second half began (dead pieces if it began none)
+            EOE_CLUSTER256(xa0, wb0, xa1, wb1, sc, 1, P1, PER, part);
+            if (P1 < PER && part) { stage_advance(); part = false; }
+            // k-tile it+1 has landed; the k-tile staged after it (3 stages) stays in flight.  Every iteration issues exactly PER
+            // pieces, live or dead, so the count does not depend on where in the sequence we are
+            EOE_WAIT_GROUPS(NST - 2);
             EOE_LANDED256(xa1, wb1);               // this wave's reads of slot `cur` are complete
             __builtin_amdgcn_s_barrier();
-            // second half: MFMA(F1) with the reads of the next k-tile's F0 and this wave's share of the LDS-DMA of k-tile it+NST
-            // (into the slot just consumed -- unless that slot is about to serve as the epilogue's scratch) woven in
+            // the four waves one MFMA (16 cycles = one piece on the shared LDS-DMA path) apart until the next barrier
+            if (wave_u & 1) asm volatile("s_nop 15" ::: "memory");
+            if (wave_u & 2) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+            // second half: MFMA(F1) with the reads of the next k-tile's F0 and the first P1 pieces of k-tile it+NST (into the slot just
+            // consumed -- unless that slot is about to serve as the epilogue's scratch: then the pieces are dead and the k-tile is staged
+            // in one burst behind the epilogue)
             const bool defer = (NST == 3) && (kt == nk - 1);
             const bool dma = !defer && it + NST < iters && !(p.dbg & 2);
-            EOE_CLUSTER256(xa1, wb1, xa0, wb0, sn, 0, dma);
-            if (dma) stage_advance();
+            EOE_CLUSTER256(xa1, wb1, xa0, wb0, sn, 0, 0, P1, dma);
+            if (P1 == PER) { if (dma) stage_advance(); } else { part = dma; }
             EOE_LANDED256(xa0, wb0);               // before the back edge: no fragment register is in flight across it
             cur = nxt;
         }

@@ -517,9 +517,17 @@ static bool streamk_applies(int tiles, int splits, int gather, int T, const void
     return streamk_flags(s, ncu, nullptr, nullptr);
 }
 
-// for vit.cpp: will eoe_gemm_tn_grouped(args, count, stream) run as stream-K?
+int eoe_tn256_splits(const eoe_gemm_args* args, int count, int64_t ws_bytes, const void* ws);      // gemm_tn256.hip
+int eoe_launch_tn256(const eoe_gemm_args* args, int count, int splits, hipStream_t s);
+
+// for vit.cpp: will eoe_gemm_tn_grouped(args, count, stream) fill every CU by itself (stream-K)?  (The wide-tile kernel's aligned
+// slices leave CUs free -- 216 of 256 for a ViT block -- so LayerNorm-1 backward is worth running next to it.)
 bool eoe_tn_streamk_would_run(const eoe_gemm_args* args, int count, void* stream) {
     if (!args || count < 1) return false;
+    if (eoe_tn256_splits(args, count, args[0].workspace_bytes, args[0].workspace) > 0) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)stream, &st) == hipSuccess && st == hipStreamCaptureStatusNone) return false;
+    }
     int tiles = 0;
     for (int i = 0; i < count; ++i) tiles += cdiv(args[i].M, BM) * cdiv(args[i].N, BN);
     const int ncu = tn_num_cus();
@@ -570,6 +578,13 @@ extern "C" int eoe_gemm_tn_grouped(const eoe_gemm_args* args, int count, void* s
         p.bytesA = (unsigned)ba; p.bytesB = (unsigned)bb;
         flops += 2.0 * a->M * a->N * T;
         bytes += 2.0 * ((double)T * a->M + (double)T * a->N) + 4.0 * a->M * a->N;
+    }
+    // wide tiles (gemm_tn256.hip): 256x256 output tiles, the reduction in aligned slices that meet inside the launch -- the ViT block's
+    // four weight gradients; "tn_flags" bit 2 switches it off (A/B)
+    if (const int s256 = eoe_tn256_splits(args, count, args[0].workspace_bytes, args[0].workspace)) {
+        ProfScope ps256("gemm_tn", flops, bytes, stream);
+        const int rc = eoe_launch_tn256(args, count, s256, (hipStream_t)stream);
+        if (rc >= 0) return rc;                       // < 0: not available on this stream (being captured): the kernel below
     }
     static const int dbg = getenv("EOE_GEMM_DEBUG") ? atoi(getenv("EOE_GEMM_DEBUG")) : 0;
     if (dbg & 1) for (int i = 0; i < count; ++i) { g.p[i].bytesA = 0; g.p[i].bytesB = 0; }

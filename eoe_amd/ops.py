@@ -301,6 +301,18 @@ def scratch(name, shape, dtype, device):
 grad_ready_hooks = {}
 
 
+def zero_multi(*tensors):
+    """zero up to 8 fp32 buffers in ONE launch (instead of one torch fill each)"""
+    ts = [t for t in tensors if t is not None and t.numel() > 0]
+    for i in range(0, len(ts), 8):
+        chunk = ts[i:i + 8]
+        for t in chunk:
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
+        ptrs = (C.c_void_p * len(chunk))(*[t.data_ptr() for t in chunk])
+        cnts = (C.c_int * len(chunk))(*[t.numel() for t in chunk])
+        check(lib.eoe_zero_multi(ptrs, cnts, len(chunk), _stream()), "eoe_zero_multi")
+
+
 def _grad_target(p: torch.Tensor):
     """where a parameter gradient is written: a fresh alias of the parameter's registered arena view if it has one
     and is free (p.grad is None) -- a new tensor object over the same memory, so that autograd's AccumulateGrad
@@ -419,8 +431,7 @@ class VitEmbedFunction(torch.autograd.Function):
         dy = dy.contiguous()
         dtok = torch.empty((n * (L - 1), D), dtype=patches.dtype, device=dy.device)
         dcls, dpos, dg, db = (_grad_target(t) for t in (cls, pos, g, b))
-        for t in (dcls, dpos, dg, db):
-            t.zero_()
+        zero_multi(dcls, dpos, dg, db)
         part = scratch("embed_ln_part", (L * 2 * D,), torch.float32, dy.device)          # ln_pre parameter gradients without atomics
         check(lib.eoe_embed_lnpre_bwd(_p(dy), _p(x0), _p(stats), _p(g), _p(dtok), _p(dcls), _p(dpos), _p(dg), _p(db), _p(part),
                                       n, L, D, dtype_code(patches.dtype), _stream()), "eoe_embed_lnpre_bwd")
@@ -505,7 +516,7 @@ class VitBlockFunction(torch.autograd.Function):
         b.dx_mid = _p(scratch("dx_mid", (M, D), torch.float32, dev))
         nred = (M + 63) // 64 * 4 * D + 2 * LN_SCRATCH_ROWS * 3 * D + ctx.args.n * 3 * D + 256 * D          # EOE_VIT_RED_SCRATCH(n, L, D)
         b.red_scratch = _p(scratch("vit_red", (nred,), torch.float32, dev))
-        sk_bytes = torch.cuda.get_device_properties(dev).multi_processor_count * (256 * 128 * 4)      # EOE_TN_STREAMK_WORKSPACE_BYTES
+        sk_bytes = torch.cuda.get_device_properties(dev).multi_processor_count * (256 * 256 * 4)      # EOE_TN_STREAMK_WORKSPACE_BYTES
         b.tn_workspace, b.tn_workspace_bytes = _p(scratch("tn_streamk", (sk_bytes,), torch.uint8, dev)), sk_bytes
         check(lib.eoe_vit_block_bwd(C.byref(b), _stream()), "eoe_vit_block_bwd")
         hook = grad_ready_hooks.get(id(params["ln1_g"]))
@@ -545,10 +556,9 @@ class VitHeadFunction(torch.autograd.Function):
         gemm_nt(d16, p16, dcls)                            # [n, out] @ proj[D, out]^T
         dproj = _grad_target(proj)
         gemm_tn(cls16, d16, dproj)                         # [D, out] = cls16^T d16
-        dx = torch.zeros_like(x)
+        dx = torch.empty_like(x)
         dg, db = _grad_target(g), _grad_target(b)
-        dg.zero_()
-        db.zero_()
+        zero_multi(dx, dg, db)                            # one launch (the class-token rows of dx are written below, the rest stays 0)
         layernorm_bwd(dcls, x, stats, g, n, D, L * D, dx, L * D, dgamma=dg, dbeta=db)
         return dx, None, dg, db, dproj
 

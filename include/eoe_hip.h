@@ -105,7 +105,7 @@ int eoe_gemm_tn(const eoe_gemm_args* args, void* stream);
  * ONE launch (the four weight gradients of a transformer block fill the chip together: no split-K, no atomics) */
 #define EOE_TN_MAX_GROUP 4
 #define EOE_TN_WORKSPACE_BYTES (512ll * 256 * 128 * 4)   /* (#CUs rounded up) x one 256x128 fp32 tile */
-#define EOE_TN_STREAMK_WORKSPACE_BYTES(cus) ((size_t)(cus) * (256 * 128 * 4))   /* one partial fp32 tile per CU */
+#define EOE_TN_STREAMK_WORKSPACE_BYTES(cus) ((size_t)(cus) * (256 * 256 * 4))   /* one partial fp32 tile (up to 256 x 256) per CU */
 int eoe_gemm_tn_grouped(const eoe_gemm_args* args, int count, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------

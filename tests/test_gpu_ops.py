@@ -216,6 +216,61 @@ def test_gemm_tn_grouped_stream_k(ops, dtype):
         assert_close(out, 2 * ref, 4e-6, 6e-5 * math.sqrt(T), "gemm_tn_grouped stream-K accumulate")
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", ["block_s2", "ragged_s2", "two_s4"])
+def test_gemm_tn_wide_tiles(ops, dtype, case):
+    """the wide-tile wgrad kernel (gemm_tn256.hip: 256x256 tiles, the reduction in aligned slices whose workgroups meet inside the
+    launch -- last arriver owns the tile): the ViT block's group (108 tiles x 2 slices), a group with ragged M / N / T tails, and a
+    two-problem group that runs 4 slices (partials summed from memory in slice order).  Against fp64, against the 256x128 kernel
+    (`tn_flags` bit 2), bitwise repeatable whoever arrives last, accumulate and alpha"""
+    from eoe_amd import _lib
+    shapes, T = {"block_s2": ([(3072, 768), (768, 3072), (2304, 768), (768, 768)], 64 * 50 + 24),
+                 "ragged_s2": ([(3072, 768), (768, 3072), (2304, 776), (776, 520)], 64 * 49 + 8),
+                 "two_s4": ([(3072, 768), (2304, 768)], 64 * 96 + 40)}[case]
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    ws = torch.empty(cus * 256 * 256 * 4, dtype=torch.uint8, device="cuda")       # EOE_TN_STREAMK_WORKSPACE_BYTES(#CUs)
+    n = len(shapes)
+    args = (_lib.GemmArgs * n)()
+    keep, outs, refs = [], [], []
+    for i, (m, nn) in enumerate(shapes):
+        a, ar = t16(f"tnw/{case}/a{i}", (T, m), 1.0, dtype)
+        b, br = t16(f"tnw/{case}/b{i}", (T, nn), 1.0, dtype)
+        out = torch.full((m, nn), 3.0, dtype=torch.float32, device="cuda")
+        keep += [a, b]
+        outs.append(out)
+        refs.append((ar.cuda().double().t() @ br.cuda().double()).cpu())
+        args[i] = _lib.GemmArgs(a.data_ptr(), b.data_ptr(), out.data_ptr(), None, None, None, None, m, nn, T, m, nn, nn, 0,
+                                ops.dtype_code(dtype), 0, 1, 0, 1.0, ws.data_ptr(), ws.numel())
+    st = torch.cuda.current_stream().cuda_stream
+    ws.fill_(0xFF)                                   # stale partials (NaN patterns) must never be read
+    before = _lib.get_option("tn256_launches")
+    _lib.check(_lib.lib.eoe_gemm_tn_grouped(args, n, st), "grouped wide")
+    assert _lib.get_option("tn256_launches") == before + 1, "the group did not take the wide-tile kernel"
+    first = [o.clone() for o in outs]
+    for out, ref in zip(outs, refs):
+        assert_close(out, ref, 2e-6, 3e-5 * math.sqrt(T), f"gemm_tn wide {case}")
+    for rep in range(4):
+        for o in outs:
+            o.fill_(-1.0)
+        _lib.check(_lib.lib.eoe_gemm_tn_grouped(args, n, st), "grouped wide again")
+        assert all(torch.equal(o, f) for o, f in zip(outs, first)), "the wide-tile wgrad is not bitwise repeatable"
+    old = _lib.set_option("tn_flags", 4)             # the 256x128 kernel on the same problems
+    try:
+        _lib.check(_lib.lib.eoe_gemm_tn_grouped(args, n, st), "grouped 256x128")
+    finally:
+        _lib.set_option("tn_flags", old)
+    for o, f in zip(outs, first):                    # same products, different partial-sum boundaries
+        assert (o - f).abs().max().item() <= 1e-5 * math.sqrt(T) * 4
+    for i in range(n):
+        args[i].accumulate = 1
+        args[i].alpha = 0.5
+    for o, f in zip(outs, first):
+        o.copy_(f)
+    _lib.check(_lib.lib.eoe_gemm_tn_grouped(args, n, st), "grouped wide acc")
+    for out, ref in zip(outs, refs):
+        assert_close(out, 1.5 * ref, 4e-6, 6e-5 * math.sqrt(T), f"gemm_tn wide accumulate {case}")
+
+
 def test_gemm_rejects_bad_shapes(ops):
     a = torch.zeros((8, 40), dtype=torch.bfloat16, device="cuda")
     b = torch.zeros((8, 40), dtype=torch.bfloat16, device="cuda")

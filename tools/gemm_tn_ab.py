@@ -11,7 +11,7 @@ variants = [int(v) for v in sys.argv[1:]] or [0, 2]
 dt = torch.float16
 M = 12800
 args = (_lib.GemmArgs * 4)()
-ws = torch.empty(ops.TN_WORKSPACE_BYTES, dtype=torch.uint8, device="cuda")      # tn_flags bit 1 = 2 switches stream-K off
+ws = torch.empty(max(ops.TN_WORKSPACE_BYTES, 256 * 256 * 256 * 4), dtype=torch.uint8, device="cuda")      # tn_flags: 2 = no stream-K, 4 = no wide tiles
 keep, fl, outs = [], 0, []
 for i, (m, n, t) in enumerate([(3072, 768, M), (768, 3072, M), (2304, 768, M), (768, 768, M)]):
     a = torch.randn(t, m, device="cuda").to(dt)

@@ -1,0 +1,3 @@
+cd /root/repo
+timeout -k 10 900 python -m pytest tests/test_gpu_ops.py -q -m gpu -x -k "gemm_nt or gemm_shapes or epilogue" 2>&1 | tail -3
+timeout -k 10 600 python tools/gemm_ab.py 1 129 257 513 2>&1 | grep -v amdgpu.ids
