@@ -17,12 +17,12 @@ namespace {
 constexpr int b256_bytes() { return 256 * BK * 2; }                               // 32 KiB
 constexpr int a256_bytes(int MI) { return 32 * MI * BK * 2; }                      // 20 / 32 KiB
 constexpr int stage256_bytes(int MI) { return a256_bytes(MI) + b256_bytes(); }     // 52 / 64 KiB
-// ring depth: 3 stages where they fit the 160 KiB (MI = 5: 156 KiB; the epilogue's transposition scratch then aliases the stage
-// that was consumed last), else 2 stages + 16 KiB of scratch (MI = 8: 144 KiB)
+// ring depth: 3 stages where they fit the 160 KiB (MI = 5: 156 KiB), else 2 (MI = 8: 128 KiB).  The epilogue needs no LDS
+// (epilogue_direct, gemm_common.h)
 constexpr int nstage256(int MI) { return 3 * stage256_bytes(MI) <= 160 * 1024 ? 3 : 2; }
 // + 4 KiB behind the ring (and scratch): the target of LDS-DMA pieces that are issued unconditionally but have nothing to fetch
 // (out-of-range offset -> zero fill), one KiB per wave -- cheaper than a branch around every piece
-constexpr int spare256_off(int MI) { return nstage256(MI) == 3 ? 3 * stage256_bytes(MI) : 2 * stage256_bytes(MI) + 4 * 4096; }
+constexpr int spare256_off(int MI) { return nstage256(MI) * stage256_bytes(MI); }
 constexpr int smem256_bytes(int MI) { return spare256_off(MI) + 4096; }
 static_assert(smem256_bytes(5) <= 160 * 1024 && smem256_bytes(8) <= 160 * 1024, "LDS");
 
@@ -37,7 +37,6 @@ template <> __device__ __forceinline__ void mfma_inplace<bf16_t>(f32x4& c, bf16x
 template <typename T, int EPI, int MI>
 __global__ __launch_bounds__(256, 1) void gemm_nt256_kernel(GemmP p) {
     constexpr int BMT = 32 * MI, A_B = a256_bytes(MI), STAGE = stage256_bytes(MI), NST = nstage256(MI), PER = MI + 8;
-    static_assert(NST == 2 || MI >= 4, "the aliased scratch is the wave's own MI KiB of A pieces (>= 4 KiB)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_n = (p.N + 255) / 256;
@@ -69,9 +68,14 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_kernel(GemmP p) {
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
+            // LDS row 16*ni + i of each 64-row group holds weight row 16*(i >> 2) + 4*ni + (i & 3): the accumulator tiles ni = 0..3 of
+            // a band then leave a lane with 16 CONSECUTIVE output columns (epilogue_direct).  A permutation of whole rows: the LDS
+            // image, its swizzle and the fragment reads are unchanged
             const int row = (wave * 8 + j) * 8 + (lane >> 3);
             const int c = (lane & 7) ^ ((row >> 1) & 7);
-            offB[j] = (n0 + row < p.N) ? (unsigned)(((size_t)(n0 + row) * p.ldb + c * 8) * 2) : EOE_OOB;
+            const int x = row & 63;
+            const int grow = (row & ~63) + ((x & 15) >> 2) * 16 + (x >> 4) * 4 + (x & 3);
+            offB[j] = (n0 + grow < p.N) ? (unsigned)(((size_t)(n0 + grow) * p.ldb + c * 8) * 2) : EOE_OOB;
         }
     };
     // LDS-DMA as inline asm (buffer_load_dwordx4 ... offen lds; M0 = the wave-uniform LDS byte address of the 1-KiB piece, written in
@@ -199,6 +203,22 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_kernel(GemmP p) {
         else { if (PER == 13) { EOE_WAIT_VM(26); } else { EOE_WAIT_VM(32); } }                         \
     } while (0)
     static_assert(PER == 13 || PER == 16, "EOE_WAIT_GROUPS knows MI = 5 and MI = 8");
+    // the first wait of a tile that follows an epilogue: the epilogue's E stores (inline asm, counted like every vector-memory operation,
+    // in issue order) sit between the pieces that must have landed and the younger ones that may stay in flight -- leave them in flight
+    // too: vmcnt((NST - 2) * PER + E), capped at the counter's 63
+#define EOE_WAIT_AFTER_EPILOGUE(E)                                                                     \
+    do {                                                                                               \
+        const int n_ = (NST - 2) * PER + (E);                                                          \
+        if (n_ >= 63) { EOE_WAIT_VM(63); }                                                             \
+        else if (n_ >= 61) { EOE_WAIT_VM(61); }                                                        \
+        else if (n_ >= 53) { EOE_WAIT_VM(53); }                                                        \
+        else if (n_ >= 41) { EOE_WAIT_VM(41); }                                                        \
+        else if (n_ >= 40) { EOE_WAIT_VM(40); }                                                        \
+        else if (n_ >= 33) { EOE_WAIT_VM(33); }                                                        \
+        else if (n_ >= 32) { EOE_WAIT_VM(32); }                                                        \
+        else if (n_ >= 20) { EOE_WAIT_VM(20); }                                                        \
+        else { EOE_WAIT_GROUPS(NST - 2); }                                                             \
+    } while (0)
     V8 xa0[MI], wb0[8], xa1[MI], wb1[8];
     set_offsets(0);
     const int pre = iters < NST ? iters : NST;
@@ -208,9 +228,16 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_kernel(GemmP p) {
     EOE_READ256(xa0, wb0, smem, 0);
     EOE_LANDED256(xa0, wb0);
     int cur = 0, it = 0;
+    // diagnostics (EOE_GEMM_STAMP=1): wave 0's cycles per workgroup -- [0] kernel entry -> first operands landed, [1] sum over the
+    // k-tiles of (first half + DMA wait), [2] at the barrier, [3] second half, [4] epilogues (issue only), [5] whole kernel, [6] tiles
+    unsigned long long* stp = (p.stamp && wave == 0) ? p.stamp + (size_t)blockIdx.x * 16 : nullptr;
+    unsigned long long t_a = 0, t_b = 0, t_c = 0, c_first = 0, c_bar = 0, c_second = 0, c_epi = 0, t_entry = 0;
+    if (stp) { t_entry = __builtin_amdgcn_s_memtime(); }
     bool part = false;                             // the staging cursor's k-tile has its first P1 pieces issued, the rest are due
+    int stores_in_flight = 0;                      // the previous tile's epilogue stores (per wave), for the first wait of this tile
     // two nested loops (tile, k-tile) over the flattened iteration space `it`: the accumulators live from their zero
     // initialisation to the tile's epilogue and are not carried around the outer loop
+    if (stp) { t_c = __builtin_amdgcn_s_memtime(); if (lane == 0) stp[0] = t_c - t_entry; }
     for (int c_tile = 0; c_tile < my_tiles; ++c_tile) {
         f32x4 acc[2][MI][4];                        // [64-column half][16-row tile][16-column tile]
 #pragma unroll
@@ -219,10 +246,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_kernel(GemmP p) {
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[h][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // every counter the COMPILER tracks is drained here, once per tile (the previous tile's epilogue stores and scratch
-        // reads): otherwise its waitcnt pass, merging that state into the loop header, opens every iteration with
-        // s_waitcnt vmcnt(0) lgkmcnt(0) -- and the hardware counter makes that a wait for the hand-issued LDS-DMA too
-        __builtin_amdgcn_s_waitcnt(0);
+        // (no drain here: the epilogue's stores are inline asm and its few loads were consumed there, so the compiler's waitcnt pass has
+        //  nothing pending to merge into the loop header)
         for (int kt = 0; kt < nk; ++kt, ++it) {
             const int nxt = (cur == NST - 1) ? 0 : cur + 1;
             const char* sc = smem + cur * STAGE;
@@ -233,40 +258,53 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_kernel(GemmP p) {
             if (P1 < PER && part) { stage_advance(); part = false; }
             // k-tile it+1 has landed; the k-tile staged after it (3 stages) stays in flight.  Every iteration issues exactly PER
             // pieces, live or dead, so the count does not depend on where in the sequence we are
-            EOE_WAIT_GROUPS(NST - 2);
+            if (kt == 0 && stores_in_flight) { EOE_WAIT_AFTER_EPILOGUE(stores_in_flight); } else { EOE_WAIT_GROUPS(NST - 2); }
             EOE_LANDED256(xa1, wb1);               // this wave's reads of slot `cur` are complete
+            if (stp) { t_a = __builtin_amdgcn_s_memtime(); c_first += t_a - t_c; }
             __builtin_amdgcn_s_barrier();
+            if (stp) { t_b = __builtin_amdgcn_s_memtime(); c_bar += t_b - t_a; }
             // the four waves one MFMA (16 cycles = one piece on the shared LDS-DMA path) apart until the next barrier
             if (wave_u & 1) asm volatile("s_nop 15" ::: "memory");
             if (wave_u & 2) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
             // second half: MFMA(F1) with the reads of the next k-tile's F0 and the first P1 pieces of k-tile it+NST (into the slot just
-            // consumed -- unless that slot is about to serve as the epilogue's scratch: then the pieces are dead and the k-tile is staged
-            // in one burst behind the epilogue)
-            const bool defer = (NST == 3) && (kt == nk - 1);
-            const bool dma = !defer && it + NST < iters && !(p.dbg & 2);
+            // consumed; dead pieces past the last k-tile)
+            const bool dma = it + NST < iters && !(p.dbg & 2);
             EOE_CLUSTER256(xa1, wb1, xa0, wb0, sn, 0, 0, P1, dma);
             if (P1 == PER) { if (dma) stage_advance(); } else { part = dma; }
             EOE_LANDED256(xa0, wb0);               // before the back edge: no fragment register is in flight across it
+            if (stp) { t_c = __builtin_amdgcn_s_memtime(); c_second += t_c - t_b; }
             cur = nxt;
         }
-        // epilogue while the next tile's first k-tiles are in flight (their fragments of k-step 0 are already in xa0 / wb0)
+        // epilogue while the next tile's first k-tiles are in flight (their fragments of k-step 0 are already in xa0 / wb0); no LDS, no
+        // drain: the stores stay in flight under the next tile's first MFMAs
         EOE_MFMA_DRAIN();                           // the last MFMAs' results must have landed before the accumulators are read
         int m0, n0;
         tile_origin(c_tile, m0, n0);
         GemmP ep;
         load_epilogue_args(ep, p);
-        // scratch (4 KiB per wave).  NST == 3: inside the slot consumed last (every wave's reads of it completed before the last
-        // barrier), in the MI KiB that THIS wave's own A pieces of the next k-tile will overwrite -- issued below, after this
-        // wave's epilogue, so no other wave's DMA can land in it
-        const int last = (cur == 0) ? NST - 1 : cur - 1;
-        char* scr = (NST == 3) ? smem + last * STAGE + wave * (MI * 1024) : smem + 2 * STAGE + wave * 4096;
-        epilogue<T, EPI, 4, MI, false>(ep, acc[0], m0 + wm0, n0 + wn0, lane, scr);
-        epilogue<T, EPI, 4, MI, false>(ep, acc[1], m0 + wm0, n0 + wn0 + 64, lane, scr);
-        if (NST == 3 && it - 1 + NST < iters) {
-            __builtin_amdgcn_s_waitcnt(0xc07f);    // lgkmcnt(0): the scratch reads have returned before the DMA may overwrite them
-            stage_next();                           // the deferred k-tile (it-1)+NST
-        }
+        // buffer descriptors for the asm stores / bounds-checked loads (the epilogue arguments come through vector registers:
+        // readfirstlane makes pointers and sizes provably wave-uniform, i.e. SGPR operands)
+        auto uni_ptr = [](const void* q) -> const void* {
+            const unsigned long long v = (unsigned long long)(uintptr_t)q;
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+            return (const void*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+        };
+        auto uni_u32 = [](size_t b) -> unsigned { return (unsigned)__builtin_amdgcn_readfirstlane((unsigned)b); };
+        const size_t esz = ep.out_f32 ? 4 : 2;
+        const size_t c_elems = ((size_t)ep.M - 1) * ep.ldc + ep.N, a_elems = ((size_t)ep.M - 1) * ep.ldaux + ep.N;
+        __amdgpu_buffer_rsrc_t rc = make_rsrc(uni_ptr(ep.C), uni_u32(c_elems * esz));
+        __amdgpu_buffer_rsrc_t rpre = make_rsrc(uni_ptr(ep.aux_out ? ep.aux_out : ep.C), uni_u32(ep.aux_out ? c_elems * 2 : 0));
+        __amdgpu_buffer_rsrc_t raux = make_rsrc(uni_ptr(ep.aux ? ep.aux : ep.C), uni_u32(ep.aux ? a_elems * (EPI == EOE_EPI_RESIDUAL ? 4 : 2) : 0));
+        const size_t part_rows = (size_t)((ep.M + 16 * MI - 1) / (16 * MI));
+        __amdgpu_buffer_rsrc_t rpart = make_rsrc(uni_ptr(ep.colsum_part ? (const void*)ep.colsum_part : ep.C),
+                                                 uni_u32(ep.colsum_part ? part_rows * (size_t)ep.N * 4 : 0));
+        asm volatile("s_nop 4" ::: "memory");      // SGPRs fresh from readfirstlane -> a buffer instruction's descriptor (section 5.7, item 2)
+        epilogue_direct<T, EPI, MI>(ep, acc, m0 + wm0, n0 + wn0, lane, rc, rpre, raux, rpart);
+        stores_in_flight = epilogue_direct_stores(ep, EPI, MI);
+        if (stp) { const unsigned long long t_e = __builtin_amdgcn_s_memtime(); c_epi += t_e - t_c; t_c = t_e; }
     }
+    if (stp && lane == 0) { stp[1] = c_first; stp[2] = c_bar; stp[3] = c_second; stp[4] = c_epi; stp[5] = t_c - t_entry; stp[6] = (unsigned long long)my_tiles; }
+#undef EOE_WAIT_AFTER_EPILOGUE
 #undef EOE_WAIT_GROUPS
 #undef EOE_DMA16
 #undef EOE_READ256
