@@ -692,7 +692,7 @@ int launch_nt(const GemmP& p, int epi, int gather, hipStream_t s) {
     // 83 -> 68 us = 887 TF, K = 2304: 61 -> 50 us = 916 TF).  The persistent 256-row kernel keeps large square problems
     // (4096^3: 1046 vs 984 TF).  nt_flags: bit 3 forces the two-workgroup kernel, bit 2 forbids it, bit 4 / 5 force 128 / 160 rows.
     // the one-wave-per-SIMD kernel (gemm256.hip) has only the LDS-transposed epilogue compiled in
-    if (!p.colsum_sq && (g_nt_flags & (128 | 256)) && epilogue_fast_ok(p))
+    if ((g_nt_flags & (128 | 256)) && epilogue_direct_ok(p, epi))
         return eoe_launch_nt256(&p, std::is_same<T, f16_t>::value ? EOE_F16 : EOE_BF16, epi, (g_nt_flags & 256) ? 8 : 5, s);
     const bool big = p.K >= 4096 && p.N >= 2048;
     // The one-wave-per-SIMD kernel (gemm256.hip; 160x256 or 256x256 tiles by the cost model below) for every large NT GEMM: OPT-IN
@@ -704,7 +704,7 @@ int launch_nt(const GemmP& p, int epi, int gather, hipStream_t s) {
     // 64.2 / 61.9, c_proj 86.5 / 81.7, GELU' x dY 114 / 103; only c_fc forward 102 / 105.6 wins; step 12.35 against 12.13 ms): one
     // wave per SIMD behind a 2-k-tile LDS-DMA lead cannot hide an HBM miss the way two independent workgroups per CU do.
     // Large square problems (below) keep it: there the 256x256 tile's halved operand traffic decides.
-    if (!p.colsum_sq && (g_nt_flags & 512) && !(g_nt_flags & (4 | 8)) && epilogue_fast_ok(p) && p.M >= 2048 && p.N >= 512) {
+    if ((g_nt_flags & 512) && !(g_nt_flags & (4 | 8)) && epilogue_direct_ok(p, epi) && p.M >= 2048 && p.N >= 512) {
         // time of a launch in units of one 16-row x 256-column x 64-deep slab of MFMAs: rounds over the CUs x (rows per tile x
         // (k-tiles + 2 for the pipeline fill) + 30 for a tile's epilogue and hand-over)
         const int nk = p.K / BK;
@@ -717,7 +717,7 @@ int launch_nt(const GemmP& p, int epi, int gather, hipStream_t s) {
         }
         return eoe_launch_nt256(&p, std::is_same<T, f16_t>::value ? EOE_F16 : EOE_BF16, epi, mi_best, s);
     }
-    if (big && !p.colsum_sq && !(g_nt_flags & (4 | 8)) && epilogue_fast_ok(p) && p.M >= 2048)
+    if (big && !(g_nt_flags & (4 | 8)) && epilogue_direct_ok(p, epi) && p.M >= 2048)
         return eoe_launch_nt256(&p, std::is_same<T, f16_t>::value ? EOE_F16 : EOE_BF16, epi, 8, s);
     if (!p.colsum_sq && ((g_nt_flags & 8) || (!big && !(g_nt_flags & 4)))) return launch_nt128_auto<T>(p, epi, s);
     // tile width: 256x128 unless 256x96 needs >= 10 % fewer (rounds x width) units over the CUs

@@ -68,13 +68,12 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_kernel(GemmP p) {
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            // LDS row 16*ni + i of each 64-row group holds weight row 16*(i >> 2) + 4*ni + (i & 3): the accumulator tiles ni = 0..3 of
-            // a band then leave a lane with 16 CONSECUTIVE output columns (epilogue_direct).  A permutation of whole rows: the LDS
+            // the rows of each 64-row group permuted (eoe_direct_row) so that a lane's accumulator values are runs of consecutive output
+            // columns and the lanes of a row write adjacent 16-byte pieces (epilogue_direct).  A permutation of whole rows: the LDS
             // image, its swizzle and the fragment reads are unchanged
             const int row = (wave * 8 + j) * 8 + (lane >> 3);
             const int c = (lane & 7) ^ ((row >> 1) & 7);
-            const int x = row & 63;
-            const int grow = (row & ~63) + ((x & 15) >> 2) * 16 + (x >> 4) * 4 + (x & 3);
+            const int grow = (row & ~63) + eoe_direct_row(row & 63, p.out_f32);
             offB[j] = (n0 + grow < p.N) ? (unsigned)(((size_t)(n0 + grow) * p.ldb + c * 8) * 2) : EOE_OOB;
         }
     };

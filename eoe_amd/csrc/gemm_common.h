@@ -302,13 +302,23 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][NI], i
 
 // Direct epilogue (round 3; gemm256.hip).  The LDS-transposed form above costs a workgroup that has nothing else resident on its CU
 // an LDS round trip per 16-row band, a ring slot to transpose in (the k-tile that would have been staged there is deferred past the
-// epilogue) and a full drain of the memory counters before the next tile.  Here the B tile's rows are PERMUTED at staging -- LDS row
-// 16*ni + i of each 64-row group holds weight row 16*(i>>2) + 4*ni + (i&3) --, so that the four accumulator tiles ni = 0..3 of a band
-// give lane (lr = lane & 15, lg = lane >> 4) the 16 CONSECUTIVE output columns 16*lg .. 16*lg + 15 of output row lr: the same 32- / 64-
-// byte pieces per lane as above with no LDS at all.  Global stores are inline asm (buffer_store_dwordx4, bounds-checked: rows / columns
-// outside C carry the out-of-range offset), so that the compiler's waitcnt pass has nothing of the epilogue to drain at the top of the
-// next tile and the kernel's own counted vmcnt can leave them in flight under the next tile's first MFMAs.  Every wave issues the same
-// number of stores per tile whatever its position (epilogue_direct_stores): the caller's first wait of the next tile counts them.
+// epilogue) and a full drain of the memory counters before the next tile.  Here the B tile's rows are PERMUTED at staging so that a
+// lane's 16 accumulator values of a band (tiles ni = 0..3 x r = 0..3; lane = (lr = lane & 15: output row, lg = lane >> 4)) are runs of
+// consecutive output columns, and so that the four lanes lg = 0..3 of a row write ADJACENT 16-byte pieces with each store instruction
+// (a store instruction then covers 16 rows x 64 contiguous bytes; 64 scattered 16-byte pieces per instruction ran the epilogue at
+// ~14 B/clk per CU):
+//   16-bit C:  value c = 4*ni + r  ->  column 32*(c >> 3) + 8*lg + (c & 7)      two 16-byte stores per lane and band
+//   fp32 C:    value c = 4*ni + r  ->  column 16*ni + 4*lg + r                  the MFMA's own layout: four 16-byte stores
+// eoe_direct_row() is the matching row permutation (LDS row 16*ni + i of a 64-row group <- weight row ...); no LDS is used here.  Every
+// memory operation is a buffer builtin the compiler counts itself (its vmcnt(N) for a load leaves exactly the younger stores in flight
+// -- the LDS-DMA pieces, which it cannot see, are all OLDER than anything issued here); per-band operands (the fp32 residual, the saved
+// pre-activation) are requested one band ahead, in source order.  Every wave issues the same number of stores per tile whatever its
+// position (epilogue_direct_stores; rows / columns outside C carry the out-of-range offset): the caller's first wait of the next tile
+// counts them.
+__host__ __device__ __forceinline__ int eoe_direct_row(int x /* LDS row within its 64-row group: 16*ni + i */, int out_f32) {
+    const int ni = x >> 4, i = x & 15;
+    return out_f32 ? x : ((ni >> 1) * 32 + (i >> 2) * 8 + (ni & 1) * 4 + (i & 3));
+}
 __device__ __forceinline__ void store_b128(__amdgpu_buffer_rsrc_t r, unsigned voff, u32x4 d) {
     __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)voff, 0, 0);
 }
@@ -317,48 +327,57 @@ __host__ __device__ __forceinline__ int epilogue_direct_stores(const GemmP& p, i
     const int per_band = (epi == EOE_EPI_GELU) ? (p.aux_out ? 4 : 2) : (p.out_f32 ? 4 : 2);
     return 2 * MI * per_band + ((epi != EOE_EPI_GELU && p.colsum_part) ? 8 : 0);
 }
+// the combinations the direct form implements (the launcher sends anything else to the other kernels)
+static inline bool epilogue_direct_ok(const GemmP& p, int epi) {
+    if (!epilogue_fast_ok(p) || p.colsum_sq) return false;
+    if (epi == EOE_EPI_GELU || epi == EOE_EPI_GELU_BWD) return !p.out_f32;
+    if (epi == EOE_EPI_RESIDUAL) return p.out_f32 != 0;
+    return true;
+}
 
-// Both 64-column halves of a wave's (16*MI) x 128 tile.  Every memory operation of the epilogue is a buffer builtin the compiler
-// counts itself (its vmcnt(N) for a load then leaves exactly the younger stores in flight -- the LDS-DMA pieces, which it cannot see,
-// are all OLDER than anything issued here); per-band operands (the fp32 residual, the saved pre-activation) are requested one band
-// ahead, in source order, so a band's loads travel under the previous band's arithmetic and stores.
 template <typename T, int EPI, int MI>
 __device__ __forceinline__ void epilogue_direct(const GemmP& p, f32x4 (&acc)[2][MI][4], int m_base, int n_base, int lane,
                                                 __amdgpu_buffer_rsrc_t rc, __amdgpu_buffer_rsrc_t rpre, __amdgpu_buffer_rsrc_t raux,
                                                 __amdgpu_buffer_rsrc_t rpart) {
     const int lr = lane & 15, lg = lane >> 4;
     constexpr int NB = 2 * MI;                                 // bands: b = half * MI + mi
-    constexpr int NL = (EPI == EOE_EPI_RESIDUAL) ? 4 : (EPI == EOE_EPI_GELU_BWD ? 2 : 0);      // asm loads per band
-    const unsigned esz = p.out_f32 ? 4u : 2u;
-    const unsigned asz = (EPI == EOE_EPI_RESIDUAL) ? 4u : 2u;
+    constexpr bool F32 = (EPI == EOE_EPI_RESIDUAL);            // RESIDUAL is fp32 in, fp32 out; GELU / GELU_BWD are 16-bit out
+    const bool f32 = F32 || (EPI == EOE_EPI_NONE && p.out_f32);
+    // column of value c (relative to the half's first column) and the start of run q: fp32 -> 4 runs of 4, 16-bit -> 2 runs of 8
+    auto col_of = [&](int c) -> int { return f32 ? (c >> 2) * 16 + lg * 4 + (c & 3) : (c >> 3) * 32 + lg * 8 + (c & 7); };
+    constexpr int NL = (EPI == EOE_EPI_RESIDUAL) ? 4 : (EPI == EOE_EPI_GELU_BWD ? 2 : 0);      // loads per band
     float bias[2][16];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const int n = n_base + h * 64 + lg * 16;
 #pragma unroll
         for (int c = 0; c < 16; ++c) bias[h][c] = 0.f;
-        if (p.bias && n < p.N) {
+        if (p.bias) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 bv = *(const f32x4*)(p.bias + n + q * 4);
+                const int n = n_base + h * 64 + col_of(q * 4);
+                if (n < p.N) {
+                    const f32x4 bv = *(const f32x4*)(p.bias + n);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) bias[h][q * 4 + r] = bv[r];
+                    for (int r = 0; r < 4; ++r) bias[h][q * 4 + r] = bv[r];
+                }
             }
         }
     }
-    auto band_off = [&](int b, unsigned ld, unsigned es) -> unsigned {
+    // byte offset of run q of the lane's values of band b in a matrix of leading dimension ld, element size es; rows / runs outside the
+    // matrix: the out-of-range offset (N % 16 == 0: a run of 4 or 8 columns is all in or all out).  Runs are 64 bytes apart in both
+    // layouts (fp32: 16 columns x 4 B; 16-bit: 32 columns x 2 B)
+    auto run_off = [&](int b, int q, unsigned ld, unsigned es) -> unsigned {
         const int h = b / MI, mi = b - h * MI;
-        const int m = m_base + mi * 16 + lr, n = n_base + h * 64 + lg * 16;
+        const int m = m_base + mi * 16 + lr, n = n_base + h * 64 + (f32 ? q * 16 + lg * 4 : q * 32 + lg * 8);
         return (m < p.M && n < p.N) ? (unsigned)(((size_t)m * ld + n) * es) : EOE_OOB;
     };
     u32x4 ld[2][NL > 0 ? NL : 1];
     auto issue_loads = [&](int b, int buf) {
-        const unsigned ao = band_off(b, (unsigned)p.ldaux, asz);
 #pragma unroll
-        for (int q = 0; q < NL; ++q) ld[buf][q] = __builtin_amdgcn_raw_buffer_load_b128(raux, (int)(ao + 16u * q), 0, 0);
+        for (int q = 0; q < NL; ++q)
+            ld[buf][q] = __builtin_amdgcn_raw_buffer_load_b128(raux, (int)run_off(b, q, (unsigned)p.ldaux, F32 ? 4u : 2u), 0, 0);
     };
     if (NL > 0) issue_loads(0, 0);
-    const int spb = (EPI == EOE_EPI_GELU) ? (p.aux_out ? 4 : 2) : (p.out_f32 ? 4 : 2);         // stores per band (wave-uniform)
     float cs[2][16];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -367,17 +386,17 @@ __device__ __forceinline__ void epilogue_direct(const GemmP& p, f32x4 (&acc)[2][
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int h = b / MI, mi = b - h * MI, buf = b & 1;
-        const int m = m_base + mi * 16 + lr, n = n_base + h * 64 + lg * 16;
-        const bool ok = m < p.M && n < p.N;
-        if (NL > 0) {
-            if (b + 1 < NB) issue_loads(b + 1, buf ^ 1);
-        }
+        const int m = m_base + mi * 16 + lr;
+        const bool row_ok = m < p.M;
+        if (NL > 0 && b + 1 < NB) issue_loads(b + 1, buf ^ 1);
         float v[16];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[ni * 4 + r] = acc[h][mi][ni][r] * p.alpha + bias[h][ni * 4 + r];
-        const unsigned off = ok ? (unsigned)(((size_t)m * p.ldc + n) * esz) : EOE_OOB;
+        unsigned off[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) off[q] = run_off(b, q, (unsigned)p.ldc, f32 ? 4u : 2u);      // (16-bit layout: runs 0 and 1 only)
         if (EPI == EOE_EPI_GELU) {
             float pr[16], ac[16];
             u32x4 pk[2];
@@ -387,13 +406,13 @@ __device__ __forceinline__ void epilogue_direct(const GemmP& p, f32x4 (&acc)[2][
                 unpack8<T>(pk[hh], pr + 8 * hh);               // activate its ROUNDED value
             }
             if (p.aux_out) {
-                store_b128(rpre, off, pk[0]);
-                store_b128(rpre, off + 16u, pk[1]);
+                store_b128(rpre, off[0], pk[0]);
+                store_b128(rpre, off[1], pk[1]);
             }
 #pragma unroll
             for (int c = 0; c < 16; ++c) ac[c] = quick_gelu_f(pr[c]);
-            store_b128(rc, off, pack8<T>(ac));
-            store_b128(rc, off + 16u, pack8<T>(ac + 8));
+            store_b128(rc, off[0], pack8<T>(ac));
+            store_b128(rc, off[1], pack8<T>(ac + 8));
             continue;
         }
         if (EPI == EOE_EPI_RESIDUAL) {
@@ -412,46 +431,47 @@ __device__ __forceinline__ void epilogue_direct(const GemmP& p, f32x4 (&acc)[2][
 #pragma unroll
             for (int c = 0; c < 16; ++c) v[c] *= quick_gelu_grad_f(pr[c]);
         }
-        if (ok) {
+        if (row_ok) {                                          // (columns outside N: their sums are never stored)
 #pragma unroll
             for (int c = 0; c < 16; ++c) cs[h][c] += v[c];
         }
-        if (p.out_f32) {
+        if (f32) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x4 o = {v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]};
-                if (p.accumulate) {                            // (not on the ViT path: compiler-issued load, waits for everything older)
-                    o += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rc, off + 16u * q, 0, 0));
-                }
-                store_b128(rc, off + 16u * q, __builtin_bit_cast(u32x4, o));
+                if (p.accumulate)                              // (not on the ViT path: the load waits for everything older)
+                    o += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rc, (int)off[q], 0, 0));
+                store_b128(rc, off[q], __builtin_bit_cast(u32x4, o));
             }
         } else {
-            store_b128(rc, off, pack8<T>(v));
-            store_b128(rc, off + 16u, pack8<T>(v + 8));
+            store_b128(rc, off[0], pack8<T>(v));
+            store_b128(rc, off[1], pack8<T>(v + 8));
         }
     }
     if (EPI != EOE_EPI_GELU && (p.colsum_part || p.colsum)) {
         // column sums of this wave's 16*MI rows: the 16 lanes lr = 0..15 of a column group are one DPP row -- xor-reduce in a fixed
-        // order, lane lr == 0 stores the group's 16 sums (one 64-byte piece of the wave's partial row; always 4 stores per lane and
-        // half, out-of-range for the other lanes)
+        // order, lane lr == 0 stores its runs of the wave's partial row (always 4 stores per lane and half, out-of-range for the other
+        // lanes; 16-bit layout: 2 runs of 8 columns = 2 x 32 B, fp32 layout: 4 runs of 4 = 4 x 16 B)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int n = n_base + h * 64 + lg * 16;
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
                 float t = cs[h][c];
                 t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
                 cs[h][c] = t;
             }
-            if (p.colsum_part) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n_base + h * 64 + col_of(q * 4);
                 const bool st_ok = lr == 0 && n < p.N && m_base < p.M;
-                const unsigned po = st_ok ? (unsigned)(eoe_part_index(n, m_base / (16 * MI), (p.M + 16 * MI - 1) / (16 * MI), p.N, p.colsum_blocked) * 4) : EOE_OOB;
+                const f32x4 t4 = {cs[h][q * 4], cs[h][q * 4 + 1], cs[h][q * 4 + 2], cs[h][q * 4 + 3]};
+                if (p.colsum_part) {
+                    const unsigned po = st_ok ? (unsigned)(eoe_part_index(n, m_base / (16 * MI), (p.M + 16 * MI - 1) / (16 * MI), p.N, p.colsum_blocked) * 4) : EOE_OOB;
+                    store_b128(rpart, po, __builtin_bit_cast(u32x4, t4));
+                } else if (st_ok) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    store_b128(rpart, po + 16u * q, __builtin_bit_cast(u32x4, (f32x4){cs[h][q * 4], cs[h][q * 4 + 1], cs[h][q * 4 + 2], cs[h][q * 4 + 3]}));
-            } else if (lr == 0 && n < p.N) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c) atomicAdd(p.colsum + n + c, cs[h][c]);
+                    for (int r = 0; r < 4; ++r) atomicAdd(p.colsum + n + r, t4[r]);
+                }
             }
         }
     }
@@ -461,10 +481,14 @@ __device__ __forceinline__ void epilogue_direct(const GemmP& p, f32x4 (&acc)[2][
 // that they do not occupy ~40 SGPRs across the k-loop (the loop otherwise carries SGPR spills and extra waits)
 __device__ __forceinline__ void load_epilogue_args(GemmP& ep, const GemmP& p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    // read through a CONSTANT-address-space pointer: scalar loads (s_load_dwordx16: SMEM, counted by lgkmcnt, a couple of hundred
+    // cycles).  Through a generic pointer (round 1-2: memcpy from `(const void*)kp`) the struct came back by per-lane vector loads,
+    // i.e. behind every LDS-DMA piece still in flight (vmcnt is in issue order): one to two thousand cycles at the top of every epilogue
+    typedef const __attribute__((address_space(4))) GemmP* kernarg_ptr;
     const __attribute__((address_space(4))) char* kp =
         (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(kp));
-    __builtin_memcpy(&ep, (const void*)kp, sizeof(GemmP));
+    ep = *(kernarg_ptr)kp;
 #else
     ep = p;
 #endif
