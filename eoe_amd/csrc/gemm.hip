@@ -28,6 +28,7 @@ extern int g_tn_flags;     // gemm_tn.hip
 extern int g_vit_side_stream;   // vit.cpp
 extern int g_attn_flags;        // attention.hip
 extern int g_tn256_launches;    // gemm_tn256.hip
+extern int g_parity_flags;      // parity.hip
 int eoe_launch_nt256(const void* gemm_p, int dtype, int epi, int mi, hipStream_t s);   // gemm256.hip
 
 namespace {
@@ -848,6 +849,7 @@ extern "C" int eoe_set_option(const char* name, int value) {
     if (name && !strcmp(name, "tn_flags")) { g_tn_flags = value; return 0; }
     if (name && !strcmp(name, "vit_side_stream")) { g_vit_side_stream = value; return 0; }
     if (name && !strcmp(name, "attn_flags")) { g_attn_flags = value; return 0; }
+    if (name && !strcmp(name, "parity_flags")) { g_parity_flags = value; return 0; }
     return eoe_set_error(EOE_ERR_ARG, "unknown option");
 }
 
@@ -858,5 +860,6 @@ extern "C" int eoe_get_option(const char* name, int* value) {
     if (!strcmp(name, "vit_side_stream")) { *value = g_vit_side_stream; return 0; }
     if (!strcmp(name, "attn_flags")) { *value = g_attn_flags; return 0; }
     if (!strcmp(name, "tn256_launches")) { *value = g_tn256_launches; return 0; }       // read-only diagnostics
+    if (!strcmp(name, "parity_flags")) { *value = g_parity_flags; return 0; }
     return eoe_set_error(EOE_ERR_ARG, "unknown option");
 }

@@ -15,6 +15,8 @@
 //           kernel sums in slab order (no atomics: bitwise reproducible)
 #include "common.h"
 
+int g_parity_flags = 0;      // option "parity_flags": bit 0 = the fp32 VALU kernels instead of the fp32 MFMA ones (A/B, tests)
+
 namespace {
 
 struct PGeo {
@@ -125,6 +127,360 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const float* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------ fp32 on the matrix cores (round 3)
+// The same three implicit GEMMs on v_mfma_f32_16x16x4_f32: fp32 operands in, fp32 accumulate, every product exact in fp32 and summed
+// in a fixed k order (gfx950 has no tf32 / xf32 path: this instruction runs at the fp32 vector rate, 64 flop/clk/SIMD = 157 TF peak --
+// 16x below the 16-bit MFMA but ~20x above the scalar-gather VALU kernel above, which spent its time in per-element index arithmetic).
+// 128 x BN x 16 tiles (BN = 128 or 64), four waves of 64 x BN/2, operands staged through a double-buffered k-major LDS image
+// (As[k][m], Bs[k][n]: a fragment read is 16 consecutive floats of one k row), ONE barrier per k-tile, the next k-tile's global loads
+// in flight under the current MFMAs.  Activations are fetched as float4 along their contiguous axis (NHWC channels: the k axis of
+// forward / dgrad, the m / n axis of wgrad) with one pixel decode per thread per kernel (forward / dgrad: a thread stages the same two
+// rows for every k-tile) or per k-tile (wgrad, multiply-shift divisions); the weights (small, L2-resident, OIHW) by scalar loads.
+//   requirements: forward C % 16 == 0 and an NHWC activation; dgrad cout % 16 == 0; wgrad C % 4 == 0 and cout % 4 == 0, NHWC.
+//   Anything else (the 3-channel NCHW stem with its fused Normalize) keeps the kernel above.
+// The N-side fragment is the MFMA's A operand, the M-side its B operand: lane (lr = lane & 15, lg = lane >> 4) then holds output row
+// m = lr and the 4 CONSECUTIVE columns n = 4*lg .. 4*lg + 3 of each 16 x 16 tile -- 16-byte stores along the contiguous axis.
+template <int MODE, int BN, int WV = 0>      // WV (wgrad variants): 0 = both sides float4, 1 = the x side element-wise (OIHW order), 2 = roles exchanged
+__global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ dy, const float* __restrict__ bias,
+                                                            float* __restrict__ out, PGeo g, int M, int N, int K, int k_per_slab,
+                                                            int accumulate, FDiv dHoWo, FDiv dWo, FDiv dHW, FDiv dW, FDiv dC,
+                                                            const float* __restrict__ mean = nullptr, const float* __restrict__ stdv = nullptr,
+                                                            FDiv dtaps = FDiv(1), FDiv dkw = FDiv(1)) {
+    constexpr bool b_oihw = (WV == 1), swap = (WV == 2);
+    constexpr int BM = 128, BK = 16, LDA = BM + 4, LDB = BN + 4, NI = BN / 32, NBV = BN / 16;
+    __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 15, lg = lane >> 4;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int k_lo = blockIdx.z * k_per_slab, k_hi = min(K, k_lo + k_per_slab);
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * (BN / 2);
+    const int taps = g.kh * g.kw;
+    f32x4 acc[4][NI];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- per-thread staging coordinates
+    // forward / dgrad: A = 128 rows x 16 k as 2 float4 per thread (row ar[i], k quad akq[i]); the row's pixel is decoded once
+    int a_img[2], a_y[2], a_x[2], a_r[2], a_kq[2];
+    bool a_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = t + 256 * i;
+        if (MODE == P_WGRAD) { a_r[i] = e >> 5; a_kq[i] = e & 31; a_ok[i] = true; a_img[i] = a_y[i] = a_x[i] = 0; continue; }     // (kk, m quad)
+        a_r[i] = e >> 2; a_kq[i] = e & 3;
+        const int m = m0 + a_r[i];
+        a_ok[i] = m < M;
+        unsigned img = 0, rem = 0, yy = 0, xx = 0;
+        if (a_ok[i]) {
+            if (MODE == P_FWD) { dHoWo.divmod((unsigned)m, img, rem); dWo.divmod(rem, yy, xx); }
+            else { dHW.divmod((unsigned)m, img, rem); dW.divmod(rem, yy, xx); }
+        }
+        a_img[i] = (int)img;
+        a_y[i] = MODE == P_FWD ? (int)yy * g.stride - g.pad : (int)yy + g.pad;
+        a_x[i] = MODE == P_FWD ? (int)xx * g.stride - g.pad : (int)xx + g.pad;
+    }
+    f32x4 ra[2];
+    float rb[NBV];
+    f32x4 rbv[2];
+    auto load_tile = [&](int k0) {
+        if (MODE == P_WGRAD) {
+            // k = output pixel.  A(m = co, k) = dy[k][co]: float4 along m.  B(n' = tap * C + ci, k) = x at the pixel's tap window: float4
+            // along ci.  `swap` (cout <= 64: the 128-row side would be half empty): the roles exchanged, C^T[n'][co] is computed
+            auto gather_x = [&](int k, int nn, int lim) -> f32x4 {
+                f32x4 vb = {0.f, 0.f, 0.f, 0.f};
+                if (nn >= lim) return vb;
+                unsigned img, rem, oy, ox;
+                dHoWo.divmod((unsigned)k, img, rem); dWo.divmod(rem, oy, ox);
+                if (b_oihw) {
+                    // a layer whose input the float4 fetch cannot serve (the NCHW image with its fused Normalize, C % 4 != 0): element by
+                    // element, n = (ci, ky, kx) in the weight's own order; the dy side stays float4
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        if (nn + jj >= lim) break;
+                        unsigned ci, tap, ky, kx;
+                        dtaps.divmod((unsigned)(nn + jj), ci, tap); dkw.divmod(tap, ky, kx);
+                        vb[jj] = load_x(x, mean, stdv, g, (int)img, (int)oy * g.stride - g.pad + (int)ky, (int)ox * g.stride - g.pad + (int)kx, (int)ci);
+                    }
+                    return vb;
+                }
+                unsigned tap, ci;
+                dC.divmod((unsigned)nn, tap, ci);
+                const int ky = (int)tap / g.kw, kx = (int)tap - ky * g.kw;
+                const int iy = (int)oy * g.stride - g.pad + ky, ix = (int)ox * g.stride - g.pad + kx;
+                if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
+                    vb = *(const f32x4*)(x + (((size_t)img * g.H + iy) * g.W + ix) * g.C + ci);
+                return vb;
+            };
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int kk = a_r[i], q4 = a_kq[i] * 4, k = k0 + kk;
+                f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+                if (k < k_hi) {
+                    if (!swap) {
+                        if (m0 + q4 < M) va = *(const f32x4*)(dy + (size_t)k * g.cout + m0 + q4);
+                        if (q4 < BN) vb = gather_x(k, n0 + q4, N);
+                    } else {
+                        va = gather_x(k, m0 + q4, M);
+                        if (q4 < BN && n0 + q4 < N) vb = *(const f32x4*)(dy + (size_t)k * g.cout + n0 + q4);
+                    }
+                }
+                ra[i] = va; rbv[i] = vb;
+            }
+            return;
+        }
+        const int tap = k0 / (MODE == P_FWD ? g.C : g.cout), c0 = k0 - tap * (MODE == P_FWD ? g.C : g.cout);
+        const int ky = tap / g.kw, kx = tap - ky * g.kw;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (a_ok[i]) {
+                if (MODE == P_FWD) {
+                    const int iy = a_y[i] + ky, ix = a_x[i] + kx;
+                    if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
+                        v = *(const f32x4*)(x + (((size_t)a_img[i] * g.H + iy) * g.W + ix) * g.C + c0 + a_kq[i] * 4);
+                } else {
+                    const int ny = a_y[i] - ky, nx = a_x[i] - kx;                       // (iy + pad - ky, ix + pad - kx)
+                    if (ny >= 0 && nx >= 0) {
+                        int oy = ny, ox = nx;
+                        bool okd = true;
+                        if (g.stride != 1) { oy = ny / g.stride; ox = nx / g.stride; okd = (oy * g.stride == ny) && (ox * g.stride == nx); }
+                        if (okd && oy < g.Ho && ox < g.Wo)
+                            v = *(const f32x4*)(dy + (((size_t)a_img[i] * g.Ho + oy) * g.Wo + ox) * g.cout + c0 + a_kq[i] * 4);
+                    }
+                }
+            }
+            ra[i] = v;
+        }
+        // weights: BN rows x 16 k scalars, NBV per thread; element (n, kk): forward w[n][c0+kk][ky][kx], dgrad w[c0+kk][n][ky][kx]
+#pragma unroll
+        for (int i = 0; i < NBV; ++i) {
+            const int e = t + 256 * i, kk = e & 15, r = e >> 4, nn = n0 + r;
+            float b = 0.f;
+            if (nn < N)
+                b = MODE == P_FWD ? w[(((size_t)nn * g.C + c0 + kk) * g.kh + ky) * g.kw + kx]
+                                  : w[(((size_t)(c0 + kk) * g.C + nn) * g.kh + ky) * g.kw + kx];
+            rb[i] = b;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        if (MODE == P_WGRAD) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                *(f32x4*)&As[buf][a_r[i]][a_kq[i] * 4] = ra[i];
+                if (a_kq[i] * 4 < BN) *(f32x4*)&Bs[buf][a_r[i]][a_kq[i] * 4] = rbv[i];
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) As[buf][a_kq[i] * 4 + j][a_r[i]] = ra[i][j];
+#pragma unroll
+        for (int i = 0; i < NBV; ++i) {
+            const int e = t + 256 * i;
+            Bs[buf][e & 15][e >> 4] = rb[i];
+        }
+    };
+
+    const int nkt = (k_hi - k_lo + BK - 1) / BK;
+    if (nkt > 0) {
+        load_tile(k_lo);
+        store_tile(0);
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nkt) load_tile(k_lo + (kt + 1) * BK);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                float am[4], bn[NI];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) am[i] = As[buf][ks * 4 + lg][wm0 + i * 16 + lr];
+#pragma unroll
+                for (int j = 0; j < NI; ++j) bn[j] = Bs[buf][ks * 4 + lg][wn0 + j * 16 + lr];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bn[j], am[i], acc[i][j], 0, 0, 0);
+            }
+            if (kt + 1 < nkt) store_tile(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    // ---- epilogue: lane holds row m = lr, columns 4*lg .. 4*lg+3 of each tile
+    float* dst = out + (MODE == P_WGRAD ? (size_t)blockIdx.z * M * N : 0);
+    const bool vec = (N & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm0 + i * 16 + lr;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int nn = n0 + wn0 + j * 16 + lg * 4;
+            if (nn >= N) continue;
+            f32x4 v = acc[i][j];
+            float* d = dst + (size_t)m * N + nn;
+            if (vec) {
+                if (MODE == P_FWD && bias) v += *(const f32x4*)(bias + nn);
+                if (MODE == P_DGRAD && accumulate) v += *(const f32x4*)d;
+                *(f32x4*)d = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (nn + r >= N) break;
+                    float s1 = v[r];
+                    if (MODE == P_FWD && bias) s1 += bias[nn + r];
+                    d[r] = (MODE == P_DGRAD && accumulate) ? d[r] + s1 : s1;
+                }
+            }
+        }
+    }
+}
+
+// The same tiles for the shapes the float4 fetches cannot serve -- the 3-channel NCHW image of the first layer with its fused
+// Normalize (ad_trainer.py:413-425), channel counts that are not multiples of 4 / 16: operands fetched element by element, but with the
+// index arithmetic hoisted -- a thread stages the same k column (forward: one (tap, channel) decode per k-tile; wgrad: one pixel decode)
+// and the same eight rows (decoded once per kernel) for the whole launch.  Forward: k = tap * C + c as above; wgrad: n = (ci, ky, kx) in
+// the weight's own OIHW order (no remap afterwards), k = output pixel.
+template <int MODE, int BN>
+__global__ __launch_bounds__(256) void conv_f32_mfma_scalar_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                                   const float* __restrict__ stdv, const float* __restrict__ w,
+                                                                   const float* __restrict__ dy, const float* __restrict__ bias,
+                                                                   float* __restrict__ out, PGeo g, int M, int N, int K, int k_per_slab,
+                                                                   FDiv dHoWo, FDiv dWo, FDiv dC, FDiv dkw, FDiv dtaps) {
+    constexpr int BM = 128, BK = 16, LDA = BM + 4, LDB = BN + 4, NI = BN / 32, NBV = BN / 16;
+    __shared__ float As[2][BK][LDA];
+    __shared__ float Bs[2][BK][LDB];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 15, lg = lane >> 4;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int k_lo = blockIdx.z * k_per_slab, k_hi = min(K, k_lo + k_per_slab);
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * (BN / 2);
+    const int kk = t & 15, r0 = t >> 4;                     // this thread's k column of every k-tile; its rows are r0 + 16 i
+    f32x4 acc[4][NI];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // forward: rows = output pixels (decoded once); wgrad: B rows = weight elements j = (ci, ky, kx) (decoded once)
+    int a_img[8], a_y[8], a_x[8];
+    int b_ci[NBV], b_ky[NBV], b_kx[NBV];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        a_img[i] = -1; a_y[i] = a_x[i] = 0;
+        if (MODE == P_FWD) {
+            const int m = m0 + r0 + 16 * i;
+            if (m < M) {
+                unsigned img, rem, oy, ox;
+                dHoWo.divmod((unsigned)m, img, rem); dWo.divmod(rem, oy, ox);
+                a_img[i] = (int)img; a_y[i] = (int)oy * g.stride - g.pad; a_x[i] = (int)ox * g.stride - g.pad;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NBV; ++i) {
+        b_ci[i] = -1; b_ky[i] = b_kx[i] = 0;
+        if (MODE == P_WGRAD) {
+            const int j = n0 + r0 + 16 * i;
+            if (j < N) {
+                unsigned ci, tap, ky, kx;
+                dtaps.divmod((unsigned)j, ci, tap); dkw.divmod(tap, ky, kx);
+                b_ci[i] = (int)ci; b_ky[i] = (int)ky; b_kx[i] = (int)kx;
+            }
+        }
+    }
+    float ra[8], rb[NBV];
+    auto load_tile = [&](int k0) {
+        const int k = k0 + kk;
+        const bool kok = k < k_hi;
+        if (MODE == P_FWD) {
+            unsigned tap = 0, c = 0, ky = 0, kx = 0;
+            if (kok) { dC.divmod((unsigned)k, tap, c); dkw.divmod(tap, ky, kx); }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                ra[i] = (kok && a_img[i] >= 0) ? load_x(x, mean, stdv, g, a_img[i], a_y[i] + (int)ky, a_x[i] + (int)kx, (int)c) : 0.f;
+#pragma unroll
+            for (int i = 0; i < NBV; ++i) {
+                const int nn = n0 + r0 + 16 * i;
+                rb[i] = (kok && nn < N) ? w[(((size_t)nn * g.C + c) * g.kh + ky) * g.kw + kx] : 0.f;
+            }
+        } else {
+            unsigned img = 0, rem = 0, oy = 0, ox = 0;
+            if (kok) { dHoWo.divmod((unsigned)k, img, rem); dWo.divmod(rem, oy, ox); }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int co = m0 + r0 + 16 * i;
+                ra[i] = (kok && co < M) ? dy[(size_t)k * g.cout + co] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < NBV; ++i)
+                rb[i] = (kok && b_ci[i] >= 0) ? load_x(x, mean, stdv, g, (int)img, (int)oy * g.stride - g.pad + b_ky[i],
+                                                       (int)ox * g.stride - g.pad + b_kx[i], b_ci[i]) : 0.f;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) As[buf][kk][r0 + 16 * i] = ra[i];
+#pragma unroll
+        for (int i = 0; i < NBV; ++i) Bs[buf][kk][r0 + 16 * i] = rb[i];
+    };
+    const int nkt = (k_hi - k_lo + BK - 1) / BK;
+    if (nkt > 0) {
+        load_tile(k_lo);
+        store_tile(0);
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nkt) load_tile(k_lo + (kt + 1) * BK);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                float am[4], bn[NI];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) am[i] = As[buf][ks * 4 + lg][wm0 + i * 16 + lr];
+#pragma unroll
+                for (int j = 0; j < NI; ++j) bn[j] = Bs[buf][ks * 4 + lg][wn0 + j * 16 + lr];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bn[j], am[i], acc[i][j], 0, 0, 0);
+            }
+            if (kt + 1 < nkt) store_tile(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    float* dst = out + (MODE == P_WGRAD ? (size_t)blockIdx.z * M * N : 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm0 + i * 16 + lr;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int nn = n0 + wn0 + j * 16 + lg * 4 + r;
+                if (nn >= N) continue;
+                float v = acc[i][j][r];
+                if (MODE == P_FWD && bias) v += bias[nn];
+                dst[(size_t)m * N + nn] = v;
+            }
+        }
+    }
+}
+
+// dw[co][ci][tap] = sum over slabs (in slab order) of the MFMA kernel's [co][tap * C + ci] partials
+__global__ __launch_bounds__(256) void slab_sum_remap_kernel(const float* __restrict__ slabs, float* __restrict__ out, int cout, int C,
+                                                             int taps, int S, int swapped) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x, count = (size_t)cout * C * taps;
+    if (e >= count) return;
+    const int co = (int)(e / ((size_t)C * taps)), r = (int)(e - (size_t)co * C * taps), ci = r / taps, tap = r - ci * taps;
+    // partials [co][tap * C + ci], or (swapped) [tap * C + ci][co]
+    const size_t src = swapped ? ((size_t)tap * C + ci) * cout + co : (size_t)co * C * taps + (size_t)tap * C + ci;
+    float s = 0.f;
+    for (int z = 0; z < S; ++z) s += slabs[(size_t)z * count + src];
+    out[e] = s;
+}
+
 // dw[e] = sum over slabs in slab order
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, float* __restrict__ out, size_t count, int S) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -134,7 +490,9 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
     out[e] = s;
 }
 
-// x fp32 -> (hi, lo) is not needed here: operands stay fp32.
+#define MFMA_DIVS(g)                                                                                                          \
+    const FDiv dHoWo((unsigned)((g).Ho * (g).Wo)), dWo((unsigned)(g).Wo), dHW((unsigned)((g).H * (g).W)), dW((unsigned)(g).W), \
+        dC((unsigned)(g).C)
 
 int fill_geo(const char* who, const eoe_conv_geometry* geo, int cout, int nchw, PGeo& g) {
     EOE_CHECK_ARG(geo && geo->n > 0 && geo->H > 0 && geo->W > 0 && geo->C > 0 && geo->kh > 0 && geo->kw > 0 && geo->stride > 0 &&
@@ -158,6 +516,24 @@ extern "C" int eoe_conv_f32_fwd(const float* x, int x_nchw, const float* mean, c
     EOE_TRY(fill_geo("conv_f32_fwd", geo, cout, x_nchw, g));
     const int M = g.n * g.Ho * g.Wo, N = cout, K = g.kh * g.kw * g.C;
     ProfScope ps("conv_f32_fwd", 2.0 * M * N * K, 4.0 * ((double)g.n * g.H * g.W * g.C + (double)N * K + (double)M * N), stream);
+    if (!x_nchw && !mean && (g.C % 16) == 0 && !(g_parity_flags & 1)) {            // fp32 MFMA (parity_flags bit 0: the VALU kernel, A/B)
+        MFMA_DIVS(g);
+        if (N <= 64) hipLaunchKernelGGL((conv_f32_mfma_kernel<P_FWD, 64>), dim3((N + 63) / 64, (M + 127) / 128, 1), dim3(256), 0, (hipStream_t)stream,
+                                        x, w, (const float*)nullptr, bias, y, g, M, N, K, K, 0, dHoWo, dWo, dHW, dW, dC);
+        else hipLaunchKernelGGL((conv_f32_mfma_kernel<P_FWD, 128>), dim3((N + 127) / 128, (M + 127) / 128, 1), dim3(256), 0, (hipStream_t)stream,
+                                x, w, (const float*)nullptr, bias, y, g, M, N, K, K, 0, dHoWo, dWo, dHW, dW, dC);
+        EOE_CHECK_LAUNCH("conv_f32_fwd (mfma)");
+        return 0;
+    }
+    if (!(g_parity_flags & 1)) {                    // fp32 MFMA, element-wise fetches (NCHW image + Normalize, odd channel counts)
+        const FDiv sHoWo((unsigned)(g.Ho * g.Wo)), sWo((unsigned)g.Wo), sC((unsigned)g.C), skw((unsigned)g.kw), staps((unsigned)(g.kh * g.kw));
+        if (N <= 64) hipLaunchKernelGGL((conv_f32_mfma_scalar_kernel<P_FWD, 64>), dim3((N + 63) / 64, (M + 127) / 128, 1), dim3(256), 0,
+                                        (hipStream_t)stream, x, mean, stdv, w, (const float*)nullptr, bias, y, g, M, N, K, K, sHoWo, sWo, sC, skw, staps);
+        else hipLaunchKernelGGL((conv_f32_mfma_scalar_kernel<P_FWD, 128>), dim3((N + 127) / 128, (M + 127) / 128, 1), dim3(256), 0,
+                                (hipStream_t)stream, x, mean, stdv, w, (const float*)nullptr, bias, y, g, M, N, K, K, sHoWo, sWo, sC, skw, staps);
+        EOE_CHECK_LAUNCH("conv_f32_fwd (mfma, scalar)");
+        return 0;
+    }
     hipLaunchKernelGGL((conv_f32_kernel<P_FWD>), dim3((N + 63) / 64, (M + 63) / 64, 1), dim3(256), 0, (hipStream_t)stream, x, mean, stdv,
                        w, (const float*)nullptr, bias, y, g, M, N, K, K, 0);
     EOE_CHECK_LAUNCH("conv_f32_fwd");
@@ -171,6 +547,15 @@ extern "C" int eoe_conv_f32_dgrad(const float* dy, const float* w, float* dx, co
     EOE_TRY(fill_geo("conv_f32_dgrad", geo, cout, 0, g));
     const int M = g.n * g.H * g.W, N = g.C, K = g.kh * g.kw * cout;
     ProfScope ps("conv_f32_dgrad", 2.0 * M * N * K, 4.0 * ((double)g.n * g.Ho * g.Wo * cout + (double)N * K + (double)M * N), stream);
+    if ((cout % 16) == 0 && !(g_parity_flags & 1)) {
+        MFMA_DIVS(g);
+        if (N <= 64) hipLaunchKernelGGL((conv_f32_mfma_kernel<P_DGRAD, 64>), dim3((N + 63) / 64, (M + 127) / 128, 1), dim3(256), 0, (hipStream_t)stream,
+                                        (const float*)nullptr, w, dy, (const float*)nullptr, dx, g, M, N, K, K, accumulate, dHoWo, dWo, dHW, dW, dC);
+        else hipLaunchKernelGGL((conv_f32_mfma_kernel<P_DGRAD, 128>), dim3((N + 127) / 128, (M + 127) / 128, 1), dim3(256), 0, (hipStream_t)stream,
+                                (const float*)nullptr, w, dy, (const float*)nullptr, dx, g, M, N, K, K, accumulate, dHoWo, dWo, dHW, dW, dC);
+        EOE_CHECK_LAUNCH("conv_f32_dgrad (mfma)");
+        return 0;
+    }
     hipLaunchKernelGGL((conv_f32_kernel<P_DGRAD>), dim3((N + 63) / 64, (M + 63) / 64, 1), dim3(256), 0, (hipStream_t)stream,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, w, dy, (const float*)nullptr, dx, g, M, N, K, K,
                        accumulate);
@@ -181,7 +566,11 @@ extern "C" int eoe_conv_f32_dgrad(const float* dy, const float* w, float* dx, co
 extern "C" size_t eoe_conv_f32_wgrad_workspace(const eoe_conv_geometry* geo, int cout) {
     if (!geo) return 0;
     const size_t count = (size_t)cout * geo->C * geo->kh * geo->kw;
-    return count * sizeof(float) * 64;             // at most 64 slabs
+    // at most 64 slabs; small weights (the first layers: few output tiles, millions of pixels to reduce over) up to 1024 within 16 MB
+    size_t slabs = 64;
+    if (count * sizeof(float) * slabs < (16u << 20)) slabs = (16u << 20) / (count * sizeof(float));
+    if (slabs > 1024) slabs = 1024;
+    return count * sizeof(float) * slabs;
 }
 
 extern "C" int eoe_conv_f32_wgrad(const float* x, int x_nchw, const float* mean, const float* stdv, const float* dy, float* dw,
@@ -191,6 +580,88 @@ extern "C" int eoe_conv_f32_wgrad(const float* x, int x_nchw, const float* mean,
     PGeo g;
     EOE_TRY(fill_geo("conv_f32_wgrad", geo, cout, x_nchw, g));
     const int M = cout, N = g.C * g.kh * g.kw, K = g.n * g.Ho * g.Wo;
+    if (!x_nchw && !mean && (g.C % 4) == 0 && (cout % 4) == 0 && !(g_parity_flags & 1)) {
+        // fp32 MFMA: partial sums [S][cout][tap * C + ci] over S pixel slabs, summed in slab order into the OIHW gradient.  cout <= 64:
+        // the roles of the two sides exchanged ([S][tap * C + ci][cout]: the 128-row side of the tile is the long one)
+        const int swap = (M <= 64 && N > 64) ? 1 : 0;
+        const int Mk = swap ? N : M, Nk = swap ? M : N;
+        const bool narrow = Nk <= 64;
+        const int tiles = ((Mk + 127) / 128) * (narrow ? (Nk + 63) / 64 : (Nk + 127) / 128);
+        int S = (1024 + tiles - 1) / tiles;
+        if (S > 64) S = 64;
+        int per = ((K + S - 1) / S + 15) / 16 * 16;
+        S = (K + per - 1) / per;
+        const size_t count = (size_t)M * N;
+        EOE_CHECK_ARG(workspace_bytes >= count * sizeof(float) * S, "conv_f32_wgrad: workspace of %zu bytes, need %zu", workspace_bytes,
+                      count * sizeof(float) * S);
+        ProfScope ps("conv_f32_wgrad", 2.0 * M * N * K, 4.0 * ((double)g.n * g.H * g.W * g.C + (double)K * M + (double)M * N), stream);
+        MFMA_DIVS(g);
+#define EOE_WG_LAUNCH(BNV, WVV)                                                                                                          \
+        hipLaunchKernelGGL((conv_f32_mfma_kernel<P_WGRAD, BNV, WVV>), dim3((Nk + BNV - 1) / BNV, (Mk + 127) / 128, S), dim3(256), 0,       \
+                           (hipStream_t)stream, x, (const float*)nullptr, dy, (const float*)nullptr, (float*)workspace, g, Mk, Nk, K, per, 0, \
+                           dHoWo, dWo, dHW, dW, dC)
+        if (swap) { if (narrow) EOE_WG_LAUNCH(64, 2); else EOE_WG_LAUNCH(128, 2); }
+        else { if (narrow) EOE_WG_LAUNCH(64, 0); else EOE_WG_LAUNCH(128, 0); }
+#undef EOE_WG_LAUNCH
+        EOE_CHECK_LAUNCH("conv_f32_wgrad (mfma)");
+        hipLaunchKernelGGL(slab_sum_remap_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)workspace, dw, cout, g.C, g.kh * g.kw, S, swap);
+        EOE_CHECK_LAUNCH("conv_f32_wgrad_sum");
+        return 0;
+    }
+    if (!(g_parity_flags & 1) && (cout % 4) == 0) {
+        // dy side float4, x side element by element in OIHW order (the stem: NCHW image + Normalize, 3 channels)
+        const bool narrow = N <= 64;
+        const int tiles = ((M + 127) / 128) * (narrow ? (N + 63) / 64 : (N + 127) / 128);
+        const size_t count = (size_t)M * N;
+        const int s_max = (int)(workspace_bytes / (count * sizeof(float)));
+        int S = (2048 + tiles - 1) / tiles;
+        if (S > s_max) S = s_max;
+        if (S > 1024) S = 1024;
+        if (S < 1) S = 1;
+        int per = ((K + S - 1) / S + 15) / 16 * 16;
+        S = (K + per - 1) / per;
+        EOE_CHECK_ARG(workspace_bytes >= count * sizeof(float) * S, "conv_f32_wgrad: workspace of %zu bytes, need %zu", workspace_bytes,
+                      count * sizeof(float) * S);
+        ProfScope ps("conv_f32_wgrad", 2.0 * M * N * K, 4.0 * ((double)g.n * g.H * g.W * g.C + (double)K * M + (double)M * N), stream);
+        MFMA_DIVS(g);
+        const FDiv staps((unsigned)(g.kh * g.kw)), skw((unsigned)g.kw);
+        if (narrow) hipLaunchKernelGGL((conv_f32_mfma_kernel<P_WGRAD, 64, 1>), dim3((N + 63) / 64, (M + 127) / 128, S), dim3(256), 0, (hipStream_t)stream,
+                                       x, (const float*)nullptr, dy, (const float*)nullptr, (float*)workspace, g, M, N, K, per, 0, dHoWo, dWo, dHW, dW, dC,
+                                       mean, stdv, staps, skw);
+        else hipLaunchKernelGGL((conv_f32_mfma_kernel<P_WGRAD, 128, 1>), dim3((N + 127) / 128, (M + 127) / 128, S), dim3(256), 0, (hipStream_t)stream,
+                                x, (const float*)nullptr, dy, (const float*)nullptr, (float*)workspace, g, M, N, K, per, 0, dHoWo, dWo, dHW, dW, dC,
+                                mean, stdv, staps, skw);
+        EOE_CHECK_LAUNCH("conv_f32_wgrad (mfma, dy float4)");
+        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dw,
+                           count, S);
+        EOE_CHECK_LAUNCH("conv_f32_wgrad_sum");
+        return 0;
+    }
+    if (!(g_parity_flags & 1)) {
+        const bool narrow = N <= 64;
+        const int tiles = ((M + 127) / 128) * (narrow ? (N + 63) / 64 : (N + 127) / 128);
+        int S = (1024 + tiles - 1) / tiles;
+        if (S > 64) S = 64;
+        int per = ((K + S - 1) / S + 15) / 16 * 16;
+        S = (K + per - 1) / per;
+        const size_t count = (size_t)M * N;
+        EOE_CHECK_ARG(workspace_bytes >= count * sizeof(float) * S, "conv_f32_wgrad: workspace of %zu bytes, need %zu", workspace_bytes,
+                      count * sizeof(float) * S);
+        ProfScope ps("conv_f32_wgrad", 2.0 * M * N * K, 4.0 * ((double)g.n * g.H * g.W * g.C + (double)K * M + (double)M * N), stream);
+        const FDiv sHoWo((unsigned)(g.Ho * g.Wo)), sWo((unsigned)g.Wo), sC((unsigned)g.C), skw((unsigned)g.kw), staps((unsigned)(g.kh * g.kw));
+        if (narrow) hipLaunchKernelGGL((conv_f32_mfma_scalar_kernel<P_WGRAD, 64>), dim3((N + 63) / 64, (M + 127) / 128, S), dim3(256), 0,
+                                       (hipStream_t)stream, x, mean, stdv, (const float*)nullptr, dy, (const float*)nullptr, (float*)workspace, g,
+                                       M, N, K, per, sHoWo, sWo, sC, skw, staps);
+        else hipLaunchKernelGGL((conv_f32_mfma_scalar_kernel<P_WGRAD, 128>), dim3((N + 127) / 128, (M + 127) / 128, S), dim3(256), 0,
+                                (hipStream_t)stream, x, mean, stdv, (const float*)nullptr, dy, (const float*)nullptr, (float*)workspace, g,
+                                M, N, K, per, sHoWo, sWo, sC, skw, staps);
+        EOE_CHECK_LAUNCH("conv_f32_wgrad (mfma, scalar)");
+        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dw,
+                           count, S);
+        EOE_CHECK_LAUNCH("conv_f32_wgrad_sum");
+        return 0;
+    }
     const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
     int S = (1024 + tiles - 1) / tiles;            // about four workgroups per CU
     if (S > 64) S = 64;

@@ -73,14 +73,28 @@ def _fmt(a):
 
 @pytest.mark.parametrize("name,n,cin,cout,H,k,stride,pad,nchw", [
     ("5x5", 3, 32, 64, 16, 5, 1, 2, False), ("3x3s2", 2, 64, 128, 14, 3, 2, 1, False), ("1x1s2", 2, 64, 128, 14, 1, 2, 0, False),
-    ("stem7x7s2", 2, 3, 64, 38, 7, 2, 3, True), ("ragged", 1, 5, 7, 9, 3, 1, 1, False), ("linear", 70, 100, 130, 1, 1, 1, 0, False)])
-def test_conv_f32_kernels_vs_fp64(name, n, cin, cout, H, k, stride, pad, nchw):
+    ("stem7x7s2", 2, 3, 64, 38, 7, 2, 3, True), ("ragged", 1, 5, 7, 9, 3, 1, 1, False), ("linear", 70, 100, 130, 1, 1, 1, 0, False),
+    # shapes of the fp32 MFMA kernels (round 3): C % 16 == 0 forward, cout % 16 == 0 dgrad, C / cout % 4 == 0 wgrad; narrow (cout <= 64)
+    # and wide tiles, M tails, stride 2, the 1 x 1 "linear" form, a wide layer
+    ("c32to32", 5, 32, 32, 9, 5, 1, 2, False), ("c64to256s2", 3, 64, 256, 13, 3, 2, 1, False), ("c128to128", 2, 128, 128, 11, 3, 1, 1, False),
+    ("fc2048", 200, 2048, 512, 1, 1, 1, 0, False), ("fc512to256", 256, 512, 256, 1, 1, 1, 0, False), ("c16to20", 2, 16, 20, 7, 3, 1, 1, False)])
+@pytest.mark.parametrize("kernels", ["mfma", "valu"])
+def test_conv_f32_kernels_vs_fp64(name, n, cin, cout, H, k, stride, pad, nchw, kernels):
     """the parity-mode fp32 convolution kernels (forward incl. fused Normalize on an NCHW image, dgrad incl. accumulate, wgrad)
-    against torch-CPU fp64 on the same fp32 inputs: fp32-summation-order accuracy, i.e. ~1e-6 relative"""
+    against torch-CPU fp64 on the same fp32 inputs: fp32-summation-order accuracy, i.e. ~1e-6 relative.  `mfma`: the fp32 matrix-core
+    kernels wherever the shape allows (v_mfma_f32_16x16x4_f32: exact fp32 products, fixed k order); `valu`: the vector-ALU kernels"""
     import torch.nn.functional as F
-    from eoe_amd import ops
+    from eoe_amd import ops, _lib
     from eoe_amd._lib import lib, check
     from gpu_util import f32
+    old_flags = _lib.set_option("parity_flags", 0 if kernels == "mfma" else 1)
+    try:
+        _conv_f32_case(name, n, cin, cout, H, k, stride, pad, nchw, F, ops, lib, check, f32)
+    finally:
+        _lib.set_option("parity_flags", old_flags)
+
+
+def _conv_f32_case(name, n, cin, cout, H, k, stride, pad, nchw, F, ops, lib, check, f32):
     W = H
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     x, xr = f32(f"p/{name}/x", (n, cin, H, W) if nchw else (n, H, W, cin), 1.0)
