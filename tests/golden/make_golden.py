@@ -656,6 +656,21 @@ def g3bigfrozen():
     save("g3_vit_l12_hsc_frozen_big", losses=losses, scores=scores, **first)
 
 
+def g3bigfrozenlr():
+    """config 4 again with a head learning rate at which the ranking means something: with lr 1e-4 the head hardly moves in ten steps,
+    every score stays within 1e-5 of 1 and the single-batch AUC ranks float32 ulps.  Adam at lr 1e-2 for K = 80 steps pulls the normal
+    half towards the centre (scores spread over (0, 1)); same frozen encoder, the batches b0 .. b79 with the OE half shifted by 3 x the fixed pattern (shift 0.5 leaves the random-weight encoder's
+    AUC at 0.5: both halves interleave and any rounding swaps dozens of pairs)"""
+    m = RefClipNet(12, freeze=True)
+    omodels.deterministic_init(m, tag="vit", layers=12)
+
+    def gen():
+        for i in range(80):
+            yield otrainer.synthetic_batch(f"g3big/b{i}", 128, 128, 224, shift=3.0)
+    losses, scores, first = run_trajectory(m, gen(), "hsc", lr=1e-2, wd=1e-3, freeze=True)
+    save("g3_vit_l12_hsc_frozen_lr", losses=losses, scores=scores, **first)
+
+
 def g3bigbce():
     """BASELINE config 5 ("CLIP ViT-B/32 full fine-tune, BCE"): the 12-layer ViT with the 1-logit head (clf=True) and the BCE objective,
     K = 10 steps at the benchmark batch, same batches as g3big"""
@@ -668,6 +683,6 @@ def g3bigbce():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12",
-                             "g2big", "g11big", "g5big", "g5full", "g3big", "g3long", "g3bigfrozen", "g3bigbce", "g13", "g14", "g15"]
+                             "g2big", "g11big", "g5big", "g5full", "g3big", "g3long", "g3bigfrozen", "g3bigfrozenlr", "g3bigbce", "g13", "g14", "g15"]
     for w in which:
         globals()[w]()
