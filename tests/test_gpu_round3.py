@@ -111,7 +111,8 @@ def test_trainer_halves_an_overflowing_scale(monkeypatch):
     torch.manual_seed(3)
     ds = SyntheticAD(n_train_normal=64, n_oe=64, n_test=32, res=32, shift=1.0, seed=2)
     m0 = CNN32(bias=True)
-    tr = TRAINER["hsc"](copy.deepcopy(m0), dataset=ds, epochs=8, lr=1e-3, wdk=0.0, milestones=[], batch_size=16, classes=["only"])
+    tr = TRAINER["hsc"](copy.deepcopy(m0), dataset=ds, epochs=8, lr=1e-3, wdk=0.0, milestones=[], batch_size=16, classes=["only"],
+                        exact_bn=False)                      # the 16-bit path is the one that can overflow
     tr.SCALE_POLL_EVERY = 1
     model, roc = tr.train_cls(copy.deepcopy(m0), ds, 0, "only", 0)
     assert len(tr.scale_events) >= 4, tr.scale_events                 # several halvings
@@ -236,3 +237,31 @@ def test_class_seed_loop_over_a_labelled_set(ad_mode):
     print(f"[{ad_mode}] worst |score - oracle| {worst_score:.2e}, worst |AUC - oracle| {worst_auc:.2e}, mean AUC {res['mean_auc']:.4f}")
     assert worst_score < 1e-3
     assert 0.0 <= res["mean_auc"] <= 1.0
+
+
+def test_batchnorm_encoders_train_in_exact_fp32_by_default():
+    """`ADTrainer(exact_bn="auto")`: a BatchNorm encoder at lr >= 1e-3 is trained and scored with the exact-fp32 matrix-core convolutions
+    (the mode that holds the trajectory bar), the ViT and small-lr runs keep the 16-bit path; the process-wide switch is restored"""
+    import eoe_amd
+    from eoe_amd import ops
+    from eoe_amd.data import SyntheticAD
+    from eoe_amd.models import CNN32
+    from eoe_amd.training import TRAINER
+    seen = []
+
+    class Spy(TRAINER["hsc"]):
+        def loss(self, *a, **k):
+            seen.append(ops.parity_mode())
+            return super().loss(*a, **k)
+
+        def compute_anomaly_score(self, *a, **k):
+            seen.append(ops.parity_mode())
+            return super().compute_anomaly_score(*a, **k)
+    ds = SyntheticAD(n_train_normal=16, n_oe=16, n_test=16, res=32, shift=1.0, seed=2)
+    for lr, exact, want in ((1e-3, "auto", True), (1e-4, "auto", False), (1e-3, False, False), (1e-4, True, True)):
+        seen.clear()
+        tr = Spy(CNN32(bias=True), dataset=ds, epochs=1, lr=lr, wdk=0.0, milestones=[], batch_size=16, classes=["only"], exact_bn=exact)
+        model, _ = tr.train_cls(copy.deepcopy(tr.model), ds, 0, "only", 0)
+        tr.eval_cls(model, ds, 0, "only", 0)
+        assert seen and all(s == want for s in seen), (lr, exact, seen)
+        assert ops.parity_mode() is False

@@ -134,7 +134,7 @@ def test_trainer_graph_steps_equals_eager(objective):
         torch.manual_seed(5)                                 # same data and loader shuffles in both runs
         ds = SyntheticAD(n_train_normal=40, n_oe=16, n_test=32, res=32, shift=1.0, seed=2, normalize=([0.1, 0.0, -0.1], [1.0, 2.0, 0.5]))
         tr = TRAINER[objective](copy.deepcopy(m0), dataset=ds, epochs=2, lr=1e-3, wdk=0.0, milestones=[], batch_size=16,
-                                classes=["only"], graph_steps=graph)
+                                classes=["only"], graph_steps=graph, exact_bn=False)        # (the 16-bit path: bitwise replay is its property)
         model, roc = tr.train_cls(copy.deepcopy(m0), ds, 0, "only", 0)
         out[graph] = (list(tr.last_losses), roc.auc)
     (le, ae), (lg, ag) = out[False], out[True]
