@@ -407,7 +407,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // its ~14 k issue cycles per wave sit inside ~55 k cycles of exposed global / LDS / store latency.  Here the same seven products are
 // split by 16-row slabs: wave w owns queries 16w..16w+15 in phase A (S^T, dP^T columns of its queries, all keys -> row statistics, dS^T,
 // dQ) and keys 16w..16w+15 in phase B (S, dP rows of all queries x its keys -> dV, dK), the three LDS images are shared, the row
-// statistics cross between the phases behind one workgroup barrier.  A wave holds a quarter of the accumulators (<= 128 registers),
+// statistics cross between the phases behind one workgroup barrier.  (Round 3, measured and rejected: the dQ / dK / dV slabs through a
+// per-wave [16][64] LDS tile so that every global store is a 16-byte piece of a whole 128-byte row segment instead of 8 bytes per lane --
+// 48 -> 37.5 us stand-alone without the bias sums, but 9 KB more LDS per workgroup (5 -> 4 workgroups per CU) and in the training step
+// the kernel went from 51-53 to 55.7 us per layer: its time is latency covered by occupancy, not store issue.)  A wave holds a quarter of the accumulators (<= 128 registers),
 // so 4 workgroups = 16 waves fit a CU and one workgroup's load / store latency is another's issue time.  Same arithmetic per element
 // as the one-wave kernel (same products, same k order); only the bias column sums associate differently (per-wave partials summed in
 // wave order).
@@ -439,11 +442,7 @@ __device__ __forceinline__ f32x4 slab_sum(const f32x4& o, bool valid) {
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd4_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, T* __restrict__ dqkv,
                                                         float* __restrict__ bias_part, int L, int heads, float scale) {
-    // + per wave a [16 rows][64 columns] 16-bit staging tile (144-byte pitch): the wave's dQ / dK / dV slab goes through it so that the
-    // global stores are whole 128-byte row segments, 16 B per lane (round 3: the accumulator layout gave 8-byte stores, 32 B per row
-    // and instruction -- 12 store instructions per wave at 0.5-0.7 of the 16-byte rate)
-    constexpr int OSTB = 16 * 144;
-    __shared__ __attribute__((aligned(16))) char smem[3 * TILEB + 2 * 64 * 4 + 4 * 192 * 4 + 4 * OSTB];
+    __shared__ __attribute__((aligned(16))) char smem[3 * TILEB + 2 * 64 * 4 + 4 * 192 * 4];
     char* qs = smem;
     char* ks_ = smem + TILEB;
     char* dos = smem + 2 * TILEB;
@@ -465,17 +464,6 @@ __global__ __launch_bounds__(256) void attn_bwd4_kernel(const T* __restrict__ qk
     const size_t bseg = (size_t)heads * n_img * 64;
     const int mine = 16 * w + lr;                             // this lane's query (phase A) / key (phase B)
     float* myred = red + w * 192;
-    char* ost = smem + 3 * TILEB + 2 * 64 * 4 + 4 * 192 * 4 + w * OSTB;
-    // write the wave's 16 x 64 slab (tile columns 16 td + 4 lg of row lr) to the staging tile / flush it as 2 x (8 rows x 128 B)
-    auto ost_put = [&](int td, const f32x4& o) { *(u32x2*)(ost + lr * 144 + (16 * td + 4 * lg) * 2) = pack4<T>(o[0], o[1], o[2], o[3]); };
-    auto ost_flush = [&](T* dst /* column base of the slab's first row */) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = (lane >> 3) + 8 * i, ch = lane & 7;
-            const u32x4 v = *(const u32x4*)(ost + row * 144 + ch * 16);
-            if (16 * w + row < L) *(u32x4*)(dst + (size_t)(16 * w + row) * ld + ch * 8) = v;
-        }
-    };
 
     // V only ever is a row-major MFMA operand: fragments straight from global memory (phase A: all keys; phase B: this wave's keys)
     V8<T> vfr[2][4], vfw[2];
@@ -554,13 +542,12 @@ __global__ __launch_bounds__(256) void attn_bwd4_kernel(const T* __restrict__ qk
 #pragma unroll
             for (int st = 0; st < 2; ++st)
                 o = T16<T>::mfma16(tfrag<T>(ks_, td, st, lane), acc_as_operand<T>(dp[2 * st], dp[2 * st + 1]), o);
-            ost_put(td, o);
+            if (mine < L) *(u32x2*)(dqp + (size_t)mine * ld + 16 * td + 4 * lg) = pack4<T>(o[0], o[1], o[2], o[3]);
             if (bpart) {
                 const f32x4 cs = slab_sum(o, mine < L);
                 if (lr == 0) *(f32x4*)(myred + 16 * td + 4 * lg) = cs;
             }
         }
-        ost_flush(dqp);
     }
     __syncthreads();
 
@@ -594,7 +581,6 @@ __global__ __launch_bounds__(256) void attn_bwd4_kernel(const T* __restrict__ qk
             }
         }
         // dV^T[d][key] = sum_q dO^T[d][q] P[q][key] ;  dK^T[d][key] = sum_q Q^T[d][q] dS[q][key]
-        f32x4 okk[4];
 #pragma unroll
         for (int td = 0; td < 4; ++td) {
             f32x4 ov = {0.f, 0.f, 0.f, 0.f}, ok = {0.f, 0.f, 0.f, 0.f};
@@ -603,8 +589,10 @@ __global__ __launch_bounds__(256) void attn_bwd4_kernel(const T* __restrict__ qk
                 ov = T16<T>::mfma16(tfrag<T>(dos, td, st, lane), acc_as_operand<T>(s[2 * st], s[2 * st + 1]), ov);
                 ok = T16<T>::mfma16(tfrag<T>(qs, td, st, lane), acc_as_operand<T>(dp[2 * st], dp[2 * st + 1]), ok);
             }
-            ost_put(td, ov);                                  // dV through the staging tile now, dK kept for a second pass
-            okk[td] = ok;
+            if (mine < L) {
+                *(u32x2*)(dqp + (size_t)mine * ld + 2 * D + 16 * td + 4 * lg) = pack4<T>(ov[0], ov[1], ov[2], ov[3]);
+                *(u32x2*)(dqp + (size_t)mine * ld + D + 16 * td + 4 * lg) = pack4<T>(ok[0], ok[1], ok[2], ok[3]);
+            }
             if (bpart) {
                 const f32x4 cv = slab_sum(ov, mine < L), ck = slab_sum(ok, mine < L);
                 if (lr == 0) {
@@ -613,10 +601,6 @@ __global__ __launch_bounds__(256) void attn_bwd4_kernel(const T* __restrict__ qk
                 }
             }
         }
-        ost_flush(dqp + 2 * D);
-#pragma unroll
-        for (int td = 0; td < 4; ++td) ost_put(td, okk[td]);
-        ost_flush(dqp + D);
     }
     if (bpart) {
         __syncthreads();

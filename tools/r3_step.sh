@@ -1,0 +1,6 @@
+cd /root/repo
+O=gpurun_out/r3; mkdir -p $O
+for f in "" "--tn-flags 4" "--nt-flags 513"; do
+timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-torch-baseline $f > $O/b.json 2> $O/b.err && python -c "
+import json;d=json.load(open('$O/b.json'));k=d['roofline']['kernels_ms_per_step'];print('$f', d['value'],d['ms_per_step'],'tn',k['gemm_tn'],'nt',k['gemm_nt'],'lnb',k['layernorm_bwd'],'attn_bwd',k['attn_bwd'], 'sum', d['roofline']['profiled_ms_per_step'])"
+done
