@@ -18,6 +18,7 @@ EOE_RESIZE_BILINEAR, EOE_RESIZE_BICUBIC = 2, 3
 EOE_COMM_I64, EOE_COMM_ID_BYTES, EOE_COMM_ALGO_RING, EOE_COMM_ALGO_RS_AG = 8, 128, 0, 1
 EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_GELU_BWD = 0, 1, 2, 3
 ADAM_CHUNK, ADAM_GROUPS = 8192, 4
+CHUNK_FP16 = 0x100                 # eoe_adam_chunk.group flag (EOE_CHUNK_FP16): fp16-weights update in eoe_sgd_multi
 
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
@@ -155,8 +156,8 @@ SIGNATURES = {
                             C.c_int, C.c_int, _f32, C.c_int, _vp],
     "eoe_bn_act_maxpool_fwd": [_vp] * 7 + [C.c_int] * 7 + [_f32, C.c_int, _vp],
     "eoe_bn_act_maxpool_bwd": [_vp] * 10 + [C.c_int] * 8 + [_f32, C.c_int, _vp],
-    "eoe_conv_f32_fwd": [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.POINTER(ConvGeometry), C.c_int, _vp],
-    "eoe_conv_f32_dgrad": [_vp, _vp, _vp, C.POINTER(ConvGeometry), C.c_int, C.c_int, _vp],
+    "eoe_conv_f32_fwd": [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.POINTER(ConvGeometry), C.c_int, _vp, C.c_size_t, _vp],
+    "eoe_conv_f32_dgrad": [_vp, _vp, _vp, C.POINTER(ConvGeometry), C.c_int, C.c_int, _vp, C.c_size_t, _vp],
     "eoe_conv_f32_wgrad_workspace": [C.POINTER(ConvGeometry), C.c_int],
     "eoe_conv_f32_wgrad": [_vp, C.c_int, _vp, _vp, _vp, _vp, C.POINTER(ConvGeometry), C.c_int, _vp, _sz, _vp],
     "eoe_maxpool_fwd": [_vp, _vp, _vp, _vp] + [C.c_int] * 8 + [_vp],

@@ -967,6 +967,17 @@ __global__ __launch_bounds__(256) void linear_small_dw_kernel(const float* __res
 // fused multi-tensor SGD with momentum / Nesterov (torch.optim.SGD, dampening 0; ad_trainer.py:380-381): g += wd * p;
 // buf = momentum * buf + g (buf starts at 0, which reproduces torch's "first step: buf = g"); p -= lr * (nesterov ? g + momentum * buf : buf).
 // Same chunk tables as the Adam kernel (m_off = the momentum buffer, v_off unused).
+// Chunks flagged EOE_CHUNK_FP16 (the "fp16-weights mode", clip/model.py:371-392 convert_weights: CLIP's convolution / linear / attention /
+// projection parameters are fp16 tensors on a GPU and torch.optim.SGD updates them in fp16): the fp32 storage holds fp16-representable
+// values and every elementwise op of torch's update rounds its result to fp16, op by op as torch's kernels do (fp32 arithmetic inside an
+// op, one rounding at its end): g = r(g + wd p); buf = r(momentum buf); buf = r(buf + g); g = r(g + momentum buf); p = r(p - lr g).
+// round an fp32 op result to fp16 (nearest even), as torch stores the result of an op on half tensors.  The empty asm keeps the fp32 value
+// materialised: without it the compiler folds fma + conversion into v_fma_mixlo_f16 -- ONE rounding from the exact sum, where torch's
+// kernels round to fp32 first (a sum that lands on an fp16 tie in fp32 then goes to even: 1.2 % of the elements differed per step)
+__device__ __forceinline__ float r16(float x) {
+    asm volatile("" : "+v"(x));
+    return (float)(_Float16)x;
+}
 __global__ __launch_bounds__(256) void sgd_multi_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
                                                         const eoe_adam_chunk* __restrict__ chunks, float lr, float momentum, float wd,
                                                         int nesterov, float grad_scale_inv, const int* __restrict__ skip) {
@@ -975,6 +986,22 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(float* __restrict__ p, c
     float* pp = p + ck.p_off;
     const float* gg = g + ck.g_off;
     float* bb = buf + ck.m_off;
+    if (ck.group & EOE_CHUNK_FP16) {
+        for (int i = threadIdx.x; i < ck.n; i += blockDim.x) {
+            const float pv = pp[i];
+            float gv = r16(gg[i] * grad_scale_inv);                                  // the fp16 gradient autograd hands torch's optimiser
+            if (wd != 0.f) gv = r16(__fmaf_rn(wd, pv, gv));                          // grad.add(param, alpha=wd): a + alpha * b in fp32, contracted
+            float step = gv;
+            if (momentum != 0.f) {
+                float bv = r16(__fmul_rn(bb[i], momentum));                          // buf.mul_(momentum)
+                bv = r16(__fadd_rn(bv, gv));                                         // buf.add_(grad, alpha=1 - dampening)
+                bb[i] = bv;
+                step = nesterov ? r16(__fmaf_rn(momentum, bv, gv)) : bv;             // grad.add(buf, alpha=momentum)
+            }
+            pp[i] = r16(__fmaf_rn(-lr, step, pv));                                   // param.add_(grad, alpha=-lr)
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < ck.n; i += blockDim.x) {
         const float pv = pp[i];
         float gv = gg[i] * grad_scale_inv;

@@ -140,20 +140,39 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const float* __restrict__
 //   Anything else (the 3-channel NCHW stem with its fused Normalize) keeps the kernel above.
 // The N-side fragment is the MFMA's A operand, the M-side its B operand: lane (lr = lane & 15, lg = lane >> 4) then holds output row
 // m = lr and the 4 CONSECUTIVE columns n = 4*lg .. 4*lg + 3 of each 16 x 16 tile -- 16-byte stores along the contiguous axis.
-template <int MODE, int BN, int WV = 0>      // WV (wgrad variants): 0 = both sides float4, 1 = the x side element-wise (OIHW order), 2 = roles exchanged
+// S2 (dgrad of a stride-2 convolution over an even map): an input pixel (iy, ix) only meets the taps with ky = iy + pad, kx = ix + pad
+// (mod 2); gathering all kh x kw taps for every pixel runs 4x the useful MFMAs on zeros (measured: 15-20 TF against 66-76 TF for the
+// stride-1 layers).  Instead the four parity classes (iy & 1, ix & 1) are four GEMMs over a quarter of the pixels each, with the class's
+// own tap list (3x3, pad 1: 1 / 2 / 2 / 4 taps; 1x1: one class has the tap, three write zeros) -- blockIdx.z = class * nslab + slab.  The
+// valid taps come in the same (ky, kx, channel) order as before: bitwise the same sums.
+// Split k (forward / dgrad with few output tiles and a long reduction: the small maps of the 32 x 32 WideResNet, the FC layers): nslab > 1
+// slabs of the reduction write partial outputs [slab][rows][N] (`out` = the workspace), summed in slab order by slab_sum_out_kernel.
+template <int MODE, int BN, int WV = 0, bool S2 = false>      // WV (wgrad variants): 0 = both sides float4, 1 = the x side element-wise (OIHW order), 2 = roles exchanged
 __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ dy, const float* __restrict__ bias,
                                                             float* __restrict__ out, PGeo g, int M, int N, int K, int k_per_slab,
                                                             int accumulate, FDiv dHoWo, FDiv dWo, FDiv dHW, FDiv dW, FDiv dC,
                                                             const float* __restrict__ mean = nullptr, const float* __restrict__ stdv = nullptr,
-                                                            FDiv dtaps = FDiv(1), FDiv dkw = FDiv(1)) {
+                                                            FDiv dtaps = FDiv(1), FDiv dkw = FDiv(1), int nslab = 1) {
     constexpr bool b_oihw = (WV == 1), swap = (WV == 2);
     constexpr int BM = 128, BK = 16, LDA = BM + 4, LDB = BN + 4, NI = BN / 32, NBV = BN / 16;
     __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 15, lg = lane >> 4;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int k_lo = blockIdx.z * k_per_slab, k_hi = min(K, k_lo + k_per_slab);
+    int slab = (int)blockIdx.z;
+    int s2_py = 0, s2_px = 0, s2_ky0 = 0, s2_kx0 = 0, s2_ntx = 1;
+    if (S2) {
+        const int cls = (int)blockIdx.z / nslab;
+        slab = (int)blockIdx.z - cls * nslab;
+        s2_py = cls >> 1; s2_px = cls & 1;
+        s2_ky0 = (s2_py + g.pad) & 1; s2_kx0 = (s2_px + g.pad) & 1;
+        const int nty = g.kh > s2_ky0 ? (g.kh - s2_ky0 + 1) >> 1 : 0;
+        s2_ntx = g.kw > s2_kx0 ? (g.kw - s2_kx0 + 1) >> 1 : 0;
+        K = nty * s2_ntx * g.cout;                         // this class's reduction length
+        k_per_slab = ((K + nslab - 1) / nslab + 15) / 16 * 16;
+    }
+    const int k_lo = slab * k_per_slab, k_hi = min(K, k_lo + k_per_slab);
     const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * (BN / 2);
     const int taps = g.kh * g.kw;
     f32x4 acc[4][NI];
@@ -179,6 +198,7 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const float* __restr
             else { dHW.divmod((unsigned)m, img, rem); dW.divmod(rem, yy, xx); }
         }
         a_img[i] = (int)img;
+        if (S2) { yy = 2 * yy + s2_py; xx = 2 * xx + s2_px; }       // (dHW, dW divide by the class's quarter map)
         a_y[i] = MODE == P_FWD ? (int)yy * g.stride - g.pad : (int)yy + g.pad;
         a_x[i] = MODE == P_FWD ? (int)xx * g.stride - g.pad : (int)xx + g.pad;
     }
@@ -232,7 +252,8 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const float* __restr
             return;
         }
         const int tap = k0 / (MODE == P_FWD ? g.C : g.cout), c0 = k0 - tap * (MODE == P_FWD ? g.C : g.cout);
-        const int ky = tap / g.kw, kx = tap - ky * g.kw;
+        int ky = tap / g.kw, kx = tap - ky * g.kw;
+        if (S2) { const int ty = tap / s2_ntx; ky = s2_ky0 + 2 * ty; kx = s2_kx0 + 2 * (tap - ty * s2_ntx); }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -310,29 +331,37 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const float* __restr
         }
     }
     // ---- epilogue: lane holds row m = lr, columns 4*lg .. 4*lg+3 of each tile
-    float* dst = out + (MODE == P_WGRAD ? (size_t)blockIdx.z * M * N : 0);
-    const bool vec = (N & 3) == 0;
+    // split k (nslab > 1): slab partials [slab][rows][N]; bias / accumulate are applied by the slab sum.  S2: the class's row -> its pixel
+    const size_t rows_all = S2 ? (size_t)g.n * g.H * g.W : (size_t)M;
+    float* dst = out + (MODE == P_WGRAD ? (size_t)blockIdx.z * M * N : (nslab > 1 ? (size_t)slab * rows_all * N : 0));
+    const bool vec = (N & 3) == 0, plain = nslab > 1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm0 + i * 16 + lr;
         if (m >= M) continue;
+        size_t row = (size_t)m;
+        if (S2) {
+            unsigned img, rem, yy, xx;
+            dHW.divmod((unsigned)m, img, rem); dW.divmod(rem, yy, xx);
+            row = ((size_t)img * g.H + 2 * yy + s2_py) * g.W + 2 * xx + s2_px;
+        }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int nn = n0 + wn0 + j * 16 + lg * 4;
             if (nn >= N) continue;
             f32x4 v = acc[i][j];
-            float* d = dst + (size_t)m * N + nn;
+            float* d = dst + row * N + nn;
             if (vec) {
-                if (MODE == P_FWD && bias) v += *(const f32x4*)(bias + nn);
-                if (MODE == P_DGRAD && accumulate) v += *(const f32x4*)d;
+                if (MODE == P_FWD && bias && !plain) v += *(const f32x4*)(bias + nn);
+                if (MODE == P_DGRAD && accumulate && !plain) v += *(const f32x4*)d;
                 *(f32x4*)d = v;
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (nn + r >= N) break;
                     float s1 = v[r];
-                    if (MODE == P_FWD && bias) s1 += bias[nn + r];
-                    d[r] = (MODE == P_DGRAD && accumulate) ? d[r] + s1 : s1;
+                    if (MODE == P_FWD && bias && !plain) s1 += bias[nn + r];
+                    d[r] = (MODE == P_DGRAD && accumulate && !plain) ? d[r] + s1 : s1;
                 }
             }
         }
@@ -490,6 +519,29 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
     out[e] = s;
 }
 
+// forward / dgrad split k: out[e] = (accumulate ? out[e] : 0) + bias[e % N] + sum over slabs in slab order
+__global__ __launch_bounds__(256) void slab_sum_out_kernel(const float* __restrict__ slabs, float* __restrict__ out, const float* __restrict__ bias,
+                                                           size_t count4, int N, int S, int accumulate) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count4) return;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < S; ++z) s += *(const f32x4*)(slabs + ((size_t)z * count4 + e) * 4);
+    if (bias) s += *(const f32x4*)(bias + (e * 4) % (size_t)N);
+    if (accumulate) s += *(const f32x4*)(out + e * 4);
+    *(f32x4*)(out + e * 4) = s;
+}
+
+// how many k slabs a forward / dgrad launch of `tiles` output tiles (x `classes`) over a reduction of K should use: none when the launch
+// fills the chip or the reduction is short; else about two workgroups per CU, >= 128 k per slab, within the workspace
+int fwd_slabs(int tiles, int K, size_t out_elems, size_t ws_bytes, const void* ws) {
+    if (!ws || (((uintptr_t)ws) & 15) || (out_elems & 3) || tiles >= 128 || K < 512) return 1;
+    int S = (512 + tiles - 1) / tiles;
+    if (S > K / 128) S = K / 128;
+    const size_t fit = ws_bytes / (out_elems * sizeof(float));
+    if ((size_t)S > fit) S = (int)fit;
+    return S < 2 ? 1 : S;
+}
+
 #define MFMA_DIVS(g)                                                                                                          \
     const FDiv dHoWo((unsigned)((g).Ho * (g).Wo)), dWo((unsigned)(g).Wo), dHW((unsigned)((g).H * (g).W)), dW((unsigned)(g).W), \
         dC((unsigned)(g).C)
@@ -509,7 +561,7 @@ int fill_geo(const char* who, const eoe_conv_geometry* geo, int cout, int nchw, 
 }  // namespace
 
 extern "C" int eoe_conv_f32_fwd(const float* x, int x_nchw, const float* mean, const float* stdv, const float* w, const float* bias,
-                                float* y, const eoe_conv_geometry* geo, int cout, void* stream) {
+                                float* y, const eoe_conv_geometry* geo, int cout, void* workspace, size_t workspace_bytes, void* stream) {
     EOE_CHECK_ARG(x && w && y, "conv_f32_fwd: null pointer");
     EOE_CHECK_ARG((mean == nullptr) == (stdv == nullptr), "conv_f32_fwd: mean/std must both be given or both NULL");
     PGeo g;
@@ -518,11 +570,23 @@ extern "C" int eoe_conv_f32_fwd(const float* x, int x_nchw, const float* mean, c
     ProfScope ps("conv_f32_fwd", 2.0 * M * N * K, 4.0 * ((double)g.n * g.H * g.W * g.C + (double)N * K + (double)M * N), stream);
     if (!x_nchw && !mean && (g.C % 16) == 0 && !(g_parity_flags & 1)) {            // fp32 MFMA (parity_flags bit 0: the VALU kernel, A/B)
         MFMA_DIVS(g);
-        if (N <= 64) hipLaunchKernelGGL((conv_f32_mfma_kernel<P_FWD, 64>), dim3((N + 63) / 64, (M + 127) / 128, 1), dim3(256), 0, (hipStream_t)stream,
-                                        x, w, (const float*)nullptr, bias, y, g, M, N, K, K, 0, dHoWo, dWo, dHW, dW, dC);
-        else hipLaunchKernelGGL((conv_f32_mfma_kernel<P_FWD, 128>), dim3((N + 127) / 128, (M + 127) / 128, 1), dim3(256), 0, (hipStream_t)stream,
-                                x, w, (const float*)nullptr, bias, y, g, M, N, K, K, 0, dHoWo, dWo, dHW, dW, dC);
+        const int gx = N <= 64 ? (N + 63) / 64 : (N + 127) / 128, gy = (M + 127) / 128;
+        const int S = (N & 3) ? 1 : fwd_slabs(gx * gy, K, (size_t)M * N, workspace_bytes, workspace);
+        const int per = S > 1 ? ((K + S - 1) / S + 15) / 16 * 16 : K;
+        float* dst = S > 1 ? (float*)workspace : y;
+        if (N <= 64) hipLaunchKernelGGL((conv_f32_mfma_kernel<P_FWD, 64>), dim3(gx, gy, S), dim3(256), 0, (hipStream_t)stream,
+                                        x, w, (const float*)nullptr, bias, dst, g, M, N, K, per, 0, dHoWo, dWo, dHW, dW, dC,
+                                        (const float*)nullptr, (const float*)nullptr, FDiv(1), FDiv(1), S);
+        else hipLaunchKernelGGL((conv_f32_mfma_kernel<P_FWD, 128>), dim3(gx, gy, S), dim3(256), 0, (hipStream_t)stream,
+                                x, w, (const float*)nullptr, bias, dst, g, M, N, K, per, 0, dHoWo, dWo, dHW, dW, dC,
+                                (const float*)nullptr, (const float*)nullptr, FDiv(1), FDiv(1), S);
         EOE_CHECK_LAUNCH("conv_f32_fwd (mfma)");
+        if (S > 1) {
+            const size_t count4 = (size_t)M * N / 4;
+            hipLaunchKernelGGL(slab_sum_out_kernel, dim3((unsigned)((count4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                               (const float*)workspace, y, bias, count4, N, S, 0);
+            EOE_CHECK_LAUNCH("conv_f32_fwd_sum");
+        }
         return 0;
     }
     if (!(g_parity_flags & 1)) {                    // fp32 MFMA, element-wise fetches (NCHW image + Normalize, odd channel counts)
@@ -541,7 +605,7 @@ extern "C" int eoe_conv_f32_fwd(const float* x, int x_nchw, const float* mean, c
 }
 
 extern "C" int eoe_conv_f32_dgrad(const float* dy, const float* w, float* dx, const eoe_conv_geometry* geo, int cout, int accumulate,
-                                  void* stream) {
+                                  void* workspace, size_t workspace_bytes, void* stream) {
     EOE_CHECK_ARG(dy && w && dx, "conv_f32_dgrad: null pointer");
     PGeo g;
     EOE_TRY(fill_geo("conv_f32_dgrad", geo, cout, 0, g));
@@ -549,11 +613,46 @@ extern "C" int eoe_conv_f32_dgrad(const float* dy, const float* w, float* dx, co
     ProfScope ps("conv_f32_dgrad", 2.0 * M * N * K, 4.0 * ((double)g.n * g.Ho * g.Wo * cout + (double)N * K + (double)M * N), stream);
     if ((cout % 16) == 0 && !(g_parity_flags & 1)) {
         MFMA_DIVS(g);
-        if (N <= 64) hipLaunchKernelGGL((conv_f32_mfma_kernel<P_DGRAD, 64>), dim3((N + 63) / 64, (M + 127) / 128, 1), dim3(256), 0, (hipStream_t)stream,
-                                        (const float*)nullptr, w, dy, (const float*)nullptr, dx, g, M, N, K, K, accumulate, dHoWo, dWo, dHW, dW, dC);
-        else hipLaunchKernelGGL((conv_f32_mfma_kernel<P_DGRAD, 128>), dim3((N + 127) / 128, (M + 127) / 128, 1), dim3(256), 0, (hipStream_t)stream,
-                                (const float*)nullptr, w, dy, (const float*)nullptr, dx, g, M, N, K, K, accumulate, dHoWo, dWo, dHW, dW, dC);
+        const int gx = N <= 64 ? (N + 63) / 64 : (N + 127) / 128;
+        if (g.stride == 2 && (g.H % 2) == 0 && (g.W % 2) == 0 && !(g_parity_flags & 2)) {
+            // the four parity classes of the input pixels, each with its own tap list (conv_f32_mfma_kernel, S2); parity_flags bit 1: off
+            const int Mc = g.n * (g.H / 2) * (g.W / 2), gy = (Mc + 127) / 128;
+            const FDiv cHW((unsigned)((g.H / 2) * (g.W / 2))), cW((unsigned)(g.W / 2));
+            const int kmax = ((g.kh + 1) / 2) * ((g.kw + 1) / 2) * cout;            // the longest class
+            const int S = (N & 3) ? 1 : fwd_slabs(gx * gy * 4, kmax, (size_t)M * N, workspace_bytes, workspace);
+            float* dst = S > 1 ? (float*)workspace : dx;
+            if (N <= 64) hipLaunchKernelGGL((conv_f32_mfma_kernel<P_DGRAD, 64, 0, true>), dim3(gx, gy, 4 * S), dim3(256), 0, (hipStream_t)stream,
+                                            (const float*)nullptr, w, dy, (const float*)nullptr, dst, g, Mc, N, K, K, accumulate, dHoWo, dWo, cHW, cW, dC,
+                                            (const float*)nullptr, (const float*)nullptr, FDiv(1), FDiv(1), S);
+            else hipLaunchKernelGGL((conv_f32_mfma_kernel<P_DGRAD, 128, 0, true>), dim3(gx, gy, 4 * S), dim3(256), 0, (hipStream_t)stream,
+                                    (const float*)nullptr, w, dy, (const float*)nullptr, dst, g, Mc, N, K, K, accumulate, dHoWo, dWo, cHW, cW, dC,
+                                    (const float*)nullptr, (const float*)nullptr, FDiv(1), FDiv(1), S);
+            EOE_CHECK_LAUNCH("conv_f32_dgrad (mfma, stride-2 classes)");
+            if (S > 1) {
+                const size_t count4 = (size_t)M * N / 4;
+                hipLaunchKernelGGL(slab_sum_out_kernel, dim3((unsigned)((count4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                                   (const float*)workspace, dx, (const float*)nullptr, count4, N, S, accumulate);
+                EOE_CHECK_LAUNCH("conv_f32_dgrad_sum");
+            }
+            return 0;
+        }
+        const int gy = (M + 127) / 128;
+        const int S = (N & 3) ? 1 : fwd_slabs(gx * gy, K, (size_t)M * N, workspace_bytes, workspace);
+        const int per = S > 1 ? ((K + S - 1) / S + 15) / 16 * 16 : K;
+        float* dst = S > 1 ? (float*)workspace : dx;
+        if (N <= 64) hipLaunchKernelGGL((conv_f32_mfma_kernel<P_DGRAD, 64>), dim3(gx, gy, S), dim3(256), 0, (hipStream_t)stream,
+                                        (const float*)nullptr, w, dy, (const float*)nullptr, dst, g, M, N, K, per, accumulate, dHoWo, dWo, dHW, dW, dC,
+                                        (const float*)nullptr, (const float*)nullptr, FDiv(1), FDiv(1), S);
+        else hipLaunchKernelGGL((conv_f32_mfma_kernel<P_DGRAD, 128>), dim3(gx, gy, S), dim3(256), 0, (hipStream_t)stream,
+                                (const float*)nullptr, w, dy, (const float*)nullptr, dst, g, M, N, K, per, accumulate, dHoWo, dWo, dHW, dW, dC,
+                                (const float*)nullptr, (const float*)nullptr, FDiv(1), FDiv(1), S);
         EOE_CHECK_LAUNCH("conv_f32_dgrad (mfma)");
+        if (S > 1) {
+            const size_t count4 = (size_t)M * N / 4;
+            hipLaunchKernelGGL(slab_sum_out_kernel, dim3((unsigned)((count4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                               (const float*)workspace, dx, (const float*)nullptr, count4, N, S, accumulate);
+            EOE_CHECK_LAUNCH("conv_f32_dgrad_sum");
+        }
         return 0;
     }
     hipLaunchKernelGGL((conv_f32_kernel<P_DGRAD>), dim3((N + 63) / 64, (M + 63) / 64, 1), dim3(256), 0, (hipStream_t)stream,

@@ -118,3 +118,32 @@ class VisualTransformer(nn.Module):
         for blk in self.transformer.resblocks:
             tok = blk.forward_tokens(tok, n)
         return ops.VitHeadFunction.apply(tok, n, self.ln_post.weight, self.ln_post.bias, self.proj)
+
+
+def convert_weights(model: nn.Module) -> nn.Module:
+    """The reference's fp16-weights mode (`clip/model.py:371-392`; `build_model` applies it to every CLIP model, `:430`, and `clip.load`
+    undoes it with `model.float()` on the CPU only, `clip.py:116`): the weight and bias of every convolution / linear layer, the packed
+    attention projections (`in_proj_weight`, `in_proj_bias`) and the `proj` / `text_projection` matrices become fp16 tensors; LayerNorm
+    parameters, `class_embedding` and `positional_embedding` stay fp32.  Here the storage stays fp32 (the kernels' 16-bit operand copies
+    are then exact) and holds the fp16-rounded values; the parameters are marked so that `eoe_amd.FusedSGD` -- the optimiser the
+    reference builds for CLIP models, `ad_trainer.py:380-381` -- updates them with torch's fp16 arithmetic (`eoe_sgd_multi`,
+    EOE_CHUNK_FP16).  Returns the model."""
+    def mark(p):
+        if p is None:
+            return
+        with torch.no_grad():
+            p.copy_(p.to(torch.float16).to(torch.float32))
+        p._eoe_fp16_weight = True
+
+    for m in model.modules():
+        if isinstance(m, (nn.Conv1d, nn.Conv2d, nn.Linear)):
+            mark(m.weight)
+            mark(m.bias)
+        if isinstance(m, (_PackedAttention, nn.MultiheadAttention)):
+            for name in ("in_proj_weight", "q_proj_weight", "k_proj_weight", "v_proj_weight", "in_proj_bias", "bias_k", "bias_v"):
+                mark(getattr(m, name, None))
+        for name in ("text_projection", "proj"):
+            attr = getattr(m, name, None)
+            if isinstance(attr, nn.Parameter):
+                mark(attr)
+    return model

@@ -1015,8 +1015,9 @@ class ConvBnActPoolParityFunction(torch.autograd.Function):
         geo = _geo(n, Hi, Wi, cin, kh, kw, stride, pad, H, W)
         w = conv_w.contiguous()
         y = torch.empty((M, cout), dtype=torch.float32, device=dev)
+        ws = _parity_splitk_ws(dev)
         check(lib.eoe_conv_f32_fwd(_p(x), 1 if is_image else 0, _p(mean) if is_image else None, _p(std) if is_image else None, _p(w),
-                                   _p(conv_b), _p(y), geo, cout, _stream()), "eoe_conv_f32_fwd")
+                                   _p(conv_b), _p(y), geo, cout, _p(ws), PARITY_SPLITK_BYTES, _stream()), "eoe_conv_f32_fwd")
         stats = torch.empty(2 * cout, dtype=torch.float32, device=dev)
         sums = scratch("bn_sums", (BN_SCRATCH * cout,), torch.float32, dev)
         check(lib.eoe_bn_stats(_p(y), _p(sums), _p(stats), _p(rm), _p(rv), _p(nbt), M, cout, float(eps), float(momentum),
@@ -1081,12 +1082,21 @@ class ConvBnActPoolParityFunction(torch.autograd.Function):
             acc = (d_pass is not None and d_pass.dtype == torch.float32 and d_pass.is_contiguous()
                    and d_pass.shape == (n, Hi, Wi, cin))
             dx = d_pass if acc else torch.empty((n, Hi, Wi, cin), dtype=torch.float32, device=dev)
-            check(lib.eoe_conv_f32_dgrad(_p(dy), _p(w), _p(dx), geo, cout, 1 if acc else 0, _stream()), "eoe_conv_f32_dgrad")
+            check(lib.eoe_conv_f32_dgrad(_p(dy), _p(w), _p(dx), geo, cout, 1 if acc else 0, _p(_parity_splitk_ws(dev)), PARITY_SPLITK_BYTES,
+                                         _stream()), "eoe_conv_f32_dgrad")
             if acc:
                 d_pass = None
         if d_pass is not None:
             dx = d_pass if dx is None else dx.add_(d_pass)
         return dx, dw, dcb, dg, db, None, None, None, None
+
+
+PARITY_SPLITK_BYTES = 16 << 20
+
+
+def _parity_splitk_ws(dev):
+    """slab partials of the fp32 forward / dgrad kernels when they cut a long reduction over few output tiles (eoe_conv_f32_fwd)"""
+    return scratch("parity_splitk_ws", (PARITY_SPLITK_BYTES // 4,), torch.float32, dev)
 
 
 class LinearParityFunction(torch.autograd.Function):
@@ -1100,7 +1110,7 @@ class LinearParityFunction(torch.autograd.Function):
         N = weight.shape[0]
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
         check(lib.eoe_conv_f32_fwd(_p(x2), 0, None, None, _p(weight.contiguous()), _p(bias), _p(y), _geo(M, 1, 1, K, 1, 1, 1, 0, 1, 1), N,
-                                   _stream()), "eoe_conv_f32_fwd")
+                                   _p(_parity_splitk_ws(x.device)), PARITY_SPLITK_BYTES, _stream()), "eoe_conv_f32_fwd")
         ctx.save_for_backward(x2, weight, bias)
         ctx.in_shape, ctx.x_dtype = x.shape, x.dtype
         return y.reshape(*x.shape[:-1], N)
@@ -1115,7 +1125,8 @@ class LinearParityFunction(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
-            check(lib.eoe_conv_f32_dgrad(_p(dy2), _p(weight.contiguous()), _p(dx), geo, N, 0, _stream()), "eoe_conv_f32_dgrad")
+            check(lib.eoe_conv_f32_dgrad(_p(dy2), _p(weight.contiguous()), _p(dx), geo, N, 0, _p(_parity_splitk_ws(dy.device)), PARITY_SPLITK_BYTES,
+                                         _stream()), "eoe_conv_f32_dgrad")
             dx = dx.reshape(ctx.in_shape).to(ctx.x_dtype)
         if ctx.needs_input_grad[1]:
             dw = _grad_target(weight)

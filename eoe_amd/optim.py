@@ -149,6 +149,9 @@ class FusedAdam(_NonFiniteGuard, torch.optim.Optimizer):
             for p in active:
                 if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
                     raise RuntimeError("FusedAdam needs contiguous fp32 parameters and gradients on the GPU")
+                if getattr(p, "_eoe_fp16_weight", False):
+                    raise NotImplementedError("fp16-weights mode (eoe_amd.models.convert_weights) is the CLIP objective's: the reference "
+                                              "trains such models with SGD (ad_trainer.py:380-381) -- use eoe_amd.FusedSGD")
             self._init_state(group)
             steps = []
             for p in active:
@@ -189,10 +192,18 @@ class FusedAdam(_NonFiniteGuard, torch.optim.Optimizer):
         return loss
 
 
+def is_fp16_weight(p) -> bool:
+    """True for a parameter `eoe_amd.models.convert_weights` marked: an fp16 tensor in the reference (clip/model.py:371-392)"""
+    return bool(getattr(p, "_eoe_fp16_weight", False))
+
+
 class FusedSGD(_NonFiniteGuard, torch.optim.Optimizer):
     """`torch.optim.SGD(params, lr, momentum=0.9, nesterov=True, weight_decay=wdk)` as the reference constructs it for CLIP models
     (`ad_trainer.py:380-381`), one kernel per step (`eoe_sgd_multi`): same Optimizer API, dampening 0, L2-in-gradient weight decay,
-    momentum buffers created at the first step (zero-initialised arena: `buf = momentum * 0 + g` is torch's first-step `buf = g`)."""
+    momentum buffers created at the first step (zero-initialised arena: `buf = momentum * 0 + g` is torch's first-step `buf = g`).
+    Parameters marked by `eoe_amd.models.convert_weights` (the reference's fp16-weights mode: `build_model` converts CLIP's convolution /
+    linear / attention / projection parameters to fp16, `clip/model.py:371-392, 430`, and SGD then updates fp16 tensors) are updated
+    with torch's fp16 arithmetic -- every op of the update rounded to fp16 -- on fp32 storage that keeps fp16-representable values."""
 
     def __init__(self, params, lr=1e-3, momentum=0.0, weight_decay=0.0, nesterov=False, dampening=0.0, guard=None):
         if dampening != 0.0:
@@ -221,7 +232,7 @@ class FusedSGD(_NonFiniteGuard, torch.optim.Optimizer):
             off += (n + 3) // 4 * 4
 
     def _table(self, gi, active):
-        sig = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["momentum_buffer"].data_ptr(), p.numel()) for p in active)
+        sig = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["momentum_buffer"].data_ptr(), p.numel(), is_fp16_weight(p)) for p in active)
         hit = self._tables.get(gi)
         if hit is not None and hit[0] == sig:
             return hit[1:]
@@ -233,8 +244,9 @@ class FusedSGD(_NonFiniteGuard, torch.optim.Optimizer):
             po, go = (p.data_ptr() - pb) // 4, (p.grad.data_ptr() - gb) // 4
             mo = (self.state[p]["momentum_buffer"].data_ptr() - mb) // 4
             n = p.numel()
+            flag = _lib.CHUNK_FP16 if is_fp16_weight(p) else 0       # fp16-weights mode: torch's fp16 update, op by op (eoe_sgd_multi)
             for c0 in range(0, n, _lib.ADAM_CHUNK):
-                rows.append((po + c0, go + c0, mo + c0, 0, min(_lib.ADAM_CHUNK, n - c0), 0))
+                rows.append((po + c0, go + c0, mo + c0, 0, min(_lib.ADAM_CHUNK, n - c0), flag))
         arr = np.array(rows, dtype=_CHUNK_DT)
         tab = torch.from_numpy(arr.view(np.uint8).copy()).to(active[0].device)
         self._tables[gi] = (sig, tab, len(rows), (pb, gb, mb))

@@ -235,8 +235,9 @@ int eoe_bce_bwd(const float* x, const int64_t* labels, const float* gscale, floa
 typedef struct {
     int64_t p_off, g_off, m_off, v_off; /* element offsets */
     int32_t n;                          /* elements in this chunk (<= EOE_ADAM_CHUNK) */
-    int32_t group;                      /* index into eoe_adam_scalars (parameters sharing a step count) */
+    int32_t group;                      /* index into eoe_adam_scalars (parameters sharing a step count); | EOE_CHUNK_FP16, see eoe_sgd_multi */
 } eoe_adam_chunk;
+#define EOE_CHUNK_FP16 0x100            /* eoe_sgd_multi: this chunk's parameter is an fp16 tensor in the reference (clip/model.py:371-392) */
 #define EOE_ADAM_CHUNK 8192
 #define EOE_ADAM_GROUPS 4
 typedef struct {                        /* per step-count group, computed on the host in double as torch does: */
@@ -250,7 +251,10 @@ typedef struct {                        /* per step-count group, computed on the
 } eoe_adam_scalars;
 
 /* fused multi-tensor SGD with momentum / Nesterov = torch.optim.SGD(..., dampening=0) as constructed for CLIP models
- * (ad_trainer.py:380-381: momentum 0.9, nesterov): the same chunk tables (m_off = momentum buffer, zero-initialised; v_off unused) */
+ * (ad_trainer.py:380-381: momentum 0.9, nesterov): the same chunk tables (m_off = momentum buffer, zero-initialised; v_off unused).
+ * fp16-weights mode (clip/model.py:371-392 `convert_weights`, applied by build_model :430): chunks with
+ * `group & EOE_CHUNK_FP16` are updated as torch updates an fp16 parameter with an fp16 gradient -- the fp32 storage keeps
+ * fp16-representable values, every elementwise op of the update rounds to fp16 (5 roundings per element, in torch's op order) */
 int eoe_sgd_multi(float* p, const float* g, float* buf, const eoe_adam_chunk* chunks /*device*/, int n_chunks, float lr,
                   float momentum, float weight_decay, int nesterov, float grad_scale_inv /* as in eoe_adam_scalars; <= 0 = 1 */,
                   const int32_t* skip_flag /* device, may be NULL: see eoe_grads_nonfinite */, void* stream);
@@ -449,17 +453,22 @@ int eoe_comm_sync_bn(eoe_comm_t comm, int enable);
 /* ------------------------------------------------------------------------------------------------------
  * Parity mode (SURVEY.md section 7 "Hard parts", section 8d "Parity run"): the convolutions / linear layers of the BatchNorm
  * encoders (cnn.py:73-86, resnet.py:85-149) in plain fp32 -- fp32 activations and fp32 master weights as operands, one fp32 FMA
- * per product in a fixed order, no 16-bit rounding.  A correctness instrument (a register-tiled SGEMM on the vector ALUs), used
- * by the trajectory parity tests to tell the fast path's 16-bit operand rounding from an implementation difference.
+ * per product in a fixed order, no 16-bit rounding.  Since round 3 on the fp32 matrix cores (v_mfma_f32_16x16x4_f32; the
+ * register-tiled SGEMM on the vector ALUs stays selectable: option "parity_flags" bit 0): the conformant mode of BASELINE configs 1-3
+ * and the instrument that tells the fast path's 16-bit operand rounding from an implementation difference.
  *   x: fp32 NHWC [n,H,W,C], or the fp32 NCHW image batch if x_nchw (then optional per-channel Normalize (x - mean) / std,
  *   ad_trainer.py:413-425); w: [cout, C, kh, kw] (the nn.Conv2d parameter itself; a Linear layer is H = W = kh = kw = 1);
  *   y / dy: fp32 [n*Ho*Wo, cout]; dx: fp32 NHWC (+= if accumulate); dw: [cout, C, kh, kw] overwritten (slab sums in fixed
  *   order: bitwise reproducible).  geo.C = input channels; geo.Ho / geo.Wo must match the geometry.
+ *   workspace (forward / dgrad; may be NULL / 0): with few output tiles and a long reduction (small maps, FC layers) the reduction
+ *   is cut into slabs whose partial outputs ([slab][rows][cout] floats) go here and are summed in slab order; a workspace of
+ *   k x the output size allows k slabs.  A stride-2 dgrad over an even map runs as four parity-class GEMMs (no work on taps a pixel
+ *   never meets); "parity_flags" bit 1 turns that off.
  * ---------------------------------------------------------------------------------------------------- */
 int eoe_conv_f32_fwd(const float* x, int x_nchw, const float* mean, const float* stdv, const float* w, const float* bias, float* y,
-                     const eoe_conv_geometry* geo, int cout, void* stream);
+                     const eoe_conv_geometry* geo, int cout, void* workspace, size_t workspace_bytes, void* stream);
 int eoe_conv_f32_dgrad(const float* dy, const float* w, float* dx, const eoe_conv_geometry* geo, int cout, int accumulate,
-                       void* stream);
+                       void* workspace, size_t workspace_bytes, void* stream);
 size_t eoe_conv_f32_wgrad_workspace(const eoe_conv_geometry* geo, int cout);
 int eoe_conv_f32_wgrad(const float* x, int x_nchw, const float* mean, const float* stdv, const float* dy, float* dw,
                        const eoe_conv_geometry* geo, int cout, void* workspace, size_t workspace_bytes, void* stream);

@@ -6,6 +6,7 @@ amsgrad=False)` (betas (0.9, 0.999), eps 1e-8, L2-in-gradient weight decay, bias
 torch >= 2.3.1 (`src/requirements.txt:7`), single-tensor Adam update order.
 """
 import math
+import numpy as np
 from typing import List, Optional
 import torch
 
@@ -68,3 +69,26 @@ def sgd_step(params, grads, state: SgdState, lr: float, momentum: float = 0.9, w
                     state.buf[i].mul_(momentum).add_(g)
                 g = g + momentum * state.buf[i] if nesterov else state.buf[i]
             p.add_(g * (-lr))
+
+
+def _r16(x: torch.Tensor) -> torch.Tensor:
+    return x.to(torch.float16).to(torch.float32)
+
+
+def sgd_step_fp16(p: torch.Tensor, g: torch.Tensor, buf: Optional[torch.Tensor], lr: float, momentum: float = 0.9, weight_decay: float = 0.0,
+                  nesterov: bool = True, alpha_fp16: bool = False):
+    """one step of `torch.optim.SGD` on an fp16 parameter with an fp16 gradient (the reference's fp16-weights mode: `convert_weights`,
+    clip/model.py:371-392 + ad_trainer.py:380-381), restated on fp32 tensors that hold fp16 values: torch's update is a chain of
+    elementwise ops -- grad.add(param, alpha=wd); buf.mul_(momentum); buf.add_(grad); grad.add(buf, alpha=momentum); param.add_(grad,
+    alpha=-lr) -- each computed in fp32 and rounded to fp16 once.  `alpha_fp16`: torch's CPU kernels round the `alpha` scalar of add to
+    fp16 first (fixture g16 is made on the CPU); the GPU kernels keep it in fp32 (what `eoe_sgd_multi` implements).  Returns (p, buf)."""
+    a = (lambda v: float(torch.tensor(v, dtype=torch.float16))) if alpha_fp16 else (lambda v: float(np.float32(v)))
+    f32 = lambda v: torch.tensor(v, dtype=torch.float32)      # noqa: E731
+    g = _r16(g)
+    if weight_decay != 0:
+        g = _r16(g + f32(a(weight_decay)) * p)
+    step = g
+    if momentum != 0:
+        buf = g.clone() if buf is None else _r16(_r16(buf * f32(float(np.float32(momentum)))) + g)
+        step = _r16(g + f32(a(momentum)) * buf) if nesterov else buf
+    return _r16(p + f32(a(-lr)) * step), buf

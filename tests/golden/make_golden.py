@@ -484,6 +484,30 @@ def g15():
     save("g15_tasks", **out)
 
 
+def g16():
+    """fp16-weights mode: the reference's own `convert_weights` (clip/model.py:371-392) applied to its own
+    VisualTransformer -- which parameters become fp16 tensors (by state_dict name) -- and, on a few of those tensors, the values
+    `.half()` leaves; plus five steps of torch.optim.SGD(momentum 0.9, nesterov, weight decay) as the reference constructs it for CLIP
+    models (ad_trainer.py:380-381) on fp16 CPU tensors with fp16 gradients (the CPU kernels round the `alpha` of add(x, alpha=...) to fp16
+    first, the GPU kernels keep it in fp32: tests/test_gpu_round3.py pins the GPU form against stock torch on the device, this fixture
+    pins the op order and the rounding points)"""
+    vt = ref_clip.VisualTransformer(input_resolution=64, patch_size=32, width=128, layers=2, heads=2, output_dim=32)
+    ref_clip.convert_weights(vt)
+    names = sorted(vt.state_dict().keys())
+    out = {"names": np.array(names), "is_fp16": np.array([vt.state_dict()[n].dtype == torch.float16 for n in names])}
+    torch.manual_seed(16)
+    p0 = torch.randn(4096).half()
+    grads = [(torch.randn(4096) * (0.5 + i)).half() for i in range(5)]
+    q = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.SGD([q], lr=1e-2, momentum=0.9, nesterov=True, weight_decay=1e-3)
+    for g in grads:
+        q.grad = g.clone()
+        opt.step()
+    out["sgd/p0"], out["sgd/grads"] = p0.float().numpy(), torch.stack(grads).float().numpy()
+    out["sgd/p5"], out["sgd/buf5"] = q.detach().float().numpy(), opt.state[q]["momentum_buffer"].float().numpy()
+    save("g16_fp16_weights", **out)
+
+
 # ----------------------------------------------------------------------------------------------- big, well-conditioned parity cases
 def run_trajectory_big(model, batches_fn, n_steps, objective, lr, wd, twin64=True):
     """as run_trajectory with batches produced one at a time (memory), run twice: the reference modules in fp32 (the
@@ -683,6 +707,6 @@ def g3bigbce():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12",
-                             "g2big", "g11big", "g5big", "g5full", "g3big", "g3long", "g3bigfrozen", "g3bigfrozenlr", "g3bigbce", "g13", "g14", "g15"]
+                             "g2big", "g11big", "g5big", "g5full", "g3big", "g3long", "g3bigfrozen", "g3bigfrozenlr", "g3bigbce", "g13", "g14", "g15", "g16"]
     for w in which:
         globals()[w]()

@@ -87,7 +87,10 @@ def _fmt(a):
     # shapes of the fp32 MFMA kernels (round 3): C % 16 == 0 forward, cout % 16 == 0 dgrad, C / cout % 4 == 0 wgrad; narrow (cout <= 64)
     # and wide tiles, M tails, stride 2, the 1 x 1 "linear" form, a wide layer
     ("c32to32", 5, 32, 32, 9, 5, 1, 2, False), ("c64to256s2", 3, 64, 256, 13, 3, 2, 1, False), ("c128to128", 2, 128, 128, 11, 3, 1, 1, False),
-    ("fc2048", 200, 2048, 512, 1, 1, 1, 0, False), ("fc512to256", 256, 512, 256, 1, 1, 1, 0, False), ("c16to20", 2, 16, 20, 7, 3, 1, 1, False)])
+    ("fc2048", 200, 2048, 512, 1, 1, 1, 0, False), ("fc512to256", 256, 512, 256, 1, 1, 1, 0, False), ("c16to20", 2, 16, 20, 7, 3, 1, 1, False),
+    # stride-2 dgrad as four parity-class GEMMs (even maps) + split k over few output tiles (the small maps of WideResNet at 32 x 32)
+    ("s2map4", 16, 128, 256, 4, 3, 2, 1, False), ("s2map8x1", 8, 64, 128, 8, 1, 2, 0, False), ("map2", 64, 256, 256, 2, 3, 1, 1, False),
+    ("s2c64", 3, 64, 64, 12, 3, 2, 1, False)])
 @pytest.mark.parametrize("kernels", ["mfma", "valu"])
 def test_conv_f32_kernels_vs_fp64(name, n, cin, cout, H, k, stride, pad, nchw, kernels):
     """the parity-mode fp32 convolution kernels (forward incl. fused Normalize on an NCHW image, dgrad incl. accumulate, wgrad)
@@ -116,8 +119,9 @@ def _conv_f32_case(name, n, cin, cout, H, k, stride, pad, nchw, F, ops, lib, che
     geo = ops._geo(n, H, W, cin, k, k, stride, pad, Ho, Wo)
     st = torch.cuda.current_stream().cuda_stream
     y = torch.empty((n * Ho * Wo, cout), device="cuda")
+    sk = torch.empty(4 << 20, device="cuda")                # split-k slab partials (forward / dgrad over few output tiles)
     p = lambda t: None if t is None else t.data_ptr()       # noqa: E731
-    check(lib.eoe_conv_f32_fwd(p(x), int(nchw), p(mean), p(std), p(w), p(b), p(y), geo, cout, st), "fwd")
+    check(lib.eoe_conv_f32_fwd(p(x), int(nchw), p(mean), p(std), p(w), p(b), p(y), geo, cout, p(sk), sk.numel() * 4, st), "fwd")
     xd = (xr.double() if nchw else xr.double().permute(0, 3, 1, 2))
     if nchw:
         xd = (xd - mean.cpu().double().view(1, 3, 1, 1)) / std.cpu().double().view(1, 3, 1, 1)
@@ -135,10 +139,21 @@ def _conv_f32_case(name, n, cin, cout, H, k, stride, pad, nchw, F, ops, lib, che
     if not nchw:
         base, baser = f32(f"p/{name}/base", (n, H, W, cin), 1.0)
         dx = base.clone()
-        check(lib.eoe_conv_f32_dgrad(p(dy), p(w), p(dx), geo, cout, 1, st), "dgrad")
+        check(lib.eoe_conv_f32_dgrad(p(dy), p(w), p(dx), geo, cout, 1, p(sk), sk.numel() * 4, st), "dgrad")
         assert rel_rms(dx, xd.grad.permute(0, 2, 3, 1) + baser.double()) < 2e-6
-        check(lib.eoe_conv_f32_dgrad(p(dy), p(w), p(dx), geo, cout, 0, st), "dgrad")
+        check(lib.eoe_conv_f32_dgrad(p(dy), p(w), p(dx), geo, cout, 0, p(sk), sk.numel() * 4, st), "dgrad")
         assert rel_rms(dx, xd.grad.permute(0, 2, 3, 1)) < 2e-6
+        if stride == 2 and H % 2 == 0:
+            # the parity-class form enumerates a pixel's valid taps in the order the all-taps form meets them: the same bits (no split k)
+            from eoe_amd import _lib
+            flags = _lib.get_option("parity_flags")
+            if not flags & 1:
+                a, b2 = torch.full_like(dx, 7.0), torch.full_like(dx, 7.0)
+                check(lib.eoe_conv_f32_dgrad(p(dy), p(w), p(a), geo, cout, 0, None, 0, st), "dgrad")
+                _lib.set_option("parity_flags", flags | 2)
+                check(lib.eoe_conv_f32_dgrad(p(dy), p(w), p(b2), geo, cout, 0, None, 0, st), "dgrad")
+                _lib.set_option("parity_flags", flags)
+                assert torch.equal(a, b2)
 
 
 def run_hip(m, batch_fn, steps, obj, lr, wd):

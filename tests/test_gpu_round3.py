@@ -265,3 +265,75 @@ def test_batchnorm_encoders_train_in_exact_fp32_by_default():
         tr.eval_cls(model, ds, 0, "only", 0)
         assert seen and all(s == want for s in seen), (lr, exact, seen)
         assert ops.parity_mode() is False
+
+
+# --------------------------------------------------------------------------------------------- fp16-weights mode
+def test_fp16_weights_sgd_matches_torch_on_half_tensors():
+    """the reference's CLIP models carry fp16 parameters on a GPU (`convert_weights`, clip/model.py:371-392, applied by build_model :430)
+    and are trained with torch.optim.SGD(momentum 0.9, nesterov) (ad_trainer.py:380-381).  FusedSGD on parameters marked by
+    `eoe_amd.models.convert_weights` reproduces that update -- stock torch on half CUDA tensors is the oracle here: five steps, weight
+    decay, fp16 gradients; the un-marked parameter of the same group keeps the fp32 update."""
+    import eoe_amd
+    from eoe_amd.optim import is_fp16_weight
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(300, 72).cuda()
+    ln = torch.nn.LayerNorm(72).cuda()
+    from eoe_amd.models import convert_weights
+    convert_weights(torch.nn.Sequential(lin, ln))
+    assert is_fp16_weight(lin.weight) and is_fp16_weight(lin.bias) and not is_fp16_weight(ln.weight)
+    assert torch.equal(lin.weight, lin.weight.half().float())
+    ref = [torch.nn.Parameter(lin.weight.detach().half().clone()), torch.nn.Parameter(lin.bias.detach().half().clone()),
+           torch.nn.Parameter(ln.weight.detach().clone())]
+    kw = dict(lr=1e-2, momentum=0.9, nesterov=True, weight_decay=1e-3)
+    opt_ref = torch.optim.SGD(ref, **kw)
+    ours = [lin.weight, lin.bias, ln.weight]
+    opt = eoe_amd.FusedSGD(ours, **kw)
+    for step in range(5):
+        for p, r in zip(ours, ref):
+            g = torch.randn_like(r, dtype=torch.float32) * (0.5 + step)
+            if r.dtype == torch.float16:
+                g = g.half().float()                   # autograd hands an fp16 parameter an fp16 gradient
+            p.grad, r.grad = g.clone(), g.to(r.dtype)
+        opt.step()
+        opt_ref.step()
+    for p, r in zip(ours, ref):
+        assert torch.isfinite(p).all()
+        if r.dtype == torch.float16:
+            assert torch.equal(p, p.half().float())                                  # the storage stays fp16-representable
+            # the same fp32 arithmetic and the same two roundings per op (to fp32, then to fp16) as torch's multi-tensor kernels: equal bits.
+            # (torch's own scalar tail path -- tensors whose length is not a multiple of 4 -- and its single-tensor path differ from its
+            #  vectorised path in rare double-rounding ties, 0.01 .. 1 % of the elements by one fp16 ulp: tools/dbg_sgd16.py)
+            assert torch.equal(p, r.detach().float()), ((p != r.detach().float()).float().mean().item(), (p - r.detach().float()).abs().max().item())
+            mb = opt.state[p]["momentum_buffer"]
+            assert torch.equal(mb, opt_ref.state[r]["momentum_buffer"].float())
+        else:
+            assert torch.allclose(p, r.detach(), rtol=1e-6, atol=1e-7)
+
+
+def test_fp16_weights_mode_trains_the_vit_with_sgd():
+    """end to end: a 2-layer ViT in fp16-weights mode takes SGD steps, its converted parameters stay fp16 values, LayerNorm / embeddings fp32"""
+    import eoe_amd
+    from eoe_amd.models import ClipViTB32Custom, convert_weights
+    from eoe_amd.optim import is_fp16_weight
+    torch.manual_seed(0)
+    m = ClipViTB32Custom(layers=2).cuda().train()
+    convert_weights(m.feature_model)                      # the CLIP tower only: the CustomNet head is created after build_model, in fp32
+    marked = [n for n, p in m.named_parameters() if is_fp16_weight(p)]
+    assert any("in_proj_weight" in n for n in marked) and any("c_fc.weight" in n for n in marked) and any(n.endswith("proj") for n in marked)
+    assert not any("ln_" in n or "embedding" in n for n in marked)
+    opt = eoe_amd.FusedSGD(m.parameters(), lr=1e-3, momentum=0.9, nesterov=True, weight_decay=1e-3)
+    x = torch.randn(8, 3, 224, 224, device="cuda")
+    y = torch.cat([torch.zeros(4, dtype=torch.long), torch.ones(4, dtype=torch.long)]).cuda()
+    losses = []
+    for _ in range(3):
+        opt.zero_grad(set_to_none=True)
+        loss = eoe_amd.hsc_loss(m(x), y, 0)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses))
+    for n, p in m.named_parameters():
+        if is_fp16_weight(p):
+            assert torch.equal(p, p.half().float()), n
+    with pytest.raises(NotImplementedError):
+        eoe_amd.FusedAdam(m.parameters(), lr=1e-4).step()

@@ -418,3 +418,26 @@ def test_tasks_match_reference_functions(golden):
             assert np.array_equal(batching.normal_subset(labels, normal), g[f"subset/{name}/{mode}/indices"])
             t = batching.ad_targets(labels, normal)
             assert np.array_equal(np.nonzero(t == 0)[0], g[f"subset/{name}/{mode}/indices"])      # nominal <=> in the subset
+
+
+def test_fp16_weights_mode_matches_reference(golden):
+    """fixture g16 (the reference's own convert_weights on its own VisualTransformer; torch.optim.SGD on fp16 CPU tensors): the set of
+    parameters the drop-in `convert_weights` marks, and the oracle's op-by-op restatement of the fp16 SGD update"""
+    import torch
+    from oracle import optim as ooptim
+    g = golden("g16_fp16_weights")
+    from eoe_amd.models import VisualTransformer, convert_weights
+    from eoe_amd.optim import is_fp16_weight
+    m = convert_weights(VisualTransformer(64, 32, 128, 2, 2, 32))
+    got = {n: is_fp16_weight(p) for n, p in m.named_parameters()}
+    want = dict(zip([str(n) for n in g["names"]], [bool(b) for b in g["is_fp16"]]))
+    assert got == want
+    for n, p in m.named_parameters():
+        assert torch.equal(p, p.half().float()) or not got[n]
+    p, buf = torch.from_numpy(g["sgd/p0"]).clone(), None
+    for gr in g["sgd/grads"]:
+        p, buf = ooptim.sgd_step_fp16(p, torch.from_numpy(gr), buf, 1e-2, 0.9, 1e-3, True, alpha_fp16=True)
+    # bitwise up to double-rounding ties inside one op (this torch's CPU kernels fuse or do not fuse a + alpha * b): <= 1 ulp on <= 1e-3 of the elements
+    for got_, want_ in ((p.numpy(), g["sgd/p5"]), (buf.numpy(), g["sgd/buf5"])):
+        d = np.abs(got_ - want_)
+        assert (d <= np.maximum(np.abs(want_), 2.0 ** -14) * 2.0 ** -10).all() and (d != 0).mean() < 1e-3, ((d != 0).mean(), d.max())
