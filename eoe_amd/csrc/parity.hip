@@ -147,14 +147,14 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const float* __restrict__
 // valid taps come in the same (ky, kx, channel) order as before: bitwise the same sums.
 // Split k (forward / dgrad with few output tiles and a long reduction: the small maps of the 32 x 32 WideResNet, the FC layers): nslab > 1
 // slabs of the reduction write partial outputs [slab][rows][N] (`out` = the workspace), summed in slab order by slab_sum_out_kernel.
-template <int MODE, int BN, int WV = 0, bool S2 = false>      // WV (wgrad variants): 0 = both sides float4, 1 = the x side element-wise (OIHW order), 2 = roles exchanged
+template <int MODE, int BN, int WV = 0, bool S2 = false>      // WV (wgrad variants): 0 = both sides float4, 1 = the x side element-wise (OIHW order), 2 = roles exchanged, 3 = both
 __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ dy, const float* __restrict__ bias,
                                                             float* __restrict__ out, PGeo g, int M, int N, int K, int k_per_slab,
                                                             int accumulate, FDiv dHoWo, FDiv dWo, FDiv dHW, FDiv dW, FDiv dC,
                                                             const float* __restrict__ mean = nullptr, const float* __restrict__ stdv = nullptr,
                                                             FDiv dtaps = FDiv(1), FDiv dkw = FDiv(1), int nslab = 1) {
-    constexpr bool b_oihw = (WV == 1), swap = (WV == 2);
+    constexpr bool b_oihw = (WV == 1 || WV == 3), swap = (WV == 2 || WV == 3);
     constexpr int BM = 128, BK = 16, LDA = BM + 4, LDB = BN + 4, NI = BN / 32, NBV = BN / 16;
     __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
@@ -202,6 +202,35 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const float* __restr
         a_y[i] = MODE == P_FWD ? (int)yy * g.stride - g.pad : (int)yy + g.pad;
         a_x[i] = MODE == P_FWD ? (int)xx * g.stride - g.pad : (int)xx + g.pad;
     }
+    // wgrad: the x-side column quad of this thread (the same for every k-tile): packed (channel << 16 | ky << 8 | kx) per element
+    // (b_oihw: four separate (ci, ky, kx); else one entry, four consecutive channels of one tap); -1 = past the last column
+    bool wg_ok[2] = {false, false};
+    int wg_dec[2][4];
+    if (MODE == P_WGRAD) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q4 = a_kq[i] * 4;
+            const int nn = swap ? m0 + q4 : n0 + q4, lim = swap ? M : N;
+            wg_ok[i] = nn < lim && (swap || q4 < BN);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) wg_dec[i][jj] = -1;
+            if (!wg_ok[i]) continue;
+            if (b_oihw) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    if (nn + jj >= lim) break;
+                    unsigned ci, tap, ky, kx;
+                    dtaps.divmod((unsigned)(nn + jj), ci, tap); dkw.divmod(tap, ky, kx);
+                    wg_dec[i][jj] = (int)((ci << 16) | (ky << 8) | kx);
+                }
+            } else {
+                unsigned tap, ci;
+                dC.divmod((unsigned)nn, tap, ci);
+                const int ky = (int)tap / g.kw, kx = (int)tap - ky * g.kw;
+                wg_dec[i][0] = (int)((ci << 16) | ((unsigned)ky << 8) | (unsigned)kx);
+            }
+        }
+    }
     f32x4 ra[2];
     float rb[NBV];
     f32x4 rbv[2];
@@ -209,29 +238,28 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const float* __restr
         if (MODE == P_WGRAD) {
             // k = output pixel.  A(m = co, k) = dy[k][co]: float4 along m.  B(n' = tap * C + ci, k) = x at the pixel's tap window: float4
             // along ci.  `swap` (cout <= 64: the 128-row side would be half empty): the roles exchanged, C^T[n'][co] is computed
-            auto gather_x = [&](int k, int nn, int lim) -> f32x4 {
+            // the column quad a thread gathers is the same for every k-tile: its (tap, channel) decode is hoisted (wg_*), only the pixel moves
+            auto gather_x = [&](int k, int i) -> f32x4 {
                 f32x4 vb = {0.f, 0.f, 0.f, 0.f};
-                if (nn >= lim) return vb;
+                if (!wg_ok[i]) return vb;
                 unsigned img, rem, oy, ox;
                 dHoWo.divmod((unsigned)k, img, rem); dWo.divmod(rem, oy, ox);
+                const int by = (int)oy * g.stride - g.pad, bx = (int)ox * g.stride - g.pad;
                 if (b_oihw) {
                     // a layer whose input the float4 fetch cannot serve (the NCHW image with its fused Normalize, C % 4 != 0): element by
                     // element, n = (ci, ky, kx) in the weight's own order; the dy side stays float4
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
-                        if (nn + jj >= lim) break;
-                        unsigned ci, tap, ky, kx;
-                        dtaps.divmod((unsigned)(nn + jj), ci, tap); dkw.divmod(tap, ky, kx);
-                        vb[jj] = load_x(x, mean, stdv, g, (int)img, (int)oy * g.stride - g.pad + (int)ky, (int)ox * g.stride - g.pad + (int)kx, (int)ci);
+                        const int d = wg_dec[i][jj];
+                        if (d < 0) break;
+                        vb[jj] = load_x(x, mean, stdv, g, (int)img, by + ((d >> 8) & 0xff), bx + (d & 0xff), d >> 16);
                     }
                     return vb;
                 }
-                unsigned tap, ci;
-                dC.divmod((unsigned)nn, tap, ci);
-                const int ky = (int)tap / g.kw, kx = (int)tap - ky * g.kw;
-                const int iy = (int)oy * g.stride - g.pad + ky, ix = (int)ox * g.stride - g.pad + kx;
+                const int d = wg_dec[i][0];
+                const int iy = by + ((d >> 8) & 0xff), ix = bx + (d & 0xff);
                 if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
-                    vb = *(const f32x4*)(x + (((size_t)img * g.H + iy) * g.W + ix) * g.C + ci);
+                    vb = *(const f32x4*)(x + (((size_t)img * g.H + iy) * g.W + ix) * g.C + (d >> 16));
                 return vb;
             };
 #pragma unroll
@@ -241,9 +269,9 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const float* __restr
                 if (k < k_hi) {
                     if (!swap) {
                         if (m0 + q4 < M) va = *(const f32x4*)(dy + (size_t)k * g.cout + m0 + q4);
-                        if (q4 < BN) vb = gather_x(k, n0 + q4, N);
+                        if (q4 < BN) vb = gather_x(k, i);
                     } else {
-                        va = gather_x(k, m0 + q4, M);
+                        va = gather_x(k, i);
                         if (q4 < BN && n0 + q4 < N) vb = *(const f32x4*)(dy + (size_t)k * g.cout + n0 + q4);
                     }
                 }
@@ -505,18 +533,28 @@ __global__ __launch_bounds__(256) void slab_sum_remap_kernel(const float* __rest
     const int co = (int)(e / ((size_t)C * taps)), r = (int)(e - (size_t)co * C * taps), ci = r / taps, tap = r - ci * taps;
     // partials [co][tap * C + ci], or (swapped) [tap * C + ci][co]
     const size_t src = swapped ? ((size_t)tap * C + ci) * cout + co : (size_t)co * C * taps + (size_t)tap * C + ci;
-    float s = 0.f;
-    for (int z = 0; z < S; ++z) s += slabs[(size_t)z * count + src];
-    out[e] = s;
+    double s = 0.0;                                  // slab partials are added in double: the split costs no accuracy against one long fp32 sum
+    for (int z = 0; z < S; ++z) s += (double)slabs[(size_t)z * count + src];
+    out[e] = (float)s;
+}
+
+// dw[co][n] = sum over slabs (in slab order) of partials [n][co]
+__global__ __launch_bounds__(256) void slab_sum_transpose_kernel(const float* __restrict__ slabs, float* __restrict__ out, int cout, int N, int S) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x, count = (size_t)cout * N;
+    if (e >= count) return;
+    const int co = (int)(e / (size_t)N), n = (int)(e - (size_t)co * N);
+    double s = 0.0;
+    for (int z = 0; z < S; ++z) s += (double)slabs[(size_t)z * count + (size_t)n * cout + co];
+    out[e] = (float)s;
 }
 
 // dw[e] = sum over slabs in slab order
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, float* __restrict__ out, size_t count, int S) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= count) return;
-    float s = 0.f;
-    for (int z = 0; z < S; ++z) s += slabs[(size_t)z * count + e];
-    out[e] = s;
+    double s = 0.0;
+    for (int z = 0; z < S; ++z) s += (double)slabs[(size_t)z * count + e];
+    out[e] = (float)s;
 }
 
 // forward / dgrad split k: out[e] = (accumulate ? out[e] : 0) + bias[e % N] + sum over slabs in slab order
@@ -524,11 +562,18 @@ __global__ __launch_bounds__(256) void slab_sum_out_kernel(const float* __restri
                                                            size_t count4, int N, int S, int accumulate) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= count4) return;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int z = 0; z < S; ++z) s += *(const f32x4*)(slabs + ((size_t)z * count4 + e) * 4);
-    if (bias) s += *(const f32x4*)(bias + (e * 4) % (size_t)N);
-    if (accumulate) s += *(const f32x4*)(out + e * 4);
-    *(f32x4*)(out + e * 4) = s;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};              // in double: the split costs no accuracy against one long fp32 sum
+    for (int z = 0; z < S; ++z) {
+        const f32x4 v = *(const f32x4*)(slabs + ((size_t)z * count4 + e) * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[r] += (double)v[r];
+    }
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = (float)s[r];
+    if (bias) o += *(const f32x4*)(bias + (e * 4) % (size_t)N);
+    if (accumulate) o += *(const f32x4*)(out + e * 4);
+    *(f32x4*)(out + e * 4) = o;
 }
 
 // how many k slabs a forward / dgrad launch of `tiles` output tiles (x `classes`) over a reduction of K should use: none when the launch
@@ -686,11 +731,17 @@ extern "C" int eoe_conv_f32_wgrad(const float* x, int x_nchw, const float* mean,
         const int Mk = swap ? N : M, Nk = swap ? M : N;
         const bool narrow = Nk <= 64;
         const int tiles = ((Mk + 127) / 128) * (narrow ? (Nk + 63) / 64 : (Nk + 127) / 128);
+        const size_t count = (size_t)M * N;
+        // about four workgroups per CU (25-34 KB of LDS each: several are co-resident, and 5 tiles x 64 slabs = 320 workgroups left
+        // a quarter of the CUs with twice the work of the rest), at least 8 k-tiles per slab, within the workspace
         int S = (1024 + tiles - 1) / tiles;
-        if (S > 64) S = 64;
+        const size_t s_fit = workspace_bytes / (count * sizeof(float));
+        if ((size_t)S > s_fit) S = (int)s_fit;
+        if (S > K / 128) S = K / 128;
+        if (S > 1024) S = 1024;
+        if (S < 1) S = 1;
         int per = ((K + S - 1) / S + 15) / 16 * 16;
         S = (K + per - 1) / per;
-        const size_t count = (size_t)M * N;
         EOE_CHECK_ARG(workspace_bytes >= count * sizeof(float) * S, "conv_f32_wgrad: workspace of %zu bytes, need %zu", workspace_bytes,
                       count * sizeof(float) * S);
         ProfScope ps("conv_f32_wgrad", 2.0 * M * N * K, 4.0 * ((double)g.n * g.H * g.W * g.C + (double)K * M + (double)M * N), stream);
@@ -710,8 +761,8 @@ extern "C" int eoe_conv_f32_wgrad(const float* x, int x_nchw, const float* mean,
     }
     if (!(g_parity_flags & 1) && (cout % 4) == 0) {
         // dy side float4, x side element by element in OIHW order (the stem: NCHW image + Normalize, 3 channels)
-        const bool narrow = N <= 64;
-        const int tiles = ((M + 127) / 128) * (narrow ? (N + 63) / 64 : (N + 127) / 128);
+        const bool narrow = N <= 64, swap1 = M <= 64 && N > 64;
+        const int tiles = swap1 ? ((N + 127) / 128) * ((M + 63) / 64) : ((M + 127) / 128) * (narrow ? (N + 63) / 64 : (N + 127) / 128);
         const size_t count = (size_t)M * N;
         const int s_max = (int)(workspace_bytes / (count * sizeof(float)));
         int S = (2048 + tiles - 1) / tiles;
@@ -725,14 +776,21 @@ extern "C" int eoe_conv_f32_wgrad(const float* x, int x_nchw, const float* mean,
         ProfScope ps("conv_f32_wgrad", 2.0 * M * N * K, 4.0 * ((double)g.n * g.H * g.W * g.C + (double)K * M + (double)M * N), stream);
         MFMA_DIVS(g);
         const FDiv staps((unsigned)(g.kh * g.kw)), skw((unsigned)g.kw);
-        if (narrow) hipLaunchKernelGGL((conv_f32_mfma_kernel<P_WGRAD, 64, 1>), dim3((N + 63) / 64, (M + 127) / 128, S), dim3(256), 0, (hipStream_t)stream,
+        if (swap1) {
+            // cout <= 64 (the stem): the roles exchanged -- the (ci, ky, kx) columns fill the 128-row side, partials [S][N][cout]
+            hipLaunchKernelGGL((conv_f32_mfma_kernel<P_WGRAD, 64, 3>), dim3((M + 63) / 64, (N + 127) / 128, S), dim3(256), 0, (hipStream_t)stream,
+                               x, (const float*)nullptr, dy, (const float*)nullptr, (float*)workspace, g, N, M, K, per, 0, dHoWo, dWo, dHW, dW, dC,
+                               mean, stdv, staps, skw);
+        } else if (narrow) hipLaunchKernelGGL((conv_f32_mfma_kernel<P_WGRAD, 64, 1>), dim3((N + 63) / 64, (M + 127) / 128, S), dim3(256), 0, (hipStream_t)stream,
                                        x, (const float*)nullptr, dy, (const float*)nullptr, (float*)workspace, g, M, N, K, per, 0, dHoWo, dWo, dHW, dW, dC,
                                        mean, stdv, staps, skw);
         else hipLaunchKernelGGL((conv_f32_mfma_kernel<P_WGRAD, 128, 1>), dim3((N + 127) / 128, (M + 127) / 128, S), dim3(256), 0, (hipStream_t)stream,
                                 x, (const float*)nullptr, dy, (const float*)nullptr, (float*)workspace, g, M, N, K, per, 0, dHoWo, dWo, dHW, dW, dC,
                                 mean, stdv, staps, skw);
         EOE_CHECK_LAUNCH("conv_f32_wgrad (mfma, dy float4)");
-        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dw,
+        if (swap1) hipLaunchKernelGGL(slab_sum_transpose_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                                      (const float*)workspace, dw, M, N, S);
+        else hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dw,
                            count, S);
         EOE_CHECK_LAUNCH("conv_f32_wgrad_sum");
         return 0;

@@ -14,12 +14,20 @@ from .ad_trainer import ADTrainer
 
 
 class ADClipTrainer(ADTrainer):
-    def __init__(self, model, *args, text_features=None, **kwargs):
+    def __init__(self, model, *args, text_features=None, fp16_weights=False, **kwargs):
+        """fp16_weights: the reference's CLIP towers carry fp16 convolution / linear / attention / projection parameters on a GPU
+        (`convert_weights`, clip/model.py:371-392, applied by build_model :430; `clip.load` undoes it on the CPU only) and SGD updates those
+        fp16 tensors; True reproduces that arithmetic (`eoe_amd.models.convert_weights` on the image tower + `eoe_sgd_multi`'s fp16 path).
+        The default keeps fp32 masters, which is what the reference gets on a CPU and is strictly more accurate."""
         super().__init__(model, *args, **kwargs)
         self.text_features = text_features
+        self.fp16_weights = bool(fp16_weights)
 
     def make_optimizer(self, model):
         # ad_trainer.py:380-381: CLIP models are trained with SGD(momentum 0.9, nesterov)
+        if self.fp16_weights:
+            from ..models import convert_weights
+            convert_weights(getattr(model, "feature_model", model))          # the CLIP tower; a CustomNet head is created in fp32
         return FusedSGD(model.parameters(), lr=self.lr, weight_decay=self.wdk, momentum=0.9, nesterov=True)
 
     def prepare_metric(self, cstr, loader, model, seed, **kwargs):

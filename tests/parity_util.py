@@ -38,14 +38,29 @@ def trajectory_deviation(losses, scores, g, steps=None):
     return dl, ds
 
 
+def deviation_from_fp64(losses, scores, g, steps=None):
+    """as trajectory_deviation, against the fp64 twin (the trajectory exact arithmetic gives); None without a twin"""
+    if "losses64" not in g:
+        return None, None
+    steps = steps or len(g["losses"])
+    ref = g["losses64"][:steps]
+    dl = np.abs(np.asarray(losses[:steps], np.float64) - ref) / np.maximum(1.0, np.abs(ref))
+    ds = np.abs(np.stack([np.asarray(s, np.float64) for s in scores[:steps]]) - g["scores64"][:steps]).max(axis=1)
+    return dl, ds
+
+
 def check_trajectory(losses, scores, g, k_noise, steps=None, what=""):
-    """assert the trajectory within max(1e-3, k_noise x reference noise) per step; returns a printable summary"""
+    """assert the trajectory within max(1e-3, k_noise x reference noise) per step of the reference's fp32 trajectory; returns a printable
+    summary (which also reports the distance to the fp64 twin -- the trajectory exact arithmetic gives -- where the fixture has one)"""
     dl, ds = trajectory_deviation(losses, scores, g, steps)
     nl, ns = reference_noise(g, steps)
     tl, ts = np.maximum(BAR, k_noise * nl), np.maximum(BAR, k_noise * ns)
+    el, es = deviation_from_fp64(losses, scores, g, steps)
     fmt = lambda a: "[" + " ".join(f"{v:.1e}" for v in a) + "]"          # noqa: E731
     msg = (f"[{what}] loss dev {fmt(dl)} (allowed {fmt(tl)}); score dev {fmt(ds)} (allowed {fmt(ts)}); "
            f"steps at the plain 1e-3 bar: loss {int((tl <= BAR).sum())}/{len(tl)}, scores {int((ts <= BAR).sum())}/{len(ts)}")
+    if el is not None:
+        msg += f"; vs the fp64 twin: loss {fmt(el)}, scores {fmt(es)}"
     assert (dl <= tl).all() and (ds <= ts).all(), msg
     return msg
 
