@@ -282,11 +282,21 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const float* __restr
         const int tap = k0 / (MODE == P_FWD ? g.C : g.cout), c0 = k0 - tap * (MODE == P_FWD ? g.C : g.cout);
         int ky = tap / g.kw, kx = tap - ky * g.kw;
         if (S2) { const int ty = tap / s2_ntx; ky = s2_ky0 + 2 * ty; kx = s2_kx0 + 2 * (tap - ty * s2_ntx); }
+        // forward over a 4-channel map (the 3-channel image packed to NHWC4, eoe_pack_image_nhwc4): a 16-deep k-tile is 4 taps x 4 channels,
+        // the thread's float4 is the whole pixel of tap (k0 / 4 + kq)
+        const bool c4 = MODE == P_FWD && g.C == 4;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (a_ok[i]) {
-                if (MODE == P_FWD) {
+                if (MODE == P_FWD && c4) {
+                    const int tp = (k0 >> 2) + a_kq[i];
+                    if (tp < taps) {
+                        const int ty = tp / g.kw, iy = a_y[i] + ty, ix = a_x[i] + (tp - ty * g.kw);
+                        if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
+                            v = *(const f32x4*)(x + (((size_t)a_img[i] * g.H + iy) * g.W + ix) * 4);
+                    }
+                } else if (MODE == P_FWD) {
                     const int iy = a_y[i] + ky, ix = a_x[i] + kx;
                     if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
                         v = *(const f32x4*)(x + (((size_t)a_img[i] * g.H + iy) * g.W + ix) * g.C + c0 + a_kq[i] * 4);
@@ -308,7 +318,10 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const float* __restr
         for (int i = 0; i < NBV; ++i) {
             const int e = t + 256 * i, kk = e & 15, r = e >> 4, nn = n0 + r;
             float b = 0.f;
-            if (nn < N)
+            if (MODE == P_FWD && c4) {
+                const int tp = (k0 >> 2) + (kk >> 2);
+                if (nn < N && tp < taps) { const int ty = tp / g.kw; b = w[(((size_t)nn * 4 + (kk & 3)) * g.kh + ty) * g.kw + (tp - ty * g.kw)]; }
+            } else if (nn < N)
                 b = MODE == P_FWD ? w[(((size_t)nn * g.C + c0 + kk) * g.kh + ky) * g.kw + kx]
                                   : w[(((size_t)(c0 + kk) * g.C + nn) * g.kh + ky) * g.kw + kx];
             rb[i] = b;
@@ -525,36 +538,71 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_scalar_kernel(const float* 
     }
 }
 
-// dw[co][ci][tap] = sum over slabs (in slab order) of the MFMA kernel's [co][tap * C + ci] partials
-__global__ __launch_bounds__(256) void slab_sum_remap_kernel(const float* __restrict__ slabs, float* __restrict__ out, int cout, int C,
-                                                             int taps, int S, int swapped) {
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x, count = (size_t)cout * C * taps;
-    if (e >= count) return;
-    const int co = (int)(e / ((size_t)C * taps)), r = (int)(e - (size_t)co * C * taps), ci = r / taps, tap = r - ci * taps;
-    // partials [co][tap * C + ci], or (swapped) [tap * C + ci][co]
-    const size_t src = swapped ? ((size_t)tap * C + ci) * cout + co : (size_t)co * C * taps + (size_t)tap * C + ci;
-    double s = 0.0;                                  // slab partials are added in double: the split costs no accuracy against one long fp32 sum
-    for (int z = 0; z < S; ++z) s += (double)slabs[(size_t)z * count + src];
-    out[e] = (float)s;
-}
-
-// dw[co][n] = sum over slabs (in slab order) of partials [n][co]
-__global__ __launch_bounds__(256) void slab_sum_transpose_kernel(const float* __restrict__ slabs, float* __restrict__ out, int cout, int N, int S) {
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x, count = (size_t)cout * N;
-    if (e >= count) return;
-    const int co = (int)(e / (size_t)N), n = (int)(e - (size_t)co * N);
+// The slab sums of the weight gradients.  Up to 1024 slabs per element: one thread walking them serially is a chain of a thousand dependent
+// L2 round trips (the 3 -> 32 first layer of CNN32: 0.3 of its 0.38 ms), so an element gets ZL = 16 lanes -- lane j adds slabs j, j + 16, ...
+// in ascending order (8 loads in flight), and the 16 lane sums are added in lane order: a fixed order, in double (the split costs no accuracy
+// against one long fp32 sum).  src(e) maps an output element to its place inside a slab:
+//   LAYOUT 0: the same place;  1: out [co][ci][tap] <- slab [co][tap * C + ci];  2: out [co][ci][tap] <- slab [tap * C + ci][co];
+//   3: out [co][n] <- slab [n][co]
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, size_t count, int S, int cout,
+                                                          int C, int taps) {
+    constexpr int ZL = 16;
+    __shared__ double part[ZL][16];
+    const int el = threadIdx.x & 15, j = threadIdx.x >> 4;
+    const size_t e = (size_t)blockIdx.x * 16 + el;
     double s = 0.0;
-    for (int z = 0; z < S; ++z) s += (double)slabs[(size_t)z * count + (size_t)n * cout + co];
-    out[e] = (float)s;
+    if (e < count) {
+        size_t src = e;
+        if (LAYOUT == 1 || LAYOUT == 2) {
+            const int co = (int)(e / ((size_t)C * taps)), r = (int)(e - (size_t)co * C * taps), ci = r / taps, tap = r - ci * taps;
+            src = LAYOUT == 2 ? ((size_t)tap * C + ci) * cout + co : (size_t)co * C * taps + (size_t)tap * C + ci;
+        } else if (LAYOUT == 3) {
+            const size_t N = count / (size_t)cout;
+            const int co = (int)(e / N);
+            src = (e - (size_t)co * N) * cout + co;
+        }
+        const float* p = slabs + src;
+        int z = j;
+#pragma unroll 1
+        for (; z + 7 * ZL < S; z += 8 * ZL) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(z + u * ZL) * count];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (double)v[u];
+        }
+        for (; z < S; z += ZL) s += (double)p[(size_t)z * count];
+    }
+    part[j][el] = s;
+    __syncthreads();
+    if (j == 0 && e < count) {
+        double t = 0.0;
+#pragma unroll
+        for (int u = 0; u < ZL; ++u) t += part[u][el];
+        out[e] = (float)t;
+    }
 }
+#define EOE_SLAB_REDUCE(LAYOUT, slabs, out, count, S, cout, C, taps, stream)                                                          \
+    hipLaunchKernelGGL((slab_reduce_kernel<LAYOUT>), dim3((unsigned)(((count) + 15) / 16)), dim3(256), 0, (hipStream_t)(stream), slabs, out, \
+                       (size_t)(count), S, cout, C, taps)
 
-// dw[e] = sum over slabs in slab order
-__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, float* __restrict__ out, size_t count, int S) {
+// the 3-channel NCHW image, normalised (ad_trainer.py:413-425: (x - mean) / std per channel), as an fp32 NHWC4 map (4th channel 0): the
+// first layer's forward and weight gradient then fetch whole pixels as float4 instead of gathering and normalising element by element
+// (each image element is used kh * kw times by either: the stem ran at 31 / 15 TF against 70-95 TF for the other layers)
+__global__ __launch_bounds__(256) void pack_image_nhwc4_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                               const float* __restrict__ stdv, float* __restrict__ out, size_t pixels, size_t HW) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= count) return;
-    double s = 0.0;
-    for (int z = 0; z < S; ++z) s += (double)slabs[(size_t)z * count + e];
-    out[e] = (float)s;
+    if (e >= pixels) return;
+    const size_t img = e / HW, p = e - img * HW;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float t = x[(img * 3 + c) * HW + p];
+        if (mean) t = (t - mean[c]) / stdv[c];
+        v[c] = t;
+    }
+    *(f32x4*)(out + e * 4) = v;
 }
 
 // forward / dgrad split k: out[e] = (accumulate ? out[e] : 0) + bias[e % N] + sum over slabs in slab order
@@ -605,6 +653,17 @@ int fill_geo(const char* who, const eoe_conv_geometry* geo, int cout, int nchw, 
 
 }  // namespace
 
+extern "C" int eoe_pack_image_nhwc4(const float* x_nchw, const float* mean, const float* stdv, float* out_nhwc4, int n, int H, int W, void* stream) {
+    EOE_CHECK_ARG(x_nchw && out_nhwc4 && n > 0 && H > 0 && W > 0, "pack_image_nhwc4: bad arguments");
+    EOE_CHECK_ARG((mean == nullptr) == (stdv == nullptr), "pack_image_nhwc4: mean/std must both be given or both NULL");
+    const size_t pixels = (size_t)n * H * W;
+    ProfScope ps("pack_image_nhwc4", 0, 28.0 * pixels, stream);
+    hipLaunchKernelGGL(pack_image_nhwc4_kernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_nchw, mean, stdv,
+                       out_nhwc4, pixels, (size_t)H * W);
+    EOE_CHECK_LAUNCH("pack_image_nhwc4");
+    return 0;
+}
+
 extern "C" int eoe_conv_f32_fwd(const float* x, int x_nchw, const float* mean, const float* stdv, const float* w, const float* bias,
                                 float* y, const eoe_conv_geometry* geo, int cout, void* workspace, size_t workspace_bytes, void* stream) {
     EOE_CHECK_ARG(x && w && y, "conv_f32_fwd: null pointer");
@@ -613,7 +672,7 @@ extern "C" int eoe_conv_f32_fwd(const float* x, int x_nchw, const float* mean, c
     EOE_TRY(fill_geo("conv_f32_fwd", geo, cout, x_nchw, g));
     const int M = g.n * g.Ho * g.Wo, N = cout, K = g.kh * g.kw * g.C;
     ProfScope ps("conv_f32_fwd", 2.0 * M * N * K, 4.0 * ((double)g.n * g.H * g.W * g.C + (double)N * K + (double)M * N), stream);
-    if (!x_nchw && !mean && (g.C % 16) == 0 && !(g_parity_flags & 1)) {            // fp32 MFMA (parity_flags bit 0: the VALU kernel, A/B)
+    if (!x_nchw && !mean && ((g.C % 16) == 0 || g.C == 4) && !(g_parity_flags & 1)) {   // fp32 MFMA (parity_flags bit 0: the VALU kernel, A/B)
         MFMA_DIVS(g);
         const int gx = N <= 64 ? (N + 63) / 64 : (N + 127) / 128, gy = (M + 127) / 128;
         const int S = (N & 3) ? 1 : fwd_slabs(gx * gy, K, (size_t)M * N, workspace_bytes, workspace);
@@ -754,8 +813,8 @@ extern "C" int eoe_conv_f32_wgrad(const float* x, int x_nchw, const float* mean,
         else { if (narrow) EOE_WG_LAUNCH(64, 0); else EOE_WG_LAUNCH(128, 0); }
 #undef EOE_WG_LAUNCH
         EOE_CHECK_LAUNCH("conv_f32_wgrad (mfma)");
-        hipLaunchKernelGGL(slab_sum_remap_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)workspace, dw, cout, g.C, g.kh * g.kw, S, swap);
+        if (swap) EOE_SLAB_REDUCE(2, (const float*)workspace, dw, count, S, cout, g.C, g.kh * g.kw, stream);
+        else EOE_SLAB_REDUCE(1, (const float*)workspace, dw, count, S, cout, g.C, g.kh * g.kw, stream);
         EOE_CHECK_LAUNCH("conv_f32_wgrad_sum");
         return 0;
     }
@@ -788,10 +847,8 @@ extern "C" int eoe_conv_f32_wgrad(const float* x, int x_nchw, const float* mean,
                                 x, (const float*)nullptr, dy, (const float*)nullptr, (float*)workspace, g, M, N, K, per, 0, dHoWo, dWo, dHW, dW, dC,
                                 mean, stdv, staps, skw);
         EOE_CHECK_LAUNCH("conv_f32_wgrad (mfma, dy float4)");
-        if (swap1) hipLaunchKernelGGL(slab_sum_transpose_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                                      (const float*)workspace, dw, M, N, S);
-        else hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dw,
-                           count, S);
+        if (swap1) EOE_SLAB_REDUCE(3, (const float*)workspace, dw, count, S, M, 1, 1, stream);
+        else EOE_SLAB_REDUCE(0, (const float*)workspace, dw, count, S, M, 1, 1, stream);
         EOE_CHECK_LAUNCH("conv_f32_wgrad_sum");
         return 0;
     }
@@ -814,8 +871,7 @@ extern "C" int eoe_conv_f32_wgrad(const float* x, int x_nchw, const float* mean,
                                 (hipStream_t)stream, x, mean, stdv, (const float*)nullptr, dy, (const float*)nullptr, (float*)workspace, g,
                                 M, N, K, per, sHoWo, sWo, sC, skw, staps);
         EOE_CHECK_LAUNCH("conv_f32_wgrad (mfma, scalar)");
-        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dw,
-                           count, S);
+        EOE_SLAB_REDUCE(0, (const float*)workspace, dw, count, S, M, 1, 1, stream);
         EOE_CHECK_LAUNCH("conv_f32_wgrad_sum");
         return 0;
     }
@@ -831,8 +887,7 @@ extern "C" int eoe_conv_f32_wgrad(const float* x, int x_nchw, const float* mean,
     hipLaunchKernelGGL((conv_f32_kernel<P_WGRAD>), dim3((N + 63) / 64, (M + 63) / 64, S), dim3(256), 0, (hipStream_t)stream, x, mean, stdv,
                        (const float*)nullptr, dy, (const float*)nullptr, (float*)workspace, g, M, N, K, per, 0);
     EOE_CHECK_LAUNCH("conv_f32_wgrad");
-    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dw,
-                       count, S);
+    EOE_SLAB_REDUCE(0, (const float*)workspace, dw, count, S, M, 1, 1, stream);
     EOE_CHECK_LAUNCH("conv_f32_wgrad_sum");
     return 0;
 }

@@ -1016,8 +1016,21 @@ class ConvBnActPoolParityFunction(torch.autograd.Function):
         w = conv_w.contiguous()
         y = torch.empty((M, cout), dtype=torch.float32, device=dev)
         ws = _parity_splitk_ws(dev)
-        check(lib.eoe_conv_f32_fwd(_p(x), 1 if is_image else 0, _p(mean) if is_image else None, _p(std) if is_image else None, _p(w),
-                                   _p(conv_b), _p(y), geo, cout, _p(ws), PARITY_SPLITK_BYTES, _stream()), "eoe_conv_f32_fwd")
+        packed = bool(is_image and cin == 3 and cout % 4 == 0)
+        if packed:
+            # the 3-channel image normalised once into an fp32 NHWC4 map (4th channel and 4th weight channel zero): the first layer's forward
+            # and weight gradient fetch whole pixels as float4 instead of gathering + normalising each element kh * kw times
+            x4 = torch.empty((n, Hi, Wi, 4), dtype=torch.float32, device=dev)
+            check(lib.eoe_pack_image_nhwc4(_p(x), _p(mean), _p(std), _p(x4), n, Hi, Wi, _stream()), "eoe_pack_image_nhwc4")
+            w4 = scratch("parity_w4", (cout, 4, kh, kw), torch.float32, dev)
+            w4.zero_()
+            w4[:, :3].copy_(w)
+            check(lib.eoe_conv_f32_fwd(_p(x4), 0, None, None, _p(w4), _p(conv_b), _p(y), _geo(n, Hi, Wi, 4, kh, kw, stride, pad, H, W), cout,
+                                       _p(ws), PARITY_SPLITK_BYTES, _stream()), "eoe_conv_f32_fwd")
+            x = x4
+        else:
+            check(lib.eoe_conv_f32_fwd(_p(x), 1 if is_image else 0, _p(mean) if is_image else None, _p(std) if is_image else None, _p(w),
+                                       _p(conv_b), _p(y), geo, cout, _p(ws), PARITY_SPLITK_BYTES, _stream()), "eoe_conv_f32_fwd")
         stats = torch.empty(2 * cout, dtype=torch.float32, device=dev)
         sums = scratch("bn_sums", (BN_SCRATCH * cout,), torch.float32, dev)
         check(lib.eoe_bn_stats(_p(y), _p(sums), _p(stats), _p(rm), _p(rv), _p(nbt), M, cout, float(eps), float(momentum),
@@ -1038,6 +1051,7 @@ class ConvBnActPoolParityFunction(torch.autograd.Function):
                                           1 if flat_out else 0, 1, slope, code, _stream()), "eoe_bn_act_pool_fwd")
         ctx.save_for_backward(x, y, stats, conv_w, conv_b, bn_w, bn_b, idx, mean if is_image else None, std if is_image else None)
         ctx.cfg = (n, H, W, cin, cout, pool, flat_out, training, is_image, Hi, Wi, kh, kw, stride, pad, slope)
+        ctx.packed = packed
         ctx.passthrough = passthrough
         if not passthrough:
             return out
@@ -1051,6 +1065,7 @@ class ConvBnActPoolParityFunction(torch.autograd.Function):
             return (d_pass,) + (None,) * 8
         x, y, stats, conv_w, conv_b, bn_w, bn_b, idx, mean, std = ctx.saved_tensors
         n, H, W, cin, cout, pool, flat_out, training, is_image, Hi, Wi, kh, kw, stride, pad, slope = ctx.cfg
+        packed = getattr(ctx, "packed", False)
         dev = y.device
         M = n * H * W
         dout = dout.contiguous().float()
@@ -1069,10 +1084,18 @@ class ConvBnActPoolParityFunction(torch.autograd.Function):
         geo = _geo(n, Hi, Wi, cin, kh, kw, stride, pad, H, W)
         w = conv_w.contiguous()
         dw = _grad_target(conv_w)
-        ws_bytes = int(lib.eoe_conv_f32_wgrad_workspace(geo, cout))
-        ws = scratch("parity_wgrad_ws", (ws_bytes // 4,), torch.float32, dev)
-        check(lib.eoe_conv_f32_wgrad(_p(x), 1 if is_image else 0, _p(mean), _p(std), _p(dy), _p(dw), geo, cout, _p(ws), ws_bytes,
-                                     _stream()), "eoe_conv_f32_wgrad")
+        if packed:                                   # x = the NHWC4 image saved by forward: gradient of the zero-padded [cout, 4, kh, kw] weight
+            geo4 = _geo(n, Hi, Wi, 4, kh, kw, stride, pad, H, W)
+            ws_bytes = int(lib.eoe_conv_f32_wgrad_workspace(geo4, cout))
+            ws = scratch("parity_wgrad_ws", (ws_bytes // 4,), torch.float32, dev)
+            dw4 = scratch("parity_dw4", (cout, 4, kh, kw), torch.float32, dev)
+            check(lib.eoe_conv_f32_wgrad(_p(x), 0, None, None, _p(dy), _p(dw4), geo4, cout, _p(ws), ws_bytes, _stream()), "eoe_conv_f32_wgrad")
+            dw.copy_(dw4[:, :3])
+        else:
+            ws_bytes = int(lib.eoe_conv_f32_wgrad_workspace(geo, cout))
+            ws = scratch("parity_wgrad_ws", (ws_bytes // 4,), torch.float32, dev)
+            check(lib.eoe_conv_f32_wgrad(_p(x), 1 if is_image else 0, _p(mean), _p(std), _p(dy), _p(dw), geo, cout, _p(ws), ws_bytes,
+                                         _stream()), "eoe_conv_f32_wgrad")
         dcb = None
         if conv_b is not None:
             dcb = _grad_target(conv_b)

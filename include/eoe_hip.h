@@ -465,6 +465,10 @@ int eoe_comm_sync_bn(eoe_comm_t comm, int enable);
  *   k x the output size allows k slabs.  A stride-2 dgrad over an even map runs as four parity-class GEMMs (no work on taps a pixel
  *   never meets); "parity_flags" bit 1 turns that off.
  * ---------------------------------------------------------------------------------------------------- */
+/* the 3-channel NCHW image batch, optionally normalised ((x - mean) / std, ad_trainer.py:413-425), as an fp32 NHWC map with 4 channels
+ * (the 4th = 0): with it (geo.C = 4, weights zero-padded to [cout, 4, kh, kw]) the first layer runs through the float4 paths of
+ * eoe_conv_f32_fwd / _wgrad instead of element-wise gathers */
+int eoe_pack_image_nhwc4(const float* x_nchw, const float* mean, const float* stdv, float* out_nhwc4, int n, int H, int W, void* stream);
 int eoe_conv_f32_fwd(const float* x, int x_nchw, const float* mean, const float* stdv, const float* w, const float* bias, float* y,
                      const eoe_conv_geometry* geo, int cout, void* workspace, size_t workspace_bytes, void* stream);
 int eoe_conv_f32_dgrad(const float* dy, const float* w, float* dx, const eoe_conv_geometry* geo, int cout, int accumulate,

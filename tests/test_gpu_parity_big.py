@@ -136,6 +136,23 @@ def _conv_f32_case(name, n, cin, cout, H, k, stride, pad, nchw, F, ops, lib, che
     ws = torch.empty(nbytes // 4, device="cuda")
     check(lib.eoe_conv_f32_wgrad(p(x), int(nchw), p(mean), p(std), p(dy), p(dw), geo, cout, p(ws), nbytes, st), "wgrad")
     assert rel_rms(dw, wd.grad) < 2e-6, rel_rms(dw, wd.grad)
+    if nchw and cin == 3:
+        # the same layer through the packed form the model uses (eoe_pack_image_nhwc4: image normalised into an NHWC4 map, weights zero-padded
+        # to 4 channels): float4 fetches in forward and wgrad
+        x4 = torch.empty((n, H, W, 4), device="cuda")
+        check(lib.eoe_pack_image_nhwc4(p(x), p(mean), p(std), p(x4), n, H, W, st), "pack")
+        assert torch.equal(x4[..., :3], ((x - mean.view(1, 3, 1, 1)) / std.view(1, 3, 1, 1)).permute(0, 2, 3, 1)) and (x4[..., 3] == 0).all()
+        w4 = torch.zeros((cout, 4, k, k), device="cuda")
+        w4[:, :3] = w
+        geo4 = ops._geo(n, H, W, 4, k, k, stride, pad, Ho, Wo)
+        y4 = torch.empty_like(y)
+        check(lib.eoe_conv_f32_fwd(p(x4), 0, None, None, p(w4), p(b), p(y4), geo4, cout, p(sk), sk.numel() * 4, st), "fwd4")
+        assert rel_rms(y4, want) < 2e-6, rel_rms(y4, want)
+        dw4 = torch.empty_like(w4)
+        nb4 = int(lib.eoe_conv_f32_wgrad_workspace(geo4, cout))
+        ws4 = torch.empty(nb4 // 4, device="cuda")
+        check(lib.eoe_conv_f32_wgrad(p(x4), 0, None, None, p(dy), p(dw4), geo4, cout, p(ws4), nb4, st), "wgrad4")
+        assert rel_rms(dw4[:, :3], wd.grad) < 2e-6 and (dw4[:, 3] == 0).all()
     if not nchw:
         base, baser = f32(f"p/{name}/base", (n, H, W, cin), 1.0)
         dx = base.clone()
