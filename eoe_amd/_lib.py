@@ -167,6 +167,8 @@ SIGNATURES = {
     "eoe_cgate_bwd": [C.POINTER(CGateBwdArgs), _vp],
     "eoe_sgate_fwd": [C.POINTER(SGateArgs), _vp],
     "eoe_sgate_bwd": [C.POINTER(SGateBwdArgs), _vp],
+    "eoe_cbam_junction_fwd": [C.POINTER(CGateArgs), C.POINTER(SGateArgs), _vp],
+    "eoe_cbam_junction_bwd": [C.POINTER(CGateBwdArgs), C.POINTER(SGateBwdArgs), _vp, _vp, _vp, _vp],
     "eoe_add_relu_fwd": [_vp, _vp, _vp, _vp, C.c_int, _i64, _vp],
     "eoe_relu_bwd": [_vp, _vp, _vp, _i64, _vp],
     "eoe_avgpool_fwd": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],

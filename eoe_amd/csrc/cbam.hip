@@ -464,8 +464,11 @@ __global__ __launch_bounds__(256) void sgate_bn_bwd_total_kernel(float* __restri
     }
 }
 // dcomp[p, ch] = sum_taps dz[y-ky+3, x-kx+3] * w[ch, ky, kx]
+// (pack != 0, the fused CBAM unit: dcomp holds FOUR floats per pixel -- {scale[p], dcomp0, dcomp1, argmax[p] as bits} -- so that the two passes
+//  that rebuild the spatial gate's input gradient fetch a pixel's scalars with one 16-byte load instead of three narrow ones)
 __global__ __launch_bounds__(256) void sgate_conv_bwd_data_kernel(const float* __restrict__ dz, const float* __restrict__ w,
-                                                                  float* __restrict__ dcomp, int n, int H, int W) {
+                                                                  float* __restrict__ dcomp, int n, int H, int W, int pack = 0,
+                                                                  const float* __restrict__ sp = nullptr, const int* __restrict__ am = nullptr) {
     __shared__ float lw[98];
     if (threadIdx.x < 98) lw[threadIdx.x] = w[threadIdx.x];
     __syncthreads();
@@ -485,7 +488,8 @@ __global__ __launch_bounds__(256) void sgate_conv_bwd_data_kernel(const float* _
                 a1 += d * lw[49 + ky * 7 + kx];
             }
         }
-        *(f32x2*)(dcomp + p * 2) = (f32x2){a0, a1};
+        if (pack) *(f32x4*)(dcomp + p * 4) = (f32x4){sp[p], a0, a1, __int_as_float(am[p])};
+        else *(f32x2*)(dcomp + p * 2) = (f32x2){a0, a1};
     }
 }
 // dw[ch, ky, kx] = sum_p dz[p] * comp[(y+ky-3, x+kx-3), ch].  One workgroup per image: the image's comp plane sits in LDS with
@@ -600,6 +604,157 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
         const int c = (int)(i % cc) * 4;
         const size_t p = i / cc;
         *(f32x4*)(dx + p * C + c) = *(const f32x4*)(dout + (p / HW) * C + c) * inv;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------- CBAM + residual junction, fused (round 3)
+// A BasicBlock's tail is out = relu(sgate(cgate(x)) + res) (resnet.py:143-147, cbam.py:100-106).  Run as separate units it makes 7.5 passes
+// over the activation forward (30 B per element) and 11 backward (44 B): the channel-gated tensor xc = x * sc is written, read again by the
+// spatial pooling, by the junction, and twice in backward, and the junction gradient is a pass of its own.  Here xc is never written:
+// every consumer multiplies x by sc[img, c] on the fly (the same single fp32 product: the results keep their bits), the junction's
+// ReLU mask is applied where the gradient is first read, and the spatial gate's backward feeds the channel gate's reduction and its
+// final pass without materialising its output -- 22 B forward, 32 B backward per element.
+
+// forward: comp[p] = (max_c, mean_c) of x * sc, argmax[p]; 16 lanes per pixel
+__global__ __launch_bounds__(256) void cbam_pix_pool_kernel(const float* __restrict__ x, const float* __restrict__ sc, float* __restrict__ comp,
+                                                            int* __restrict__ oarg, size_t P, int HW, int C) {
+    const int sub = threadIdx.x & 15;
+    for (size_t p = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4); p < (P + 15) / 16 * 16; p += (size_t)gridDim.x * 16) {
+        const bool live = p < P;
+        float s = 0.f, m = -INFINITY;
+        int arg = 0;
+        if (live) {
+            const float* scp = sc + (p / HW) * C;
+            for (int c = sub * 4; c < C; c += 64) {
+                const f32x4 v = *(const f32x4*)(x + p * C + c) * *(const f32x4*)(scp + c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s += v[r];
+                    if (v[r] > m) { m = v[r]; arg = c + r; }
+                }
+            }
+        }
+#pragma unroll
+        for (int sft = 8; sft >= 1; sft >>= 1) {
+            s += __shfl_xor(s, sft, 16);
+            const float om = __shfl_xor(m, sft, 16);
+            const int oa = __shfl_xor(arg, sft, 16);
+            if (om > m || (om == m && oa < arg)) { m = om; arg = oa; }
+        }
+        if (live && sub == 0) {
+            comp[p * 2 + 0] = m;
+            comp[p * 2 + 1] = s / (float)C;
+            oarg[p] = arg;
+        }
+    }
+}
+// forward: out = relu((x * sc[img, c]) * sp[p] + res) (+ 16-bit copy)
+template <typename T>
+__global__ __launch_bounds__(256) void cbam_apply_add_relu_kernel(const float* __restrict__ x, const float* __restrict__ sc,
+                                                                  const float* __restrict__ sp, const float* __restrict__ res,
+                                                                  float* __restrict__ out, T* __restrict__ out16, size_t P, int HW, int C) {
+    const int cc = C / 4;
+    const size_t total = P * cc;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cc) * 4;
+        const size_t p = i / cc;
+        const f32x4 xc = *(const f32x4*)(x + p * C + c) * *(const f32x4*)(sc + (p / HW) * C + c);
+        f32x4 v = xc * sp[p] + *(const f32x4*)(res + p * C + c);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        *(f32x4*)(out + p * C + c) = v;
+        if (out16) *(u32x2*)(out16 + p * C + c) = pack4<T>(v[0], v[1], v[2], v[3]);
+    }
+}
+// backward 1: g = dout * [out > 0] (written: it is also the shortcut's gradient), dsp[p] = sum_c g * (x * sc); 16 lanes per pixel
+__global__ __launch_bounds__(256) void cbam_relu_pix_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                                   const float* __restrict__ x, const float* __restrict__ sc,
+                                                                   float* __restrict__ g, float* __restrict__ dsp, size_t P, int HW, int C) {
+    const int sub = threadIdx.x & 15;
+    for (size_t p = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4); p < (P + 15) / 16 * 16; p += (size_t)gridDim.x * 16) {
+        const bool live = p < P;
+        float s = 0.f;
+        if (live) {
+            const float* scp = sc + (p / HW) * C;
+            for (int c = sub * 4; c < C; c += 64) {
+                f32x4 d = *(const f32x4*)(dout + p * C + c);
+                const f32x4 o = *(const f32x4*)(out + p * C + c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d[r] = o[r] > 0.f ? d[r] : 0.f;
+                *(f32x4*)(g + p * C + c) = d;
+                const f32x4 w = *(const f32x4*)(x + p * C + c) * *(const f32x4*)(scp + c);
+                s += d[0] * w[0] + d[1] * w[1] + d[2] * w[2] + d[3] * w[3];
+            }
+        }
+#pragma unroll
+        for (int sft = 8; sft >= 1; sft >>= 1) s += __shfl_xor(s, sft, 16);
+        if (live && sub == 0) dsp[p] = s;
+    }
+}
+// the spatial gate's input gradient at (p, c..c+3), never stored: dxc = g * sp[p] + [c == argmax_p] * dcomp[p, 0] + dcomp[p, 1] / C;
+// pk[p] = {sp, dcomp0, dcomp1, argmax bits} (sgate_conv_bwd_data_kernel, pack)
+__device__ __forceinline__ f32x4 cbam_dxc(const float* __restrict__ g, const float* __restrict__ pk, size_t p, int c, int C, float invC) {
+    const f32x4 d = *(const f32x4*)(g + p * C + c);
+    const f32x4 q = *(const f32x4*)(pk + p * 4);
+    const int am = __float_as_int(q[3]);
+    f32x4 o = d * q[0] + q[2] * invC;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (c + r == am) o[r] += q[1];
+    return o;
+}
+// backward 2: dsc[img, c] = sum_hw dxc * x   (the layout of chan_reduce_kernel<1>)
+__global__ __launch_bounds__(256) void cbam_chan_reduce_kernel(const float* __restrict__ g, const float* __restrict__ pk,
+                                                               const float* __restrict__ x, float* __restrict__ dsc, int HW, int C, int cpb) {
+    __shared__ f32x4 ls[256];
+    const int img = blockIdx.x, rpb = 256 / cpb;
+    const int tc = threadIdx.x % cpb, rl = threadIdx.x / cpb;
+    const int c = (blockIdx.y * cpb + tc) * 4;
+    const float invC = 1.0f / (float)C;
+    const size_t p0 = (size_t)img * HW;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 4;
+    int hw = rl;
+    for (; hw + (U - 1) * rpb < HW; hw += U * rpb) {
+        f32x4 v[U], w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v[u] = cbam_dxc(g, pk, p0 + hw + u * rpb, c, C, invC);
+            w[u] = *(const f32x4*)(x + (p0 + hw + u * rpb) * C + c);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) s += v[u] * w[u];
+    }
+    for (; hw < HW; hw += rpb) s += cbam_dxc(g, pk, p0 + hw, c, C, invC) * *(const f32x4*)(x + (p0 + hw) * C + c);
+    ls[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0) {
+        for (int k = 1; k < rpb; ++k) s += ls[threadIdx.x + k * cpb];
+        *(f32x4*)(dsc + (size_t)img * C + c) = s;
+    }
+}
+// backward 3: dx = dxc * sc[img, c] + dpooled_avg[img, c] / HW + [hw == argmax_c[img, c]] * dpooled_max[img, c]
+__global__ __launch_bounds__(256) void cbam_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ pk,
+                                                             const float* __restrict__ sc, const float* __restrict__ dpooled,
+                                                             const int* __restrict__ am_c, float* __restrict__ dx, int n, int HW, int C) {
+    const int cc = C / 4;
+    const size_t total = (size_t)n * HW * cc;
+    const float inv = 1.0f / (float)HW, invC = 1.0f / (float)C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cc) * 4;
+        const size_t p = i / cc;
+        const size_t img = p / HW;
+        const int hw = (int)(p % HW);
+        const f32x4 d = cbam_dxc(g, pk, p, c, C, invC);
+        const f32x4 s = *(const f32x4*)(sc + img * C + c);
+        const f32x4 da = *(const f32x4*)(dpooled + (img * 2 + 0) * C + c);
+        const f32x4 dm = *(const f32x4*)(dpooled + (img * 2 + 1) * C + c);
+        f32x4 o = d * s + da * inv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (am_c[img * C + c + r] == hw) o[r] += dm[r];
+        *(f32x4*)(dx + p * C + c) = o;
     }
 }
 
@@ -770,6 +925,110 @@ extern "C" int eoe_sgate_bwd(const eoe_sgate_bwd_args* b, void* stream) {
     hipLaunchKernelGGL(sgate_bwd_apply_kernel, dim3(grid_for(P * a->C / 4)), dim3(256), 0, s, b->dout, a->scale, (const float*)b->dcomp,
                        a->argmax, b->dx, P, a->C);
     EOE_CHECK_LAUNCH("sgate_bwd_apply");
+    return 0;
+}
+
+// CBAM + residual junction in one unit (see the kernels above): cg = the channel gate's arguments (cg->out unused), sg = the spatial
+// gate's (sg->x unused: its input x * scale is never written; sg->res / out / out16 as in eoe_sgate_fwd)
+extern "C" int eoe_cbam_junction_fwd(const eoe_cgate_args* cg, const eoe_sgate_args* sg, void* stream) {
+    EOE_TRY(check_cgate(cg));
+    EOE_CHECK_ARG(sg && sg->w && sg->comp && sg->argmax && sg->z && sg->stats && sg->scale && sg->sums && sg->res && sg->out, "cbam_junction_fwd: null args");
+    EOE_CHECK_ARG((sg->gamma == nullptr) == (sg->beta == nullptr), "cbam_junction: gamma/beta must both be given or both NULL");
+    EOE_CHECK_ARG(sg->n == cg->n && sg->H * sg->W == cg->HW && sg->C == cg->C, "cbam_junction: the two gates disagree on the shape");
+    EOE_CHECK_ARG(!sg->out16 || sg->dtype == EOE_F16 || sg->dtype == EOE_BF16, "cbam_junction_fwd: bad dtype %d", sg->dtype);
+    hipStream_t s = (hipStream_t)stream;
+    const int cpb = chan_cpb(cg->C), C = cg->C, HW = cg->HW;
+    const size_t P = (size_t)cg->n * HW;
+    EOE_CHECK_ARG(P < 0x7fffffffull, "cbam_junction: too many pixels");
+    {
+        ProfScope ps("cgate_fwd", 0, 4.0 * P * C, stream);
+        hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3(cg->n, C / 4 / cpb), dim3(256), 0, s, cg->x, (const float*)nullptr, cg->pooled,
+                           cg->argmax, HW, C, cpb);
+        EOE_CHECK_LAUNCH("cbam_chan_pool");
+        hipLaunchKernelGGL(cgate_mlp_fwd_kernel, dim3(cg->n), dim3(256), (2 * C + 2 * cg->Ch) * sizeof(float), s, cg->pooled, cg->w1, cg->b1,
+                           cg->w2, cg->b2, cg->hidden, cg->scale, C, cg->Ch);
+        EOE_CHECK_LAUNCH("cbam_mlp_fwd");
+    }
+    {
+        ProfScope ps("sgate_fwd", 0, 4.0 * P * C, stream);
+        hipLaunchKernelGGL(cbam_pix_pool_kernel, dim3(grid_for(P * 16)), dim3(256), 0, s, cg->x, (const float*)cg->scale, sg->comp, sg->argmax,
+                           P, HW, C);
+        EOE_CHECK_LAUNCH("cbam_pix_pool");
+        hipLaunchKernelGGL(sgate_conv_fwd_kernel, dim3(grid_for(P)), dim3(256), 0, s, sg->comp, sg->w, sg->z, sg->n, sg->H, sg->W);
+        EOE_CHECK_LAUNCH("cbam_conv_fwd");
+    }
+    EOE_TRY(eoe_bn_stats(sg->z, sg->sums, sg->stats, sg->running_mean, sg->running_var, sg->num_batches_tracked, (int)P, 1, sg->eps,
+                         sg->momentum, sg->training, stream));
+    ProfScope ps("sgate_fwd", 0, 14.0 * P * C, stream);
+    hipLaunchKernelGGL(sgate_sigmoid_kernel, dim3(grid_for(P)), dim3(256), 0, s, sg->z, sg->stats, sg->gamma, sg->beta, sg->scale, P);
+    EOE_CHECK_LAUNCH("cbam_sigmoid");
+    if (sg->out16 && sg->dtype == EOE_BF16)
+        hipLaunchKernelGGL((cbam_apply_add_relu_kernel<bf16_t>), dim3(grid_for(P * C / 4)), dim3(256), 0, s, cg->x, (const float*)cg->scale,
+                           (const float*)sg->scale, sg->res, sg->out, (bf16_t*)sg->out16, P, HW, C);
+    else
+        hipLaunchKernelGGL((cbam_apply_add_relu_kernel<f16_t>), dim3(grid_for(P * C / 4)), dim3(256), 0, s, cg->x, (const float*)cg->scale,
+                           (const float*)sg->scale, sg->res, sg->out, (f16_t*)sg->out16, P, HW, C);
+    EOE_CHECK_LAUNCH("cbam_apply_add_relu");
+    return 0;
+}
+
+// backward of the unit: dout = gradient at the block's output, out = the block's output (the ReLU mask); g (written) = the junction
+// gradient = the residual branch's gradient; cb->dx = the gradient of the channel gate's input; sb->dout / sb->dx unused
+extern "C" int eoe_cbam_junction_bwd(const eoe_cgate_bwd_args* cb, const eoe_sgate_bwd_args* sb, const float* dout, const float* out, float* g,
+                                     void* stream) {
+    EOE_CHECK_ARG(cb && sb && dout && out && g, "cbam_junction_bwd: null args");
+    const eoe_cgate_args* cg = &cb->f;
+    const eoe_sgate_args* sg = &sb->f;
+    EOE_TRY(check_cgate(cg));
+    EOE_CHECK_ARG(cb->dx && cb->dscale && cb->dpooled && cb->dhidden && cb->dw1 && cb->db1 && cb->dw2 && cb->db2, "cbam_junction_bwd: null cgate args");
+    EOE_CHECK_ARG(sg->w && sg->comp && sg->argmax && sg->z && sg->stats && sg->scale && sb->dscale && sb->dcomp && sb->red && sb->dw && sb->wpart,
+                  "cbam_junction_bwd: null sgate args");
+    EOE_CHECK_ARG((sb->dgamma == nullptr) == (sb->dbeta == nullptr), "cbam_junction_bwd: dgamma/dbeta must both be given or both NULL");
+    EOE_CHECK_ARG(sg->n == cg->n && sg->H * sg->W == cg->HW && sg->C == cg->C, "cbam_junction: the two gates disagree on the shape");
+    EOE_CHECK_ARG((sg->H + 6) * (sg->W + 6) <= 8192, "cbam_junction_bwd: feature map too large (%d x %d)", sg->H, sg->W);
+    hipStream_t s = (hipStream_t)stream;
+    const int cpb = chan_cpb(cg->C), C = cg->C, HW = cg->HW;
+    const size_t P = (size_t)cg->n * HW;
+    {
+        ProfScope ps("sgate_bwd", 0, 16.0 * P * C, stream);
+        hipLaunchKernelGGL(cbam_relu_pix_reduce_kernel, dim3(grid_for(P * 16)), dim3(256), 0, s, dout, out, cg->x, (const float*)cg->scale, g,
+                           sb->dscale, P, HW, C);
+        EOE_CHECK_LAUNCH("cbam_relu_pix_reduce");
+        int gr = grid_for(P, EOE_SGATE_PARTIALS);
+        hipLaunchKernelGGL(sgate_bn_bwd_reduce_kernel, dim3(gr), dim3(256), 0, s, sg->z, sg->stats, sg->scale, sb->dscale, sb->red, P);
+        EOE_CHECK_LAUNCH("cbam_bn_bwd_reduce");
+        if (sg->training && eoe_bn_sync_active()) {
+            hipLaunchKernelGGL(sgate_bn_bwd_total_kernel, dim3(1), dim3(256), 0, s, sb->red, gr, (float)P);
+            EOE_CHECK_LAUNCH("cbam_bn_bwd_total");
+            EOE_TRY(eoe_bn_sync_allreduce(sb->red, 3, 0, stream));
+            gr = -1;
+        }
+        hipLaunchKernelGGL(sgate_bn_bwd_apply_kernel, dim3(grid_for(P)), dim3(256), 0, s, sg->z, sg->stats, sg->gamma, (const float*)sb->red, gr,
+                           sb->dscale, sb->dgamma, sb->dbeta, P, sg->training);
+        EOE_CHECK_LAUNCH("cbam_bn_bwd_apply");
+        hipLaunchKernelGGL(sgate_conv_bwd_data_kernel, dim3(grid_for(P)), dim3(256), 0, s, (const float*)sb->dscale, sg->w, sb->dcomp, sg->n,
+                           sg->H, sg->W, 1, (const float*)sg->scale, (const int*)sg->argmax);      // dcomp: 4 floats per pixel here
+        EOE_CHECK_LAUNCH("cbam_conv_bwd_data");
+        size_t lds = (size_t)(sg->H + 6) * (sg->W + 6) * 2 * sizeof(float);
+        if (lds < (256 + 4) * 49 * sizeof(float)) lds = (256 + 4) * 49 * sizeof(float);
+        hipLaunchKernelGGL(sgate_conv_bwd_weight_kernel, dim3(sg->n), dim3(256), lds, s, (const float*)sb->dscale, sg->comp, sb->wpart, sg->H,
+                           sg->W);
+        hipLaunchKernelGGL(sgate_wpart_sum_kernel, dim3(98), dim3(64), 0, s, (const float*)sb->wpart, sb->dw, sg->n);
+        EOE_CHECK_LAUNCH("cbam_conv_bwd_weight");
+    }
+    ProfScope ps("cgate_bwd", 0, 16.0 * P * C, stream);
+    hipLaunchKernelGGL(cbam_chan_reduce_kernel, dim3(cg->n, C / 4 / cpb), dim3(256), 0, s, (const float*)g, (const float*)sb->dcomp, cg->x,
+                       cb->dscale, HW, C, cpb);
+    EOE_CHECK_LAUNCH("cbam_chan_reduce");
+    hipLaunchKernelGGL(cgate_mlp_bwd_kernel, dim3(cg->n), dim3(256), (C + 2 * cg->Ch) * sizeof(float), s, cg->scale, cg->hidden, cg->w1,
+                       cg->w2, cb->dscale, cb->dhidden, cb->dpooled, C, cg->Ch);
+    EOE_CHECK_LAUNCH("cbam_mlp_bwd");
+    hipLaunchKernelGGL(cgate_mlp_wgrad_kernel, dim3(cdiv(C * cg->Ch, 16)), dim3(256), 0, s, cg->pooled, cg->hidden, cb->dscale,
+                       cb->dhidden, cb->dw1, cb->db1, cb->dw2, cb->db2, cg->n, C, cg->Ch);
+    EOE_CHECK_LAUNCH("cbam_mlp_wgrad");
+    hipLaunchKernelGGL(cbam_bwd_apply_kernel, dim3(grid_for(P * C / 4)), dim3(256), 0, s, (const float*)g, (const float*)sb->dcomp,
+                       (const float*)cg->scale, (const float*)cb->dpooled, (const int*)cg->argmax, cb->dx, cg->n, HW, C);
+    EOE_CHECK_LAUNCH("cbam_bwd_apply");
     return 0;
 }
 

@@ -56,7 +56,10 @@ class BasicBlock(nn.Module):
         if self.downsample is not None:
             residual = _conv_bn(residual, self.downsample[0], self.downsample[1], self.training, 1.0)
         if self.cbam is not None and not self.cbam.no_spatial:
-            # channel gate, then the spatial gate fused with the residual junction (the gated tensor is never written)
+            # channel gate, spatial gate and the residual junction as one unit (neither the channel-gated tensor nor the spatial gate's
+            # input gradient is ever written; ops_resnet.FUSE_CBAM = False: the two-unit form of round 2, for A/B and tests)
+            if ops_resnet.FUSE_CBAM:
+                return ops_resnet.cbam_junction(out, residual, self.cbam, self.training)
             out = self.cbam.ChannelGate(out)
             sg = self.cbam.SpatialGate.spatial
             return ops_resnet.spatial_gate_add_relu(out, residual, sg.conv.weight, sg.bn, self.training)

@@ -13,6 +13,11 @@ SGATE_RED = 2 + 2 * 512         # EOE_SGATE_RED (include/eoe_hip.h)
 from .ops import BN_SCRATCH, _chk, _grad_target, _p, _stream, scratch, dtype_code
 
 
+import os as _os
+
+FUSE_CBAM = _os.environ.get("EOE_FUSE_CBAM", "1") != "0"        # BasicBlock: ChannelGate + SpatialGate + residual junction through CbamJunctionFunction (0: the two units of round 2, A/B)
+
+
 class MaxPoolFunction(torch.autograd.Function):
     """nn.MaxPool2d(k, stride, pad) on fp32 NHWC (`resnet.py:35,96`)"""
 
@@ -189,6 +194,85 @@ class SpatialGateAddReluFunction(torch.autograd.Function):
         b = _lib.SGateBwdArgs(f, _p(g), _p(dx), _p(dscale), _p(dcomp), _p(red), _p(dw), _p(dg), _p(db), _p(wpart))
         check(lib.eoe_sgate_bwd(C.byref(b), _stream()), "eoe_sgate_bwd")
         return dx, g, dw, dg, db, None, None, None, None
+
+
+class CbamJunctionFunction(torch.autograd.Function):
+    """relu(SpatialGate(ChannelGate(x)) + res): a BasicBlock's whole tail (`cbam.py:100-106`, `resnet.py:143-147`) as one unit
+    (`eoe_cbam_junction_fwd / _bwd`): the channel-gated tensor and the spatial gate's input gradient are never written -- 22 + 32 bytes per
+    activation element instead of the 30 + 44 of ChannelGateFunction + SpatialGateAddReluFunction.  Returns (out, 16-bit copy)."""
+
+    @staticmethod
+    def forward(ctx, x, res, w1, b1, w2, b2, w, bn_w, bn_b, rm, rv, nbt, cfg):
+        _chk(x, res, w1, b1, w2, b2, w, bn_w, bn_b, rm, rv)
+        training, eps, momentum = cfg
+        x, res = x.contiguous().float(), res.contiguous().float()
+        n, H, W, Cc = x.shape
+        Ch = w1.shape[0]
+        dev = x.device
+        out = torch.empty_like(x)
+        out16 = torch.empty(x.shape, dtype=ops.compute_dtype(), device=dev)
+        pooled = torch.empty((n, 2, Cc), dtype=torch.float32, device=dev)
+        argmax_c = torch.empty((n, Cc), dtype=torch.int32, device=dev)
+        hidden = torch.empty((n, 2, Ch), dtype=torch.float32, device=dev)
+        sc = torch.empty((n, Cc), dtype=torch.float32, device=dev)
+        comp = torch.empty((n, H, W, 2), dtype=torch.float32, device=dev)
+        argmax_p = torch.empty((n, H, W), dtype=torch.int32, device=dev)
+        z = torch.empty((n, H, W), dtype=torch.float32, device=dev)
+        stats = torch.empty(2, dtype=torch.float32, device=dev)
+        sp = torch.empty((n, H, W), dtype=torch.float32, device=dev)
+        sums = scratch("sg_sums", (BN_SCRATCH,), torch.float32, dev)
+        w1c, b1c, w2c, b2c, wc = (t.detach().contiguous() for t in (w1, b1, w2, b2, w))
+        cg = _lib.CGateArgs(_p(x), None, _p(w1c), _p(b1c), _p(w2c), _p(b2c), _p(pooled), _p(argmax_c), _p(hidden), _p(sc), n, H * W, Cc, Ch)
+        sg = _lib.SGateArgs(None, _p(out), _p(wc), _p(bn_w), _p(bn_b), _p(rm), _p(rv), _p(nbt), _p(comp), _p(argmax_p), _p(z),
+                            _p(stats), _p(sp), _p(sums), n, H, W, Cc, float(eps), float(momentum), 1 if training else 0,
+                            _p(res), _p(out16), dtype_code(out16.dtype))
+        check(lib.eoe_cbam_junction_fwd(C.byref(cg), C.byref(sg), _stream()), "eoe_cbam_junction_fwd")
+        ctx.save_for_backward(x, w1, b1, w2, b2, w, bn_w, bn_b, pooled, argmax_c, hidden, sc, comp, argmax_p, z, stats, sp, out)
+        ctx.cfg = (training, float(eps), float(momentum))
+        ctx.mark_non_differentiable(out16)
+        ctx.set_materialize_grads(False)       # else autograd zero-fills a gradient for the 16-bit copy every step
+        return out, out16
+
+    @staticmethod
+    def backward(ctx, dout, _d16=None):
+        x, w1, b1, w2, b2, w, bn_w, bn_b, pooled, argmax_c, hidden, sc, comp, argmax_p, z, stats, sp, out = ctx.saved_tensors
+        training, eps, momentum = ctx.cfg
+        n, H, W, Cc = x.shape
+        Ch = w1.shape[0]
+        dev = x.device
+        dout = dout.contiguous().float()
+        g = torch.empty_like(out)                      # gradient at the junction = gradient of the residual branch
+        dx = torch.empty_like(x)
+        dsc = scratch("cg_dscale", (n, Cc), torch.float32, dev)
+        dpooled = scratch("cg_dpooled", (n, 2, Cc), torch.float32, dev)
+        dhidden = scratch("cg_dhidden", (n, 2, Ch), torch.float32, dev)
+        dsp = scratch("sg_dscale", (n, H, W), torch.float32, dev)
+        dcomp = scratch("sg_dcomp4", (n, H, W, 4), torch.float32, dev)           # the unit's per-pixel record: 4 floats
+        red = scratch("sg_red", (SGATE_RED,), torch.float32, dev)
+        wpart = scratch("sg_wpart", (n, 98), torch.float32, dev)
+        sums = scratch("sg_sums", (BN_SCRATCH,), torch.float32, dev)
+        dw1, db1, dw2, db2, dw = (_grad_target(t) for t in (w1, b1, w2, b2, w))
+        dg = _grad_target(bn_w) if bn_w is not None else None
+        db = _grad_target(bn_b) if bn_b is not None else None
+        w1c, b1c, w2c, b2c, wc = (t.detach().contiguous() for t in (w1, b1, w2, b2, w))
+        cg = _lib.CGateArgs(_p(x), None, _p(w1c), _p(b1c), _p(w2c), _p(b2c), _p(pooled), _p(argmax_c), _p(hidden), _p(sc), n, H * W, Cc, Ch)
+        cb = _lib.CGateBwdArgs(cg, None, _p(dx), _p(dsc), _p(dpooled), _p(dhidden), _p(dw1), _p(db1), _p(dw2), _p(db2))
+        sg = _lib.SGateArgs(None, None, _p(wc), _p(bn_w), _p(bn_b), None, None, None, _p(comp), _p(argmax_p), _p(z), _p(stats),
+                            _p(sp), _p(sums), n, H, W, Cc, eps, momentum, 1 if training else 0, None, None, 0)
+        sb = _lib.SGateBwdArgs(sg, None, None, _p(dsp), _p(dcomp), _p(red), _p(dw), _p(dg), _p(db), _p(wpart))
+        check(lib.eoe_cbam_junction_bwd(C.byref(cb), C.byref(sb), _p(dout), _p(out), _p(g), _stream()), "eoe_cbam_junction_bwd")
+        return dx, g, dw1, db1, dw2, db2, dw, dg, db, None, None, None, None
+
+
+def cbam_junction(x, res, cbam, training):
+    """relu(cbam(x) + res) through the fused unit (ChannelGate MLP = cbam.ChannelGate.mlp[1] / [3], SpatialGate = cbam.SpatialGate.spatial)"""
+    l1, l3 = cbam.ChannelGate.mlp[1], cbam.ChannelGate.mlp[3]
+    sg = cbam.SpatialGate.spatial
+    bn = sg.bn
+    out, out16 = CbamJunctionFunction.apply(x, res, l1.weight, l1.bias, l3.weight, l3.bias, sg.conv.weight, bn.weight, bn.bias,
+                                            bn.running_mean, bn.running_var, bn.num_batches_tracked, (training, bn.eps, bn.momentum))
+    out._eoe16 = out16
+    return out
 
 
 def spatial_gate_add_relu(x, res, conv_w, bn, training):

@@ -556,6 +556,16 @@ typedef struct {
 } eoe_sgate_bwd_args;
 int eoe_sgate_fwd(const eoe_sgate_args* a, void* stream);
 int eoe_sgate_bwd(const eoe_sgate_bwd_args* a, void* stream);
+/* A BasicBlock's tail out = relu(SpatialGate(ChannelGate(x)) + res) (resnet.py:143-147, cbam.py:100-106) as ONE unit: the channel-gated
+ * tensor is never written (every consumer multiplies x by the channel scale on the fly -- the same fp32 product), the junction's ReLU mask
+ * is applied where the gradient is first read, and the spatial gate's input gradient feeds the channel gate's reduction and its final
+ * pass without being stored: 22 + 32 bytes per activation element instead of 30 + 44.  cg / cb: the channel gate's argument blocks
+ * (cg->out unused); sg / sb: the spatial gate's (sg->x, sb->dout, sb->dx unused; sg->res, sg->out, sg->out16 required / as in eoe_sgate_fwd).
+ * backward: dout = gradient at the block's output, out = that output (the mask); g (written) = the residual branch's gradient,
+ * cb->dx = the gradient of x; sb->dcomp must hold FOUR floats per pixel here (scale, dcomp0, dcomp1, argmax bits: one 16-byte record). */
+int eoe_cbam_junction_fwd(const eoe_cgate_args* cg, const eoe_sgate_args* sg, void* stream);
+int eoe_cbam_junction_bwd(const eoe_cgate_bwd_args* cb, const eoe_sgate_bwd_args* sb, const float* dout, const float* out, float* g,
+                          void* stream);
 
 /* out = relu(a + b) (resnet.py:146-147); g = dout * [out > 0] (the gradient of both summands) */
 int eoe_add_relu_fwd(const float* a, const float* b, float* out, void* out16 /* optional 16-bit copy */, int dtype,

@@ -461,3 +461,45 @@ def test_wideresnet32_graph_replay_equals_eager(dtype):
             assert torch.equal(got, ref), (rep, (got != ref).nonzero().flatten()[:4].tolist(), (got - ref).abs().max().item())
     finally:
         eoe_amd.set_compute_dtype("fp16")
+
+
+@pytest.mark.parametrize("cin,planes,stride,H", [(64, 64, 1, 14), (64, 128, 2, 14), (128, 128, 1, 9)])
+def test_cbam_junction_fused_equals_the_two_units(cin, planes, stride, H):
+    """round 3: ChannelGate + SpatialGate + residual junction as ONE unit (eoe_cbam_junction_*: the channel-gated tensor and the spatial
+    gate's input gradient are never written) against the two units of round 2 on a whole BasicBlock: the same fp32 products in the same
+    order -- output, input gradient, every parameter gradient and the running buffers agree to the last bits (reductions are summed in
+    the same order too; allowance 1e-6 for contraction differences between the kernels)"""
+    import copy
+    import torch.nn as nn
+    import eoe_amd
+    from eoe_amd import ops_resnet
+    from eoe_amd.models.resnet import BasicBlock
+    eoe_amd.set_compute_dtype("fp16")
+    eoe_amd.set_parity_mode(True)           # fp32 convolutions around the unit: a last-bit difference is not amplified by a 16-bit rounding
+    torch.manual_seed(4)
+    ds = stride != 1 or cin != planes
+    down = nn.Sequential(nn.Conv2d(cin, planes, 1, stride=stride, bias=False), nn.BatchNorm2d(planes)) if ds else None
+    blk0 = BasicBlock(cin, planes, stride, down, use_cbam=True).cuda().train()
+    x = torch.randn(6, H, H, cin, device="cuda")
+    w = torch.randn(6, (H - 1) // stride + 1, (H - 1) // stride + 1, planes, device="cuda")
+    res = {}
+    old = ops_resnet.FUSE_CBAM
+    try:
+        for fused in (False, True):
+            ops_resnet.FUSE_CBAM = fused
+            blk = copy.deepcopy(blk0)
+            xin = x.clone().requires_grad_(True)
+            y = blk(xin)
+            (y * w).sum().backward()
+            res[fused] = (y.detach(), None, xin.grad, {n: p.grad for n, p in blk.named_parameters()},
+                          {n: b.clone() for n, b in blk.named_buffers()})
+    finally:
+        ops_resnet.FUSE_CBAM = old
+        eoe_amd.set_parity_mode(False)
+    (y0, h0, dx0, g0, b0), (y1, h1, dx1, g1, b1) = res[False], res[True]
+    assert torch.equal(y0, y1) or rel_rms(y1, y0.cpu()) < 1e-6
+    assert rel_rms(dx1, dx0.cpu()) < 1e-6, rel_rms(dx1, dx0.cpu())
+    for n in g0:
+        assert rel_rms(g1[n], g0[n].cpu()) < 1e-5, (n, rel_rms(g1[n], g0[n].cpu()))
+    for n in b0:
+        assert torch.allclose(b1[n].float(), b0[n].float(), rtol=1e-6, atol=1e-7), n
