@@ -190,14 +190,18 @@ __global__ __launch_bounds__(256) void cgate_mlp_fwd_kernel(const float* __restr
 __global__ __launch_bounds__(256) void cgate_mlp_bwd_kernel(const float* __restrict__ scale, const float* __restrict__ hidden,
                                                             const float* __restrict__ w1, const float* __restrict__ w2,
                                                             float* __restrict__ dscale, float* __restrict__ dhidden,
-                                                            float* __restrict__ dpooled, int C, int Ch) {
+                                                            float* __restrict__ dpooled, int C, int Ch, int nz = 1) {
+    // nz > 1 (the fused CBAM unit): dscale arrives as nz partial slices [z][n][C] (the pixel range of an image cut over nz workgroups),
+    // added here in slice order; slice 0 then holds the result
     extern __shared__ float lds[];                // [C] datt, [2*Ch] dhidden
     float* ld = lds;
     float* lh = lds + C;
     const int img = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int c = threadIdx.x; c < C; c += 256) {
         const float s = scale[(size_t)img * C + c];
-        const float d = dscale[(size_t)img * C + c] * s * (1.f - s);
+        float ds = dscale[(size_t)img * C + c];
+        for (int z = 1; z < nz; ++z) ds += dscale[((size_t)z * gridDim.x + img) * C + c];
+        const float d = ds * s * (1.f - s);
         ld[c] = d;
         dscale[(size_t)img * C + c] = d;
     }
@@ -705,17 +709,21 @@ __device__ __forceinline__ f32x4 cbam_dxc(const float* __restrict__ g, const flo
     return o;
 }
 // backward 2: dsc[img, c] = sum_hw dxc * x   (the layout of chan_reduce_kernel<1>)
+// (grid.z workgroups share an image's pixels -- one workgroup per image is one per CU at 256 images: too few loads in flight -- and write
+//  partial slices dsc[z][img][C], added in slice order by cgate_mlp_bwd_kernel)
 __global__ __launch_bounds__(256) void cbam_chan_reduce_kernel(const float* __restrict__ g, const float* __restrict__ pk,
-                                                               const float* __restrict__ x, float* __restrict__ dsc, int HW, int C, int cpb) {
+                                                               const float* __restrict__ x, float* __restrict__ dsc, int HW_all, int C, int cpb) {
     __shared__ f32x4 ls[256];
     const int img = blockIdx.x, rpb = 256 / cpb;
     const int tc = threadIdx.x % cpb, rl = threadIdx.x / cpb;
     const int c = (blockIdx.y * cpb + tc) * 4;
     const float invC = 1.0f / (float)C;
-    const size_t p0 = (size_t)img * HW;
+    const int per = (HW_all + (int)gridDim.z - 1) / (int)gridDim.z, hw_lo = (int)blockIdx.z * per;
+    const int HW = min(HW_all, hw_lo + per);                   // this workgroup's pixels: [hw_lo, HW)
+    const size_t p0 = (size_t)img * HW_all;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     constexpr int U = 4;
-    int hw = rl;
+    int hw = hw_lo + rl;
     for (; hw + (U - 1) * rpb < HW; hw += U * rpb) {
         f32x4 v[U], w[U];
 #pragma unroll
@@ -731,7 +739,7 @@ __global__ __launch_bounds__(256) void cbam_chan_reduce_kernel(const float* __re
     __syncthreads();
     if (rl == 0) {
         for (int k = 1; k < rpb; ++k) s += ls[threadIdx.x + k * cpb];
-        *(f32x4*)(dsc + (size_t)img * C + c) = s;
+        *(f32x4*)(dsc + ((size_t)blockIdx.z * gridDim.x + img) * C + c) = s;
     }
 }
 // backward 3: dx = dxc * sc[img, c] + dpooled_avg[img, c] / HW + [hw == argmax_c[img, c]] * dpooled_max[img, c]
@@ -1017,11 +1025,14 @@ extern "C" int eoe_cbam_junction_bwd(const eoe_cgate_bwd_args* cb, const eoe_sga
         EOE_CHECK_LAUNCH("cbam_conv_bwd_weight");
     }
     ProfScope ps("cgate_bwd", 0, 16.0 * P * C, stream);
-    hipLaunchKernelGGL(cbam_chan_reduce_kernel, dim3(cg->n, C / 4 / cpb), dim3(256), 0, s, (const float*)g, (const float*)sb->dcomp, cg->x,
+    // cb->dscale: EOE_CBAM_DSCALE_SLICES slices of [n, C] here
+    int nz = 1;
+    while (nz < EOE_CBAM_DSCALE_SLICES && (size_t)cg->n * (C / 4 / cpb) * nz < 1024 && HW / (nz * 2) >= 64) nz *= 2;
+    hipLaunchKernelGGL(cbam_chan_reduce_kernel, dim3(cg->n, C / 4 / cpb, nz), dim3(256), 0, s, (const float*)g, (const float*)sb->dcomp, cg->x,
                        cb->dscale, HW, C, cpb);
     EOE_CHECK_LAUNCH("cbam_chan_reduce");
     hipLaunchKernelGGL(cgate_mlp_bwd_kernel, dim3(cg->n), dim3(256), (C + 2 * cg->Ch) * sizeof(float), s, cg->scale, cg->hidden, cg->w1,
-                       cg->w2, cb->dscale, cb->dhidden, cb->dpooled, C, cg->Ch);
+                       cg->w2, cb->dscale, cb->dhidden, cb->dpooled, C, cg->Ch, nz);
     EOE_CHECK_LAUNCH("cbam_mlp_bwd");
     hipLaunchKernelGGL(cgate_mlp_wgrad_kernel, dim3(cdiv(C * cg->Ch, 16)), dim3(256), 0, s, cg->pooled, cg->hidden, cb->dscale,
                        cb->dhidden, cb->dw1, cb->db1, cb->dw2, cb->db2, cg->n, C, cg->Ch);

@@ -243,7 +243,7 @@ class CbamJunctionFunction(torch.autograd.Function):
         dout = dout.contiguous().float()
         g = torch.empty_like(out)                      # gradient at the junction = gradient of the residual branch
         dx = torch.empty_like(x)
-        dsc = scratch("cg_dscale", (n, Cc), torch.float32, dev)
+        dsc = scratch("cg_dscale8", (8, n, Cc), torch.float32, dev)               # EOE_CBAM_DSCALE_SLICES partial slices
         dpooled = scratch("cg_dpooled", (n, 2, Cc), torch.float32, dev)
         dhidden = scratch("cg_dhidden", (n, 2, Ch), torch.float32, dev)
         dsp = scratch("sg_dscale", (n, H, W), torch.float32, dev)

@@ -562,7 +562,8 @@ int eoe_sgate_bwd(const eoe_sgate_bwd_args* a, void* stream);
  * pass without being stored: 22 + 32 bytes per activation element instead of 30 + 44.  cg / cb: the channel gate's argument blocks
  * (cg->out unused); sg / sb: the spatial gate's (sg->x, sb->dout, sb->dx unused; sg->res, sg->out, sg->out16 required / as in eoe_sgate_fwd).
  * backward: dout = gradient at the block's output, out = that output (the mask); g (written) = the residual branch's gradient,
- * cb->dx = the gradient of x; sb->dcomp must hold FOUR floats per pixel here (scale, dcomp0, dcomp1, argmax bits: one 16-byte record). */
+ * cb->dx = the gradient of x; cb->dscale must hold EOE_CBAM_DSCALE_SLICES slices of [n, C] and sb->dcomp FOUR floats per pixel here (scale, dcomp0, dcomp1, argmax bits: one 16-byte record). */
+#define EOE_CBAM_DSCALE_SLICES 8
 int eoe_cbam_junction_fwd(const eoe_cgate_args* cg, const eoe_sgate_args* sg, void* stream);
 int eoe_cbam_junction_bwd(const eoe_cgate_bwd_args* cb, const eoe_sgate_bwd_args* sb, const float* dout, const float* out, float* g,
                           void* stream);
