@@ -480,6 +480,54 @@ __device__ __forceinline__ void block_channel_sums(const float (&acc0)[4], const
     }
 }
 
+// the gradient at the BatchNorm output of one (pooled position, channel quad): xh / z of the P x P window, the winning tap per channel
+// and the upstream gradient (one 16-byte load in the NHWC layout)
+template <int P>
+struct BnBwdElem {
+    f32x4 xh[P * P], z[P * P];
+    int arg[4];
+    float d[4];
+    unsigned opu, wo, ho, img;
+    int c;
+    __device__ __forceinline__ void load(unsigned i, const float* __restrict__ y, const float* __restrict__ dout, const f32x4& mu, const f32x4& rs,
+                                         const f32x4& g, const f32x4& b, int nchw_flat, int H, int W, int C, float slope, const QuadDecode& dec) {
+        unsigned c4;
+        dec(i, c4, opu, wo, ho, img);
+        c = (int)c4 * 4;
+        const int Ho = H / P, Wo = W / P;
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        arg[0] = arg[1] = arg[2] = arg[3] = 0;
+#pragma unroll
+        for (int k = 0; k < P * P; ++k) {
+            const int dy_ = k / P, dx_ = k % P;
+            const f32x4 v = *(const f32x4*)(y + (((size_t)img * H + ho * P + dy_) * W + wo * P + dx_) * C + c);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                xh[k][r] = (v[r] - mu[r]) * rs[r];
+                z[k][r] = xh[k][r] * g[r] + b[r];
+                const float a = lrelu(z[k][r], slope);
+                if (a > best[r]) { best[r] = a; arg[r] = k; }      // first maximum wins, as max_pool2d does
+            }
+        }
+        if (!nchw_flat) {
+            const f32x4 dv = *(const f32x4*)(dout + (((size_t)img * Ho + ho) * Wo + wo) * C + c);
+            d[0] = dv[0]; d[1] = dv[1]; d[2] = dv[2]; d[3] = dv[3];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d[r] = load_dout(dout, 1, img, ho, wo, c + r, Ho, Wo, C);
+        }
+    }
+    // sum contributions of channel r: gz = gradient at the winning tap, gz * xhat there
+    __device__ __forceinline__ void sums(int r, float slope, float& gz, float& gx) const {
+        gz = 0.f;
+        float xk = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < P * P; ++kk)
+            if (kk == arg[r]) { gz = d[r] * (z[kk][r] > 0.f ? 1.f : slope); xk = xh[kk][r]; }
+        gx = gz * xk;
+    }
+};
+
 // backward pass 1: per-channel sums of g and g*xhat, where g is the gradient at the BatchNorm OUTPUT (un-pooled through
 // the first maximum of each window, times LeakyReLU').  One thread per (pooled position, 4 channels); LDS + atomics.
 // mode 0 = reduce into red[0..C)=sum g, red[C..2C)=sum g*xhat;  mode 1 = write dy (16-bit [n*H*W, C]) using those sums.
@@ -501,61 +549,64 @@ __global__ __launch_bounds__(256) void bn_act_pool_bwd_kernel(const float* __res
     // MODE 0: the launch keeps gridDim.x * 256 a multiple of C/4, so a thread sees ONE channel quad for its whole loop
     // and sums in registers; LDS / global atomics only once per thread / workgroup at the end
     float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        unsigned c4, opu, wo, ho, img;
-        dec(i, c4, opu, wo, ho, img);
-        const int c = (int)c4 * 4;
-        const f32x4 mu = *(const f32x4*)(stats + c), rs = *(const f32x4*)(stats + C + c);
-        f32x4 g = {1.f, 1.f, 1.f, 1.f}, b = {0.f, 0.f, 0.f, 0.f};
-        if (gamma) { g = *(const f32x4*)(gamma + c); b = *(const f32x4*)(beta + c); }
-        f32x4 xh[P * P], z[P * P];
-        int arg[4] = {0, 0, 0, 0};
-        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    const unsigned first = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    // (block_channel_sums must be reached through ONE call site by every thread of the workgroup: inlined at two sites its static LDS
+    //  staging array was two arrays, and the idle threads of a small problem met the busy ones at the barrier with different ones)
+    // the thread's channel quad (and its per-channel constants) never change
+    const int c_own = (int)(first % (unsigned)cc) * 4;
+    const f32x4 mu = *(const f32x4*)(stats + c_own), rs = *(const f32x4*)(stats + C + c_own);
+    f32x4 g = {1.f, 1.f, 1.f, 1.f}, b = {0.f, 0.f, 0.f, 0.f};
+    if (gamma) { g = *(const f32x4*)(gamma + c_own); b = *(const f32x4*)(beta + c_own); }
+    const bool fixed_quad = (stride % (unsigned)cc) == 0;       // always so in MODE 0 (the launch arranges it); MODE 1 reloads otherwise
+    if (MODE == 0) {
+        // two positions per iteration: twice the loads in flight (this pass ran at 3.7 TB/s with one), same summation order
+        unsigned i = first;
+        for (; i < total && i + stride < total && i + stride > i; i += 2 * stride) {
+            BnBwdElem<P> e0, e1;
+            e0.load(i, y, dout, mu, rs, g, b, nchw_flat, H, W, C, slope, dec);
+            e1.load(i + stride, y, dout, mu, rs, g, b, nchw_flat, H, W, C, slope, dec);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { float gz, gx; e0.sums(r, slope, gz, gx); acc0[r] += gz; acc1[r] += gx; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { float gz, gx; e1.sums(r, slope, gz, gx); acc0[r] += gz; acc1[r] += gx; }
+        }
+        for (; i < total; i += stride) {
+            BnBwdElem<P> e0;
+            e0.load(i, y, dout, mu, rs, g, b, nchw_flat, H, W, C, slope, dec);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { float gz, gx; e0.sums(r, slope, gz, gx); acc0[r] += gz; acc1[r] += gx; }
+            if (i + stride < i) break;
+        }
+        block_channel_sums(acc0, acc1, lds, red + (size_t)(1 + blockIdx.x) * 2 * C, C, total);
+        return;
+    }
+    for (unsigned i = first; i < total; i += stride) {
+        f32x4 mu_ = mu, rs_ = rs, g_ = g, b_ = b;
+        if (!fixed_quad) {
+            const int c = (int)(i % (unsigned)cc) * 4;
+            mu_ = *(const f32x4*)(stats + c); rs_ = *(const f32x4*)(stats + C + c);
+            if (gamma) { g_ = *(const f32x4*)(gamma + c); b_ = *(const f32x4*)(beta + c); }
+        }
+        BnBwdElem<P> e;
+        e.load(i, y, dout, mu_, rs_, g_, b_, nchw_flat, H, W, C, slope, dec);
+        const int c = e.c;
+        const f32x4 s1 = *(const f32x4*)(red + c), s2 = *(const f32x4*)(red + C + c);
 #pragma unroll
         for (int k = 0; k < P * P; ++k) {
             const int dy_ = k / P, dx_ = k % P;
-            const f32x4 v = *(const f32x4*)(y + (((size_t)img * H + ho * P + dy_) * W + wo * P + dx_) * C + c);
+            float o[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                xh[k][r] = (v[r] - mu[r]) * rs[r];
-                z[k][r] = xh[k][r] * g[r] + b[r];
-                const float a = lrelu(z[k][r], slope);
-                if (a > best[r]) { best[r] = a; arg[r] = k; }      // first maximum wins, as max_pool2d does
+                const float gz = (k == e.arg[r]) ? e.d[r] * (e.z[k][r] > 0.f ? 1.f : slope) : 0.f;
+                // training: dy = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)); eval (running stats): gamma*rstd*g
+                o[r] = use_batch_stats ? g_[r] * rs_[r] * (gz - s1[r] * invM - e.xh[k][r] * s2[r] * invM) : g_[r] * rs_[r] * gz;
             }
+            const size_t oo = (((size_t)e.img * H + e.ho * P + dy_) * W + e.wo * P + dx_) * C + c;
+            if (dy_f32) *(f32x4*)((float*)dy + oo) = (f32x4){o[0], o[1], o[2], o[3]};
+            else *(u32x2*)((T*)dy + oo) = pack4<T>(o[0], o[1], o[2], o[3]);
         }
-        float d[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) d[r] = load_dout(dout, nchw_flat, img, ho, wo, c + r, Ho, Wo, C);
-        if (MODE == 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k = arg[r];
-                float gz = 0.f, xk = 0.f;
-#pragma unroll
-                for (int kk = 0; kk < P * P; ++kk)
-                    if (kk == k) { gz = d[r] * (z[kk][r] > 0.f ? 1.f : slope); xk = xh[kk][r]; }
-                acc0[r] += gz;
-                acc1[r] += gz * xk;
-            }
-        } else {
-            const f32x4 s1 = *(const f32x4*)(red + c), s2 = *(const f32x4*)(red + C + c);
-#pragma unroll
-            for (int k = 0; k < P * P; ++k) {
-                const int dy_ = k / P, dx_ = k % P;
-                float o[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float gz = (k == arg[r]) ? d[r] * (z[k][r] > 0.f ? 1.f : slope) : 0.f;
-                    // training: dy = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)); eval (running stats): gamma*rstd*g
-                    o[r] = use_batch_stats ? g[r] * rs[r] * (gz - s1[r] * invM - xh[k][r] * s2[r] * invM) : g[r] * rs[r] * gz;
-                }
-                const size_t oo = (((size_t)img * H + ho * P + dy_) * W + wo * P + dx_) * C + c;
-                if (dy_f32) *(f32x4*)((float*)dy + oo) = (f32x4){o[0], o[1], o[2], o[3]};
-                else *(u32x2*)((T*)dy + oo) = pack4<T>(o[0], o[1], o[2], o[3]);
-            }
-        }
+        if (i + stride < i) break;
     }
-    if (MODE == 0) block_channel_sums(acc0, acc1, lds, red + (size_t)(1 + blockIdx.x) * 2 * C, C, total);
 }
 
 // ---------------------------------------------------------------------------------------------- BN + act + overlapping MaxPool
