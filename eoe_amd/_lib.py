@@ -99,7 +99,8 @@ class VitBlockBwdArgs(C.Structure):
                 ("g_w_in", _vp), ("g_w_out", _vp), ("g_w_fc", _vp), ("g_w_proj", _vp),
                 ("accumulate", _i32),
                 ("d16_a", _vp), ("d16_b", _vp), ("d16_c", _vp), ("dh", _vp), ("dqkv", _vp), ("dx_mid", _vp), ("red_scratch", _vp),
-                ("tn_workspace", _vp), ("tn_workspace_bytes", _i64)]
+                ("tn_workspace", _vp), ("tn_workspace_bytes", _i64),
+                ("next_d16", _vp), ("in_d16", _vp), ("in_red_scratch", _vp)]
 
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); must match include/eoe_hip.h

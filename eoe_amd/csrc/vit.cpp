@@ -124,8 +124,20 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
     eoe_gemm_args g, w[4];
     // ---- MLP branch:  x_out = x_mid + c_proj(gelu(c_fc(ln_2(x_mid))))
     // bias gradients are column sums of the dY tensors: fused into the kernels that produce them (fp32 atomics)
-    TRY(eoe_cast_colsum(b->dx_out, b->d16_a, b->g_b_proj, red_cast, M, D, dt, 1, stream));     // dY of c_proj + db_proj
-    g = gemm(b->d16_a, a->w_proj_t, b->dh, nullptr, M, H, D, D, D, H, dt);                  // d hact, then * gelu'(hpre)
+    // dY of c_proj (the 16-bit copy of dx_out) + db_proj (its column sums): handed over by the previous call's LayerNorm-1 backward when
+    // that call was given `next_d16` (see eoe_hip.h) -- its partial rows are finished by this call's finish kernel --, else one pass here
+    const bool handed = b->in_d16 && b->in_red_scratch && b->red_scratch && b->in_red_scratch != b->red_scratch;
+    const void* dy_proj = handed ? b->in_d16 : b->d16_a;
+    if (handed) {
+        const float* in_ln1 = b->in_red_scratch + (size_t)((M + 63) / 64) * H + EOE_LN_SCRATCH(D) + (size_t)a->n * 3 * D;
+        int rows = (M + 7) / 8;
+        if (rows > EOE_LN_PARTIALS) rows = EOE_LN_PARTIALS;
+        if (!eoe_defer_reduce(in_ln1, rows, 3 * D, D, nullptr, nullptr, b->g_b_proj, 1))
+            return eoe_set_error(EOE_ERR_ARG, "vit_block_bwd: could not queue the handed-over column sums");
+    } else {
+        TRY(eoe_cast_colsum(b->dx_out, b->d16_a, b->g_b_proj, red_cast, M, D, dt, 1, stream));
+    }
+    g = gemm(dy_proj, a->w_proj_t, b->dh, nullptr, M, H, D, D, D, H, dt);                  // d hact, then * gelu'(hpre)
     g.epilogue = EOE_EPI_GELU_BWD; g.aux = a->hpre; g.ldaux = H;
     if (b->red_scratch) {
         // db_fc = column sums of dh, from the GEMM's epilogue through per-wave partial rows in the scratch (with fp32 atomics
@@ -150,7 +162,7 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
     if (!b->red_scratch) TRY(eoe_colsum(b->dqkv, 3 * D, b->g_b_in, M, 3 * D, dt, 1, stream));
     // ---- the four weight gradients of the block in one grouped launch (every dY and X is still live)
     w[0] = gemm(b->dh, a->xn2, b->g_w_fc, nullptr, H, D, M, H, D, D, dt);                    // dW_fc[4D,D]   = dh^T xn2
-    w[1] = gemm(b->d16_a, a->hact, b->g_w_proj, nullptr, D, H, M, D, H, H, dt);             // dW_proj[D,4D] = dY^T hact
+    w[1] = gemm(dy_proj, a->hact, b->g_w_proj, nullptr, D, H, M, D, H, H, dt);              // dW_proj[D,4D] = dY^T hact
     w[2] = gemm(b->dqkv, a->xn1, b->g_w_in, nullptr, 3 * D, D, M, 3 * D, D, D, dt);         // dW_in[3D,D]   = dqkv^T xn1
     w[3] = gemm(b->d16_c, a->att, b->g_w_out, nullptr, D, D, M, D, D, D, dt);               // dW_out[D,D]   = dmid^T att
     for (int i = 0; i < 4; ++i) { w[i].out_f32 = 1; w[i].accumulate = acc; }
@@ -166,13 +178,13 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
         if (hipEventRecord(ss->fork, s) != hipSuccess) return eoe_set_error(EOE_ERR_LAUNCH, "vit_block_bwd: event record failed");
         TRY(eoe_gemm_tn_grouped(w, 4, stream));
         if (hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return eoe_set_error(EOE_ERR_LAUNCH, "vit_block_bwd: stream wait failed");
-        TRY(eoe_layernorm_bwd(b->d16_b, 0, a->x_in, D, a->stats1, a->ln1_g, b->dx_mid, b->dx_in, D, nullptr, b->g_ln1_g,
+        TRY(eoe_layernorm_bwd(b->d16_b, 0, a->x_in, D, a->stats1, a->ln1_g, b->dx_mid, b->dx_in, D, b->next_d16, b->g_ln1_g,
                               b->g_ln1_b, nullptr, red_ln1, M, D, dt, (void*)ss->s));
         if (hipEventRecord(ss->join, ss->s) != hipSuccess || hipStreamWaitEvent(s, ss->join, 0) != hipSuccess)
             return eoe_set_error(EOE_ERR_LAUNCH, "vit_block_bwd: join failed");
     } else {
         TRY(eoe_gemm_tn_grouped(w, 4, stream));
-        TRY(eoe_layernorm_bwd(b->d16_b, 0, a->x_in, D, a->stats1, a->ln1_g, b->dx_mid, b->dx_in, D, nullptr, b->g_ln1_g,
+        TRY(eoe_layernorm_bwd(b->d16_b, 0, a->x_in, D, a->stats1, a->ln1_g, b->dx_mid, b->dx_in, D, b->next_d16, b->g_ln1_g,
                               b->g_ln1_b, nullptr, red_ln1, M, D, dt, stream));
     }
     TRY(eoe_flush_reduce(b->red_scratch ? &jobs : nullptr, stream));

@@ -6,6 +6,7 @@ and raise otherwise -- there is no CPU path in this package.
 """
 import ctypes as C
 import math
+import os
 import weakref
 from typing import Optional
 
@@ -458,6 +459,11 @@ def _block_ws(M, D, device, dtype):
     return buf, {k: base + o for k, o in offs.items()}
 
 
+VIT_HANDOVER = os.environ.get("EOE_VIT_HANDOVER", "1") != "0"     # block-to-block hand-over of dY(c_proj) in the backward sweep (0: A/B)
+_vit_handoff = None
+_vit_parity = 0
+
+
 class VitBlockFunction(torch.autograd.Function):
     """one ResidualAttentionBlock (clip/model.py:167-188) on the batch-major token matrix, fp32 residual stream
     [n*L, D] in and out; a single C call launches the whole kernel chain."""
@@ -508,6 +514,18 @@ class VitBlockFunction(torch.autograd.Function):
         b.g_b_in, b.g_b_out, b.g_b_fc, b.g_b_proj = (_p(grads[k]) for k in ("b_in", "b_out", "b_fc", "b_proj"))
         b.g_w_in, b.g_w_out, b.g_w_fc, b.g_w_proj = (_p(grads[k]) for k in ("w_in", "w_out", "w_fc", "w_proj"))
         b.accumulate = 0
+        # hand-over between consecutive blocks of the backward sweep (eoe_hip.h, eoe_vit_block_bwd_args): this block's LayerNorm-1 backward
+        # also writes the 16-bit copy of dx_in and leaves its column sums in its partial rows -- what the next block to run would compute
+        # with a pass of its own (eoe_cast_colsum).  Two alternating sets of (copy, reduction scratch): the previous call's are still read.
+        global _vit_handoff, _vit_parity
+        par = _vit_parity = _vit_parity ^ 1
+        h = _vit_handoff
+        _vit_handoff = None
+        d16_next = scratch(f"d16_next{par}", (M, D), dt, dev)
+        b.next_d16 = _p(d16_next) if VIT_HANDOVER else None
+        if (h is not None and h["dx"] is dx_out and dx_out._version == h["version"] and h["shape"] == (M, D, ctx.args.n) and h["dt"] == dt
+                and h["stream"] == _stream()):
+            b.in_d16, b.in_red_scratch = _p(h["d16"]), _p(h["red"])
         b.d16_a = _p(scratch("d16_a", (M, D), dt, dev))
         b.d16_b = _p(scratch("d16_b", (M, D), dt, dev))
         b.d16_c = _p(scratch("d16_c", (M, D), dt, dev))
@@ -515,10 +533,13 @@ class VitBlockFunction(torch.autograd.Function):
         b.dqkv = _p(scratch("dqkv", (M, 3 * D), dt, dev))
         b.dx_mid = _p(scratch("dx_mid", (M, D), torch.float32, dev))
         nred = (M + 63) // 64 * 4 * D + 2 * LN_SCRATCH_ROWS * 3 * D + ctx.args.n * 3 * D + 256 * D          # EOE_VIT_RED_SCRATCH(n, L, D)
-        b.red_scratch = _p(scratch("vit_red", (nred,), torch.float32, dev))
+        red = scratch(f"vit_red{par}", (nred,), torch.float32, dev)
+        b.red_scratch = _p(red)
         sk_bytes = torch.cuda.get_device_properties(dev).multi_processor_count * (256 * 256 * 4)      # EOE_TN_STREAMK_WORKSPACE_BYTES
         b.tn_workspace, b.tn_workspace_bytes = _p(scratch("tn_streamk", (sk_bytes,), torch.uint8, dev)), sk_bytes
         check(lib.eoe_vit_block_bwd(C.byref(b), _stream()), "eoe_vit_block_bwd")
+        if VIT_HANDOVER:
+            _vit_handoff = dict(dx=dx_in, version=dx_in._version, shape=(M, D, ctx.args.n), dt=dt, stream=_stream(), d16=d16_next, red=red)
         hook = grad_ready_hooks.get(id(params["ln1_g"]))
         if hook is not None and hook[0]() is params["ln1_g"]:      # (weakref to the parameter, callable)
             hook[1]()

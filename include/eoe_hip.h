@@ -311,6 +311,17 @@ typedef struct {
     void* tn_workspace; /* optional: EOE_TN_STREAMK_WORKSPACE_BYTES(#CUs) bytes -> the grouped wgrad launch balances its 216 tiles
                          * over all CUs (eoe_gemm_args.workspace) */
     int64_t tn_workspace_bytes;
+    /* Hand-over between consecutive blocks of the backward sweep (all optional; round 3).  The producer of a block's dx_out is the NEXT
+     * block's LayerNorm-1 backward, which can emit what this block's first step (eoe_cast_colsum: the 16-bit copy of dx_out = dY of
+     * c_proj, and its column sums = the gradient of c_proj.bias) would otherwise compute in a pass of its own:
+     *   next_d16       out: 16-bit copy [n*L, D] of THIS call's dx_in, for the block that runs next in backward
+     *   in_d16         in:  that copy of THIS call's dx_out, written by the previous call (a different buffer than next_d16: the
+     *                       previous call's weight-gradient GEMM still reads it while this call's LayerNorm writes)
+     *   in_red_scratch in:  the previous call's red_scratch (must differ from this call's: alternate two): the column sums of dx_out
+     *                       sit in its LayerNorm-1 partial rows and are finished into g_b_proj by this call's one finish kernel */
+    void* next_d16;
+    const void* in_d16;
+    const float* in_red_scratch;
 } eoe_vit_block_bwd_args;
 
 /* floats: partial rows of the fc dgrad GEMM's fused column sums [ceil(n*L/64)][4D] + of the two LayerNorm backwards + the attention

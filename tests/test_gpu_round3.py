@@ -337,3 +337,37 @@ def test_fp16_weights_mode_trains_the_vit_with_sgd():
             assert torch.equal(p, p.half().float()), n
     with pytest.raises(NotImplementedError):
         eoe_amd.FusedAdam(m.parameters(), lr=1e-4).step()
+
+
+def test_vit_block_handover_equals_the_separate_pass():
+    """the backward sweep hands dY of c_proj (the 16-bit copy of a block's dx_out) and its column sums from the producing block's
+    LayerNorm-1 backward to the consuming block instead of recomputing them with eoe_cast_colsum: the same 16-bit values, so every
+    gradient except the c_proj biases (column sums in another fixed order) keeps its bits"""
+    import eoe_amd
+    from eoe_amd import ops
+    from eoe_amd.models import ClipViTB32Custom
+    eoe_amd.set_compute_dtype("fp16")
+    torch.manual_seed(0)
+    m = ClipViTB32Custom(layers=3).cuda().train()
+    x = torch.randn(16, 3, 224, 224, device="cuda")
+    y = torch.cat([torch.zeros(8, dtype=torch.long), torch.ones(8, dtype=torch.long)]).cuda()
+    res = {}
+    old = ops.VIT_HANDOVER
+    try:
+        for on in (False, True, True):
+            ops.VIT_HANDOVER = on
+            for p in m.parameters():
+                p.grad = None
+            loss = eoe_amd.hsc_loss(m(x), y, 0)
+            loss.backward()
+            res.setdefault(on, []).append({n: p.grad.clone() for n, p in m.named_parameters()})
+    finally:
+        ops.VIT_HANDOVER = old
+    off, on1, on2 = res[False][0], res[True][0], res[True][1]
+    for n in off:
+        assert torch.equal(on1[n], on2[n]), n                                   # reproducible
+        if n.endswith("mlp.c_proj.bias") and "resblocks.2." not in n:           # the last block has no producer: its own pass
+            d = (on1[n] - off[n]).abs().max().item() / (off[n].abs().max().item() + 1e-30)
+            assert d < 1e-5, (n, d)
+        else:
+            assert torch.equal(on1[n], off[n]), n
