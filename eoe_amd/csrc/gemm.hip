@@ -705,7 +705,12 @@ int launch_nt(const GemmP& p, int epi, int gather, hipStream_t s) {
     // 64.2 / 61.9, c_proj 86.5 / 81.7, GELU' x dY 114 / 103; only c_fc forward 102 / 105.6 wins; step 12.35 against 12.13 ms): one
     // wave per SIMD behind a 2-k-tile LDS-DMA lead cannot hide an HBM miss the way two independent workgroups per CU do.
     // Large square problems (below) keep it: there the 256x256 tile's halved operand traffic decides.
-    if ((g_nt_flags & 512) && !(g_nt_flags & (4 | 8)) && epilogue_direct_ok(p, epi) && p.M >= 2048 && p.N >= 512) {
+    // Per-shape in-step timing (round 3, tools/nt_shapes_ab.sh: EOE_PROF_SHAPES=1, both kernels interleaved on one box, ms per step over the 12
+    // layers): the one-wave kernel wins where the epilogue is the GELU pair of outputs behind a short K loop -- c_fc forward 1.167 against
+    // 1.260 --, ties on the K >= 2304 shapes (-0.001 ... -0.010) and loses on QKV (+0.135), GELU' x dY (+0.057) and the two K = 768 -> 768
+    // shapes (+0.056, +0.020).  So: c_fc forward only (nt_flags bit 10 = 1024 turns the rule off).
+    const bool gelu_wide = epi == EOE_EPI_GELU && p.N >= 2048 && p.K <= 1024 && !(g_nt_flags & 1024);
+    if (((g_nt_flags & 512) || gelu_wide) && !(g_nt_flags & (4 | 8)) && epilogue_direct_ok(p, epi) && p.M >= 2048 && p.N >= 512) {
         // time of a launch in units of one 16-row x 256-column x 64-deep slab of MFMAs: rounds over the CUs x (rows per tile x
         // (k-tiles + 2 for the pipeline fill) + 30 for a tile's epilogue and hand-over)
         const int nk = p.K / BK;
