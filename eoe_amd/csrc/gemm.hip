@@ -594,7 +594,9 @@ int launch_nt128_auto(const GemmP& p, int epi, hipStream_t s) {
     const int slots = 2 * num_cus();
     const long t4 = (long)cdiv(p.M, 128) * cdiv(p.N, 128), t5 = (long)cdiv(p.M, 160) * cdiv(p.N, 128);
     const long c4 = (t4 + slots - 1) / slots * 128, c5 = (t5 + slots - 1) / slots * 160;
-    const bool five = (g_nt_flags & 32) || (!(g_nt_flags & 16) && c5 < c4);
+    // (a tie goes to the 160-row tiles: N = 3072 at M = 12800 is 5 x 128 = 4 x 160 rounds x rows, and the in-step timing of
+    //  tools/nt_shapes_sweep.sh has GELU' x dY at 1.226 against 1.260 ms per step with them -- fewer, larger tiles per slot)
+    const bool five = (g_nt_flags & 32) || (!(g_nt_flags & 16) && c5 <= c4);
     return five ? launch_nt128<T, 5>(p, epi, s) : launch_nt128<T, 4>(p, epi, s);
 }
 
