@@ -196,6 +196,27 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][NI], i
             for (int r = 0; r < 4; ++r) bias[q * 4 + r] = bv[r];
         }
     }
+    // per-band operands (the saved pre-activation of GELU' x dY: 32 B per lane and band; the fp32 residual: 64 B) are requested for ALL
+    // bands before the first transposition: inside the band loop each request sat behind the band's LDS round trip and its latency was
+    // exposed once per band (the GELU' epilogue cost 9.8 k cycles per tile against 5.4 k for the plain one)
+    u32x4 pre_[EPI == EOE_EPI_GELU_BWD ? MI : 1][2];
+    f32x4 res_[EPI == EOE_EPI_RESIDUAL ? MI : 1][4];
+    if (EPI == EOE_EPI_GELU_BWD || EPI == EOE_EPI_RESIDUAL) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = m_base + mi * 16 + rrow;
+            const bool ok = m < p.M && col_ok;
+            if (EPI == EOE_EPI_GELU_BWD) {
+                const T* pre = (const T*)p.aux + (size_t)m * p.ldaux + n;
+                pre_[mi][0] = ok ? *(const u32x4*)pre : (u32x4){0u, 0u, 0u, 0u};
+                pre_[mi][1] = ok ? *(const u32x4*)(pre + 8) : (u32x4){0u, 0u, 0u, 0u};
+            } else {
+                const float* res = (const float*)p.aux + (size_t)m * p.ldaux + n;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) res_[mi][q] = ok ? *(const f32x4*)(res + q * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         // accumulator layout -> LDS [16 rows][64 cols] fp32, 16-B chunk index XOR row (bank spread)
@@ -228,19 +249,17 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][NI], i
             continue;
         }
         if (EPI == EOE_EPI_RESIDUAL) {
-            const float* res = (const float*)p.aux + (size_t)m * p.ldaux + n;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 rv = *(const f32x4*)(res + q * 4);
+                const f32x4 rv = res_[EPI == EOE_EPI_RESIDUAL ? mi : 0][q];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[q * 4 + r] += rv[r];
             }
         }
         if (EPI == EOE_EPI_GELU_BWD) {
-            const T* pre = (const T*)p.aux + (size_t)m * p.ldaux + n;
             float pr[16];
-            unpack8<T>(*(const u32x4*)pre, pr);
-            unpack8<T>(*(const u32x4*)(pre + 8), pr + 8);
+            unpack8<T>(pre_[EPI == EOE_EPI_GELU_BWD ? mi : 0][0], pr);
+            unpack8<T>(pre_[EPI == EOE_EPI_GELU_BWD ? mi : 0][1], pr + 8);
 #pragma unroll
             for (int c = 0; c < 16; ++c) v[c] *= quick_gelu_grad_f(pr[c]);
         }
