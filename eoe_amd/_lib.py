@@ -100,7 +100,7 @@ class VitBlockBwdArgs(C.Structure):
                 ("accumulate", _i32),
                 ("d16_a", _vp), ("d16_b", _vp), ("d16_c", _vp), ("dh", _vp), ("dqkv", _vp), ("dx_mid", _vp), ("red_scratch", _vp),
                 ("tn_workspace", _vp), ("tn_workspace_bytes", _i64),
-                ("next_d16", _vp), ("in_d16", _vp), ("in_red_scratch", _vp)]
+                ("next_d16", _vp), ("in_d16", _vp), ("in_red_scratch", _vp), ("async_wgrad", _i32)]
 
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); must match include/eoe_hip.h
@@ -111,6 +111,7 @@ SIGNATURES = {
     "eoe_abi_version": [],
     "eoe_struct_size": [C.c_int],
     "eoe_last_error": [],
+    "eoe_vit_side_join": [_vp],
     "eoe_gemm_nt": [C.POINTER(GemmArgs), _vp],
     "eoe_gemm_tn": [C.POINTER(GemmArgs), _vp],
     "eoe_gemm_tn_grouped": [C.POINTER(GemmArgs), C.c_int, _vp],

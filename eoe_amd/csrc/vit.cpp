@@ -2,6 +2,7 @@
 // enqueues kernels on the caller's stream; there is no host synchronisation and no allocation in here.
 #include "common.h"
 #include <mutex>
+#include <stdlib.h>
 
 #define TRY(expr)                   \
     do {                            \
@@ -20,8 +21,9 @@ namespace {
 // launched on this stream next to it and fills those CUs (measured: 12 of its 31 us hidden, -0.14 ms per step).  Eager launches only.
 struct SideStream {
     hipStream_t s = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr, wgrad_done = nullptr;
     bool ok = false;
+    bool wgrad_pending = false;      // a weight-gradient launch is on the side stream that no compute stream has been ordered behind yet
 };
 // per-device handle table (the only mutable state this file keeps), created once per device under a mutex
 SideStream* side_stream(hipStream_t main) {
@@ -39,7 +41,8 @@ SideStream* side_stream(hipStream_t main) {
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // lo = numerically largest = lowest priority
         if (hipStreamCreateWithPriority(&ss.s, hipStreamNonBlocking, lo) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) != hipSuccess)
+            hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ss.wgrad_done, hipEventDisableTiming) != hipSuccess)
             return nullptr;
         ss.ok = true;
     }
@@ -172,7 +175,26 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
     // stream, capturable)
     // (asked of the launch itself: small or ragged batches, captured streams and "tn_flags" bit 1 all run the plain 216-tile form)
     const bool streamk = eoe_tn_streamk_would_run(w, 4, stream);
-    SideStream* ss = (g_vit_side_stream == 2 || (g_vit_side_stream && !streamk)) && b->red_scratch ? side_stream(s) : nullptr;
+    SideStream* ss = (g_vit_side_stream == 2 || (g_vit_side_stream && (!streamk || b->async_wgrad))) && b->red_scratch ? side_stream(s) : nullptr;
+    // Asynchronous weight gradients (b->async_wgrad; round 3).  Nothing in the backward sweep needs a block's weight gradients, and the
+    // grouped wgrad launch leaves 40 of the 256 CUs idle for its ~213 us (216 one-per-CU workgroups): launched on the side stream, it runs
+    // UNDER the next block's chain (LayerNorm-1 backward here, then that block's dgrad GEMMs on the free CUs) instead of in front of it --
+    // measured 11.65 -> 11.24 ms per step.  Contract with the caller (eoe_hip.h): every buffer the launch reads (dh, dqkv, d16_c, the dY of
+    // c_proj, the saved activations) stays untouched until a later call on this stream has passed its own fork point -- there the compute
+    // stream is ordered behind the previous launch, long finished by then -- or eoe_vit_side_join() was called.
+    if (ss && b->async_wgrad) {
+        if (ss->wgrad_pending && hipStreamWaitEvent(s, ss->wgrad_done, 0) != hipSuccess)
+            return eoe_set_error(EOE_ERR_LAUNCH, "vit_block_bwd: stream wait failed");
+        if (hipEventRecord(ss->fork, s) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess)
+            return eoe_set_error(EOE_ERR_LAUNCH, "vit_block_bwd: fork failed");
+        TRY(eoe_gemm_tn_grouped(w, 4, (void*)ss->s));
+        if (hipEventRecord(ss->wgrad_done, ss->s) != hipSuccess) return eoe_set_error(EOE_ERR_LAUNCH, "vit_block_bwd: event record failed");
+        ss->wgrad_pending = true;
+        TRY(eoe_layernorm_bwd(b->d16_b, 0, a->x_in, D, a->stats1, a->ln1_g, b->dx_mid, b->dx_in, D, b->next_d16, b->g_ln1_g,
+                              b->g_ln1_b, nullptr, red_ln1, M, D, dt, stream));
+        TRY(eoe_flush_reduce(b->red_scratch ? &jobs : nullptr, stream));
+        return 0;
+    }
     if (ss) {
         // fork before the wgrad launch (LayerNorm-1 backward depends on d xn1 and dx_mid only), join before the finish kernel
         if (hipEventRecord(ss->fork, s) != hipSuccess) return eoe_set_error(EOE_ERR_LAUNCH, "vit_block_bwd: event record failed");
@@ -188,5 +210,18 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
                               b->g_ln1_b, nullptr, red_ln1, M, D, dt, stream));
     }
     TRY(eoe_flush_reduce(b->red_scratch ? &jobs : nullptr, stream));
+    return 0;
+}
+
+// orders `stream` behind the weight-gradient launch an asynchronous eoe_vit_block_bwd left on the side stream (no-op if there is none):
+// call it before anything reads the weight gradients or reuses the buffers that launch reads (see eoe_vit_block_bwd_args.async_wgrad)
+extern "C" int eoe_vit_side_join(void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return 0;      // never used while capturing
+    SideStream* ss = side_stream(s);
+    if (!ss || !ss->wgrad_pending) return 0;
+    if (hipStreamWaitEvent(s, ss->wgrad_done, 0) != hipSuccess) return eoe_set_error(EOE_ERR_LAUNCH, "vit_side_join: stream wait failed");
+    ss->wgrad_pending = false;
     return 0;
 }

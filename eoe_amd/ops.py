@@ -460,8 +460,21 @@ def _block_ws(M, D, device, dtype):
 
 
 VIT_HANDOVER = os.environ.get("EOE_VIT_HANDOVER", "1") != "0"     # block-to-block hand-over of dY(c_proj) in the backward sweep (0: A/B)
+VIT_ASYNC_WGRAD = os.environ.get("EOE_VIT_ASYNC_WGRAD", "1") != "0"      # a block's weight gradients on the side stream, under the next block (0: A/B)
 _vit_handoff = None
 _vit_parity = 0
+_vit_pending = None
+_vit_join_queued = False
+
+
+def vit_side_join():
+    """orders the current stream behind the last asynchronous weight-gradient launch and releases what it was reading; called by the
+    autograd engine at the end of a backward pass that used the asynchronous path (and harmless at any other time)"""
+    global _vit_pending, _vit_join_queued
+    _vit_join_queued = False
+    check(lib.eoe_vit_side_join(_stream()), "eoe_vit_side_join")
+    _vit_pending = None
+
 
 
 class VitBlockFunction(torch.autograd.Function):
@@ -526,11 +539,19 @@ class VitBlockFunction(torch.autograd.Function):
         if (h is not None and h["dx"] is dx_out and dx_out._version == h["version"] and h["shape"] == (M, D, ctx.args.n) and h["dt"] == dt
                 and h["stream"] == _stream()):
             b.in_d16, b.in_red_scratch = _p(h["d16"]), _p(h["red"])
-        b.d16_a = _p(scratch("d16_a", (M, D), dt, dev))
+        # asynchronous weight gradients (eoe_hip.h, eoe_vit_block_bwd_args.async_wgrad): the block's grouped wgrad launch goes to the
+        # library's side stream and runs under the NEXT block's kernels.  What it reads -- dh, dqkv, d16_c, the dY of c_proj and the saved
+        # activations in `ws` -- must outlive this call: two alternating sets of those scratch buffers (`par`), `ws` parked in `_vit_pending`
+        # until the next block's call has returned (it orders the stream behind this launch), and one join when the backward pass ends.
+        hook = grad_ready_hooks.get(id(params["ln1_g"]))
+        has_hook = hook is not None and hook[0]() is params["ln1_g"]
+        use_async = VIT_ASYNC_WGRAD and not has_hook and not torch.cuda.is_current_stream_capturing()
+        b.async_wgrad = 1 if use_async else 0
+        b.d16_a = _p(scratch(f"d16_a{par}", (M, D), dt, dev))
         b.d16_b = _p(scratch("d16_b", (M, D), dt, dev))
-        b.d16_c = _p(scratch("d16_c", (M, D), dt, dev))
-        b.dh = _p(scratch("dh", (M, 4 * D), dt, dev))
-        b.dqkv = _p(scratch("dqkv", (M, 3 * D), dt, dev))
+        b.d16_c = _p(scratch(f"d16_c{par}", (M, D), dt, dev))
+        b.dh = _p(scratch(f"dh{par}", (M, 4 * D), dt, dev))
+        b.dqkv = _p(scratch(f"dqkv{par}", (M, 3 * D), dt, dev))
         b.dx_mid = _p(scratch("dx_mid", (M, D), torch.float32, dev))
         nred = (M + 63) // 64 * 4 * D + 2 * LN_SCRATCH_ROWS * 3 * D + ctx.args.n * 3 * D + 256 * D          # EOE_VIT_RED_SCRATCH(n, L, D)
         red = scratch(f"vit_red{par}", (nred,), torch.float32, dev)
@@ -540,8 +561,12 @@ class VitBlockFunction(torch.autograd.Function):
         check(lib.eoe_vit_block_bwd(C.byref(b), _stream()), "eoe_vit_block_bwd")
         if VIT_HANDOVER:
             _vit_handoff = dict(dx=dx_in, version=dx_in._version, shape=(M, D, ctx.args.n), dt=dt, stream=_stream(), d16=d16_next, red=red)
-        hook = grad_ready_hooks.get(id(params["ln1_g"]))
-        if hook is not None and hook[0]() is params["ln1_g"]:      # (weakref to the parameter, callable)
+        global _vit_pending, _vit_join_queued
+        _vit_pending = (x, ws) if use_async else None      # (replaces the previous block's: this call has ordered the stream behind its launch)
+        if use_async and not _vit_join_queued:
+            _vit_join_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(vit_side_join)      # runs when this backward pass is complete
+        if has_hook:      # (weakref to the parameter, callable): the bucket's all-reduce reads the weight gradients -> synchronous launch above
             hook[1]()
         return (dx_in, None, None) + tuple(grads[k] for k in _BLOCK_PARAMS)
 

@@ -322,6 +322,13 @@ typedef struct {
     void* next_d16;
     const void* in_d16;
     const float* in_red_scratch;
+    /* != 0: the four weight gradients are launched on the library's side stream and this call returns without ordering `stream` behind
+     * them: the launch (216 one-per-CU workgroups, ~213 us, 40 CUs idle) then runs under the NEXT block's kernels.  The caller keeps
+     * every buffer that launch reads -- dh, dqkv, d16_c, the dY of c_proj (d16_a or in_d16), the saved activations xn1 / xn2 / att / hact --
+     * untouched until a later eoe_vit_block_bwd on the same stream has returned (alternate two sets of scratch; that call orders the stream
+     * behind the previous launch at its own fork point) or eoe_vit_side_join(stream) was called; the weight gradients themselves may only
+     * be read after eoe_vit_side_join.  Ignored (synchronous launch) while the stream is being captured or without red_scratch. */
+    int32_t async_wgrad;
 } eoe_vit_block_bwd_args;
 
 /* floats: partial rows of the fc dgrad GEMM's fused column sums [ceil(n*L/64)][4D] + of the two LayerNorm backwards + the attention
@@ -330,6 +337,7 @@ typedef struct {
     ((size_t)(((size_t)(n) * (L) + 63) / 64) * 4 * (D) + 2 * EOE_LN_SCRATCH(D) + (size_t)(n) * 3 * (D) + (size_t)EOE_CAST_COLSUM_PARTIALS * (D))
 int eoe_vit_block_fwd(const eoe_vit_block_fwd_args* a, void* stream);
 int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* a, void* stream);
+int eoe_vit_side_join(void* stream);      /* see eoe_vit_block_bwd_args.async_wgrad */
 
 /* ------------------------------------------------------------------------------------------------------
  * CNN backbones (cnn.py:44-86 CNN32; resnet.py:25-152 WideResNet): convolution = im2col + eoe_gemm_nt (forward),

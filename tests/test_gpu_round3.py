@@ -371,3 +371,41 @@ def test_vit_block_handover_equals_the_separate_pass():
             assert d < 1e-5, (n, d)
         else:
             assert torch.equal(on1[n], off[n]), n
+
+
+def test_vit_async_weight_gradients_keep_their_bits():
+    """a block's grouped weight-gradient launch on the side stream, under the next block's kernels (ops.VIT_ASYNC_WGRAD): the same kernels
+    on the same operands -- every gradient and a 6-step Adam trajectory are bitwise those of the synchronous launch order"""
+    import copy
+    import eoe_amd
+    from eoe_amd import ops
+    from eoe_amd.models import ClipViTB32Custom
+    eoe_amd.set_compute_dtype("fp16")
+    torch.manual_seed(0)
+    m0 = ClipViTB32Custom(layers=4).cuda().train()
+    x = torch.randn(32, 3, 224, 224, device="cuda")
+    y = torch.cat([torch.zeros(16, dtype=torch.long), torch.ones(16, dtype=torch.long)]).cuda()
+    out = {}
+    old = ops.VIT_ASYNC_WGRAD
+    try:
+        for on in (False, True):
+            ops.VIT_ASYNC_WGRAD = on
+            m = copy.deepcopy(m0)
+            opt = eoe_amd.FusedAdam(m.parameters(), lr=1e-4, weight_decay=1e-3)
+            losses = []
+            for _ in range(6):
+                opt.zero_grad(set_to_none=True)
+                loss = eoe_amd.hsc_loss(m(x), y, 0)
+                loss.backward()
+                if _ == 0:
+                    g0 = {n: p.grad.clone() for n, p in m.named_parameters()}
+                opt.step()
+                losses.append(loss.item())
+            out[on] = (losses, g0, {n: p.detach().clone() for n, p in m.named_parameters()})
+    finally:
+        ops.VIT_ASYNC_WGRAD = old
+    (l0, g0, p0), (l1, g1, p1) = out[False], out[True]
+    assert l0 == l1, (l0, l1)
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n
+        assert torch.equal(p0[n], p1[n]), n
