@@ -215,6 +215,7 @@ class GradArena:
             for p in ps:
                 self._hook_handles.append(p.register_post_accumulate_grad_hook(lambda p, b=b: self._arrived(p, b)))
         self._installed = True
+        ops.async_wgrad_blockers += 1          # the hooks send a gradient the moment autograd has it: no weight gradient may still be in flight
         # With collectives in flight RCCL's workgroups occupy CUs for the length of a bucket, and the stream-K wgrad launch wants every CU
         # at once (one k-range per CU, each waiting for its predecessor's partial): ranges that find no CU would start a second round.
         # Data parallel runs keep the one-tile-per-workgroup launch (216 of 256 CUs) with LayerNorm-1 backward beside it instead.
@@ -242,6 +243,8 @@ class GradArena:
         for h in self._hook_handles:
             h.remove()
         self._hook_handles.clear()
+        if self._installed:
+            ops.async_wgrad_blockers = max(0, ops.async_wgrad_blockers - 1)
         self._installed = False
 
     def _into_arena(self, p):

@@ -409,3 +409,38 @@ def test_vit_async_weight_gradients_keep_their_bits():
     for n in g0:
         assert torch.equal(g0[n], g1[n]), n
         assert torch.equal(p0[n], p1[n]), n
+
+
+def test_conv_async_weight_gradients_keep_their_bits():
+    """the convolutions' weight-gradient GEMMs on a side stream (ops.CONV_ASYNC_WGRAD): a 4-step WideResNet-32 / CNN32 Adam trajectory is
+    bitwise that of the synchronous order"""
+    import copy
+    import eoe_amd
+    from eoe_amd import ops
+    from eoe_amd.models import CNN32, WideResNet
+    eoe_amd.set_compute_dtype("fp16")
+    for make, res in ((lambda: CNN32(bias=True), 32), (lambda: WideResNet(res=32), 32)):
+        torch.manual_seed(1)
+        m0 = make().cuda().train()
+        x = torch.randn(32, 3, res, res, device="cuda")
+        y = torch.cat([torch.zeros(16, dtype=torch.long), torch.ones(16, dtype=torch.long)]).cuda()
+        out = {}
+        old = ops.CONV_ASYNC_WGRAD
+        try:
+            for on in (False, True):
+                ops.CONV_ASYNC_WGRAD = on
+                m = copy.deepcopy(m0)
+                opt = eoe_amd.FusedAdam(m.parameters(), lr=1e-3)
+                losses = []
+                for _ in range(4):
+                    opt.zero_grad(set_to_none=True)
+                    loss = eoe_amd.hsc_loss(m(x), y, 0)
+                    loss.backward()
+                    opt.step()
+                    losses.append(loss.item())
+                out[on] = (losses, {n: p.detach().clone() for n, p in m.named_parameters()})
+        finally:
+            ops.CONV_ASYNC_WGRAD = old
+        assert out[False][0] == out[True][0], (out[False][0], out[True][0])
+        for n in out[False][1]:
+            assert torch.equal(out[False][1][n], out[True][1][n]), n
