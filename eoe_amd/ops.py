@@ -1142,6 +1142,7 @@ class ConvBnActPoolParityFunction(torch.autograd.Function):
         geo = _geo(n, Hi, Wi, cin, kh, kw, stride, pad, H, W)
         w = conv_w.contiguous()
         dw = _grad_target(conv_w)
+        _side_ctx = _conv_wgrad_side_begin(dy, x) if CONV_ASYNC_WGRAD else None      # (see _conv_wgrad_side_begin: under dgrad + the next layer)
         if packed:                                   # x = the NHWC4 image saved by forward: gradient of the zero-padded [cout, 4, kh, kw] weight
             geo4 = _geo(n, Hi, Wi, 4, kh, kw, stride, pad, H, W)
             ws_bytes = int(lib.eoe_conv_f32_wgrad_workspace(geo4, cout))
@@ -1154,6 +1155,8 @@ class ConvBnActPoolParityFunction(torch.autograd.Function):
             ws = scratch("parity_wgrad_ws", (ws_bytes // 4,), torch.float32, dev)
             check(lib.eoe_conv_f32_wgrad(_p(x), 1 if is_image else 0, _p(mean), _p(std), _p(dy), _p(dw), geo, cout, _p(ws), ws_bytes,
                                          _stream()), "eoe_conv_f32_wgrad")
+        if _side_ctx is not None:
+            _conv_wgrad_side_end(_side_ctx)
         dcb = None
         if conv_b is not None:
             dcb = _grad_target(conv_b)
