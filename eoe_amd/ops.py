@@ -464,15 +464,13 @@ VIT_ASYNC_WGRAD = os.environ.get("EOE_VIT_ASYNC_WGRAD", "1") != "0"      # a blo
 _vit_handoff = None
 _vit_parity = 0
 _vit_pending = None
-_vit_join_queued = False
 _vit_deferred_hook = None
 
 
 def vit_side_join():
     """orders the current stream behind the last asynchronous weight-gradient launch and releases what it was reading; called by the
     autograd engine at the end of a backward pass that used the asynchronous path (and harmless at any other time)"""
-    global _vit_pending, _vit_join_queued, _vit_deferred_hook
-    _vit_join_queued = False
+    global _vit_pending, _vit_deferred_hook
     check(lib.eoe_vit_side_join(_stream()), "eoe_vit_side_join")
     _vit_pending = None
     if _vit_deferred_hook is not None:                     # the last block of the sweep: its bucket goes out behind the join
@@ -567,14 +565,15 @@ class VitBlockFunction(torch.autograd.Function):
         check(lib.eoe_vit_block_bwd(C.byref(b), _stream()), "eoe_vit_block_bwd")
         if VIT_HANDOVER:
             _vit_handoff = dict(dx=dx_in, version=dx_in._version, shape=(M, D, ctx.args.n), dt=dt, stream=_stream(), d16=d16_next, red=red)
-        global _vit_pending, _vit_join_queued, _vit_deferred_hook
+        global _vit_pending, _vit_deferred_hook
         _vit_pending = (x, ws) if use_async else None      # (replaces the previous block's: this call has ordered the stream behind its launch)
         if _vit_deferred_hook is not None:                 # the previous block's bucket: its weight gradients are complete in stream order now
             prev, _vit_deferred_hook = _vit_deferred_hook, None
             prev()
-        if use_async and not _vit_join_queued:
-            _vit_join_queued = True
-            torch.autograd.Variable._execution_engine.queue_callback(vit_side_join)      # runs when this backward pass is complete
+        if use_async:
+            # runs when this backward pass is complete; queued by every block (idempotent): a flag "already queued" would survive a pass
+            # that died with an exception and leave the next pass without its join
+            torch.autograd.Variable._execution_engine.queue_callback(vit_side_join)
         if has_hook:      # (weakref to the parameter, callable): the bucket's all-reduce reads this block's weight gradients
             if use_async:
                 _vit_deferred_hook = hook[1]
@@ -1416,12 +1415,11 @@ class ConvBnActPoolFunction(torch.autograd.Function):
 CONV_ASYNC_WGRAD = os.environ.get("EOE_CONV_ASYNC_WGRAD", "1") != "0"
 async_wgrad_blockers = 0
 _conv_side = None
-_conv_join_queued = False
 _conv_keep = []
 
 
 def _conv_wgrad_side_begin(*tensors):
-    global _conv_side, _conv_join_queued
+    global _conv_side
     if async_wgrad_blockers > 0 or torch.cuda.is_current_stream_capturing():
         return None
     if _conv_side is None:
@@ -1433,9 +1431,7 @@ def _conv_wgrad_side_begin(*tensors):
     _conv_keep.extend(tensors)                  # what the launch reads stays alive until the join
     cm = torch.cuda.stream(_conv_side)
     cm.__enter__()
-    if not _conv_join_queued:
-        _conv_join_queued = True
-        torch.autograd.Variable._execution_engine.queue_callback(_conv_wgrad_join)
+    torch.autograd.Variable._execution_engine.queue_callback(_conv_wgrad_join)      # every layer queues it (idempotent, see vit_side_join)
     return cm
 
 
@@ -1444,9 +1440,8 @@ def _conv_wgrad_side_end(cm):
 
 
 def _conv_wgrad_join():
-    global _conv_join_queued
-    _conv_join_queued = False
-    torch.cuda.current_stream().wait_stream(_conv_side)
+    if _conv_side is not None and _conv_keep:
+        torch.cuda.current_stream().wait_stream(_conv_side)
     _conv_keep.clear()
 
 
