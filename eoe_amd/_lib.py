@@ -154,6 +154,7 @@ SIGNATURES = {
     "eoe_bn_stats_partials": [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _f32, _vp],
     "eoe_bn_act_pool_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32,
                             C.c_int, _vp],
+    "eoe_colsum_f32": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
     "eoe_bn_act_pool_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                             C.c_int, C.c_int, _f32, C.c_int, _vp],
     "eoe_bn_act_maxpool_fwd": [_vp] * 7 + [C.c_int] * 7 + [_f32, C.c_int, _vp],

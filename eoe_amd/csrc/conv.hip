@@ -801,6 +801,34 @@ __global__ __launch_bounds__(256) void bn_act_maxpool_bwd_s2k3_kernel(const floa
     if (MODE == 0) block_channel_sums(acc0, acc1, lds, red + (size_t)(1 + blockIdx.x) * 2 * C, C, total);
 }
 
+// out[c] = sum over the rows of an fp32 matrix [rows, C] (C % 4 == 0): the bias gradient of a convolution in the exact-fp32 mode.  The
+// BatchNorm reduce passes' scheme: a thread keeps ONE channel quad for its whole grid-stride loop (two rows in flight), the workgroup's
+// 256 threads are added in a fixed order into its partial row, reduce_partials_kernel adds the rows -- no atomics.  (eoe_cast_colsum, built
+// for the ViT's 768-wide matrices, used 8 of its 64 column lanes on a 32-channel map and walked 256 rows serially per thread: 0.18 of
+// CNN32's 1.75 ms step in that mode.)
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ x, float* __restrict__ red, int rows, int C) {
+    extern __shared__ float lds[];
+    const int cc = C / 4;
+    const unsigned total = (unsigned)rows * cc;
+    float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
+    const unsigned first = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    unsigned i = first;
+    for (; i < total && i + stride < total && i + stride > i; i += 2 * stride) {
+        const f32x4 a = *(const f32x4*)(x + (size_t)i * 4), b = *(const f32x4*)(x + (size_t)(i + stride) * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc0[r] += a[r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc0[r] += b[r];
+    }
+    for (; i < total; i += stride) {
+        const f32x4 a = *(const f32x4*)(x + (size_t)i * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc0[r] += a[r];
+        if (i + stride < i) break;
+    }
+    block_channel_sums(acc0, acc1, lds, red + (size_t)(1 + blockIdx.x) * 2 * C, C, total);
+}
+
 int grid_for(size_t total) {
     size_t g = (total + 255) / 256;
     if (g > 4096) g = 4096;
@@ -1080,6 +1108,30 @@ extern "C" int eoe_bn_act_pool_bwd(const float* y, const float* stats, const flo
     if (pool == 1) { EOE_BNB(1, 1, grid, 0); } else { EOE_BNB(1, 2, grid, 0); }
     EOE_CHECK_LAUNCH("bn_act_pool_bwd_apply");
 #undef EOE_BNB
+    return 0;
+}
+
+extern "C" int eoe_colsum_f32(const float* x, float* out, float* red_scratch, int rows, int C, int accumulate, void* stream) {
+    EOE_CHECK_ARG(x && out && red_scratch && rows > 0 && C > 0 && C % 4 == 0 && C <= 4096, "colsum_f32: bad args");
+    EOE_CHECK_IDX((size_t)rows * C / 4, "colsum_f32");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("colsum_f32", 0, 4.0 * rows * C, stream);
+    const int grid = grid_for((size_t)rows * C / 4);
+    int g0 = grid > EOE_BN_PARTIALS ? EOE_BN_PARTIALS : grid;
+    {   // gridDim.x * 256 must be a multiple of C/4 (one channel quad per thread)
+        int cc = C / 4, a = cc, b = 256;
+        while (b) { const int t = a % b; a = b; b = t; }
+        const int q = cc / a;
+        EOE_CHECK_ARG(q <= EOE_BN_PARTIALS, "colsum_f32: C = %d not supported", C);
+        g0 = g0 / q * q;
+        if (g0 < q) g0 = q;
+    }
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3(g0), dim3(256), 2 * C * sizeof(float), s, x, red_scratch, rows, C);
+    EOE_CHECK_LAUNCH("colsum_f32");
+    // partial rows [g0][2C] behind the first 2C floats; the second half of every row is zero and goes to a spare row of the scratch
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * C, 16)), dim3(1024), 0, s, (const float*)(red_scratch + 2 * C), red_scratch, g0,
+                       2 * C, out, red_scratch + (size_t)(EOE_BN_PARTIALS + 2) * 2 * C, C, accumulate);
+    EOE_CHECK_LAUNCH("colsum_f32_reduce");
     return 0;
 }
 

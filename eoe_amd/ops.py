@@ -1042,8 +1042,12 @@ def _geo(n, H, W, C, kh, kw, stride, pad, Ho, Wo):
 
 
 def _f32_colsum(x2d: torch.Tensor, out: torch.Tensor):
-    """out[c] = sum_r x[r, c] of an fp32 matrix through the partial-row (atomics-free) path of eoe_cast_colsum"""
+    """out[c] = sum_r x[r, c] of an fp32 matrix, atomics-free (eoe_colsum_f32; widths that are not multiples of 4 through eoe_cast_colsum)"""
     rows, cols = x2d.shape
+    if cols % 4 == 0 and cols <= 4096:
+        red = scratch("bn_red", (BN_SCRATCH * cols,), torch.float32, x2d.device)
+        check(lib.eoe_colsum_f32(_p(x2d), _p(out), _p(red), rows, cols, 0, _stream()), "eoe_colsum_f32")
+        return
     dummy = scratch("parity_colsum_dst", (rows * cols,), torch.float16, x2d.device)
     part = scratch("parity_colsum_part", (256 * cols,), torch.float32, x2d.device)
     check(lib.eoe_cast_colsum(_p(x2d), _p(dummy), _p(out), _p(part), rows, cols, _lib.EOE_F16, 0, _stream()), "eoe_cast_colsum")

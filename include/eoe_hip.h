@@ -404,6 +404,9 @@ int eoe_bn_act_pool_fwd(const float* y, const float* stats, const float* gamma, 
                         int n, int H, int W, int C, int pool, int nchw_flat, int out_f32, float slope, int dtype, void* stream);
 /* backward of the above: dout fp32 (layout of `out`) -> dy [n*H*W, C] 16-bit (dY operand of the conv wgrad/dgrad), or
  * fp32 if dy_f32; dgamma, dbeta.  red_scratch: EOE_BN_SCRATCH(C) floats. */
+/* out[c] (+= if accumulate) = sum over the rows of an fp32 matrix [rows, C], C % 4 == 0: a convolution's bias gradient in the exact-fp32
+ * mode; red_scratch: EOE_BN_SCRATCH(C) floats; fixed summation order, no atomics */
+int eoe_colsum_f32(const float* x, float* out, float* red_scratch, int rows, int C, int accumulate, void* stream);
 int eoe_bn_act_pool_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* dout,
                         float* red_scratch, void* dy, int dy_f32, float* dgamma, float* dbeta, int n, int H, int W, int C,
                         int pool, int nchw_flat, int training, int accumulate, float slope, int dtype, void* stream);

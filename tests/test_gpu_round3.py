@@ -9,6 +9,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import batching, models as omodels, trainer as otrainer   # noqa: E402
+from gpu_util import rel_rms   # noqa: E402
 
 
 @pytest.fixture(autouse=True)
@@ -444,3 +445,18 @@ def test_conv_async_weight_gradients_keep_their_bits():
         assert out[False][0] == out[True][0], (out[False][0], out[True][0])
         for n in out[False][1]:
             assert torch.equal(out[False][1][n], out[True][1][n]), n
+
+
+@pytest.mark.parametrize("rows,cols", [(262144, 32), (4099, 64), (17, 128), (256, 512), (300, 2048), (33, 20)])
+def test_f32_colsum(rows, cols):
+    """the exact-fp32 mode's bias gradients: column sums of an fp32 matrix through the atomics-free partial-row scheme"""
+    from eoe_amd import ops
+    torch.manual_seed(rows + cols)
+    x = torch.randn(rows, cols, device="cuda")
+    out = torch.full((cols,), 7.0, device="cuda")
+    ops._f32_colsum(x, out)
+    want = x.double().sum(0)
+    assert rel_rms(out, want.cpu()) < 2e-6, rel_rms(out, want.cpu())
+    out2 = torch.full((cols,), 7.0, device="cuda")
+    ops._f32_colsum(x, out2)
+    assert torch.equal(out, out2)                       # fixed summation order
