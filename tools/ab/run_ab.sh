@@ -1,18 +1,24 @@
-# A/B of two builds of the library on ONE box, interleaved: the in-tree build (new) against one built with tools/ab/gemm_common_prev.h
-# (produce that file with `git show <rev>:eoe_amd/csrc/gemm_common.h > tools/ab/gemm_common_prev.h`; the GPU box has no git history)
+# A/B of two builds of the library on ONE box, interleaved: the in-tree build (new) against one built with the files under tools/ab/prev/
+# swapped in (same relative paths; produce them with `git show <rev>:<path> > tools/ab/prev/<path>` -- the GPU box has no git history).
+# Usage: bash tools/ab/run_ab.sh [bench.py arguments]; EOE_PROF_SHAPES=1 for per-shape NT GEMM times.
 set -e
 cd $GRAFT_REPO_ROOT
-cp eoe_amd/libeoe_hip.so /tmp/new.so; cp eoe_amd/libeoe_hip.so.stamp /tmp/new.stamp
-cp eoe_amd/csrc/gemm_common.h /tmp/new_common.h
-cp tools/ab/gemm_common_prev.h eoe_amd/csrc/gemm_common.h
-python -c "from eoe_amd import _build; _build.build(force=True, verbose=False)" > /tmp/build.log 2>&1 || { tail -5 /tmp/build.log; exit 1; }
-cp eoe_amd/libeoe_hip.so /tmp/old.so; cp eoe_amd/libeoe_hip.so.stamp /tmp/old.stamp
-cp eoe_amd/csrc/gemm_common.h /tmp/old_common.h
-# (the loader checks the library's content stamp against the sources: each run sees the header its library was built from)
-run() { cp /tmp/$1.so eoe_amd/libeoe_hip.so; cp /tmp/$1.stamp eoe_amd/libeoe_hip.so.stamp; cp /tmp/$1_common.h eoe_amd/csrc/gemm_common.h; EOE_PROF_SHAPES=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-torch-baseline 2>/dev/null > gpurun_out/sh/ab_$1_$2.json; }
-mkdir -p gpurun_out/sh
+ARGS="${@:---steps 20 --warmup 5 --no-cpu-baseline --no-torch-baseline --no-roofline}"
+FILES=$(cd tools/ab/prev && find . -type f | sed 's|^\./||')
+mkdir -p /tmp/ab/new /tmp/ab/old gpurun_out/sh
+for f in $FILES; do mkdir -p /tmp/ab/new/$(dirname $f); cp $f /tmp/ab/new/$f; done
+cp eoe_amd/libeoe_hip.so /tmp/ab/new.so; cp eoe_amd/libeoe_hip.so.stamp /tmp/ab/new.stamp
+for f in $FILES; do cp tools/ab/prev/$f $f; done
+python -c "from eoe_amd import _build; _build.build(force=True, verbose=False)" > /tmp/ab/build.log 2>&1 || { tail -5 /tmp/ab/build.log; exit 1; }
+cp eoe_amd/libeoe_hip.so /tmp/ab/old.so; cp eoe_amd/libeoe_hip.so.stamp /tmp/ab/old.stamp
+# (the loader checks the library's content stamp against the sources: each run sees the sources its library was built from)
+run() {
+    cp /tmp/ab/$1.so eoe_amd/libeoe_hip.so; cp /tmp/ab/$1.stamp eoe_amd/libeoe_hip.so.stamp
+    for f in $FILES; do if [ $1 = old ]; then cp tools/ab/prev/$f $f; else cp /tmp/ab/new/$f $f; fi; done
+    python bench.py $ARGS 2>/dev/null > gpurun_out/sh/ab_$1_$2.json
+}
 for r in 1 2 3; do run old $r; run new $r; done
-cp /tmp/new.so eoe_amd/libeoe_hip.so; cp /tmp/new.stamp eoe_amd/libeoe_hip.so.stamp; cp /tmp/new_common.h eoe_amd/csrc/gemm_common.h
+run new 0
 python - <<'PY'
 import json
 res, steps = {}, {}
@@ -20,7 +26,7 @@ for v in ("old", "new"):
     for r in (1, 2, 3):
         d = json.loads(open(f"gpurun_out/sh/ab_{v}_{r}.json").read())
         steps.setdefault(v, []).append(d["ms_per_step"])
-        for n, x in d["roofline"]["kernels_ms_per_step"].items():
+        for n, x in (d.get("roofline") or {}).get("kernels_ms_per_step", {}).items():
             if n.startswith("nt_128"):
                 res.setdefault(n, {}).setdefault(v, []).append(x)
 print("step ms:", steps)
