@@ -160,8 +160,9 @@ SIGNATURES = {
     "eoe_bn_act_maxpool_fwd": [_vp] * 7 + [C.c_int] * 7 + [_f32, C.c_int, _vp],
     "eoe_bn_act_maxpool_bwd": [_vp] * 10 + [C.c_int] * 8 + [_f32, C.c_int, _vp],
     "eoe_pack_image_nhwc4": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
-    "eoe_conv_f32_fwd": [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.POINTER(ConvGeometry), C.c_int, _vp, C.c_size_t, _vp],
-    "eoe_conv_f32_dgrad": [_vp, _vp, _vp, C.POINTER(ConvGeometry), C.c_int, C.c_int, _vp, C.c_size_t, _vp],
+    "eoe_conv_f32_pack_weights": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "eoe_conv_f32_fwd": [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.POINTER(ConvGeometry), C.c_int, _vp, C.c_size_t, _vp, _vp],
+    "eoe_conv_f32_dgrad": [_vp, _vp, _vp, C.POINTER(ConvGeometry), C.c_int, C.c_int, _vp, C.c_size_t, _vp, _vp],
     "eoe_conv_f32_wgrad_workspace": [C.POINTER(ConvGeometry), C.c_int],
     "eoe_conv_f32_wgrad": [_vp, C.c_int, _vp, _vp, _vp, _vp, C.POINTER(ConvGeometry), C.c_int, _vp, _sz, _vp],
     "eoe_maxpool_fwd": [_vp, _vp, _vp, _vp] + [C.c_int] * 8 + [_vp],

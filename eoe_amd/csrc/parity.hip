@@ -147,13 +147,14 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const float* __restrict__
 // valid taps come in the same (ky, kx, channel) order as before: bitwise the same sums.
 // Split k (forward / dgrad with few output tiles and a long reduction: the small maps of the 32 x 32 WideResNet, the FC layers): nslab > 1
 // slabs of the reduction write partial outputs [slab][rows][N] (`out` = the workspace), summed in slab order by slab_sum_out_kernel.
-template <int MODE, int BN, int WV = 0, bool S2 = false>      // WV (wgrad variants): 0 = both sides float4, 1 = the x side element-wise (OIHW order), 2 = roles exchanged, 3 = both
+template <int MODE, int BN, int WV = 0, bool S2 = false, bool WK = false>      // WK: forward / dgrad weights from the k-major packed copy `wk` (eoe_conv_f32_pack_weights); WV (wgrad variants): 0 = both sides float4, 1 = the x side element-wise (OIHW order), 2 = roles exchanged, 3 = both
 __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ dy, const float* __restrict__ bias,
                                                             float* __restrict__ out, PGeo g, int M, int N, int K, int k_per_slab,
                                                             int accumulate, FDiv dHoWo, FDiv dWo, FDiv dHW, FDiv dW, FDiv dC,
                                                             const float* __restrict__ mean = nullptr, const float* __restrict__ stdv = nullptr,
-                                                            FDiv dtaps = FDiv(1), FDiv dkw = FDiv(1), int nslab = 1) {
+                                                            FDiv dtaps = FDiv(1), FDiv dkw = FDiv(1), int nslab = 1,
+                                                            const float* __restrict__ wk = nullptr, int wk_rows = 0) {
     constexpr bool b_oihw = (WV == 1 || WV == 3), swap = (WV == 2 || WV == 3);
     constexpr int BM = 128, BK = 16, LDA = BM + 4, LDB = BN + 4, NI = BN / 32, NBV = BN / 16;
     __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const float* __restr
     f32x4 ra[2];
     float rb[NBV];
     f32x4 rbv[2];
+    f32x4 rbq[NBV / 4];                               // WK: the weight tile as BN / 4 float4 along n per k row, NBV / 4 per thread
     auto load_tile = [&](int k0) {
         if (MODE == P_WGRAD) {
             // k = output pixel.  A(m = co, k) = dy[k][co]: float4 along m.  B(n' = tap * C + ci, k) = x at the pixel's tap window: float4
@@ -313,6 +315,18 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const float* __restr
             }
             ra[i] = v;
         }
+        if (WK) {
+            // k-major packed weights wk[k row][N] (forward: row = tap * C + c; dgrad: row = tap * cout + co, tap = ky * kw + kx of the FULL
+            // kernel): a thread fetches 4 consecutive n of one k row -- one 16-byte load and one 16-byte LDS store instead of four scalar
+            // loads gathered with a stride of kh * kw floats and four scalar stores
+#pragma unroll
+            for (int i = 0; i < NBV / 4; ++i) {
+                const int e = t + 256 * i, kk = e / (BN / 4), nq = (e - kk * (BN / 4)) * 4, nn = n0 + nq;
+                const int krow = (MODE == P_DGRAD && S2) ? (ky * g.kw + kx) * g.cout + c0 + kk : k0 + kk;
+                rbq[i] = (nn < N && krow < wk_rows) ? *(const f32x4*)(wk + (size_t)krow * N + nn) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            return;
+        }
         // weights: BN rows x 16 k scalars, NBV per thread; element (n, kk): forward w[n][c0+kk][ky][kx], dgrad w[c0+kk][n][ky][kx]
 #pragma unroll
         for (int i = 0; i < NBV; ++i) {
@@ -340,6 +354,14 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const float* __restr
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) As[buf][a_kq[i] * 4 + j][a_r[i]] = ra[i][j];
+        if (WK) {
+#pragma unroll
+            for (int i = 0; i < NBV / 4; ++i) {
+                const int e = t + 256 * i, kk = e / (BN / 4), nq = (e - kk * (BN / 4)) * 4;
+                *(f32x4*)&Bs[buf][kk][nq] = rbq[i];
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NBV; ++i) {
             const int e = t + 256 * i;
@@ -653,6 +675,28 @@ int fill_geo(const char* who, const eoe_conv_geometry* geo, int cout, int nchw, 
 
 }  // namespace
 
+// k-major fp32 copies of a convolution weight [cout][cin][kh][kw]: wf[(tap * cin + ci)][cout] (forward) and wd[(tap * cout + co)][cin]
+// (dgrad), tap = ky * kw + kx -- what the forward / dgrad kernels stage as 16-byte rows (conv_f32_mfma_kernel, WK)
+__global__ __launch_bounds__(256) void conv_f32_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wd,
+                                                                    int cout, int cin, int taps) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x, count = (size_t)cout * cin * taps;
+    if (e >= count) return;
+    // e enumerates the OUTPUT of the forward copy: (tap, ci, co) with co fastest (coalesced stores; the gather side is small and cached)
+    const int co = (int)(e % cout), ci = (int)((e / cout) % cin), tap = (int)(e / ((size_t)cout * cin));
+    const float v = w[((size_t)co * cin + ci) * taps + tap];
+    if (wf) wf[e] = v;
+    if (wd) wd[((size_t)tap * cout + co) * cin + ci] = v;
+}
+
+extern "C" int eoe_conv_f32_pack_weights(const float* w, float* wf, float* wd, int cout, int cin, int kh, int kw, void* stream) {
+    EOE_CHECK_ARG(w && (wf || wd) && cout > 0 && cin > 0 && kh > 0 && kw > 0, "conv_f32_pack_weights: bad arguments");
+    const size_t count = (size_t)cout * cin * kh * kw;
+    hipLaunchKernelGGL(conv_f32_pack_weights_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, wf, wd, cout, cin,
+                       kh * kw);
+    EOE_CHECK_LAUNCH("conv_f32_pack_weights");
+    return 0;
+}
+
 extern "C" int eoe_pack_image_nhwc4(const float* x_nchw, const float* mean, const float* stdv, float* out_nhwc4, int n, int H, int W, void* stream) {
     EOE_CHECK_ARG(x_nchw && out_nhwc4 && n > 0 && H > 0 && W > 0, "pack_image_nhwc4: bad arguments");
     EOE_CHECK_ARG((mean == nullptr) == (stdv == nullptr), "pack_image_nhwc4: mean/std must both be given or both NULL");
@@ -665,7 +709,8 @@ extern "C" int eoe_pack_image_nhwc4(const float* x_nchw, const float* mean, cons
 }
 
 extern "C" int eoe_conv_f32_fwd(const float* x, int x_nchw, const float* mean, const float* stdv, const float* w, const float* bias,
-                                float* y, const eoe_conv_geometry* geo, int cout, void* workspace, size_t workspace_bytes, void* stream) {
+                                float* y, const eoe_conv_geometry* geo, int cout, void* workspace, size_t workspace_bytes, const float* w_kmajor,
+                                void* stream) {
     EOE_CHECK_ARG(x && w && y, "conv_f32_fwd: null pointer");
     EOE_CHECK_ARG((mean == nullptr) == (stdv == nullptr), "conv_f32_fwd: mean/std must both be given or both NULL");
     PGeo g;
@@ -678,12 +723,14 @@ extern "C" int eoe_conv_f32_fwd(const float* x, int x_nchw, const float* mean, c
         const int S = (N & 3) ? 1 : fwd_slabs(gx * gy, K, (size_t)M * N, workspace_bytes, workspace);
         const int per = S > 1 ? ((K + S - 1) / S + 15) / 16 * 16 : K;
         float* dst = S > 1 ? (float*)workspace : y;
-        if (N <= 64) hipLaunchKernelGGL((conv_f32_mfma_kernel<P_FWD, 64>), dim3(gx, gy, S), dim3(256), 0, (hipStream_t)stream,
-                                        x, w, (const float*)nullptr, bias, dst, g, M, N, K, per, 0, dHoWo, dWo, dHW, dW, dC,
-                                        (const float*)nullptr, (const float*)nullptr, FDiv(1), FDiv(1), S);
-        else hipLaunchKernelGGL((conv_f32_mfma_kernel<P_FWD, 128>), dim3(gx, gy, S), dim3(256), 0, (hipStream_t)stream,
-                                x, w, (const float*)nullptr, bias, dst, g, M, N, K, per, 0, dHoWo, dWo, dHW, dW, dC,
-                                (const float*)nullptr, (const float*)nullptr, FDiv(1), FDiv(1), S);
+        const bool wkp = w_kmajor != nullptr && (N & 3) == 0 && !(g_parity_flags & 8);       // parity_flags bit 3: the scalar weight gather (A/B)
+#define EOE_FWD_LAUNCH(BNV, WKV)                                                                                                        \
+        hipLaunchKernelGGL((conv_f32_mfma_kernel<P_FWD, BNV, 0, false, WKV>), dim3(gx, gy, S), dim3(256), 0, (hipStream_t)stream,       \
+                           x, w, (const float*)nullptr, bias, dst, g, M, N, K, per, 0, dHoWo, dWo, dHW, dW, dC,                          \
+                           (const float*)nullptr, (const float*)nullptr, FDiv(1), FDiv(1), S, w_kmajor, K)
+        if (N <= 64) { if (wkp) EOE_FWD_LAUNCH(64, true); else EOE_FWD_LAUNCH(64, false); }
+        else { if (wkp) EOE_FWD_LAUNCH(128, true); else EOE_FWD_LAUNCH(128, false); }
+#undef EOE_FWD_LAUNCH
         EOE_CHECK_LAUNCH("conv_f32_fwd (mfma)");
         if (S > 1) {
             const size_t count4 = (size_t)M * N / 4;
@@ -709,7 +756,7 @@ extern "C" int eoe_conv_f32_fwd(const float* x, int x_nchw, const float* mean, c
 }
 
 extern "C" int eoe_conv_f32_dgrad(const float* dy, const float* w, float* dx, const eoe_conv_geometry* geo, int cout, int accumulate,
-                                  void* workspace, size_t workspace_bytes, void* stream) {
+                                  void* workspace, size_t workspace_bytes, const float* w_kmajor, void* stream) {
     EOE_CHECK_ARG(dy && w && dx, "conv_f32_dgrad: null pointer");
     PGeo g;
     EOE_TRY(fill_geo("conv_f32_dgrad", geo, cout, 0, g));
@@ -725,12 +772,14 @@ extern "C" int eoe_conv_f32_dgrad(const float* dy, const float* w, float* dx, co
             const int kmax = ((g.kh + 1) / 2) * ((g.kw + 1) / 2) * cout;            // the longest class
             const int S = (N & 3) ? 1 : fwd_slabs(gx * gy * 4, kmax, (size_t)M * N, workspace_bytes, workspace);
             float* dst = S > 1 ? (float*)workspace : dx;
-            if (N <= 64) hipLaunchKernelGGL((conv_f32_mfma_kernel<P_DGRAD, 64, 0, true>), dim3(gx, gy, 4 * S), dim3(256), 0, (hipStream_t)stream,
-                                            (const float*)nullptr, w, dy, (const float*)nullptr, dst, g, Mc, N, K, K, accumulate, dHoWo, dWo, cHW, cW, dC,
-                                            (const float*)nullptr, (const float*)nullptr, FDiv(1), FDiv(1), S);
-            else hipLaunchKernelGGL((conv_f32_mfma_kernel<P_DGRAD, 128, 0, true>), dim3(gx, gy, 4 * S), dim3(256), 0, (hipStream_t)stream,
-                                    (const float*)nullptr, w, dy, (const float*)nullptr, dst, g, Mc, N, K, K, accumulate, dHoWo, dWo, cHW, cW, dC,
-                                    (const float*)nullptr, (const float*)nullptr, FDiv(1), FDiv(1), S);
+            const bool wkp = w_kmajor != nullptr && (N & 3) == 0 && !(g_parity_flags & 8);
+#define EOE_DG2_LAUNCH(BNV, WKV)                                                                                                        \
+            hipLaunchKernelGGL((conv_f32_mfma_kernel<P_DGRAD, BNV, 0, true, WKV>), dim3(gx, gy, 4 * S), dim3(256), 0, (hipStream_t)stream,  \
+                               (const float*)nullptr, w, dy, (const float*)nullptr, dst, g, Mc, N, K, K, accumulate, dHoWo, dWo, cHW, cW, dC, \
+                               (const float*)nullptr, (const float*)nullptr, FDiv(1), FDiv(1), S, w_kmajor, K)
+            if (N <= 64) { if (wkp) EOE_DG2_LAUNCH(64, true); else EOE_DG2_LAUNCH(64, false); }
+            else { if (wkp) EOE_DG2_LAUNCH(128, true); else EOE_DG2_LAUNCH(128, false); }
+#undef EOE_DG2_LAUNCH
             EOE_CHECK_LAUNCH("conv_f32_dgrad (mfma, stride-2 classes)");
             if (S > 1) {
                 const size_t count4 = (size_t)M * N / 4;
@@ -744,12 +793,14 @@ extern "C" int eoe_conv_f32_dgrad(const float* dy, const float* w, float* dx, co
         const int S = (N & 3) ? 1 : fwd_slabs(gx * gy, K, (size_t)M * N, workspace_bytes, workspace);
         const int per = S > 1 ? ((K + S - 1) / S + 15) / 16 * 16 : K;
         float* dst = S > 1 ? (float*)workspace : dx;
-        if (N <= 64) hipLaunchKernelGGL((conv_f32_mfma_kernel<P_DGRAD, 64>), dim3(gx, gy, S), dim3(256), 0, (hipStream_t)stream,
-                                        (const float*)nullptr, w, dy, (const float*)nullptr, dst, g, M, N, K, per, accumulate, dHoWo, dWo, dHW, dW, dC,
-                                        (const float*)nullptr, (const float*)nullptr, FDiv(1), FDiv(1), S);
-        else hipLaunchKernelGGL((conv_f32_mfma_kernel<P_DGRAD, 128>), dim3(gx, gy, S), dim3(256), 0, (hipStream_t)stream,
-                                (const float*)nullptr, w, dy, (const float*)nullptr, dst, g, M, N, K, per, accumulate, dHoWo, dWo, dHW, dW, dC,
-                                (const float*)nullptr, (const float*)nullptr, FDiv(1), FDiv(1), S);
+        const bool wkp = w_kmajor != nullptr && (N & 3) == 0 && !(g_parity_flags & 8);
+#define EOE_DG_LAUNCH(BNV, WKV)                                                                                                         \
+        hipLaunchKernelGGL((conv_f32_mfma_kernel<P_DGRAD, BNV, 0, false, WKV>), dim3(gx, gy, S), dim3(256), 0, (hipStream_t)stream,     \
+                           (const float*)nullptr, w, dy, (const float*)nullptr, dst, g, M, N, K, per, accumulate, dHoWo, dWo, dHW, dW, dC, \
+                           (const float*)nullptr, (const float*)nullptr, FDiv(1), FDiv(1), S, w_kmajor, K)
+        if (N <= 64) { if (wkp) EOE_DG_LAUNCH(64, true); else EOE_DG_LAUNCH(64, false); }
+        else { if (wkp) EOE_DG_LAUNCH(128, true); else EOE_DG_LAUNCH(128, false); }
+#undef EOE_DG_LAUNCH
         EOE_CHECK_LAUNCH("conv_f32_dgrad (mfma)");
         if (S > 1) {
             const size_t count4 = (size_t)M * N / 4;

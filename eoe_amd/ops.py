@@ -1086,12 +1086,15 @@ class ConvBnActPoolParityFunction(torch.autograd.Function):
             w4 = scratch("parity_w4", (cout, 4, kh, kw), torch.float32, dev)
             w4.zero_()
             w4[:, :3].copy_(w)
+            w4f = scratch("parity_w4f", (kh * kw * 4, cout), torch.float32, dev)
+            check(lib.eoe_conv_f32_pack_weights(_p(w4), _p(w4f), None, cout, 4, kh, kw, _stream()), "eoe_conv_f32_pack_weights")
             check(lib.eoe_conv_f32_fwd(_p(x4), 0, None, None, _p(w4), _p(conv_b), _p(y), _geo(n, Hi, Wi, 4, kh, kw, stride, pad, H, W), cout,
-                                       _p(ws), PARITY_SPLITK_BYTES, _stream()), "eoe_conv_f32_fwd")
+                                       _p(ws), PARITY_SPLITK_BYTES, _p(w4f), _stream()), "eoe_conv_f32_fwd")
             x = x4
         else:
+            wkf = _parity_packed(conv_w, "f") if (not is_image and cout % 4 == 0) else None
             check(lib.eoe_conv_f32_fwd(_p(x), 1 if is_image else 0, _p(mean) if is_image else None, _p(std) if is_image else None, _p(w),
-                                       _p(conv_b), _p(y), geo, cout, _p(ws), PARITY_SPLITK_BYTES, _stream()), "eoe_conv_f32_fwd")
+                                       _p(conv_b), _p(y), geo, cout, _p(ws), PARITY_SPLITK_BYTES, _p(wkf), _stream()), "eoe_conv_f32_fwd")
         stats = torch.empty(2 * cout, dtype=torch.float32, device=dev)
         sums = scratch("bn_sums", (BN_SCRATCH * cout,), torch.float32, dev)
         check(lib.eoe_bn_stats(_p(y), _p(sums), _p(stats), _p(rm), _p(rv), _p(nbt), M, cout, float(eps), float(momentum),
@@ -1169,8 +1172,9 @@ class ConvBnActPoolParityFunction(torch.autograd.Function):
             acc = (d_pass is not None and d_pass.dtype == torch.float32 and d_pass.is_contiguous()
                    and d_pass.shape == (n, Hi, Wi, cin))
             dx = d_pass if acc else torch.empty((n, Hi, Wi, cin), dtype=torch.float32, device=dev)
+            wkd = _parity_packed(conv_w, "d") if cin % 4 == 0 else None
             check(lib.eoe_conv_f32_dgrad(_p(dy), _p(w), _p(dx), geo, cout, 1 if acc else 0, _p(_parity_splitk_ws(dev)), PARITY_SPLITK_BYTES,
-                                         _stream()), "eoe_conv_f32_dgrad")
+                                         _p(wkd), _stream()), "eoe_conv_f32_dgrad")
             if acc:
                 d_pass = None
         if d_pass is not None:
@@ -1179,6 +1183,28 @@ class ConvBnActPoolParityFunction(torch.autograd.Function):
 
 
 PARITY_SPLITK_BYTES = 16 << 20
+_parity_packs = {}            # id(weight) -> (weakref, version, wf, wd): k-major fp32 copies of a convolution / linear weight, per version
+
+
+def _parity_packed(w, want, shape4=None):
+    """the k-major fp32 copy (`want` = "f": forward [kh*kw*cin, cout]; "d": dgrad [kh*kw*cout, cin]) of a weight [cout, cin, kh, kw]
+    (`shape4`: how to read a Linear weight [out, in] as one) for the exact-fp32 kernels (eoe_conv_f32_pack_weights): made once per
+    weight version (the optimiser bumps it), both layouts in one launch"""
+    key = id(w)
+    hit = _parity_packs.get(key)
+    if hit is not None and hit[0]() is w and hit[1] == (w._version, w.data_ptr()) and hit[2].device == w.device:
+        return hit[2] if want == "f" else hit[3]
+    cout, cin, kh, kw = shape4 if shape4 is not None else w.shape
+    wc = w.detach().contiguous()
+    if hit is not None and hit[0]() is w and hit[2].numel() == wc.numel() and hit[2].device == w.device:
+        wf, wd = hit[2], hit[3]                                       # reuse the buffers of the previous version
+    else:
+        wf = torch.empty((kh * kw * cin, cout), dtype=torch.float32, device=w.device)
+        wd = torch.empty((kh * kw * cout, cin), dtype=torch.float32, device=w.device)
+    check(lib.eoe_conv_f32_pack_weights(_p(wc), _p(wf), _p(wd), cout, cin, kh, kw, _stream()), "eoe_conv_f32_pack_weights")
+    if not torch.cuda.is_current_stream_capturing():
+        _parity_packs[key] = (weakref.ref(w), (w._version, w.data_ptr()), wf, wd)
+    return wf if want == "f" else wd
 
 
 def _parity_splitk_ws(dev):
@@ -1196,8 +1222,9 @@ class LinearParityFunction(torch.autograd.Function):
         M, K = x2.shape
         N = weight.shape[0]
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        wkf = _parity_packed(weight, "f", (N, K, 1, 1)) if N % 4 == 0 else None      # W^T, once per weight version
         check(lib.eoe_conv_f32_fwd(_p(x2), 0, None, None, _p(weight.contiguous()), _p(bias), _p(y), _geo(M, 1, 1, K, 1, 1, 1, 0, 1, 1), N,
-                                   _p(_parity_splitk_ws(x.device)), PARITY_SPLITK_BYTES, _stream()), "eoe_conv_f32_fwd")
+                                   _p(_parity_splitk_ws(x.device)), PARITY_SPLITK_BYTES, _p(wkf), _stream()), "eoe_conv_f32_fwd")
         ctx.save_for_backward(x2, weight, bias)
         ctx.in_shape, ctx.x_dtype = x.shape, x.dtype
         return y.reshape(*x.shape[:-1], N)
@@ -1212,8 +1239,9 @@ class LinearParityFunction(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
-            check(lib.eoe_conv_f32_dgrad(_p(dy2), _p(weight.contiguous()), _p(dx), geo, N, 0, _p(_parity_splitk_ws(dy.device)), PARITY_SPLITK_BYTES,
-                                         _stream()), "eoe_conv_f32_dgrad")
+            wc = weight.contiguous()             # a 1 x 1 kernel's dgrad layout [cout][cin] is the weight itself
+            check(lib.eoe_conv_f32_dgrad(_p(dy2), _p(wc), _p(dx), geo, N, 0, _p(_parity_splitk_ws(dy.device)), PARITY_SPLITK_BYTES,
+                                         _p(wc) if K % 4 == 0 else None, _stream()), "eoe_conv_f32_dgrad")
             dx = dx.reshape(ctx.in_shape).to(ctx.x_dtype)
         if ctx.needs_input_grad[1]:
             dw = _grad_target(weight)

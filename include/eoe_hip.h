@@ -491,10 +491,14 @@ int eoe_comm_sync_bn(eoe_comm_t comm, int enable);
  * (the 4th = 0): with it (geo.C = 4, weights zero-padded to [cout, 4, kh, kw]) the first layer runs through the float4 paths of
  * eoe_conv_f32_fwd / _wgrad instead of element-wise gathers */
 int eoe_pack_image_nhwc4(const float* x_nchw, const float* mean, const float* stdv, float* out_nhwc4, int n, int H, int W, void* stream);
+/* w_kmajor (forward / dgrad; may be NULL): the k-major fp32 copy of w made by eoe_conv_f32_pack_weights (forward: wf, dgrad: wd) -- the
+ * kernels then stage the weight tile with 16-byte loads and stores instead of scalar gathers with a stride of kh * kw floats (+5-10 %) */
+int eoe_conv_f32_pack_weights(const float* w /* [cout, cin, kh, kw] */, float* wf /* [kh*kw*cin, cout] or NULL */,
+                              float* wd /* [kh*kw*cout, cin] or NULL */, int cout, int cin, int kh, int kw, void* stream);
 int eoe_conv_f32_fwd(const float* x, int x_nchw, const float* mean, const float* stdv, const float* w, const float* bias, float* y,
-                     const eoe_conv_geometry* geo, int cout, void* workspace, size_t workspace_bytes, void* stream);
+                     const eoe_conv_geometry* geo, int cout, void* workspace, size_t workspace_bytes, const float* w_kmajor, void* stream);
 int eoe_conv_f32_dgrad(const float* dy, const float* w, float* dx, const eoe_conv_geometry* geo, int cout, int accumulate,
-                       void* workspace, size_t workspace_bytes, void* stream);
+                       void* workspace, size_t workspace_bytes, const float* w_kmajor, void* stream);
 size_t eoe_conv_f32_wgrad_workspace(const eoe_conv_geometry* geo, int cout);
 int eoe_conv_f32_wgrad(const float* x, int x_nchw, const float* mean, const float* stdv, const float* dy, float* dw,
                        const eoe_conv_geometry* geo, int cout, void* workspace, size_t workspace_bytes, void* stream);

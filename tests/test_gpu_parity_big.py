@@ -121,7 +121,17 @@ def _conv_f32_case(name, n, cin, cout, H, k, stride, pad, nchw, F, ops, lib, che
     y = torch.empty((n * Ho * Wo, cout), device="cuda")
     sk = torch.empty(4 << 20, device="cuda")                # split-k slab partials (forward / dgrad over few output tiles)
     p = lambda t: None if t is None else t.data_ptr()       # noqa: E731
-    check(lib.eoe_conv_f32_fwd(p(x), int(nchw), p(mean), p(std), p(w), p(b), p(y), geo, cout, p(sk), sk.numel() * 4, st), "fwd")
+    # the k-major packed weight copies (eoe_conv_f32_pack_weights) wherever the kernels take them (NHWC input, widths multiples of 4)
+    wf = torch.empty((k * k * cin, cout), device="cuda") if (not nchw and cout % 4 == 0) else None
+    wd_ = torch.empty((k * k * cout, cin), device="cuda") if (not nchw and cin % 4 == 0) else None
+    if wf is not None or wd_ is not None:
+        check(lib.eoe_conv_f32_pack_weights(p(w), p(wf), p(wd_), cout, cin, k, k, st), "pack")
+        if wf is not None:
+            assert torch.equal(wf.view(k * k, cin, cout), w.permute(2, 3, 1, 0).reshape(k * k, cin, cout))
+        if wd_ is not None:
+            assert torch.equal(wd_.view(k * k, cout, cin), w.permute(2, 3, 0, 1).reshape(k * k, cout, cin))
+    WKF, WKD = p(wf), p(wd_)
+    check(lib.eoe_conv_f32_fwd(p(x), int(nchw), p(mean), p(std), p(w), p(b), p(y), geo, cout, p(sk), sk.numel() * 4, WKF, st), "fwd")
     xd = (xr.double() if nchw else xr.double().permute(0, 3, 1, 2))
     if nchw:
         xd = (xd - mean.cpu().double().view(1, 3, 1, 1)) / std.cpu().double().view(1, 3, 1, 1)
@@ -146,7 +156,9 @@ def _conv_f32_case(name, n, cin, cout, H, k, stride, pad, nchw, F, ops, lib, che
         w4[:, :3] = w
         geo4 = ops._geo(n, H, W, 4, k, k, stride, pad, Ho, Wo)
         y4 = torch.empty_like(y)
-        check(lib.eoe_conv_f32_fwd(p(x4), 0, None, None, p(w4), p(b), p(y4), geo4, cout, p(sk), sk.numel() * 4, st), "fwd4")
+        w4f = torch.empty((k * k * 4, cout), device="cuda")
+        check(lib.eoe_conv_f32_pack_weights(p(w4), p(w4f), None, cout, 4, k, k, st), "pack4")
+        check(lib.eoe_conv_f32_fwd(p(x4), 0, None, None, p(w4), p(b), p(y4), geo4, cout, p(sk), sk.numel() * 4, p(w4f), st), "fwd4")
         assert rel_rms(y4, want) < 2e-6, rel_rms(y4, want)
         dw4 = torch.empty_like(w4)
         nb4 = int(lib.eoe_conv_f32_wgrad_workspace(geo4, cout))
@@ -156,19 +168,23 @@ def _conv_f32_case(name, n, cin, cout, H, k, stride, pad, nchw, F, ops, lib, che
     if not nchw:
         base, baser = f32(f"p/{name}/base", (n, H, W, cin), 1.0)
         dx = base.clone()
-        check(lib.eoe_conv_f32_dgrad(p(dy), p(w), p(dx), geo, cout, 1, p(sk), sk.numel() * 4, st), "dgrad")
+        check(lib.eoe_conv_f32_dgrad(p(dy), p(w), p(dx), geo, cout, 1, p(sk), sk.numel() * 4, WKD, st), "dgrad")
         assert rel_rms(dx, xd.grad.permute(0, 2, 3, 1) + baser.double()) < 2e-6
-        check(lib.eoe_conv_f32_dgrad(p(dy), p(w), p(dx), geo, cout, 0, p(sk), sk.numel() * 4, st), "dgrad")
+        check(lib.eoe_conv_f32_dgrad(p(dy), p(w), p(dx), geo, cout, 0, p(sk), sk.numel() * 4, WKD, st), "dgrad")
         assert rel_rms(dx, xd.grad.permute(0, 2, 3, 1)) < 2e-6
+        if WKD is not None:                      # packed and gathered weights: the same products in the same order
+            dx2 = torch.empty_like(dx)
+            check(lib.eoe_conv_f32_dgrad(p(dy), p(w), p(dx2), geo, cout, 0, p(sk), sk.numel() * 4, None, st), "dgrad")
+            assert torch.equal(dx, dx2)
         if stride == 2 and H % 2 == 0:
             # the parity-class form enumerates a pixel's valid taps in the order the all-taps form meets them: the same bits (no split k)
             from eoe_amd import _lib
             flags = _lib.get_option("parity_flags")
             if not flags & 1:
                 a, b2 = torch.full_like(dx, 7.0), torch.full_like(dx, 7.0)
-                check(lib.eoe_conv_f32_dgrad(p(dy), p(w), p(a), geo, cout, 0, None, 0, st), "dgrad")
+                check(lib.eoe_conv_f32_dgrad(p(dy), p(w), p(a), geo, cout, 0, None, 0, WKD, st), "dgrad")
                 _lib.set_option("parity_flags", flags | 2)
-                check(lib.eoe_conv_f32_dgrad(p(dy), p(w), p(b2), geo, cout, 0, None, 0, st), "dgrad")
+                check(lib.eoe_conv_f32_dgrad(p(dy), p(w), p(b2), geo, cout, 0, None, 0, WKD, st), "dgrad")
                 _lib.set_option("parity_flags", flags)
                 assert torch.equal(a, b2)
 

@@ -41,15 +41,19 @@ for name, cin, cout, H, k, s, pad, nchw in shapes:
     geo = ops._geo(N, H, H, cin, k, k, s, pad, Ho, Ho)
     nb = int(lib.eoe_conv_f32_wgrad_workspace(geo, cout)); ws = torch.empty(nb // 4, device="cuda")
     fl = 2.0 * N * Ho * Ho * cout * cin * k * k
-    tf = timeit(lambda: check(lib.eoe_conv_f32_fwd(p(x), int(nchw), p(mean), p(std), p(w), None, p(y), geo, cout, p(sk), sk.numel() * 4, st), "f"))
+    pk = (not nchw) and cout % 4 == 0 and cin % 4 == 0 and len(sys.argv) <= 3
+    wf = torch.empty(k * k * cin, cout, device="cuda") if pk else None; wd_ = torch.empty(k * k * cout, cin, device="cuda") if pk else None
+    if pk: check(lib.eoe_conv_f32_pack_weights(p(w), p(wf), p(wd_), cout, cin, k, k, st), "pk")
+    WKF, WKD = p(wf), p(wd_)
+    tf = timeit(lambda: check(lib.eoe_conv_f32_fwd(p(x), int(nchw), p(mean), p(std), p(w), None, p(y), geo, cout, p(sk), sk.numel() * 4, WKF, st), "f"))
     tw = timeit(lambda: check(lib.eoe_conv_f32_wgrad(p(x), int(nchw), p(mean), p(std), p(dy), p(dw), geo, cout, p(ws), nb, st), "w"))
-    td = 0.0 if nchw else timeit(lambda: check(lib.eoe_conv_f32_dgrad(p(dy), p(w), p(dx), geo, cout, 0, p(sk), sk.numel() * 4, st), "d"))
+    td = 0.0 if nchw else timeit(lambda: check(lib.eoe_conv_f32_dgrad(p(dy), p(w), p(dx), geo, cout, 0, p(sk), sk.numel() * 4, WKD, st), "d"))
     if nchw:
         x4 = torch.empty((N, H, H, 4), device="cuda"); w4 = torch.zeros(cout, 4, k, k, device="cuda"); w4[:, :3] = w; dw4 = torch.empty_like(w4)
         geo4 = ops._geo(N, H, H, 4, k, k, s, pad, Ho, Ho)
         nb4 = int(lib.eoe_conv_f32_wgrad_workspace(geo4, cout)); ws4 = torch.empty(nb4 // 4, device="cuda")
         tp = timeit(lambda: check(lib.eoe_pack_image_nhwc4(p(x), p(mean), p(std), p(x4), N, H, H, st), "p"))
-        tf4 = timeit(lambda: check(lib.eoe_conv_f32_fwd(p(x4), 0, None, None, p(w4), None, p(y), geo4, cout, p(sk), sk.numel() * 4, st), "f"))
+        tf4 = timeit(lambda: check(lib.eoe_conv_f32_fwd(p(x4), 0, None, None, p(w4), None, p(y), geo4, cout, p(sk), sk.numel() * 4, None, st), "f"))
         tw4 = timeit(lambda: check(lib.eoe_conv_f32_wgrad(p(x4), 0, None, None, p(dy), p(dw4), geo4, cout, p(ws4), nb4, st), "w"))
         print(f"{name + ' (NHWC4)':22s} {fl/1e9:7.1f} GF | fwd {tf4:7.3f} ms {fl/tf4/1e9:6.1f} TF | pack  {tp:7.3f} ms               | wgrad {tw4:7.3f} ms {fl/tw4/1e9:6.1f} TF")
     print(f"{name:22s} {fl/1e9:7.1f} GF | fwd {tf:7.3f} ms {fl/tf/1e9:6.1f} TF | dgrad {td:7.3f} ms {(fl/td/1e9 if td else 0):6.1f} TF | wgrad {tw:7.3f} ms {fl/tw/1e9:6.1f} TF")
