@@ -156,7 +156,10 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const float* __restr
                                                             FDiv dtaps = FDiv(1), FDiv dkw = FDiv(1), int nslab = 1,
                                                             const float* __restrict__ wk = nullptr, int wk_rows = 0) {
     constexpr bool b_oihw = (WV == 1 || WV == 3), swap = (WV == 2 || WV == 3);
-    constexpr int BM = 128, BK = 16, LDA = BM + 4, LDB = BN + 4, NI = BN / 32, NBV = BN / 16;
+    // BK: 16-deep k-tiles; the narrow weight-gradient tiles (BN = 64: half the MFMAs per k-tile for the same barrier and staging overhead)
+    // take 32 -- their reduction runs over millions of pixels anyway.  AV = float4 per thread and operand and k-tile
+    constexpr int BM = 128, BK = (MODE == P_WGRAD && BN == 64) ? 32 : 16, LDA = BM + 4, LDB = BN + 4, NI = BN / 32, NBV = BN / 16;
+    constexpr int AV = BM * BK / 4 / 256;
     __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 15, lg = lane >> 4;
@@ -184,10 +187,10 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const float* __restr
 
     // ---- per-thread staging coordinates
     // forward / dgrad: A = 128 rows x 16 k as 2 float4 per thread (row ar[i], k quad akq[i]); the row's pixel is decoded once
-    int a_img[2], a_y[2], a_x[2], a_r[2], a_kq[2];
-    bool a_ok[2];
+    int a_img[AV], a_y[AV], a_x[AV], a_r[AV], a_kq[AV];
+    bool a_ok[AV];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < AV; ++i) {
         const int e = t + 256 * i;
         if (MODE == P_WGRAD) { a_r[i] = e >> 5; a_kq[i] = e & 31; a_ok[i] = true; a_img[i] = a_y[i] = a_x[i] = 0; continue; }     // (kk, m quad)
         a_r[i] = e >> 2; a_kq[i] = e & 3;
@@ -205,11 +208,13 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const float* __restr
     }
     // wgrad: the x-side column quad of this thread (the same for every k-tile): packed (channel << 16 | ky << 8 | kx) per element
     // (b_oihw: four separate (ci, ky, kx); else one entry, four consecutive channels of one tap); -1 = past the last column
-    bool wg_ok[2] = {false, false};
-    int wg_dec[2][4];
+    bool wg_ok[AV];
+    int wg_dec[AV][4];
+#pragma unroll
+    for (int i = 0; i < AV; ++i) wg_ok[i] = false;
     if (MODE == P_WGRAD) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < AV; ++i) {
             const int q4 = a_kq[i] * 4;
             const int nn = swap ? m0 + q4 : n0 + q4, lim = swap ? M : N;
             wg_ok[i] = nn < lim && (swap || q4 < BN);
@@ -232,9 +237,9 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const float* __restr
             }
         }
     }
-    f32x4 ra[2];
+    f32x4 ra[AV];
     float rb[NBV];
-    f32x4 rbv[2];
+    f32x4 rbv[AV];
     f32x4 rbq[NBV / 4];                               // WK: the weight tile as BN / 4 float4 along n per k row, NBV / 4 per thread
     auto load_tile = [&](int k0) {
         if (MODE == P_WGRAD) {
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const float* __restr
                 return vb;
             };
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < AV; ++i) {
                 const int kk = a_r[i], q4 = a_kq[i] * 4, k = k0 + kk;
                 f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
                 if (k < k_hi) {
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const float* __restr
         // the thread's float4 is the whole pixel of tap (k0 / 4 + kq)
         const bool c4 = MODE == P_FWD && g.C == 4;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < AV; ++i) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (a_ok[i]) {
                 if (MODE == P_FWD && c4) {
@@ -344,14 +349,14 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const float* __restr
     auto store_tile = [&](int buf) {
         if (MODE == P_WGRAD) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < AV; ++i) {
                 *(f32x4*)&As[buf][a_r[i]][a_kq[i] * 4] = ra[i];
                 if (a_kq[i] * 4 < BN) *(f32x4*)&Bs[buf][a_r[i]][a_kq[i] * 4] = rbv[i];
             }
             return;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < AV; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) As[buf][a_kq[i] * 4 + j][a_r[i]] = ra[i][j];
         if (WK) {
@@ -378,7 +383,7 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const float* __restr
             const int buf = kt & 1;
             if (kt + 1 < nkt) load_tile(k_lo + (kt + 1) * BK);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            for (int ks = 0; ks < BK / 4; ++ks) {
                 float am[4], bn[NI];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) am[i] = As[buf][ks * 4 + lg][wm0 + i * 16 + lr];
