@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const float* __restrict__
 // Split k (forward / dgrad with few output tiles and a long reduction: the small maps of the 32 x 32 WideResNet, the FC layers): nslab > 1
 // slabs of the reduction write partial outputs [slab][rows][N] (`out` = the workspace), summed in slab order by slab_sum_out_kernel.
 template <int MODE, int BN, int WV = 0, bool S2 = false, bool WK = false>      // WK: forward / dgrad weights from the k-major packed copy `wk` (eoe_conv_f32_pack_weights); WV (wgrad variants): 0 = both sides float4, 1 = the x side element-wise (OIHW order), 2 = roles exchanged, 3 = both
-__global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256, (WK && BN == 128) ? 4 : 1) void conv_f32_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ dy, const float* __restrict__ bias,
                                                             float* __restrict__ out, PGeo g, int M, int N, int K, int k_per_slab,
                                                             int accumulate, FDiv dHoWo, FDiv dWo, FDiv dHW, FDiv dW, FDiv dC,
