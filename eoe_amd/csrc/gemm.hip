@@ -303,7 +303,10 @@ constexpr int a128_bytes(int MI) { return 32 * MI * BK * 2; }                   
 constexpr int stage128_bytes(int MI) { return a128_bytes(MI) + B128_BYTES; }      // 32 / 36 KiB
 constexpr int smem128_bytes(int MI) { return 2 * stage128_bytes(MI); }            // 64 / 72 KiB: two workgroups per CU
 
-template <typename T, int EPI, int MI>
+// GATHER = 1: A is a convolution's implicit patch matrix (C % 64 == 0: one tap per k-tile), as in gemm_nt64_kernel below -- the layers with
+// cout >= 128 ran on the persistent 256x128 kernel, whose 784 tiles at M = 200704 (28 x 28 maps) are four rounds over 256 CUs for 3.06 rounds
+// of work; 160-row tiles on the 2 x #CU slots quantise at 98 % there.
+template <typename T, int EPI, int MI, int GATHER = 0>
 __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmP p) {
     constexpr int BM = 32 * MI, A128_BYTES = a128_bytes(MI), STAGE128_BYTES = stage128_bytes(MI);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -323,11 +326,29 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmP p) {
     // stub of every instantiation of this kernel and the library fails to load with an undefined symbol
     unsigned offA[5], offB[4];
     static_assert(MI <= 5, "offA");
+    int gh[5], gw[5];                               // GATHER: top-left input coordinate of each staged row's window
+    int g_ky = 0, g_kx = 0, g_c0 = 0;               // GATHER: tap / channel offset of the next k-tile to be staged (uniform)
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
         const int row = (wave * MI + j) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);
-        offA[j] = (m0 + row < p.M) ? (unsigned)(((size_t)(m0 + row) * p.lda + c * 8) * 2) : EOE_OOB;
+        const int ga = m0 + row;
+        if (GATHER == 1) {
+            if (ga < p.M) {
+                const int img = ga / p.gHoWo, rem = ga - img * p.gHoWo;
+                const int ho = rem / p.gWo, wo = rem - ho * p.gWo;
+                gh[j] = ho * p.gstride - p.gpad;
+                gw[j] = wo * p.gstride - p.gpad;
+                offA[j] = (unsigned)((((img * p.gH + gh[j]) * p.gW + gw[j]) * p.gC + c * 8) * 2);   // wraps for h < 0: only used when valid
+            } else {
+                gh[j] = -(1 << 24);
+                gw[j] = 0;
+                offA[j] = 0;
+            }
+        } else {
+            gh[j] = 0; gw[j] = 0;
+            offA[j] = (ga < p.M) ? (unsigned)(((size_t)ga * p.lda + c * 8) * 2) : EOE_OOB;
+        }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -341,8 +362,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmP p) {
         char* sa_ = smem + (slot) * STAGE128_BYTES;                                                                         \
         char* sb_ = sa_ + A128_BYTES;                                                                                       \
         const unsigned k0_ = (unsigned)(kt) * (BK * 2u);                                                                    \
-        _Pragma("unroll") for (int j = 0; j < MI; ++j)                                                                      \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(sa_ + (wave * MI + j) * 1024), 16, offA[j] + k0_, 0, 0, 0); \
+        if (GATHER == 1) {                                                                                                  \
+            /* k-tiles are staged in order 0, 1, 2, ...: the tap cursor advances with them */                                 \
+            const unsigned delta_ = (unsigned)(((g_ky * p.gW + g_kx) * p.gC + g_c0) * 2);                                   \
+            _Pragma("unroll") for (int j = 0; j < MI; ++j) {                                                                \
+                const bool ok_ = (unsigned)(gh[j] + g_ky) < (unsigned)p.gH && (unsigned)(gw[j] + g_kx) < (unsigned)p.gW;    \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(sa_ + (wave * MI + j) * 1024), 16,               \
+                                                         ok_ ? offA[j] + delta_ : EOE_OOB, 0, 0, 0);                        \
+            }                                                                                                               \
+            g_c0 += BK;                                                                                                     \
+            if (g_c0 == p.gC) {                                                                                             \
+                g_c0 = 0;                                                                                                   \
+                if (++g_kx == p.gkw) { g_kx = 0; ++g_ky; }                                                                  \
+            }                                                                                                               \
+        } else {                                                                                                            \
+            _Pragma("unroll") for (int j = 0; j < MI; ++j)                                                                  \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(sa_ + (wave * MI + j) * 1024), 16, offA[j] + k0_, 0, 0, 0); \
+        }                                                                                                                   \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                       \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(sb_ + (wave * 4 + j) * 1024), 16, offB[j] + k0_, 0, 0, 0); \
     } while (0)
@@ -569,6 +605,17 @@ int launch_nt64(const GemmP& p, hipStream_t s) {
     return 0;
 }
 
+// the implicit-convolution form (plain epilogue, optional BatchNorm statistics for MI = 4: 64 output rows per wave = the partial rows' unit)
+template <typename T, int MI>
+int launch_nt128_gather(const GemmP& p, hipStream_t s) {
+    const int tiles = cdiv(p.M, 32 * MI) * cdiv(p.N, 128);
+    static bool once = (hipFuncSetAttribute((const void*)gemm_nt128_kernel<T, EOE_EPI_NONE, MI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem128_bytes(MI)), true);
+    (void)once;
+    hipLaunchKernelGGL((gemm_nt128_kernel<T, EOE_EPI_NONE, MI, 1>), dim3(tiles), dim3(256), smem128_bytes(MI), s, p);
+    EOE_CHECK_LAUNCH("gemm_nt128 (gather)");
+    return finish_colsum(p, EOE_EPI_NONE, MI, s);
+}
+
 template <typename T, int MI>
 int launch_nt128(const GemmP& p, int epi, hipStream_t s) {
     const int tiles = cdiv(p.M, 32 * MI) * cdiv(p.N, 128);
@@ -678,6 +725,15 @@ int launch_nt(const GemmP& p, int epi, int gather, hipStream_t s) {
         // cout <= 64: four 64x64 waves per 256x64 tile, two workgroups per CU (nt_flags bit 6: the persistent 256x64 kernel instead)
         const int rc = gather ? launch_nt64<T, 1>(p, s) : launch_nt64<T, 0>(p, s);
         return rc ? rc : finish_colsum(p, EOE_EPI_NONE, 4, s);
+    }
+    if (gather == 1 && epi == EOE_EPI_NONE && p.N >= 128 && !(g_nt_flags & 2048)) {
+        // cout >= 128, one tap per k-tile: the two-workgroup kernel (nt_flags bit 11 = 2048: the persistent 256x128 kernel, A/B).  160-row
+        // tiles where they need fewer (rounds x rows) -- not with BatchNorm statistics in the epilogue, whose partial rows are per 64 rows
+        const int slots = 2 * ncu;
+        const long t4 = (long)cdiv(p.M, 128) * cdiv(p.N, 128), t5 = (long)cdiv(p.M, 160) * cdiv(p.N, 128);
+        const long c4 = (t4 + slots - 1) / slots * 128, c5 = (t5 + slots - 1) / slots * 160;
+        if (!p.colsum_sq && c5 < c4) return launch_nt128_gather<T, 5>(p, s);
+        return launch_nt128_gather<T, 4>(p, s);
     }
     if (gather || (epi == EOE_EPI_NONE && p.N <= 64)) {
         const bool narrow = p.N <= 64;               // 256x64 tiles: no MFMA / LDS work on columns that do not exist
