@@ -508,6 +508,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt64_kernel(GemmP p) {
                 gw[j] = 0;
                 offA[j] = 0;
             }
+        } else if (GATHER == 2) {
+            // the stem over the zero-padded NHWC4 image (packed k axis: a k-tile = two kernel rows x 8 pixels x 4 channels; gemm_nt_kernel)
+            gh[j] = 0; gw[j] = 0;
+            if (ga < p.M) {
+                const int img = ga / p.gHoWo, rem = ga - img * p.gHoWo;
+                const int ho = rem / p.gWo, wo = rem - ho * p.gWo;
+                offA[j] = (unsigned)((((img * p.gH + ho * p.gstride + (c >> 2)) * p.gW + wo * p.gstride + 2 * (c & 3)) * 4) * 2);
+            } else {
+                offA[j] = EOE_OOB;
+            }
         } else {
             gh[j] = 0; gw[j] = 0;
             offA[j] = (ga < p.M) ? (unsigned)(((size_t)ga * p.lda + c * 8) * 2) : EOE_OOB;
@@ -538,8 +548,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt64_kernel(GemmP p) {
                 if (++g_kx == p.gkw) { g_kx = 0; ++g_ky; }                                                                   \
             }                                                                                                                \
         } else {                                                                                                             \
+            const unsigned kA_ = (GATHER == 2) ? (unsigned)((kt) * p.gkstep) : k0_;                                          \
             _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                    \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(sa_ + (wave * 8 + j) * 1024), 16, offA[j] + k0_, 0, 0, 0); \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(sa_ + (wave * 8 + j) * 1024), 16, offA[j] + kA_, 0, 0, 0); \
         }                                                                                                                    \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                        \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(sb_ + (wave * 2 + j) * 1024), 16, offB[j] + k0_, 0, 0, 0); \
@@ -721,9 +732,9 @@ int launch_nt_ni(const GemmP& p, int epi, int grid, hipStream_t s) {
 template <typename T>
 int launch_nt(const GemmP& p, int epi, int gather, hipStream_t s) {
     const int ncu = num_cus();
-    if (epi == EOE_EPI_NONE && p.N <= 64 && (gather == 0 || gather == 1) && !(g_nt_flags & 64)) {
+    if (epi == EOE_EPI_NONE && p.N <= 64 && (gather == 0 || gather == 1 || gather == 2) && !(g_nt_flags & 64)) {
         // cout <= 64: four 64x64 waves per 256x64 tile, two workgroups per CU (nt_flags bit 6: the persistent 256x64 kernel instead)
-        const int rc = gather ? launch_nt64<T, 1>(p, s) : launch_nt64<T, 0>(p, s);
+        const int rc = gather == 2 ? launch_nt64<T, 2>(p, s) : (gather ? launch_nt64<T, 1>(p, s) : launch_nt64<T, 0>(p, s));
         return rc ? rc : finish_colsum(p, EOE_EPI_NONE, 4, s);
     }
     if (gather == 1 && epi == EOE_EPI_NONE && p.N >= 128 && !(g_nt_flags & 2048)) {
