@@ -19,11 +19,15 @@ def conv3x3(in_planes, out_planes, stride=1):
     return nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)
 
 
-def _conv_bn(x, conv, bn, training, slope, is_image=False, normalize=None, want16=False, pool=1, passthrough=False):
-    """conv (no bias) -> BatchNorm2d -> ReLU (slope 0) or nothing (slope 1); fp32 NHWC in/out"""
+_ONLY16 = __import__("os").environ.get("EOE_ONLY16", "1") != "0"      # conv1 -> bn1 -> relu writes its 16-bit copy only (0: A/B)
+
+
+def _conv_bn(x, conv, bn, training, slope, is_image=False, normalize=None, want16=False, pool=1, passthrough=False, only16=False):
+    """conv (no bias) -> BatchNorm2d -> ReLU (slope 0) or nothing (slope 1); fp32 NHWC in/out (only16: the output is consumed through its
+    16-bit copy alone -- the fp32 tensor is not written)"""
     mean, std = normalize if (is_image and normalize is not None) else (None, None)
     k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
-    cfg = (training, bn.eps, bn.momentum, pool, is_image, mean, std, False, (k, k, s, p), slope, want16, passthrough)
+    cfg = (training, bn.eps, bn.momentum, pool, is_image, mean, std, False, (k, k, s, p), slope, want16, passthrough, only16)
     return ops.conv_bn_act_pool(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                 bn.num_batches_tracked, cfg)
 
@@ -48,7 +52,7 @@ class BasicBlock(nn.Module):
         # (down-sampling blocks: the 1x1 convolution of the shortcut reads the handed-through input, so ITS input gradient is the
         # one that arrives at conv1's backward and is accumulated by conv1's col2im)
         fuse = x.requires_grad and torch.is_grad_enabled()
-        out = _conv_bn(x, self.conv1, self.bn1, self.training, 0.0, want16=True, passthrough=fuse)       # feeds conv2 only
+        out = _conv_bn(x, self.conv1, self.bn1, self.training, 0.0, want16=True, passthrough=fuse, only16=_ONLY16)       # feeds conv2 only
         residual = x
         if fuse:
             out, residual = out

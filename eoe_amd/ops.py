@@ -1314,6 +1314,8 @@ class ConvBnActPoolFunction(torch.autograd.Function):
         elif implicit:
             w16, _, _ = _conv_weight_copies(conv_w)
             if x16 is None or x16.dtype != dt or x16.shape != x.shape:
+                if getattr(x_in, "_eoe_unwritten", False):
+                    raise RuntimeError("this activation only exists as its 16-bit copy (cfg[12] of the producing layer) and that copy does not fit")
                 x16 = cast16(x.view(-1, cin)).view(n, Hi, Wi, cin)
             operand = x16
             conv_gemm_fwd(x16, w16, y, (n, Hi, Wi, cin, kh, kw, stride, pad, H, W), bias=conv_b, colstats_ws=part)
@@ -1347,8 +1349,15 @@ class ConvBnActPoolFunction(torch.autograd.Function):
             out = torch.empty((n, cout * Ho * Wo) if flat_out else (n, Ho, Wo, cout), dtype=torch.float32, device=dev)
             # a 16-bit copy of the output for the next convolution's implicit GEMM (saves that layer a cast pass)
             out16 = torch.empty((n, Ho, Wo, cout), dtype=dt, device=dev) if (want16 and _implicit_conv and not flat_out) else None
-            check(lib.eoe_bn_act_pool_fwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(out), _p(out16), n, H, W, cout, pool,
-                                          1 if flat_out else 0, 1, slope, code, _stream()), "eoe_bn_act_pool_fwd")
+            only16 = out16 is not None and len(cfg) > 12 and bool(cfg[12])
+            if only16:
+                # the output feeds ONE consumer that reads the 16-bit copy only (a BasicBlock's conv1 -> bn1 -> relu -> conv2): the fp32
+                # tensor is allocated for autograd's bookkeeping but never written (4 of the pass's 10 bytes per element)
+                check(lib.eoe_bn_act_pool_fwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(out16), None, n, H, W, cout, pool,
+                                              0, 0, slope, code, _stream()), "eoe_bn_act_pool_fwd")
+            else:
+                check(lib.eoe_bn_act_pool_fwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(out), _p(out16), n, H, W, cout, pool,
+                                              1 if flat_out else 0, 1, slope, code, _stream()), "eoe_bn_act_pool_fwd")
         ctx.save_for_backward(operand, y, stats, conv_w, conv_b, bn_w, bn_b, idx)
         ctx.cfg = (n, H, W, cin, cout, kp, pool, flat_out, training, is_image, Hi, Wi, kh, kw, stride, pad, slope, implicit)
         ctx.has16, ctx.passthrough = out16 is not None, passthrough
@@ -1488,6 +1497,8 @@ def conv_bn_act_pool(x, conv_w, conv_b, bn_w, bn_b, rm, rv, nbt, cfg):
     out = r[0]
     if len(r) - (1 if passthrough else 0) == 2:
         out._eoe16 = r[1]
+        if len(cfg) > 12 and cfg[12] and not (isinstance(cfg[3], tuple) or cfg[7]):
+            out._eoe_unwritten = True          # (ConvBnActPoolFunction.forward, only16: the values live in the 16-bit copy alone)
     if passthrough:
         x16 = getattr(x, "_eoe16", None)
         if x16 is not None:
