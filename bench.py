@@ -355,6 +355,12 @@ def main():
         ms = elapsed / args.steps * 1e3
         value = n_global * args.steps / elapsed
         flop_per_img = FWD_GFLOP_PER_IMG * (3.0 if args.mode == "full" else 1.0) * args.layers / 12.0
+        # the last block runs on its class-token rows only (ln_post reads nothing else): the out-projection and MLP GEMMs of the other 49
+        # tokens -- 0.520 GFLOP of the tower's forward -- are not executed and not counted
+        from eoe_amd import ops as _opsc
+        cls_only = args.model == "vit" and _opsc.VIT_CLS_ONLY_LAST
+        if cls_only:
+            flop_per_img -= 0.520 * (3.0 if args.mode == "full" else 1.0)
         mode_txt = {"full": "full fine-tune", "frozen": "frozen encoder", "eval": "forward-only scoring (eval_cls)"}[args.mode]
         if args.model == "cnn32":
             flop_per_img = 0.179
@@ -371,7 +377,8 @@ def main():
         metric = {"vit": f"{verb} images/sec, CLIP ViT-B/32 + HSC, 224x224", "cnn32": f"{verb} images/sec, CNN32 + HSC, 32x32",
                   "wrn": f"{verb} images/sec, WideResNet+CBAM + HSC, {res}x{res}"}[args.model]
         if not training:
-            flop_per_img = {"vit": FWD_GFLOP_PER_IMG * args.layers / 12.0, "cnn32": 0.0597, "wrn": 3.63 * (res / 224.0) ** 2}[args.model]
+            flop_per_img = {"vit": FWD_GFLOP_PER_IMG * args.layers / 12.0 - (0.520 if cls_only else 0.0), "cnn32": 0.0597,
+                            "wrn": 3.63 * (res / 224.0) ** 2}[args.model]
         out = {
             "metric": metric,
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -381,7 +388,9 @@ def main():
                        "launch": "hip graph replay" if use_graph else ("eager, kernels serialised" if args.serial_kernels else
                                                                         "eager, weight-gradient launches on a side stream under the dgrad chain"
                                                                         if training else "eager"),
-                       "arithmetic": "exact fp32 (fp32 MFMA convolutions / linears)" if args.parity_mode else "16-bit MFMA operands, fp32 accumulate"},
+                       "arithmetic": "exact fp32 (fp32 MFMA convolutions / linears)" if args.parity_mode else "16-bit MFMA operands, fp32 accumulate",
+                       **({"last_block": "class-token rows only past the attention (what ln_post reads; same embedding and gradients; "
+                                         "EOE_VIT_CLS_ONLY=0 computes the unread rows too)"} if cls_only else {})},
             "model_tflops": round(value * flop_per_img / 1e3, 1),
             "mfma_roofline_frac_end_to_end": round(value * flop_per_img / 1e3 / (MFMA_PEAK_TFLOPS * world), 4),
             "final_loss": round(final_loss, 5) if training else None, "auc_last_step": round(auc, 4),

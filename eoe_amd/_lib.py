@@ -89,7 +89,7 @@ class VitBlockFwdArgs(C.Structure):
                 ("w_in_t", _vp), ("w_out_t", _vp), ("w_fc_t", _vp), ("w_proj_t", _vp),
                 ("x_in", _vp), ("x_mid", _vp), ("x_out", _vp),
                 ("xn1", _vp), ("qkv", _vp), ("att", _vp), ("xn2", _vp), ("hpre", _vp), ("hact", _vp),
-                ("stats1", _vp), ("stats2", _vp)]
+                ("stats1", _vp), ("stats2", _vp), ("cls_only", _i32)]
 
 
 class VitBlockBwdArgs(C.Structure):

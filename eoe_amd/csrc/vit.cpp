@@ -80,15 +80,18 @@ extern "C" int eoe_vit_block_fwd(const eoe_vit_block_fwd_args* a, void* stream) 
     eoe_gemm_args g = gemm(a->xn1, a->w_in, a->qkv, a->b_in, M, 3 * D, D, D, D, 3 * D, dt);
     TRY(eoe_gemm_nt(&g, stream));
     TRY(eoe_attn_fwd(a->qkv, a->att, a->n, a->L, a->heads, dt, stream));
-    g = gemm(a->att, a->w_out, a->x_mid, a->b_out, M, D, D, D, D, D, dt);
-    g.epilogue = EOE_EPI_RESIDUAL; g.aux = a->x_in; g.ldaux = D; g.out_f32 = 1;
+    // (cls_only: from here on only the class-token rows -- row i*L of image i, gathered by the row strides of the GEMM's A operand
+    //  and of its residual input; everything downstream is a dense [n, ...] matrix)
+    const int Mo = a->cls_only ? a->n : M, ldrow = a->cls_only ? a->L * D : D;
+    g = gemm(a->att, a->w_out, a->x_mid, a->b_out, Mo, D, D, ldrow, D, D, dt);
+    g.epilogue = EOE_EPI_RESIDUAL; g.aux = a->x_in; g.ldaux = ldrow; g.out_f32 = 1;
     TRY(eoe_gemm_nt(&g, stream));
     // x_out = x_mid + c_proj(quick_gelu(c_fc(ln_2(x_mid))))
-    TRY(eoe_layernorm_fwd(a->x_mid, D, a->ln2_g, a->ln2_b, a->xn2, a->stats2, M, D, a->eps, dt, 0, stream));
-    g = gemm(a->xn2, a->w_fc, a->hact, a->b_fc, M, H, D, D, D, H, dt);
+    TRY(eoe_layernorm_fwd(a->x_mid, D, a->ln2_g, a->ln2_b, a->xn2, a->stats2, Mo, D, a->eps, dt, 0, stream));
+    g = gemm(a->xn2, a->w_fc, a->hact, a->b_fc, Mo, H, D, D, D, H, dt);
     g.epilogue = EOE_EPI_GELU; g.aux_out = a->hpre;
     TRY(eoe_gemm_nt(&g, stream));
-    g = gemm(a->hact, a->w_proj, a->x_out, a->b_proj, M, D, H, H, H, D, dt);
+    g = gemm(a->hact, a->w_proj, a->x_out, a->b_proj, Mo, D, H, H, H, D, dt);
     g.epilogue = EOE_EPI_RESIDUAL; g.aux = a->x_mid; g.ldaux = D; g.out_f32 = 1;
     TRY(eoe_gemm_nt(&g, stream));
     return 0;
@@ -104,6 +107,11 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
         return eoe_set_error(EOE_ERR_ARG, "vit_block_bwd: null pointer in arguments");
     const int M = a->n * a->L, D = a->D, H = 4 * a->D, dt = a->dtype, acc = b->accumulate;
     hipStream_t s = (hipStream_t)stream;
+    // cls_only (eoe_hip.h): dx_out and the MLP / out-projection chain live on the n class-token rows (dense [n, ...] matrices); the
+    // attention, the in-projection and LayerNorm-1 see every row, with zeros where the full computation has zero gradients
+    const bool cls = a->cls_only != 0;
+    const int Mo = cls ? a->n : M, ldrow = cls ? a->L * D : D;
+    if (cls && a->L < 4) return eoe_set_error(EOE_ERR_ARG, "vit_block_bwd: cls_only needs L >= 4");
     if (!acc && !b->red_scratch) {
         // without the reduction scratch these gradients are accumulated with fp32 atomics: one zeroing launch
         float* zp[8] = {b->g_ln1_g, b->g_ln1_b, b->g_ln2_g, b->g_ln2_b, b->g_b_fc, b->g_b_out, b->g_b_proj, b->g_b_in};
@@ -129,7 +137,7 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
     // bias gradients are column sums of the dY tensors: fused into the kernels that produce them (fp32 atomics)
     // dY of c_proj (the 16-bit copy of dx_out) + db_proj (its column sums): handed over by the previous call's LayerNorm-1 backward when
     // that call was given `next_d16` (see eoe_hip.h) -- its partial rows are finished by this call's finish kernel --, else one pass here
-    const bool handed = b->in_d16 && b->in_red_scratch && b->red_scratch && b->in_red_scratch != b->red_scratch;
+    const bool handed = !cls && b->in_d16 && b->in_red_scratch && b->red_scratch && b->in_red_scratch != b->red_scratch;
     const void* dy_proj = handed ? b->in_d16 : b->d16_a;
     if (handed) {
         const float* in_ln1 = b->in_red_scratch + (size_t)((M + 63) / 64) * H + EOE_LN_SCRATCH(D) + (size_t)a->n * 3 * D;
@@ -138,25 +146,35 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
         if (!eoe_defer_reduce(in_ln1, rows, 3 * D, D, nullptr, nullptr, b->g_b_proj, 1))
             return eoe_set_error(EOE_ERR_ARG, "vit_block_bwd: could not queue the handed-over column sums");
     } else {
-        TRY(eoe_cast_colsum(b->dx_out, b->d16_a, b->g_b_proj, red_cast, M, D, dt, 1, stream));
+        TRY(eoe_cast_colsum(b->dx_out, b->d16_a, b->g_b_proj, red_cast, Mo, D, dt, 1, stream));
     }
-    g = gemm(dy_proj, a->w_proj_t, b->dh, nullptr, M, H, D, D, D, H, dt);                  // d hact, then * gelu'(hpre)
+    g = gemm(dy_proj, a->w_proj_t, b->dh, nullptr, Mo, H, D, D, D, H, dt);                 // d hact, then * gelu'(hpre)
     g.epilogue = EOE_EPI_GELU_BWD; g.aux = a->hpre; g.ldaux = H;
     if (b->red_scratch) {
         // db_fc = column sums of dh, from the GEMM's epilogue through per-wave partial rows in the scratch (with fp32 atomics
         // instead, the fused sums cost +45 us -- more than a separate 16-us pass over dh)
-        g.colsum = b->g_b_fc; g.workspace = red_fc; g.workspace_bytes = (int64_t)EOE_NT_COLSUM_WORKSPACE_BYTES(M, H);
+        g.colsum = b->g_b_fc; g.workspace = red_fc; g.workspace_bytes = (int64_t)EOE_NT_COLSUM_WORKSPACE_BYTES(Mo, H);
         TRY(eoe_gemm_nt(&g, stream));
     } else {
         TRY(eoe_gemm_nt(&g, stream));
-        TRY(eoe_colsum(b->dh, H, b->g_b_fc, M, H, dt, 1, stream));
+        TRY(eoe_colsum(b->dh, H, b->g_b_fc, Mo, H, dt, 1, stream));
     }
-    g = gemm(b->dh, a->w_fc_t, b->d16_b, nullptr, M, D, H, H, H, D, dt);                    // d xn2
+    g = gemm(b->dh, a->w_fc_t, b->d16_b, nullptr, Mo, D, H, H, H, D, dt);                   // d xn2
     TRY(eoe_gemm_nt(&g, stream));
-    TRY(eoe_layernorm_bwd(b->d16_b, 0, a->x_mid, D, a->stats2, a->ln2_g, b->dx_out, b->dx_mid, D, b->d16_c, b->g_ln2_g,
-                          b->g_ln2_b, b->g_b_out, red_ln2, M, D, dt, stream));        // + db_out = colsum(dx_mid)
+    // (cls_only: dx_mid of the class-token rows goes to a dense [n, D] piece behind the dY copy in d16_a -- L >= 4 leaves the room --
+    //  and is scattered into the zeroed full dx_mid LayerNorm-1 backward reads; d att likewise through the GEMM's row stride)
+    float* dx_mid_o = cls ? (float*)((char*)b->d16_a + (((size_t)Mo * D * 2 + 255) & ~(size_t)255)) : b->dx_mid;
+    TRY(eoe_layernorm_bwd(b->d16_b, 0, a->x_mid, D, a->stats2, a->ln2_g, b->dx_out, dx_mid_o, D, b->d16_c, b->g_ln2_g,
+                          b->g_ln2_b, b->g_b_out, red_ln2, Mo, D, dt, stream));       // + db_out = colsum(dx_mid)
+    if (cls) {
+        if (hipMemsetAsync(b->dx_mid, 0, (size_t)M * D * sizeof(float), s) != hipSuccess ||
+            hipMemcpy2DAsync(b->dx_mid, (size_t)ldrow * sizeof(float), dx_mid_o, (size_t)D * sizeof(float), (size_t)D * sizeof(float), Mo,
+                             hipMemcpyDeviceToDevice, s) != hipSuccess ||
+            hipMemsetAsync(b->d16_b, 0, (size_t)M * D * 2, s) != hipSuccess)
+            return eoe_set_error(EOE_ERR_LAUNCH, "vit_block_bwd: zero-fill / scatter of the class-token rows failed");
+    }
     // ---- attention branch:  x_mid = x_in + out_proj(attn(ln_1(x_in)))
-    g = gemm(b->d16_c, a->w_out_t, b->d16_b, nullptr, M, D, D, D, D, D, dt);                // d att
+    g = gemm(b->d16_c, a->w_out_t, b->d16_b, nullptr, Mo, D, D, D, D, ldrow, dt);           // d att
     TRY(eoe_gemm_nt(&g, stream));
     // + db_in = column sums of dqkv, from the attention kernel's accumulators when the scratch is there
     TRY(eoe_attn_bwd(a->qkv, b->d16_b, b->dqkv, red_attn ? b->g_b_in : nullptr, red_attn, a->n, a->L, a->heads, dt, stream));
@@ -164,17 +182,26 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
     TRY(eoe_gemm_nt(&g, stream));
     if (!b->red_scratch) TRY(eoe_colsum(b->dqkv, 3 * D, b->g_b_in, M, 3 * D, dt, 1, stream));
     // ---- the four weight gradients of the block in one grouped launch (every dY and X is still live)
-    w[0] = gemm(b->dh, a->xn2, b->g_w_fc, nullptr, H, D, M, H, D, D, dt);                    // dW_fc[4D,D]   = dh^T xn2
-    w[1] = gemm(dy_proj, a->hact, b->g_w_proj, nullptr, D, H, M, D, H, H, dt);              // dW_proj[D,4D] = dY^T hact
+    w[0] = gemm(b->dh, a->xn2, b->g_w_fc, nullptr, H, D, Mo, H, D, D, dt);                   // dW_fc[4D,D]   = dh^T xn2
+    w[1] = gemm(dy_proj, a->hact, b->g_w_proj, nullptr, D, H, Mo, D, H, H, dt);             // dW_proj[D,4D] = dY^T hact
     w[2] = gemm(b->dqkv, a->xn1, b->g_w_in, nullptr, 3 * D, D, M, 3 * D, D, D, dt);         // dW_in[3D,D]   = dqkv^T xn1
-    w[3] = gemm(b->d16_c, a->att, b->g_w_out, nullptr, D, D, M, D, D, D, dt);               // dW_out[D,D]   = dmid^T att
+    w[3] = gemm(b->d16_c, a->att, b->g_w_out, nullptr, D, D, Mo, D, ldrow, D, dt);          // dW_out[D,D]   = dmid^T att
     for (int i = 0; i < 4; ++i) { w[i].out_f32 = 1; w[i].accumulate = acc; }
     w[0].workspace = b->tn_workspace; w[0].workspace_bytes = b->tn_workspace ? b->tn_workspace_bytes : 0;     // stream-K partials
+    // cls_only: two reduction lengths (n rows for the MLP and the out-projection, n*L for the in-projection) = two launches, in order on
+    // one stream (they share the workspace)
+    eoe_gemm_args wc[3] = {w[0], w[1], w[3]};
+    w[2].workspace = cls ? w[0].workspace : nullptr; w[2].workspace_bytes = cls ? w[0].workspace_bytes : 0;
+    auto launch_wgrads = [&](void* st) -> int {
+        if (!cls) return eoe_gemm_tn_grouped(w, 4, st);
+        TRY(eoe_gemm_tn_grouped(wc, 3, st));
+        return eoe_gemm_tn_grouped(&w[2], 1, st);
+    };
     // LayerNorm-1 backward next to the wgrad launch on a second stream pays only while that launch leaves CUs idle (216 tiles on 256
     // CUs); with the stream-K workspace the launch fills every CU itself and the side stream is left out (same step time, one
     // stream, capturable)
     // (asked of the launch itself: small or ragged batches, captured streams and "tn_flags" bit 1 all run the plain 216-tile form)
-    const bool streamk = eoe_tn_streamk_would_run(w, 4, stream);
+    const bool streamk = !cls && eoe_tn_streamk_would_run(w, 4, stream);
     SideStream* ss = (g_vit_side_stream == 2 || (g_vit_side_stream && (!streamk || b->async_wgrad))) && b->red_scratch ? side_stream(s) : nullptr;
     // Asynchronous weight gradients (b->async_wgrad; round 3).  Nothing in the backward sweep needs a block's weight gradients, and the
     // grouped wgrad launch leaves 40 of the 256 CUs idle for its ~213 us (216 one-per-CU workgroups): launched on the side stream, it runs
@@ -187,7 +214,7 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
             return eoe_set_error(EOE_ERR_LAUNCH, "vit_block_bwd: stream wait failed");
         if (hipEventRecord(ss->fork, s) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess)
             return eoe_set_error(EOE_ERR_LAUNCH, "vit_block_bwd: fork failed");
-        TRY(eoe_gemm_tn_grouped(w, 4, (void*)ss->s));
+        TRY(launch_wgrads((void*)ss->s));
         if (hipEventRecord(ss->wgrad_done, ss->s) != hipSuccess) return eoe_set_error(EOE_ERR_LAUNCH, "vit_block_bwd: event record failed");
         ss->wgrad_pending = true;
         TRY(eoe_layernorm_bwd(b->d16_b, 0, a->x_in, D, a->stats1, a->ln1_g, b->dx_mid, b->dx_in, D, b->next_d16, b->g_ln1_g,
@@ -198,14 +225,14 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
     if (ss) {
         // fork before the wgrad launch (LayerNorm-1 backward depends on d xn1 and dx_mid only), join before the finish kernel
         if (hipEventRecord(ss->fork, s) != hipSuccess) return eoe_set_error(EOE_ERR_LAUNCH, "vit_block_bwd: event record failed");
-        TRY(eoe_gemm_tn_grouped(w, 4, stream));
+        TRY(launch_wgrads(stream));
         if (hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return eoe_set_error(EOE_ERR_LAUNCH, "vit_block_bwd: stream wait failed");
         TRY(eoe_layernorm_bwd(b->d16_b, 0, a->x_in, D, a->stats1, a->ln1_g, b->dx_mid, b->dx_in, D, b->next_d16, b->g_ln1_g,
                               b->g_ln1_b, nullptr, red_ln1, M, D, dt, (void*)ss->s));
         if (hipEventRecord(ss->join, ss->s) != hipSuccess || hipStreamWaitEvent(s, ss->join, 0) != hipSuccess)
             return eoe_set_error(EOE_ERR_LAUNCH, "vit_block_bwd: join failed");
     } else {
-        TRY(eoe_gemm_tn_grouped(w, 4, stream));
+        TRY(launch_wgrads(stream));
         TRY(eoe_layernorm_bwd(b->d16_b, 0, a->x_in, D, a->stats1, a->ln1_g, b->dx_mid, b->dx_in, D, b->next_d16, b->g_ln1_g,
                               b->g_ln1_b, nullptr, red_ln1, M, D, dt, stream));
     }

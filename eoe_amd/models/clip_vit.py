@@ -60,8 +60,10 @@ class ResidualAttentionBlock(nn.Module):
                 self.attn.out_proj.weight, self.attn.out_proj.bias, self.ln_2.weight, self.ln_2.bias,
                 self.mlp.c_fc.weight, self.mlp.c_fc.bias, self.mlp.c_proj.weight, self.mlp.c_proj.bias)
 
-    def forward_tokens(self, x2d: torch.Tensor, n: int) -> torch.Tensor:
-        return ops.VitBlockFunction.apply(x2d, n, self.n_head, *self._params())
+    def forward_tokens(self, x2d: torch.Tensor, n: int, cls_only: bool = False) -> torch.Tensor:
+        """`cls_only`: return the [n, D] class-token rows only (the caller reads nothing else of this block's output); the rows nobody
+        reads are then not computed (ops.VitBlockFunction)"""
+        return ops.VitBlockFunction.apply(x2d, n, self.n_head, *self._params(), cls_only)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         n, L, D = x.shape
@@ -115,8 +117,11 @@ class VisualTransformer(nn.Module):
                            + [self.proj])
         tok = ops.VitEmbedFunction.apply(x, self.conv1.weight, self.class_embedding, self.positional_embedding,
                                          self.ln_pre.weight, self.ln_pre.bias, self.patch_size, mean, std)
-        for blk in self.transformer.resblocks:
-            tok = blk.forward_tokens(tok, n)
+        # ln_post reads x[:, 0, :] only (model.py:231-232): the last block is asked for its class-token rows alone -- [n, D], which the
+        # head takes as a one-token sequence -- and skips the out-projection, LayerNorm-2 and MLP of the other L - 1 tokens
+        blocks = list(self.transformer.resblocks)
+        for i, blk in enumerate(blocks):
+            tok = blk.forward_tokens(tok, n, cls_only=ops.VIT_CLS_ONLY_LAST and i == len(blocks) - 1)
         return ops.VitHeadFunction.apply(tok, n, self.ln_post.weight, self.ln_post.bias, self.proj)
 
 

@@ -479,18 +479,26 @@ def vit_side_join():
 
 
 
+# the last block of the vision tower computes only what its single reader -- ln_post on the class token (clip/model.py:231-232) -- uses
+# (EOE_VIT_CLS_ONLY=0, or this flag, restores the full block: A/B and tests)
+VIT_CLS_ONLY_LAST = os.environ.get("EOE_VIT_CLS_ONLY", "1") != "0"
+
+
 class VitBlockFunction(torch.autograd.Function):
     """one ResidualAttentionBlock (clip/model.py:167-188) on the batch-major token matrix, fp32 residual stream
     [n*L, D] in and out; a single C call launches the whole kernel chain."""
 
     @staticmethod
-    def forward(ctx, x, n, heads, ln1_g, ln1_b, w_in, b_in, w_out, b_out, ln2_g, ln2_b, w_fc, b_fc, w_proj, b_proj):
+    def forward(ctx, x, n, heads, ln1_g, ln1_b, w_in, b_in, w_out, b_out, ln2_g, ln2_b, w_fc, b_fc, w_proj, b_proj, cls_only=False):
         _chk(x)
         x = x.contiguous()
         M, D = x.shape
         L = M // n
         ws, ptr = _block_ws(M, D, x.device, _compute_dtype)
-        x_out = torch.empty_like(x)
+        # cls_only (the last block of the tower: eoe_hip.h, eoe_vit_block_fwd_args.cls_only): the output is the [n, D] matrix of class-token
+        # rows -- all the head reads --, and the out-projection, LayerNorm-2 and the MLP run on those rows only
+        cls_only = bool(cls_only) and L >= 4
+        x_out = x.new_empty((n, D)) if cls_only else torch.empty_like(x)
         need_t = torch.is_grad_enabled()
         sh = {k: shadow.get(w, True, True) for k, w in (("in", w_in), ("out", w_out), ("fc", w_fc), ("proj", w_proj))}
         a = _lib.VitBlockFwdArgs()
@@ -502,6 +510,7 @@ class VitBlockFunction(torch.autograd.Function):
         a.x_in, a.x_mid, a.x_out = _p(x), ptr["x_mid"], _p(x_out)
         a.xn1, a.qkv, a.att, a.xn2, a.hpre, a.hact = (ptr[k] for k in ("xn1", "qkv", "att", "xn2", "hpre", "hact"))
         a.stats1, a.stats2 = ptr["stats1"], ptr["stats2"]
+        a.cls_only = 1 if cls_only else 0
         keep = any(ctx.needs_input_grad)            # (grad mode itself is always off inside a Function's forward)
         if not keep:
             a.hpre = None          # forward only (frozen encoder, scoring): the MLP's pre-activation is not kept (79 MB per block)
@@ -579,7 +588,7 @@ class VitBlockFunction(torch.autograd.Function):
                 _vit_deferred_hook = hook[1]
             else:
                 hook[1]()
-        return (dx_in, None, None) + tuple(grads[k] for k in _BLOCK_PARAMS)
+        return (dx_in, None, None) + tuple(grads[k] for k in _BLOCK_PARAMS) + (None,)
 
 
 class VitHeadFunction(torch.autograd.Function):

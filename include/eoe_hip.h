@@ -289,11 +289,18 @@ typedef struct {
     float* x_out;        /* fp32 [M,D] residual stream out */
     void *xn1, *qkv, *att, *xn2, *hpre, *hact;   /* 16-bit [M,D] [M,3D] [M,D] [M,D] [M,4D] [M,4D] */
     float *stats1, *stats2;                      /* fp32 [M,2] */
+    /* != 0: the caller reads only the class-token rows (row i*L of image i) of x_out -- the LAST block of the vision tower, whose output
+     * goes through x[:, 0, :] to ln_post (clip/model.py:231-232).  The rows nobody reads are not computed: the out-projection, LayerNorm-2
+     * and the MLP run on the n class-token rows, and x_mid, x_out, xn2, hpre, hact, stats2 hold [n, ...] (dense, image order) instead of
+     * [n*L, ...]; xn1, qkv, att keep all rows (keys and values of every token feed the class token's attention).  Backward: dx_out is
+     * fp32 [n, D]; dx_in and every parameter gradient are what the full computation gives with zero dx_out on the other rows (the
+     * weight gradients to fp32 summation order: the zero rows are left out of the sums). */
+    int32_t cls_only;
 } eoe_vit_block_fwd_args;
 
 typedef struct {
     eoe_vit_block_fwd_args f;   /* same parameters and saved activations as the forward */
-    const float* dx_out;        /* fp32 [M,D] gradient wrt x_out */
+    const float* dx_out;        /* fp32 [M,D] gradient wrt x_out ([n,D] with f.cls_only) */
     float* dx_in;               /* fp32 [M,D] gradient wrt x_in */
     /* parameter gradients, fp32, overwritten (or += if accumulate) */
     float *g_ln1_g, *g_ln1_b, *g_ln2_g, *g_ln2_b, *g_b_in, *g_b_out, *g_b_fc, *g_b_proj;

@@ -374,6 +374,51 @@ def test_vit_block_handover_equals_the_separate_pass():
             assert torch.equal(on1[n], off[n]), n
 
 
+def test_vit_last_block_on_class_token_rows_only_equals_the_full_block():
+    """ln_post reads x[:, 0, :] only (clip/model.py:231-232): the last block run on its class-token rows alone (eoe_vit_block_fwd_args.cls_only)
+    gives the same embedding -- the same kernels' per-row results -- and the gradients of the full block fed zeros on the other rows: equal
+    up to the fp32 summation order of the last block's weight gradients (the zero rows are left out of the sums)"""
+    import eoe_amd
+    from eoe_amd import ops
+    from eoe_amd.models import ClipViTB32Custom
+    eoe_amd.set_compute_dtype("fp16")
+    torch.manual_seed(0)
+    m = ClipViTB32Custom(layers=3).cuda().train()
+    y = torch.cat([torch.zeros(12, dtype=torch.long), torch.ones(12, dtype=torch.long)]).cuda()
+    old = ops.VIT_CLS_ONLY_LAST
+    try:
+        for nimg in (24, 256):
+            x = torch.randn(nimg, 3, 224, 224, device="cuda")
+            yy = y if nimg == 24 else torch.cat([torch.zeros(128, dtype=torch.long), torch.ones(128, dtype=torch.long)]).cuda()
+            res = {}
+            for on in (False, True, True):
+                ops.VIT_CLS_ONLY_LAST = on
+                for p in m.parameters():
+                    p.grad = None
+                emb = m(x)
+                loss = eoe_amd.hsc_loss(emb, yy, 0)
+                loss.backward()
+                torch.cuda.synchronize()
+                res.setdefault(on, []).append((emb.detach().clone(), {n: p.grad.clone() for n, p in m.named_parameters()}))
+            (e0, g0), (e1, g1), (e2, g2) = res[False][0], res[True][0], res[True][1]
+            assert torch.equal(e1, e2)
+            assert (e1 - e0).abs().max().item() <= 1e-6 * e0.abs().max().item(), (e1 - e0).abs().max().item()
+            for n in g0:
+                assert torch.equal(g1[n], g2[n]), n                                          # reproducible
+                d = (g1[n] - g0[n]).abs().max().item() / (g0[n].abs().max().item() + 1e-30)
+                assert d < 2e-5, (nimg, n, d)
+        # forward only (scoring): the same embedding
+        m.eval()
+        with torch.no_grad():
+            ops.VIT_CLS_ONLY_LAST = False
+            a = m(x)
+            ops.VIT_CLS_ONLY_LAST = True
+            b = m(x)
+        assert (a - b).abs().max().item() <= 1e-6 * a.abs().max().item()
+    finally:
+        ops.VIT_CLS_ONLY_LAST = old
+
+
 def test_vit_async_weight_gradients_keep_their_bits():
     """a block's grouped weight-gradient launch on the side stream, under the next block's kernels (ops.VIT_ASYNC_WGRAD): the same kernels
     on the same operands -- every gradient and a 6-step Adam trajectory are bitwise those of the synchronous launch order"""
