@@ -1214,7 +1214,7 @@ extern "C" int eoe_layernorm_bwd(const void* dy, int dy_f32, const float* x, int
     int grid = cdiv(rows, 8);
     if (grid > EOE_LN_PARTIALS) grid = EOE_LN_PARTIALS;
     float* part = (dgamma || dxsum) ? red_scratch : nullptr;
-    // (the attribute once per instantiation: set before every launch, the call left a 13-us hole in front of each of the step's 25 launches)
+    // (the attribute once per instantiation, not per launch)
     DISPATCH_T(dtype, DISPATCH_NV(D, { static bool once = (hipFuncSetAttribute((const void*)layernorm_bwd_kernel<T, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 8 * 256 * NV * 4), true); (void)once; }
                                   hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV>), dim3(grid), dim3(512), 3 * 8 * 256 * NV * 4, (hipStream_t)stream, dy,
                                          dy_f32, x, ldx, stats, gamma, dres, dx_out, ld_out, (T*)dx16, dgamma, dbeta,
