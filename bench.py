@@ -64,6 +64,9 @@ def parse():
                     help="cnn32 / wrn: the convolutions and linear layers as exact-fp32 implicit GEMMs on the fp32 matrix cores "
                          "(v_mfma_f32_16x16x4_f32, csrc/parity.hip) -- the mode that holds the 1e-3 trajectory bar for the BatchNorm "
                          "encoders; peak 157 TFLOP/s")
+    ap.add_argument("--conv-y16", action="store_true",
+                    help="conv nets, fp16: keep the convolution outputs in fp16 in front of BatchNorm (ops.CONV_Y16; a speed option with one "
+                         "more rounding point, see DESIGN.md section 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--serial-kernels", action="store_true",
@@ -184,6 +187,10 @@ def main():
     if args.parity_mode:
         assert args.model in ("cnn32", "wrn"), "--parity-mode is for the BatchNorm encoders (the ViT meets the bar in its 16-bit mode)"
         eoe_amd.set_parity_mode(True)
+    if args.conv_y16:
+        assert args.model in ("cnn32", "wrn") and args.dtype == "fp16" and not args.parity_mode, "--conv-y16: conv nets, fp16 fast mode"
+        from eoe_amd import ops as _opsy
+        _opsy.CONV_Y16 = True
     # fp16: loss gradient x 256 against underflow in the 16-bit backward chain (FusedAdam divides it out)
     eoe_amd.set_grad_scale(args.grad_scale if args.grad_scale else eoe_amd.default_grad_scale())
     if args.tn_flags is not None:
@@ -388,7 +395,8 @@ def main():
                        "launch": "hip graph replay" if use_graph else ("eager, kernels serialised" if args.serial_kernels else
                                                                         "eager, weight-gradient launches on a side stream under the dgrad chain"
                                                                         if training else "eager"),
-                       "arithmetic": "exact fp32 (fp32 MFMA convolutions / linears)" if args.parity_mode else "16-bit MFMA operands, fp32 accumulate",
+                       "arithmetic": "exact fp32 (fp32 MFMA convolutions / linears)" if args.parity_mode else
+                                     ("16-bit MFMA operands, fp32 accumulate" + (", fp16 convolution outputs in front of BatchNorm" if args.conv_y16 else "")),
                        **({"last_block": "class-token rows only past the attention (what ln_post reads; same embedding and gradients; "
                                          "EOE_VIT_CLS_ONLY=0 computes the unread rows too)"} if cls_only else {})},
             "model_tflops": round(value * flop_per_img / 1e3, 1),

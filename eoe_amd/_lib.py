@@ -19,6 +19,7 @@ EOE_COMM_I64, EOE_COMM_ID_BYTES, EOE_COMM_ALGO_RING, EOE_COMM_ALGO_RS_AG = 8, 12
 EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_GELU_BWD = 0, 1, 2, 3
 ADAM_CHUNK, ADAM_GROUPS = 8192, 4
 CHUNK_FP16 = 0x100                 # eoe_adam_chunk.group flag (EOE_CHUNK_FP16): fp16-weights update in eoe_sgd_multi
+EOE_Y16 = 0x100             # OR-ed into the dtype argument of eoe_bn_act_*: y is the 16-bit copy (include/eoe_hip.h)
 
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 

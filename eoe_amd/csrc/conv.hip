@@ -405,10 +405,23 @@ __global__ void set_float_kernel(float* p, float v) { *p = v; }
 
 __device__ __forceinline__ float lrelu(float z, float slope) { return z > 0.f ? z : slope * z; }
 
+// four channels of the convolution output y at element index idx: y is fp32, or (YT = the 16-bit compute type, EOE_Y16 in the entry
+// points' dtype argument) the 16-bit copy the conv GEMM wrote instead -- half the bytes of the three passes that read it
+template <typename YT>
+__device__ __forceinline__ f32x4 load_y4(const void* __restrict__ y, size_t idx) {
+    if constexpr (sizeof(YT) == 4) {
+        return *(const f32x4*)((const float*)y + idx);
+    } else {
+        float t[4];
+        unpack4<YT>(*(const u32x2*)((const YT*)y + idx), t);
+        return (f32x4){t[0], t[1], t[2], t[3]};
+    }
+}
+
 // out = maxpool_P(leaky_relu(bn(y))); y fp32 [n,H,W,C] ; out 16-bit [n,H/P,W/P,C], or (nchw_flat) [n, C*(H/P)*(W/P)] in the
 // reference's NCHW flatten order (cnn.py:83), or fp32 if out_f32.  P in {1,2}.  4 channels per thread.
-template <typename T>
-__global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ stats,
+template <typename T, typename YT>
+__global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const void* __restrict__ y, const float* __restrict__ stats,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               void* __restrict__ out, T* __restrict__ out16, int n, int H, int W,
                                                               int C, int P, int nchw_flat, int out_f32, float slope,
@@ -426,7 +439,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __res
         float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         for (int dy = 0; dy < P; ++dy)
             for (int dx = 0; dx < P; ++dx) {
-                const f32x4 v = *(const f32x4*)(y + (((size_t)img * H + ho * P + dy) * W + wo * P + dx) * C + c);
+                const f32x4 v = load_y4<YT>(y, (((size_t)img * H + ho * P + dy) * W + wo * P + dx) * C + c);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) best[r] = fmaxf(best[r], lrelu((v[r] - mu[r]) * rs[r] * g[r] + b[r], slope));
             }
@@ -482,14 +495,14 @@ __device__ __forceinline__ void block_channel_sums(const float (&acc0)[4], const
 
 // the gradient at the BatchNorm output of one (pooled position, channel quad): xh / z of the P x P window, the winning tap per channel
 // and the upstream gradient (one 16-byte load in the NHWC layout)
-template <int P>
+template <int P, typename YT>
 struct BnBwdElem {
     f32x4 xh[P * P], z[P * P];
     int arg[4];
     float d[4];
     unsigned opu, wo, ho, img;
     int c;
-    __device__ __forceinline__ void load(unsigned i, const float* __restrict__ y, const float* __restrict__ dout, const f32x4& mu, const f32x4& rs,
+    __device__ __forceinline__ void load(unsigned i, const void* __restrict__ y, const float* __restrict__ dout, const f32x4& mu, const f32x4& rs,
                                          const f32x4& g, const f32x4& b, int nchw_flat, int H, int W, int C, float slope, const QuadDecode& dec) {
         unsigned c4;
         dec(i, c4, opu, wo, ho, img);
@@ -500,7 +513,7 @@ struct BnBwdElem {
 #pragma unroll
         for (int k = 0; k < P * P; ++k) {
             const int dy_ = k / P, dx_ = k % P;
-            const f32x4 v = *(const f32x4*)(y + (((size_t)img * H + ho * P + dy_) * W + wo * P + dx_) * C + c);
+            const f32x4 v = load_y4<YT>(y, (((size_t)img * H + ho * P + dy_) * W + wo * P + dx_) * C + c);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 xh[k][r] = (v[r] - mu[r]) * rs[r];
@@ -531,8 +544,8 @@ struct BnBwdElem {
 // backward pass 1: per-channel sums of g and g*xhat, where g is the gradient at the BatchNorm OUTPUT (un-pooled through
 // the first maximum of each window, times LeakyReLU').  One thread per (pooled position, 4 channels); LDS + atomics.
 // mode 0 = reduce into red[0..C)=sum g, red[C..2C)=sum g*xhat;  mode 1 = write dy (16-bit [n*H*W, C]) using those sums.
-template <typename T, int MODE, int P>
-__global__ __launch_bounds__(256) void bn_act_pool_bwd_kernel(const float* __restrict__ y, const float* __restrict__ stats,
+template <typename T, int MODE, int P, typename YT>
+__global__ __launch_bounds__(256) void bn_act_pool_bwd_kernel(const void* __restrict__ y, const float* __restrict__ stats,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               const float* __restrict__ dout, float* __restrict__ red,
                                                               void* __restrict__ dy, int dy_f32, int n, int H, int W, int C,
@@ -562,7 +575,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_bwd_kernel(const float* __res
         // two positions per iteration: twice the loads in flight (this pass ran at 3.7 TB/s with one), same summation order
         unsigned i = first;
         for (; i < total && i + stride < total && i + stride > i; i += 2 * stride) {
-            BnBwdElem<P> e0, e1;
+            BnBwdElem<P, YT> e0, e1;
             e0.load(i, y, dout, mu, rs, g, b, nchw_flat, H, W, C, slope, dec);
             e1.load(i + stride, y, dout, mu, rs, g, b, nchw_flat, H, W, C, slope, dec);
 #pragma unroll
@@ -571,7 +584,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_bwd_kernel(const float* __res
             for (int r = 0; r < 4; ++r) { float gz, gx; e1.sums(r, slope, gz, gx); acc0[r] += gz; acc1[r] += gx; }
         }
         for (; i < total; i += stride) {
-            BnBwdElem<P> e0;
+            BnBwdElem<P, YT> e0;
             e0.load(i, y, dout, mu, rs, g, b, nchw_flat, H, W, C, slope, dec);
 #pragma unroll
             for (int r = 0; r < 4; ++r) { float gz, gx; e0.sums(r, slope, gz, gx); acc0[r] += gz; acc1[r] += gx; }
@@ -587,7 +600,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_bwd_kernel(const float* __res
             mu_ = *(const f32x4*)(stats + c); rs_ = *(const f32x4*)(stats + C + c);
             if (gamma) { g_ = *(const f32x4*)(gamma + c); b_ = *(const f32x4*)(beta + c); }
         }
-        BnBwdElem<P> e;
+        BnBwdElem<P, YT> e;
         e.load(i, y, dout, mu_, rs_, g_, b_, nchw_flat, H, W, C, slope, dec);
         const int c = e.c;
         const f32x4 s1 = *(const f32x4*)(red + c), s2 = *(const f32x4*)(red + C + c);
@@ -612,8 +625,8 @@ __global__ __launch_bounds__(256) void bn_act_pool_bwd_kernel(const float* __res
 // ---------------------------------------------------------------------------------------------- BN + act + overlapping MaxPool
 // out = maxpool_{k,stride,pad}(act(bn(y))) in one pass over y (the stem of resnet.py:93-96: the 112x112x64 activation is
 // never written); idx = winning tap (first maximum), out16 = optional 16-bit copy
-template <typename T>
-__global__ __launch_bounds__(256) void bn_act_maxpool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ stats,
+template <typename T, typename YT>
+__global__ __launch_bounds__(256) void bn_act_maxpool_fwd_kernel(const void* __restrict__ y, const float* __restrict__ stats,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  float* __restrict__ out, T* __restrict__ out16,
                                                                  uint8_t* __restrict__ idx, int n, int H, int W, int C, int k,
@@ -636,7 +649,7 @@ __global__ __launch_bounds__(256) void bn_act_maxpool_fwd_kernel(const float* __
             for (int kx = 0; kx < k; ++kx) {
                 const int w = wo * stride + kx - pad;
                 if (w < 0 || w >= W) continue;
-                const f32x4 v = *(const f32x4*)(y + (((size_t)img * H + h) * W + w) * C + c);
+                const f32x4 v = load_y4<YT>(y, (((size_t)img * H + h) * W + w) * C + c);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float a = lrelu((v[r] - mu[r]) * rs[r] * g[r] + b[r], slope);
@@ -654,8 +667,8 @@ __global__ __launch_bounds__(256) void bn_act_maxpool_fwd_kernel(const float* __
 // MODE 1 = dy (16-bit) from those sums.
 // S = the pooling stride as a compile-time constant (1 or 2; 0 = use the run-time value): the window enumeration below
 // divides by it twice per pixel
-template <typename T, int MODE, int S>
-__global__ __launch_bounds__(256) void bn_act_maxpool_bwd_kernel(const float* __restrict__ y, const float* __restrict__ stats,
+template <typename T, int MODE, int S, typename YT>
+__global__ __launch_bounds__(256) void bn_act_maxpool_bwd_kernel(const void* __restrict__ y, const float* __restrict__ stats,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  const float* __restrict__ dout, const uint8_t* __restrict__ idx,
                                                                  float* __restrict__ red, T* __restrict__ dy, int n, int H, int W,
@@ -678,7 +691,7 @@ __global__ __launch_bounds__(256) void bn_act_maxpool_bwd_kernel(const float* __
         const f32x4 mu = *(const f32x4*)(stats + c), rs = *(const f32x4*)(stats + C + c);
         f32x4 g = {1.f, 1.f, 1.f, 1.f}, b = {0.f, 0.f, 0.f, 0.f};
         if (gamma) { g = *(const f32x4*)(gamma + c); b = *(const f32x4*)(beta + c); }
-        const f32x4 v = *(const f32x4*)(y + ip * C + c);
+        const f32x4 v = load_y4<YT>(y, ip * C + c);
         float gs[4] = {0.f, 0.f, 0.f, 0.f};
         {   // the windows (ho, wo) that contain this pixel: ho*st <= h+pad <= ho*st + k-1
             const int st = S ? S : stride;
@@ -721,8 +734,8 @@ __global__ __launch_bounds__(256) void bn_act_maxpool_bwd_kernel(const float* __
 // pixels of block (a, b) only ever belong to the four windows (a | a+1, b | b+1), so their winner indices and upstream gradients are
 // loaded once (4 index words + 4 gradient vectors per thread) instead of once per pixel and window (9 of each for the same four pixels
 // in the generic kernel above, which ran at 2.4-2.7 TB/s on the 822 MB stem activation); same arithmetic per pixel.
-template <typename T, int MODE>
-__global__ __launch_bounds__(256) void bn_act_maxpool_bwd_s2k3_kernel(const float* __restrict__ y, const float* __restrict__ stats,
+template <typename T, int MODE, typename YT>
+__global__ __launch_bounds__(256) void bn_act_maxpool_bwd_s2k3_kernel(const void* __restrict__ y, const float* __restrict__ stats,
                                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                       const float* __restrict__ dout, const uint8_t* __restrict__ idx,
                                                                       float* __restrict__ red, T* __restrict__ dy, int n, int H, int W,
@@ -767,7 +780,7 @@ __global__ __launch_bounds__(256) void bn_act_maxpool_bwd_s2k3_kernel(const floa
             for (int px = 0; px < 2; ++px) {
                 const int h = 2 * a + py, w = 2 * b + px;
                 const size_t ip = ((size_t)img * H + h) * W + w;
-                const f32x4 v = *(const f32x4*)(y + ip * C + c);
+                const f32x4 v = load_y4<YT>(y, ip * C + c);
                 // pixel (2a + py, 2b + px) sits at tap (py + 1 - 2 wy, px + 1 - 2 wx) of window (a + wy, b + wx): py = 0 -> wy = 0 only
                 float gs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -846,6 +859,14 @@ int grid_for(size_t total) {
         if ((dtype) == EOE_F16) { typedef f16_t T; __VA_ARGS__; } \
         else if ((dtype) == EOE_BF16) { typedef bf16_t T; __VA_ARGS__; } \
         else return eoe_set_error(EOE_ERR_ARG, "bad dtype %d", (int)(dtype)); \
+    } while (0)
+
+// T = the 16-bit compute type, YT = the type of the convolution output y the BatchNorm kernels read: fp32, or T with EOE_Y16
+#define DISPATCH_TY(dtype, y16, ...)                                                       \
+    do {                                                                                   \
+        if ((dtype) == EOE_F16) { typedef f16_t T; if (y16) { typedef f16_t YT; __VA_ARGS__; } else { typedef float YT; __VA_ARGS__; } }     \
+        else if ((dtype) == EOE_BF16) { typedef bf16_t T; if (y16) { typedef bf16_t YT; __VA_ARGS__; } else { typedef float YT; __VA_ARGS__; } } \
+        else return eoe_set_error(EOE_ERR_ARG, "bad dtype %d", (int)(dtype));              \
     } while (0)
 
 static int check_geo(const char* who, int H, int W, int kh, int kw, int stride, int pad, Geo& g) {
@@ -1052,34 +1073,38 @@ extern "C" int eoe_bn_stats_partials(const float* part, int R, float* sums_scrat
     return bn_finalize_rows(rows, P, sums_scratch, stats, running_mean, running_var, num_batches_tracked, M, C, eps, momentum, s);
 }
 
-extern "C" int eoe_bn_act_pool_fwd(const float* y, const float* stats, const float* gamma, const float* beta, void* out,
+extern "C" int eoe_bn_act_pool_fwd(const void* y, const float* stats, const float* gamma, const float* beta, void* out,
                                    void* out16, int n, int H, int W, int C, int pool, int nchw_flat, int out_f32, float slope,
                                    int dtype, void* stream) {
+    const int y16 = dtype & EOE_Y16;
+    dtype &= ~EOE_Y16;
     EOE_CHECK_ARG(!out16 || (out_f32 && !nchw_flat), "bn_act_pool_fwd: the extra 16-bit copy goes with an fp32 NHWC output");
     EOE_CHECK_ARG(y && stats && out && n > 0 && C % 4 == 0, "bn_act_pool_fwd: bad args");
     EOE_CHECK_ARG((pool == 1 || pool == 2) && H % pool == 0 && W % pool == 0, "bn_act_pool: pool must be 1 or 2 and divide H, W");
     EOE_CHECK_ARG((gamma == nullptr) == (beta == nullptr), "bn_act_pool: gamma/beta must both be given or both NULL");
     EOE_CHECK_IDX((size_t)n * H * W * C / 4, "bn_act_pool_fwd");
-    ProfScope ps("bn_act_pool_fwd", 0, 4.0 * n * H * W * C + 2.0 * n * H * W * C / (pool * pool), stream);
+    ProfScope ps("bn_act_pool_fwd", 0, (y16 ? 2.0 : 4.0) * n * H * W * C + 2.0 * n * H * W * C / (pool * pool), stream);
     const QuadDecode dec(C / 4, W / pool, H / pool);
-    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_pool_fwd_kernel<T>), dim3(grid_for((size_t)n * (H / pool) * (W / pool) * C / 4)),
+    DISPATCH_TY(dtype, y16, hipLaunchKernelGGL((bn_act_pool_fwd_kernel<T, YT>), dim3(grid_for((size_t)n * (H / pool) * (W / pool) * C / 4)),
                                          dim3(256), 0, (hipStream_t)stream, y, stats, gamma, beta, out, (T*)out16, n, H, W, C,
                                          pool, nchw_flat, out_f32, slope, dec));
     EOE_CHECK_LAUNCH("bn_act_pool_fwd");
     return 0;
 }
 
-extern "C" int eoe_bn_act_pool_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* dout,
+extern "C" int eoe_bn_act_pool_bwd(const void* y, const float* stats, const float* gamma, const float* beta, const float* dout,
                                    float* red_scratch, void* dy, int dy_f32, float* dgamma, float* dbeta, int n, int H, int W,
                                    int C, int pool, int nchw_flat, int training, int accumulate, float slope, int dtype,
                                    void* stream) {
+    const int y16 = dtype & EOE_Y16;
+    dtype &= ~EOE_Y16;
     EOE_CHECK_ARG(y && stats && dout && red_scratch && dy && n > 0 && C % 4 == 0, "bn_act_pool_bwd: bad args");
     EOE_CHECK_ARG((pool == 1 || pool == 2) && H % pool == 0 && W % pool == 0, "bn_act_pool: pool must be 1 or 2 and divide H, W");
     EOE_CHECK_ARG((gamma == nullptr) == (beta == nullptr) && (dgamma == nullptr) == (dbeta == nullptr), "bn_act_pool_bwd: gamma/beta pairs");
     EOE_CHECK_ARG(C <= 4096, "bn_act_pool_bwd: C too large");
     hipStream_t s = (hipStream_t)stream;
     EOE_CHECK_IDX((size_t)n * H * W * C / 4, "bn_act_pool_bwd");
-    ProfScope ps("bn_act_pool_bwd", 0, 2 * 4.0 * n * H * W * C + 2.0 * n * H * W * C, stream);
+    ProfScope ps("bn_act_pool_bwd", 0, 2 * (y16 ? 2.0 : 4.0) * n * H * W * C + 2.0 * n * H * W * C, stream);
     const QuadDecode dec(C / 4, W / pool, H / pool);
     const int grid = grid_for((size_t)n * (H / pool) * (W / pool) * C / 4);
     int g0 = grid > EOE_BN_PARTIALS ? EOE_BN_PARTIALS : grid;
@@ -1092,7 +1117,7 @@ extern "C" int eoe_bn_act_pool_bwd(const float* y, const float* stats, const flo
         if (g0 < q) g0 = q;
     }
 #define EOE_BNB(MODE, PP, GRID, LDS)                                                                                  \
-    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_pool_bwd_kernel<T, MODE, PP>), dim3(GRID), dim3(256), LDS, s, y, stats, gamma, \
+    DISPATCH_TY(dtype, y16, hipLaunchKernelGGL((bn_act_pool_bwd_kernel<T, MODE, PP, YT>), dim3(GRID), dim3(256), LDS, s, y, stats, gamma, \
                                          beta, dout, red_scratch, dy, dy_f32, n, H, W, C, nchw_flat, training, slope, dec))
     if (pool == 1) { EOE_BNB(0, 1, g0, 2 * C * sizeof(float)); } else { EOE_BNB(0, 2, g0, 2 * C * sizeof(float)); }
     EOE_CHECK_LAUNCH("bn_act_pool_bwd_reduce");
@@ -1135,34 +1160,39 @@ extern "C" int eoe_colsum_f32(const float* x, float* out, float* red_scratch, in
     return 0;
 }
 
-extern "C" int eoe_bn_act_maxpool_fwd(const float* y, const float* stats, const float* gamma, const float* beta, float* out,
+extern "C" int eoe_bn_act_maxpool_fwd(const void* y, const float* stats, const float* gamma, const float* beta, float* out,
                                       void* out16, uint8_t* idx, int n, int H, int W, int C, int k, int stride, int pad, float slope,
                                       int dtype, void* stream) {
+    const int y16 = dtype & EOE_Y16;
+    dtype &= ~EOE_Y16;
     EOE_CHECK_ARG(y && stats && out && idx && n > 0 && C % 4 == 0 && k >= 1 && k * k <= 255 && stride >= 1 && pad >= 0 && 2 * pad <= k,
                   "bn_act_maxpool_fwd: bad args");
     EOE_CHECK_ARG((gamma == nullptr) == (beta == nullptr), "bn_act_maxpool: gamma/beta must both be given or both NULL");
     const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
     EOE_CHECK_ARG(Ho >= 1 && Wo >= 1, "bn_act_maxpool_fwd: empty output");
     EOE_CHECK_IDX((size_t)n * H * W * C / 4, "bn_act_maxpool_fwd");
-    ProfScope ps("bn_act_maxpool_fwd", 0, 4.0 * n * H * W * C + 7.0 * n * Ho * Wo * C, stream);
+    ProfScope ps("bn_act_maxpool_fwd", 0, (y16 ? 2.0 : 4.0) * n * H * W * C + 7.0 * n * Ho * Wo * C, stream);
     const QuadDecode dec(C / 4, Wo, Ho);
-    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_maxpool_fwd_kernel<T>), dim3(grid_for((size_t)n * Ho * Wo * C / 4)), dim3(256), 0,
+    DISPATCH_TY(dtype, y16, hipLaunchKernelGGL((bn_act_maxpool_fwd_kernel<T, YT>), dim3(grid_for((size_t)n * Ho * Wo * C / 4)), dim3(256), 0,
                                          (hipStream_t)stream, y, stats, gamma, beta, out, (T*)out16, idx, n, H, W, C, k, stride, pad, Ho,
                                          Wo, slope, dec));
     EOE_CHECK_LAUNCH("bn_act_maxpool_fwd");
     return 0;
 }
 
-extern "C" int eoe_bn_act_maxpool_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* dout,
+extern "C" int eoe_bn_act_maxpool_bwd(const void* y, const float* stats, const float* gamma, const float* beta, const float* dout,
                                       const uint8_t* idx, float* red_scratch, void* dy, float* dgamma, float* dbeta, int n, int H,
                                       int W, int C, int k, int stride, int pad, int training, float slope, int dtype, void* stream) {
+    const int y16 = dtype & EOE_Y16;
+    dtype &= ~EOE_Y16;
+    EOE_CHECK_ARG(!(y16 && dtype == EOE_F32), "bn_act_maxpool_bwd: EOE_Y16 goes with a 16-bit dtype");
     EOE_CHECK_ARG(y && stats && dout && idx && red_scratch && dy && n > 0 && C % 4 == 0 && C <= 4096 && k >= 1 && stride >= 1 && pad >= 0,
                   "bn_act_maxpool_bwd: bad args");
     EOE_CHECK_ARG((gamma == nullptr) == (beta == nullptr) && (dgamma == nullptr) == (dbeta == nullptr), "bn_act_maxpool_bwd: gamma/beta pairs");
     const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
     hipStream_t s = (hipStream_t)stream;
     EOE_CHECK_IDX((size_t)n * H * W * C / 4, "bn_act_maxpool_bwd");
-    ProfScope ps("bn_act_maxpool_bwd", 0, 2 * 4.0 * n * H * W * C + 2.0 * n * H * W * C + 2 * 5.0 * n * Ho * Wo * C, stream);
+    ProfScope ps("bn_act_maxpool_bwd", 0, 2 * (y16 ? 2.0 : 4.0) * n * H * W * C + 2.0 * n * H * W * C + 2 * 5.0 * n * Ho * Wo * C, stream);
     const QuadDecode dec(C / 4, W, H);
     const int grid = grid_for((size_t)n * H * W * C / 4);
     int g0 = grid > EOE_BN_PARTIALS ? EOE_BN_PARTIALS : grid;
@@ -1175,12 +1205,12 @@ extern "C" int eoe_bn_act_maxpool_bwd(const float* y, const float* stats, const 
         if (g0 < q) g0 = q;
     }
 #define EOE_BMP_T(MODE, SS, GRID, LDS)                                                                                        \
-    hipLaunchKernelGGL((bn_act_maxpool_bwd_kernel<T, MODE, SS>), dim3(GRID), dim3(256), LDS, s, y, stats, gamma, beta, dout, idx, \
+    hipLaunchKernelGGL((bn_act_maxpool_bwd_kernel<T, MODE, SS, YT>), dim3(GRID), dim3(256), LDS, s, y, stats, gamma, beta, dout, idx, \
                        red_scratch, (T*)dy, n, H, W, C, k, stride, pad, Ho, Wo, training, slope, dec)
 #define EOE_BMP(MODE, SS, GRID, LDS)                                                                                          \
     do {                                                                                                                      \
-        if (dtype == EOE_F32) { typedef float T; EOE_BMP_T(MODE, SS, GRID, LDS); }      /* parity mode: dY in fp32 */        \
-        else DISPATCH_T(dtype, EOE_BMP_T(MODE, SS, GRID, LDS));                                                               \
+        if (dtype == EOE_F32) { typedef float T; typedef float YT; EOE_BMP_T(MODE, SS, GRID, LDS); }      /* parity mode: dY in fp32 */ \
+        else DISPATCH_TY(dtype, y16, EOE_BMP_T(MODE, SS, GRID, LDS));                                                         \
     } while (0)
     // the stem's geometry (resnet.py:95: MaxPool2d(3, 2, 1) over an even map): one thread per 2x2 pixel block
     const bool s2k3 = k == 3 && stride == 2 && pad == 1 && H % 2 == 0 && W % 2 == 0 && Ho == H / 2 && Wo == W / 2;
@@ -1195,12 +1225,12 @@ extern "C" int eoe_bn_act_maxpool_bwd(const float* y, const float* stats, const 
         if (g2 < q) g2 = q;
     }
 #define EOE_BMP2_T(MODE, GRID, LDS)                                                                                           \
-    hipLaunchKernelGGL((bn_act_maxpool_bwd_s2k3_kernel<T, MODE>), dim3(GRID), dim3(256), LDS, s, y, stats, gamma, beta, dout, idx, \
+    hipLaunchKernelGGL((bn_act_maxpool_bwd_s2k3_kernel<T, MODE, YT>), dim3(GRID), dim3(256), LDS, s, y, stats, gamma, beta, dout, idx, \
                        red_scratch, (T*)dy, n, H, W, C, Ho, Wo, training, slope, dec2)
 #define EOE_BMP2(MODE, GRID, LDS)                                                                                             \
     do {                                                                                                                      \
-        if (dtype == EOE_F32) { typedef float T; EOE_BMP2_T(MODE, GRID, LDS); }                                               \
-        else DISPATCH_T(dtype, EOE_BMP2_T(MODE, GRID, LDS));                                                                  \
+        if (dtype == EOE_F32) { typedef float T; typedef float YT; EOE_BMP2_T(MODE, GRID, LDS); }                             \
+        else DISPATCH_TY(dtype, y16, EOE_BMP2_T(MODE, GRID, LDS));                                                            \
     } while (0)
     if (s2k3) { g0 = g2; EOE_BMP2(0, g2, 2 * C * sizeof(float)); }
     else if (stride == 2) { EOE_BMP(0, 2, g0, 2 * C * sizeof(float)); } else if (stride == 1) { EOE_BMP(0, 1, g0, 2 * C * sizeof(float)); }

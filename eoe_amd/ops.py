@@ -1263,6 +1263,13 @@ class LinearParityFunction(torch.autograd.Function):
         return dx, dw, db
 
 
+# EOE_CONV_Y16=1 (bench.py --conv-y16): the convolution output between the GEMM and BatchNorm in fp16 instead of fp32
+# (ConvBnActPoolFunction.forward).  A speed option of the 16-bit fast mode, off by default: WideResNet-224 12.3 -> 11.45 ms per step, at the
+# price of one more rounding point in front of every BatchNorm -- on the full-batch fixture the loss leaves the 1e-3 the default fast
+# mode holds (3.2e-3 at worst, reference noise 2.7e-4); AUC stays within 2.4e-4.
+CONV_Y16 = os.environ.get("EOE_CONV_Y16", "0") != "0"
+
+
 class ConvBnActPoolFunction(torch.autograd.Function):
     """conv (+ bias) -> BatchNorm2d -> act -> MaxPool(pool), one layer per call: conv5x5(pad 2) + LeakyReLU(0.01) + pool 2
     for `cnn.py:73-82` (the default when cfg has 8 entries); cfg[8] = (kh, kw, stride, pad) and cfg[9] = the activation's
@@ -1298,11 +1305,17 @@ class ConvBnActPoolFunction(torch.autograd.Function):
         implicit = _implicit_conv and (not is_image) and (cin % 64 == 0 or cin in (8, 16, 32))
         stem = _implicit_conv and is_image and cin == 3 and kw <= 8 and stride % 2 == 0
         img8 = _implicit_conv and is_image and cin == 3 and not stem           # NHWC8 image, per-piece tap decoding
-        y = torch.empty((M, cout), dtype=torch.float32, device=dev)
         # training: the conv GEMM's epilogue leaves per-64-row (sum, sum of squares) of y in `part`, so that the batch
         # statistics need no pass over y (eoe_bn_stats_partials); eval: running statistics
         R = (M + 63) // 64
         part = scratch("bn_part", (R * 2 * cout,), torch.float32, dev) if (training and _fused_bn_stats and cout % 16 == 0) else None
+        # CONV_Y16: with the statistics taken from the GEMM's fp32 accumulators, y itself is written (and saved for backward) in the 16-bit
+        # compute type: the BatchNorm forward pass and the two backward passes read half the bytes, the GEMM's epilogue stores half
+        # (fp16 only: 11 significant bits in front of a normalisation are enough, bfloat16's 8 are not -- a BatchNorm input of mean 3 sigma
+        #  would carry 1e-2 sigma of rounding)
+        y16mode = CONV_Y16 and part is not None and dt == torch.float16
+        y = torch.empty((M, cout), dtype=dt if y16mode else torch.float32, device=dev)
+        ycode = code | (_lib.EOE_Y16 if y16mode else 0)
         if stem:
             # packed first layer: normalised 16-bit NHWC4 image with physical zero padding, gathered inside the GEMM
             Hp, Wp = (H - 1) * stride + (kh + 1) // 2 * 2, ((W - 1) * stride + 8 + 1) // 2 * 2
@@ -1352,7 +1365,7 @@ class ConvBnActPoolFunction(torch.autograd.Function):
             out16 = torch.empty((n, Ho, Wo, cout), dtype=dt, device=dev) if (want16 and _implicit_conv) else None
             idx = torch.empty((n, Ho, Wo, cout), dtype=torch.uint8, device=dev)
             check(lib.eoe_bn_act_maxpool_fwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(out), _p(out16), _p(idx), n, H, W, cout, pk,
-                                             pstride, ppad, slope, code, _stream()), "eoe_bn_act_maxpool_fwd")
+                                             pstride, ppad, slope, ycode, _stream()), "eoe_bn_act_maxpool_fwd")
         else:
             Ho, Wo = H // pool, W // pool
             out = torch.empty((n, cout * Ho * Wo) if flat_out else (n, Ho, Wo, cout), dtype=torch.float32, device=dev)
@@ -1363,10 +1376,10 @@ class ConvBnActPoolFunction(torch.autograd.Function):
                 # the output feeds ONE consumer that reads the 16-bit copy only (a BasicBlock's conv1 -> bn1 -> relu -> conv2): the fp32
                 # tensor is allocated for autograd's bookkeeping but never written (4 of the pass's 10 bytes per element)
                 check(lib.eoe_bn_act_pool_fwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(out16), None, n, H, W, cout, pool,
-                                              0, 0, slope, code, _stream()), "eoe_bn_act_pool_fwd")
+                                              0, 0, slope, ycode, _stream()), "eoe_bn_act_pool_fwd")
             else:
                 check(lib.eoe_bn_act_pool_fwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(out), _p(out16), n, H, W, cout, pool,
-                                              1 if flat_out else 0, 1, slope, code, _stream()), "eoe_bn_act_pool_fwd")
+                                              1 if flat_out else 0, 1, slope, ycode, _stream()), "eoe_bn_act_pool_fwd")
         ctx.save_for_backward(operand, y, stats, conv_w, conv_b, bn_w, bn_b, idx)
         ctx.cfg = (n, H, W, cin, cout, kp, pool, flat_out, training, is_image, Hi, Wi, kh, kw, stride, pad, slope, implicit)
         ctx.has16, ctx.passthrough = out16 is not None, passthrough
@@ -1390,6 +1403,7 @@ class ConvBnActPoolFunction(torch.autograd.Function):
         n, H, W, cin, cout, kp, pool, flat_out, training, is_image, Hi, Wi, kh, kw, stride, pad, slope, implicit = ctx.cfg
         dev, dt = y.device, operand.dtype
         code = dtype_code(dt)
+        ycode = code | (_lib.EOE_Y16 if y.dtype != torch.float32 else 0)
         M = n * H * W
         dout = dout.contiguous().float()
         dy16 = torch.empty((M, cout), dtype=dt, device=dev)
@@ -1398,11 +1412,11 @@ class ConvBnActPoolFunction(torch.autograd.Function):
         red = scratch("bn_red", (BN_SCRATCH * cout,), torch.float32, dev)
         if isinstance(pool, tuple):
             check(lib.eoe_bn_act_maxpool_bwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(dout), _p(idx), _p(red), _p(dy16), _p(dg), _p(db),
-                                             n, H, W, cout, pool[0], pool[1], pool[2], 1 if training else 0, slope, code, _stream()),
+                                             n, H, W, cout, pool[0], pool[1], pool[2], 1 if training else 0, slope, ycode, _stream()),
                   "eoe_bn_act_maxpool_bwd")
         else:
             check(lib.eoe_bn_act_pool_bwd(_p(y), _p(stats), _p(bn_w), _p(bn_b), _p(dout), _p(red), _p(dy16), 0, _p(dg), _p(db), n, H,
-                                          W, cout, pool, 1 if flat_out else 0, 1 if training else 0, 0, slope, code, _stream()),
+                                          W, cout, pool, 1 if flat_out else 0, 1 if training else 0, 0, slope, ycode, _stream()),
                   "eoe_bn_act_pool_bwd")
         dw = _grad_target(conv_w)
         _side_ctx = _conv_wgrad_side_begin(dy16, operand) if CONV_ASYNC_WGRAD else None

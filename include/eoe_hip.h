@@ -403,18 +403,22 @@ int eoe_bn_stats_partials(const float* part, int R, float* sums_scratch, float* 
                           int64_t* num_batches_tracked, int M, int C, float eps, float momentum, void* stream);
 int eoe_bn_stats(const float* y, float* sums_scratch, float* stats, float* running_mean, float* running_var,
                  int64_t* num_batches_tracked, int M, int C, float eps, float momentum, int training, void* stream);
+/* EOE_Y16, OR-ed into the `dtype` argument of the four eoe_bn_act_* entry points below: y is not fp32 but the 16-bit (that dtype) matrix
+ * an eoe_gemm_nt call with out_f32 = 0 and `colstats` wrote -- the batch statistics still come from the GEMM's fp32 accumulators; the
+ * three passes that read y (forward, backward reduce, backward apply) move half the bytes.  16-bit fast mode only. */
+#define EOE_Y16 0x100
 /* out = maxpool_{pool}(act(bn(y))), act(z) = z > 0 ? z : slope*z (slope 0.01 = LeakyReLU of cnn.py, 0 = ReLU of
- * resnet.py, 1 = identity); y fp32 [n,H,W,C]; out 16-bit NHWC (or fp32 if out_f32; or the reference's NCHW flatten
+ * resnet.py, 1 = identity); y fp32 [n,H,W,C] (16-bit with EOE_Y16); out 16-bit NHWC (or fp32 if out_f32; or the reference's NCHW flatten
  * order [n, C*(H/p)*(W/p)] if nchw_flat, cnn.py:83); out16 (optional, with an fp32 NHWC out): a 16-bit copy of out, the
  * operand of the next convolution's implicit GEMM */
-int eoe_bn_act_pool_fwd(const float* y, const float* stats, const float* gamma, const float* beta, void* out, void* out16,
+int eoe_bn_act_pool_fwd(const void* y, const float* stats, const float* gamma, const float* beta, void* out, void* out16,
                         int n, int H, int W, int C, int pool, int nchw_flat, int out_f32, float slope, int dtype, void* stream);
 /* backward of the above: dout fp32 (layout of `out`) -> dy [n*H*W, C] 16-bit (dY operand of the conv wgrad/dgrad), or
  * fp32 if dy_f32; dgamma, dbeta.  red_scratch: EOE_BN_SCRATCH(C) floats. */
 /* out[c] (+= if accumulate) = sum over the rows of an fp32 matrix [rows, C], C % 4 == 0: a convolution's bias gradient in the exact-fp32
  * mode; red_scratch: EOE_BN_SCRATCH(C) floats; fixed summation order, no atomics */
 int eoe_colsum_f32(const float* x, float* out, float* red_scratch, int rows, int C, int accumulate, void* stream);
-int eoe_bn_act_pool_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* dout,
+int eoe_bn_act_pool_bwd(const void* y, const float* stats, const float* gamma, const float* beta, const float* dout,
                         float* red_scratch, void* dy, int dy_f32, float* dgamma, float* dbeta, int n, int H, int W, int C,
                         int pool, int nchw_flat, int training, int accumulate, float slope, int dtype, void* stream);
 
@@ -422,10 +426,10 @@ int eoe_bn_act_pool_bwd(const float* y, const float* stats, const float* gamma, 
  * 112x112x64 post-ReLU activation is never written): out fp32 [n,Ho,Wo,C], optional 16-bit copy, idx = winning tap;
  * backward: dout fp32 [n,Ho,Wo,C] -> dy 16-bit [n*H*W, C] (gather form; fp32 with dtype = EOE_F32), dgamma, dbeta;
  * red_scratch EOE_BN_SCRATCH(C). */
-int eoe_bn_act_maxpool_fwd(const float* y, const float* stats, const float* gamma, const float* beta, float* out, void* out16,
+int eoe_bn_act_maxpool_fwd(const void* y, const float* stats, const float* gamma, const float* beta, float* out, void* out16,
                            uint8_t* idx, int n, int H, int W, int C, int k, int stride, int pad, float slope, int dtype,
                            void* stream);
-int eoe_bn_act_maxpool_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* dout,
+int eoe_bn_act_maxpool_bwd(const void* y, const float* stats, const float* gamma, const float* beta, const float* dout,
                            const uint8_t* idx, float* red_scratch, void* dy, float* dgamma, float* dbeta, int n, int H, int W,
                            int C, int k, int stride, int pad, int training, float slope, int dtype, void* stream);
 

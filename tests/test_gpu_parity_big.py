@@ -465,15 +465,18 @@ def test_wideresnet_big_parity_mode(golden):
     check("wrn hsc PARITY", torch.float16, g, *out, feat_tol=2e-5, k_noise=K_NOISE_PARITY, grad_tol=2e-3)
 
 
-@pytest.mark.parametrize("mode", ["fast", "parity"])
-def test_wideresnet_full_batch(golden, mode):
+@pytest.mark.parametrize("mode", ["fast", "fast_y16", "parity"])
+def test_wideresnet_full_batch(golden, mode, monkeypatch):
     """WideResNet + CBAM at the FULL benchmark batch (128 + 128 images of 224 x 224; every convolution at its benchmark geometry), K = 10
     steps, against the reference's own modules: fp16 fast mode at the fast-mode bars, parity mode (fp32 convolutions) at the stated bar
     scaled by the reference's own fp32-vs-fp64 noise"""
     import eoe_amd
     from eoe_amd.models import WideResNet
+    from eoe_amd import ops
     eoe_amd.set_compute_dtype(torch.float16)
     eoe_amd.set_parity_mode(mode == "parity")
+    # fast_y16: the speed option that keeps the convolution outputs in fp16 in front of BatchNorm (ops.CONV_Y16), at the same guard rails
+    monkeypatch.setattr(ops, "CONV_Y16", mode == "fast_y16")
     try:
         g = golden("g5_wideresnet_hsc_full")
         ref = omodels.deterministic_init(omodels.WideResNet(), tag="wrn")
@@ -483,7 +486,8 @@ def test_wideresnet_full_batch(golden, mode):
         if mode == "parity":
             check("wrn full PARITY", torch.float16, g, *out, feat_tol=2e-5, k_noise=K_NOISE_PARITY, grad_tol=2e-3, gate_scalar_tol=3e-2)
         else:
-            check("wrn full", torch.float16, g, *out, feat_tol=60 * 2.0 ** -11, bars=dict(FAST_BARS[torch.float16]))
+            check("wrn full" + (" fp16 conv outputs" if mode == "fast_y16" else ""), torch.float16, g, *out, feat_tol=60 * 2.0 ** -11,
+                  bars=dict(FAST_BARS[torch.float16]))
     finally:
         eoe_amd.set_parity_mode(False)
 

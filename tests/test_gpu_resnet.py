@@ -198,9 +198,10 @@ def test_add_relu_and_avgpool():
     assert_close(b.grad, bd.grad, 1e-6, 1e-7, "db")
 
 
+@pytest.mark.parametrize("y16", [False, True])
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cin,planes,stride", [(64, 64, 1), (64, 128, 2)])
-def test_basic_block_vs_oracle(dtype, cin, planes, stride):
+def test_basic_block_vs_oracle(dtype, cin, planes, stride, y16, monkeypatch):
     """one BasicBlock (conv-bn-relu-conv-bn [+ downsample] -> CBAM -> +res -> relu) forward + all gradients"""
     import eoe_amd
     from eoe_amd.models.resnet import BasicBlock
@@ -214,6 +215,22 @@ def test_basic_block_vs_oracle(dtype, cin, planes, stride):
     blk = blk.cuda().train()
     x = torch.from_numpy(fill.fill("bb/x", (4, cin, 14, 14), std=1.0))
     w = torch.from_numpy(fill.fill("bb/dy", (4, planes, 14 // stride, 14 // stride), std=1.0))
+    from eoe_amd import ops as _ops
+    if y16 and dtype != torch.float16:
+        pytest.skip("the fp16 convolution output (ops.CONV_Y16) is an fp16-only option")
+    monkeypatch.setattr(_ops, "CONV_Y16", y16)
+    if _ops.CONV_Y16 and dtype == torch.float16:
+        # the kernels keep a convolution's output in fp16 between the GEMM and BatchNorm (ops.CONV_Y16, channel counts that are multiples
+        # of 16): the fp64 reference sees the same rounded values (straight-through for the gradient), so that the ReLU masks agree
+        class _RoundedConv:
+            def __getattr__(self, k):
+                return getattr(F, k)
+
+            @staticmethod
+            def conv2d(inp, weight, bias=None, **kw):
+                o = F.conv2d(inp, weight, bias, **kw)
+                return o + (o.to(dtype).to(o.dtype) - o).detach() if weight.shape[0] % 16 == 0 else o
+        monkeypatch.setattr(omodels, "F", _RoundedConv())
     # how far the oracle's own fp32 evaluation is from fp64, per tensor (conditioning of the 4-image BatchNorm statistics)
     x32 = x.clone().requires_grad_(True)
     ref.train()
@@ -356,12 +373,16 @@ def test_wideresnet_full_batch_properties():
     assert not still, still
 
 
+@pytest.mark.parametrize("y16", [False, True])
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_stem_conv_bn_relu_maxpool_fused(dtype):
+def test_stem_conv_bn_relu_maxpool_fused(dtype, y16, monkeypatch):
     """conv7x7/2 -> BN -> ReLU -> MaxPool(3,2,1) as ONE unit (packed first layer + fused BN/ReLU/overlapping max-pool kernels)
     against torch-CPU fp64, forward and every gradient"""
     import eoe_amd
     import eoe_amd.ops as ops
+    if y16 and dtype != torch.float16:
+        pytest.skip("the fp16 convolution output (ops.CONV_Y16) is an fp16-only option")
+    monkeypatch.setattr(ops, "CONV_Y16", y16)
     eoe_amd.set_compute_dtype(dtype)
     n, cout, H = 3, 64, 36
     x, xr = f32("st/x", (n, 3, H, H), 1.0)
@@ -380,7 +401,15 @@ def test_stem_conv_bn_relu_maxpool_fused(dtype):
     wd = wr.to(dtype).double().requires_grad_(True)
     gd, bd = (t.double().requires_grad_(True) for t in (gr, br))
     rmr, rvr = torch.zeros(cout, dtype=torch.float64), torch.ones(cout, dtype=torch.float64)
-    zr = torch.relu(omodels.batch_norm(F.conv2d(xd, wd, None, stride=2, padding=3), gd, bd, rmr, rvr, True, 0.1, 1e-5))
+    yr = F.conv2d(xd, wd, None, stride=2, padding=3)
+    if ops.CONV_Y16 and dtype == torch.float16:
+        # the kernels keep the convolution output in fp16 between the GEMM and BatchNorm (statistics from the fp32 accumulators): the
+        # reference normalises the same rounded values with the unrounded statistics (straight-through for the gradient)
+        yq = yr + (yr.to(dtype).double() - yr).detach()
+        mu, var = yr.mean((0, 2, 3), keepdim=True), yr.var((0, 2, 3), unbiased=False, keepdim=True)
+        zr = torch.relu((yq - mu) / torch.sqrt(var + 1e-5) * gd.view(1, -1, 1, 1) + bd.view(1, -1, 1, 1))
+    else:
+        zr = torch.relu(omodels.batch_norm(yr, gd, bd, rmr, rvr, True, 0.1, 1e-5))
     want = F.max_pool2d(zr, 3, 2, 1).permute(0, 2, 3, 1)
     assert_close(out, want, 1e-3, 2e-3, "stem forward")
     dout, doutr = f32("st/dout", tuple(out.shape), 1.0)
