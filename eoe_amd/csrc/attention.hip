@@ -63,6 +63,22 @@ __device__ __forceinline__ V8<T> tfrag(const char* lds, int tc, int s, int lane)
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return __builtin_bit_cast(V8<T>, r);
 }
+// the same with the COLUMNS of the four tiles tc = 0..3 interleaved: lane <-> column 16*((lane&15)>>2) + 4*tc + (lane&3).  As the A operand of a
+// transposed product (rows of the result = these columns) it leaves lane (lane&15, g = lane>>4) of result tile tc with rows
+// 16*g + 4*tc + 0..3 -- over the four tiles 16 CONSECUTIVE rows per lane: a lane's share of an output row is one 32-byte run
+// (attn_bwd4_kernel's dQ / dK / dV stores) instead of four 8-byte pieces 32 bytes apart.  Only the address each lane hands the transposing read
+// changes.
+template <typename T>
+__device__ __forceinline__ V8<T> tfrag_il(const char* lds, int tc, int s, int lane) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const char* a = lds + (32 * s + 4 * g + q) * ROWB + (16 * p + 4 * tc) * 2;
+    i16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4v*)(a));
+    i16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4v*)(a + 16 * ROWB));
+    i16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return __builtin_bit_cast(V8<T>, r);
+}
 // two accumulator tiles (rows 32s+0..15 and 32s+16..31 of a transposed product) as the next B operand
 template <typename T>
 __device__ __forceinline__ V8<T> acc_as_operand(const f32x4& lo, const f32x4& hi) {
@@ -535,18 +551,25 @@ __global__ __launch_bounds__(256) void attn_bwd4_kernel(const T* __restrict__ qk
             lse_s[mine] = m + __logf(sum);
             dlt_s[mine] = dl;
         }
-        // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]
+        // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]; tile td, register r of lane (lr, lg) = d 16 lg + 4 td + r (tfrag_il): the lane's
+        // four tiles are 16 consecutive d of its query's row -- two 16-byte stores
+        u32x2 pk[4];
 #pragma unroll
         for (int td = 0; td < 4; ++td) {
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int st = 0; st < 2; ++st)
-                o = T16<T>::mfma16(tfrag<T>(ks_, td, st, lane), acc_as_operand<T>(dp[2 * st], dp[2 * st + 1]), o);
-            if (mine < L) *(u32x2*)(dqp + (size_t)mine * ld + 16 * td + 4 * lg) = pack4<T>(o[0], o[1], o[2], o[3]);
+                o = T16<T>::mfma16(tfrag_il<T>(ks_, td, st, lane), acc_as_operand<T>(dp[2 * st], dp[2 * st + 1]), o);
+            pk[td] = pack4<T>(o[0], o[1], o[2], o[3]);
             if (bpart) {
                 const f32x4 cs = slab_sum(o, mine < L);
-                if (lr == 0) *(f32x4*)(myred + 16 * td + 4 * lg) = cs;
+                if (lr == 0) *(f32x4*)(myred + 16 * lg + 4 * td) = cs;
             }
+        }
+        if (mine < L) {
+            T* d = dqp + (size_t)mine * ld + 16 * lg;
+            *(u32x4*)d = (u32x4){pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
+            *(u32x4*)(d + 8) = (u32x4){pk[2][0], pk[2][1], pk[3][0], pk[3][1]};
         }
     }
     __syncthreads();
@@ -581,25 +604,32 @@ __global__ __launch_bounds__(256) void attn_bwd4_kernel(const T* __restrict__ qk
             }
         }
         // dV^T[d][key] = sum_q dO^T[d][q] P[q][key] ;  dK^T[d][key] = sum_q Q^T[d][q] dS[q][key]
+        u32x2 pv[4], pk[4];
 #pragma unroll
         for (int td = 0; td < 4; ++td) {
             f32x4 ov = {0.f, 0.f, 0.f, 0.f}, ok = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                ov = T16<T>::mfma16(tfrag<T>(dos, td, st, lane), acc_as_operand<T>(s[2 * st], s[2 * st + 1]), ov);
-                ok = T16<T>::mfma16(tfrag<T>(qs, td, st, lane), acc_as_operand<T>(dp[2 * st], dp[2 * st + 1]), ok);
+                ov = T16<T>::mfma16(tfrag_il<T>(dos, td, st, lane), acc_as_operand<T>(s[2 * st], s[2 * st + 1]), ov);
+                ok = T16<T>::mfma16(tfrag_il<T>(qs, td, st, lane), acc_as_operand<T>(dp[2 * st], dp[2 * st + 1]), ok);
             }
-            if (mine < L) {
-                *(u32x2*)(dqp + (size_t)mine * ld + 2 * D + 16 * td + 4 * lg) = pack4<T>(ov[0], ov[1], ov[2], ov[3]);
-                *(u32x2*)(dqp + (size_t)mine * ld + D + 16 * td + 4 * lg) = pack4<T>(ok[0], ok[1], ok[2], ok[3]);
-            }
+            pv[td] = pack4<T>(ov[0], ov[1], ov[2], ov[3]);
+            pk[td] = pack4<T>(ok[0], ok[1], ok[2], ok[3]);
             if (bpart) {
                 const f32x4 cv = slab_sum(ov, mine < L), ck = slab_sum(ok, mine < L);
                 if (lr == 0) {
-                    *(f32x4*)(myred + 128 + 16 * td + 4 * lg) = cv;
-                    *(f32x4*)(myred + 64 + 16 * td + 4 * lg) = ck;
+                    *(f32x4*)(myred + 128 + 16 * lg + 4 * td) = cv;
+                    *(f32x4*)(myred + 64 + 16 * lg + 4 * td) = ck;
                 }
             }
+        }
+        if (mine < L) {
+            T* dv = dqp + (size_t)mine * ld + 2 * D + 16 * lg;
+            T* dk = dqp + (size_t)mine * ld + D + 16 * lg;
+            *(u32x4*)dv = (u32x4){pv[0][0], pv[0][1], pv[1][0], pv[1][1]};
+            *(u32x4*)(dv + 8) = (u32x4){pv[2][0], pv[2][1], pv[3][0], pv[3][1]};
+            *(u32x4*)dk = (u32x4){pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
+            *(u32x4*)(dk + 8) = (u32x4){pk[2][0], pk[2][1], pk[3][0], pk[3][1]};
         }
     }
     if (bpart) {
