@@ -1,0 +1,7 @@
+import torch
+M = 12800
+for n, k in ((2304, 768), (768, 3072), (3072, 768), (768, 768), (768, 2304)):
+    a = torch.randn(M, k, device="cuda").half(); w = torch.randn(n, k, device="cuda").half(); b = torch.randn(n, device="cuda").half()
+    for _ in range(5):
+        torch.nn.functional.linear(a, w, b)
+    torch.cuda.synchronize()
