@@ -6,6 +6,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import eoe_amd.ops as ops
 
+if os.environ.get("EOE_NT_FLAGS"):          # e.g. 512: every ViT shape on the one-wave 160x256 / 256x256 kernel (gemm256)
+    from eoe_amd import _lib
+    _lib.check(_lib.lib.eoe_set_option(b"nt_flags", int(os.environ["EOE_NT_FLAGS"])), "eoe_set_option")
 dt = torch.float16
 M = 12800
 shapes = [("qkv fwd (bias)", M, 2304, 768, True), ("fc dgrad", M, 768, 3072, False), ("out dgrad", M, 768, 768, False),
