@@ -466,6 +466,114 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmP p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ NT, 160x256x32 tiles, two workgroups per CU
+// Fourth tile shape (round 3; nt_flags bit 12 = 4096 switches it off).  Why: the 160x128 kernel above is LDS-BANDWIDTH bound -- its 80x64
+// wave tiles read 9 KB of fragments per 20 MFMAs, 112 B/clk per CU, and the LDS-DMA of the same k-tile writes 57 B/clk more: 169 B/clk asked
+// of a 128 B/clk LDS.  Here a wave owns 80x128 (13 KB per 40 MFMAs: 81 B/clk + 41 B/clk of DMA); to keep TWO workgroups on a CU the k-tile is 32
+// deep (2 x 26 KB of LDS per workgroup) and a wave stays inside 256 registers (160 accumulators, single-buffered fragments).  LDS image of a
+// k-tile: 16-row blocks of 1 KB (one LDS-DMA instruction each), row r of a block at r * 64 B, its four 16-byte k-chunks XOR-ed with (r >> 2) & 3:
+// a fragment read (16 rows x one chunk) then touches 16 different 16-byte bank groups.  Same products in the same k order as the other
+// kernels: same bits.  MI = 5 only.
+constexpr int BKW = 32;
+constexpr int AW_BYTES = 160 * BKW * 2;              // 10 KiB: ten 16-row blocks
+constexpr int BW_BYTES = 256 * BKW * 2;              // 16 KiB: sixteen blocks
+constexpr int STAGEW_BYTES = AW_BYTES + BW_BYTES;    // 26 KiB
+constexpr int SMEMW_BYTES = 2 * STAGEW_BYTES;        // 52 KiB: two workgroups per CU
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt128w_kernel(GemmP p) {
+    constexpr int MI = 5, BM = 160;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = (p.N + 255) / 256;
+    const int total_tiles = tiles_n * ((p.M + BM - 1) / BM);
+    const int r = xcd_remap((int)blockIdx.x, total_tiles);
+    const int m0 = (r / tiles_n) * BM, n0 = (r % tiles_n) * 256;
+    const int nk = p.K / BKW;
+
+    __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.bytesA);
+    __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.bytesB);
+    // one LDS-DMA instruction = one 16-row block: lane -> (row lane >> 2, chunk (lane & 3) ^ ((row >> 2) & 3)).  A: blocks wave, wave + 4,
+    // wave + 8 (< 10); B: blocks wave, wave + 4, wave + 8, wave + 12
+    const int srow = lane >> 2, schunk = (lane & 3) ^ ((srow >> 2) & 3);
+    unsigned offA[3], offB[4];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int ga = m0 + (wave + 4 * t) * 16 + srow;
+        offA[t] = (wave + 4 * t < 2 * MI && ga < p.M) ? (unsigned)(((size_t)ga * p.lda + schunk * 8) * 2) : EOE_OOB;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int gb = n0 + (wave + 4 * t) * 16 + srow;
+        offB[t] = (gb < p.N) ? (unsigned)(((size_t)gb * p.ldb + schunk * 8) * 2) : EOE_OOB;
+    }
+    const bool a3 = wave + 8 < 2 * MI;               // waves 0, 1 stage three A blocks, waves 2, 3 two (uniform)
+#define EOE_STAGEW(slot, kt)                                                                                                \
+    do {                                                                                                                    \
+        char* sa_ = smem + (slot) * STAGEW_BYTES;                                                                           \
+        char* sb_ = sa_ + AW_BYTES;                                                                                         \
+        const unsigned k0_ = (unsigned)(kt) * (BKW * 2u);                                                                   \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(sa_ + wave * 1024), 16, offA[0] + k0_, 0, 0, 0);         \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(sa_ + (wave + 4) * 1024), 16, offA[1] + k0_, 0, 0, 0);   \
+        if (a3) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(sa_ + (wave + 8) * 1024), 16, offA[2] + k0_, 0, 0, 0); \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                                       \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(sb_ + (wave + 4 * t) * 1024), 16, offB[t] + k0_, 0, 0, 0); \
+    } while (0)
+
+    const int wm0 = (wave >> 1) * (16 * MI), wn0 = (wave & 1) * 128;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int fo = lr * 64 + ((lg ^ ((lr >> 2) & 3)) * 16);                      // this lane's piece of a 16-row block
+    const int fragA = (wave >> 1) * MI * 1024 + fo, fragB = AW_BYTES + (wave & 1) * 8 * 1024 + fo;
+    typedef typename T16<T>::v8 V8;
+
+    f32x4 accL[MI][4], accR[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            accL[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            accR[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    EOE_STAGEW(0, 0);
+    if (nk > 1) {
+        EOE_STAGEW(1, 1);
+        if (a3) { EOE_WAIT_VM(7); } else { EOE_WAIT_VM(6); }        // tile 0 landed, tile 1 may stay in flight
+    } else {
+        EOE_WAIT_VM(0);
+    }
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* sc = smem + (kt & 1) * STAGEW_BYTES;
+        V8 xa[MI], wl[4], wr[4];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) xa[i] = *(const V8*)(sc + fragA + i * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wl[i] = *(const V8*)(sc + fragB + i * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wr[i] = *(const V8*)(sc + fragB + (4 + i) * 1024);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) accL[mi][ni] = T16<T>::mfma16(wl[ni], xa[mi], accL[mi][ni]);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) accR[mi][ni] = T16<T>::mfma16(wr[ni], xa[mi], accR[mi][ni]);
+        // tile kt + 1 landed (this wave's pieces), every wave done reading slot kt & 1: refill it with tile kt + 2
+        EOE_WAIT_VM(0);
+        EOE_WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) EOE_STAGEW(kt & 1, kt + 2);
+    }
+#undef EOE_STAGEW
+    GemmP ep;
+    load_epilogue_args(ep, p);
+    // two 64-column halves through the 160x128 kernel's epilogue; scratch: this wave's own 4 KiB of slot 0 (all ring reads are behind the last barrier)
+    epilogue<T, EPI, 4, MI>(ep, accL, m0 + wm0, n0 + wn0, lane, smem + wave * 4096);
+    epilogue<T, EPI, 4, MI>(ep, accR, m0 + wm0, n0 + wn0 + 64, lane, smem + wave * 4096);
+}
+
 // ------------------------------------------------------------------------------------------------ NT, N <= 64
 // Third tile shape, for cout = 64 layers (plain epilogue): 256x64x64, four waves stacked along M (64x64 each -- the same
 // 16 MFMAs per 8 fragment reads as the other kernels; the 256x64 tile of the persistent kernel gives a wave 64x32 = 8 MFMAs
@@ -646,6 +754,27 @@ int launch_nt128(const GemmP& p, int epi, hipStream_t s) {
     EOE_CHECK_LAUNCH("gemm_nt128");
     return finish_colsum(p, epi, MI, s);
 }
+
+template <typename T>
+int launch_nt128w(const GemmP& p, int epi, hipStream_t s) {
+    const int tiles = cdiv(p.M, 160) * cdiv(p.N, 256);
+#define EOE_NT128W_CASE(E)                                                                  \
+    case E:                                                                                 \
+        { static bool once = (hipFuncSetAttribute((const void*)gemm_nt128w_kernel<T, E>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEMW_BYTES), true); (void)once; } \
+        hipLaunchKernelGGL((gemm_nt128w_kernel<T, E>), dim3(tiles), dim3(256), SMEMW_BYTES, s, p); \
+        break;
+    switch (epi) {
+        EOE_NT128W_CASE(EOE_EPI_NONE)
+        EOE_NT128W_CASE(EOE_EPI_GELU)
+        EOE_NT128W_CASE(EOE_EPI_RESIDUAL)
+        EOE_NT128W_CASE(EOE_EPI_GELU_BWD)
+        default: return eoe_set_error(EOE_ERR_ARG, "gemm_nt: unknown epilogue %d", epi);
+    }
+#undef EOE_NT128W_CASE
+    EOE_CHECK_LAUNCH("gemm_nt128w");
+    return finish_colsum(p, epi, 5, s);
+}
+
 // 128- or 160-row tiles: whichever needs less (rounds over the 2 x #CU workgroup slots) x (rows per tile)
 template <typename T>
 int launch_nt128_auto(const GemmP& p, int epi, hipStream_t s) {
@@ -778,6 +907,13 @@ int launch_nt(const GemmP& p, int epi, int gather, hipStream_t s) {
     // layers): the one-wave kernel wins where the epilogue is the GELU pair of outputs behind a short K loop -- c_fc forward 1.167 against
     // 1.260 --, ties on the K >= 2304 shapes (-0.001 ... -0.010) and loses on QKV (+0.135), GELU' x dY (+0.057) and the two K = 768 -> 768
     // shapes (+0.056, +0.020).  So: c_fc forward only (nt_flags bit 10 = 1024 turns the rule off).
+    // the 160x256x32 two-workgroup kernel on the wide-N shapes (c_fc forward, GELU' x dY: 10.64 -> 10.54 ms per step, three interleaved
+    // pairs, same bits; nt_flags bit 12 = 4096 switches it off)
+    if (!(g_nt_flags & (4096 | 4 | 8 | 512)) && gather == 0 && !p.colsum_sq && (p.N % 256) == 0 && p.N >= 2048 && (p.K % 32) == 0 && p.M >= 2048) {
+        // only where its tiles fill the 2 x #CU workgroup slots to >= 90 % in every round (N = 3072 at M = 12 800: 960 of 1024; N = 2304: 720)
+        const long tiles = (long)cdiv(p.M, 160) * (p.N / 256), slots = 2L * ncu;
+        if (tiles * 10 >= ((tiles + slots - 1) / slots) * slots * 9) return launch_nt128w<T>(p, epi, s);
+    }
     const bool gelu_wide = epi == EOE_EPI_GELU && p.N >= 2048 && p.K <= 1024 && !(g_nt_flags & 1024);
     if (((g_nt_flags & 512) || gelu_wide) && !(g_nt_flags & (4 | 8)) && epilogue_direct_ok(p, epi) && p.M >= 2048 && p.N >= 512) {
         // time of a launch in units of one 16-row x 256-column x 64-deep slab of MFMAs: rounds over the CUs x (rows per tile x

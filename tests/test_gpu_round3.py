@@ -505,3 +505,43 @@ def test_f32_colsum(rows, cols):
     out2 = torch.full((cols,), 7.0, device="cuda")
     ops._f32_colsum(x, out2)
     assert torch.equal(out, out2)                       # fixed summation order
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_wide_two_workgroup_nt_kernel_keeps_the_bits(dtype):
+    """the 160x256x32 two-workgroup NT kernel (default for N >= 2048 in multiples of 256 where its tiles fill the workgroup slots) adds the
+    same products in the same k order as the kernels it replaces: plain, GELU-pair and GELU' x dY epilogues (with fused column sums), full
+    and ragged M, bitwise equal to the launch with nt_flags bit 12 set"""
+    from eoe_amd import ops, _lib
+
+    def flags(v):
+        _lib.check(_lib.lib.eoe_set_option(b"nt_flags", v), "eoe_set_option")
+
+    g = torch.Generator(device="cuda").manual_seed(5)
+    try:
+        for m, n, k in ((12800, 3072, 768), (12763, 3072, 768), (6400, 2048, 256), (12800, 3072, 96)):
+            a = (torch.randn(m, k, device="cuda", generator=g)).to(dtype)
+            w = (torch.randn(n, k, device="cuda", generator=g) * 0.05).to(dtype)
+            bias = torch.randn(n, device="cuda", generator=g)
+            pre = torch.randn(m, n, device="cuda", generator=g).to(dtype)
+            res = {}
+            for f in (4096, 0):
+                flags(f)
+                o1 = torch.empty(m, n, device="cuda", dtype=dtype)
+                ops.gemm_nt(a, w, o1, bias=bias)
+                o2, p2 = torch.empty(m, n, device="cuda", dtype=dtype), torch.empty(m, n, device="cuda", dtype=dtype)
+                ops.gemm_nt(a, w, o2, bias=bias, epilogue=ops.EPI_GELU, aux_out=p2)
+                o3, cs = torch.empty(m, n, device="cuda", dtype=dtype), torch.zeros(n, device="cuda")
+                ops.gemm_nt(a, w, o3, epilogue=ops.EPI_GELU_BWD, aux=pre, colsum_out=cs)
+                o4 = torch.empty(m, n, device="cuda", dtype=torch.float32)
+                ops.gemm_nt(a, w, o4, bias=bias, epilogue=ops.EPI_RESIDUAL, aux=pre.float())
+                torch.cuda.synchronize()
+                res[f] = (o1, o2, p2, o3, o4, cs)
+            for x, y in zip(res[0][:5], res[4096][:5]):
+                assert torch.equal(x, y), (m, n, k)
+            d = (res[0][5] - res[4096][5]).abs().max().item() / (res[4096][5].abs().max().item() + 1e-30)
+            assert d < 1e-5, (m, n, k, d)          # the column sums go through partial rows per 80 output rows either way
+            ref = (a.float() @ w.float().t() + bias)
+            assert (res[0][0].float() - ref).abs().max().item() < 0.05 * ref.abs().max().item()
+    finally:
+        flags(0)
