@@ -472,8 +472,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmP p) {
 // of a 128 B/clk LDS.  Here a wave owns 80x128 (13 KB per 40 MFMAs: 81 B/clk + 41 B/clk of DMA); to keep TWO workgroups on a CU the k-tile is 32
 // deep (2 x 26 KB of LDS per workgroup) and a wave stays inside 256 registers (160 accumulators, single-buffered fragments).  LDS image of a
 // k-tile: 16-row blocks of 1 KB (one LDS-DMA instruction each), row r of a block at r * 64 B, its four 16-byte k-chunks XOR-ed with (r >> 2) & 3:
-// a fragment read (16 rows x one chunk) then touches 16 different 16-byte bank groups.  Same products in the same k order as the other
-// kernels: same bits.  MI = 5 only.
+// a fragment read (16 rows x one chunk) then touches 16 different 16-byte bank groups.  (rocprofv3 still counts SQ_LDS_BANK_CONFLICT = 5 M
+// cycles per launch for this image; the 160x128 kernel's 128-byte-row image rebuilt from pairs of row blocks counts 0 and measured 0.04 ms
+// per step SLOWER, two builds interleaved on one box -- kept as is.)  Same products in the same k order as the other kernels: same bits.
+// MI = 5 only.
 constexpr int BKW = 32;
 constexpr int AW_BYTES = 160 * BKW * 2;              // 10 KiB: ten 16-row blocks
 constexpr int BW_BYTES = 256 * BKW * 2;              // 16 KiB: sixteen blocks
