@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmP p) {
 // Fourth tile shape (round 3; nt_flags bit 12 = 4096 switches it off).  Why: the 160x128 kernel above is LDS-BANDWIDTH bound -- its 80x64
 // wave tiles read 9 KB of fragments per 20 MFMAs, 112 B/clk per CU, and the LDS-DMA of the same k-tile writes 57 B/clk more: 169 B/clk asked
 // of a 128 B/clk LDS.  Here a wave owns 80x128 (13 KB per 40 MFMAs: 81 B/clk + 41 B/clk of DMA); to keep TWO workgroups on a CU the k-tile is 32
-// deep (2 x 26 KB of LDS per workgroup) and a wave stays inside 256 registers (160 accumulators, single-buffered fragments).  LDS image of a
+// deep (3 x 26 KB of LDS per workgroup) and a wave stays inside 256 registers (160 accumulators, single-buffered fragments).  LDS image of a
 // k-tile: 16-row blocks of 1 KB (one LDS-DMA instruction each), row r of a block at r * 64 B, its four 16-byte k-chunks XOR-ed with (r >> 2) & 3:
 // a fragment read (16 rows x one chunk) then touches 16 different 16-byte bank groups.  (rocprofv3 still counts SQ_LDS_BANK_CONFLICT = 5 M
 // cycles per launch for this image; the 160x128 kernel's 128-byte-row image rebuilt from pairs of row blocks counts 0 and measured 0.04 ms
@@ -480,7 +480,8 @@ constexpr int BKW = 32;
 constexpr int AW_BYTES = 160 * BKW * 2;              // 10 KiB: ten 16-row blocks
 constexpr int BW_BYTES = 256 * BKW * 2;              // 16 KiB: sixteen blocks
 constexpr int STAGEW_BYTES = AW_BYTES + BW_BYTES;    // 26 KiB
-constexpr int SMEMW_BYTES = 2 * STAGEW_BYTES;        // 52 KiB: two workgroups per CU
+constexpr int NSTAGEW = 3;
+constexpr int SMEMW_BYTES = NSTAGEW * STAGEW_BYTES;  // 78 KiB: two workgroups per CU (156 of 160 KiB)
 
 template <typename T, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt128w_kernel(GemmP p) {
@@ -537,6 +538,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128w_kernel(GemmP p) {
             accL[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             accR[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+    // (The same weaving in the 2-stage 160x128 kernel above -- pieces of tile kt + 2 among the second half's MFMAs -- measured 10.49 -> 10.95 ms
+    //  per step: with one tile of lead the later issue is paid in full at the next wait.  Here the third stage pays for it.)
+    // 3-stage ring.  Tile kt is multiplied from slot kt % 3 while tile kt + 1 lands and the pieces of tile kt + 2 are ISSUED BETWEEN the MFMAs of
+    // this iteration (into the slot iteration kt - 1 freed): behind the barrier, in a burst, an LDS-DMA instruction costs the issuing wave ~100
+    // cycles against ~30 spread out (gemm256's stamps), seven of them against a 640-cycle MFMA block.
+    // A wave issues 7 (waves 0, 1) or 6 loads per tile.
+#define EOE_PIECE_A(t, slot_, kt_)                                                                                            \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(smem + (slot_) * STAGEW_BYTES + (wave + 4 * (t)) * 1024), 16,       \
+                                             offA[t] + (unsigned)(kt_) * (BKW * 2u), 0, 0, 0)
+#define EOE_PIECE_B(t, slot_, kt_)                                                                                            \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(smem + (slot_) * STAGEW_BYTES + AW_BYTES + (wave + 4 * (t)) * 1024), 16, \
+                                             offB[t] + (unsigned)(kt_) * (BKW * 2u), 0, 0, 0)
     EOE_STAGEW(0, 0);
     if (nk > 1) {
         EOE_STAGEW(1, 1);
@@ -545,8 +558,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128w_kernel(GemmP p) {
         EOE_WAIT_VM(0);
     }
     __builtin_amdgcn_s_barrier();
+    int slot = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        const char* sc = smem + (kt & 1) * STAGEW_BYTES;
+        const char* sc = smem + slot * STAGEW_BYTES;
+        const int fslot = slot == 0 ? 2 : slot - 1;           // the slot iteration kt - 1 read (kt = 0: the third, untouched one)
+        const bool more = kt + 2 < nk;
         V8 xa[MI], wl[4], wr[4];
 #pragma unroll
         for (int i = 0; i < MI; ++i) xa[i] = *(const V8*)(sc + fragA + i * 1024);
@@ -555,19 +571,34 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128w_kernel(GemmP p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) wr[i] = *(const V8*)(sc + fragB + (4 + i) * 1024);
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+        for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) accL[mi][ni] = T16<T>::mfma16(wl[ni], xa[mi], accL[mi][ni]);
+            if (more) {                                       // one piece per four MFMAs
+                if (mi == 0) EOE_PIECE_A(0, fslot, kt + 2);
+                if (mi == 1) EOE_PIECE_A(1, fslot, kt + 2);
+                if (mi == 2 && a3) EOE_PIECE_A(2, fslot, kt + 2);
+                if (mi == 3) EOE_PIECE_B(0, fslot, kt + 2);
+                if (mi == 4) EOE_PIECE_B(1, fslot, kt + 2);
+            }
+        }
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+        for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) accR[mi][ni] = T16<T>::mfma16(wr[ni], xa[mi], accR[mi][ni]);
-        // tile kt + 1 landed (this wave's pieces), every wave done reading slot kt & 1: refill it with tile kt + 2
-        EOE_WAIT_VM(0);
+            if (more) {
+                if (mi == 0) EOE_PIECE_B(2, fslot, kt + 2);
+                if (mi == 1) EOE_PIECE_B(3, fslot, kt + 2);
+            }
+        }
+        // tile kt + 1 landed (this wave's pieces; those of tile kt + 2, just issued, may stay in flight), every wave done reading this slot
+        if (more) { if (a3) { EOE_WAIT_VM(7); } else { EOE_WAIT_VM(6); } } else { EOE_WAIT_VM(0); }
         EOE_WAIT_LGKM0();
         __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) EOE_STAGEW(kt & 1, kt + 2);
+        slot = slot == NSTAGEW - 1 ? 0 : slot + 1;
     }
+#undef EOE_PIECE_A
+#undef EOE_PIECE_B
 #undef EOE_STAGEW
     GemmP ep;
     load_epilogue_args(ep, p);
