@@ -35,7 +35,7 @@ class GemmArgs(C.Structure):
                 ("lda", _i32), ("ldb", _i32), ("ldc", _i32), ("ldaux", _i32),
                 ("dtype", _i32), ("epilogue", _i32), ("out_f32", _i32), ("accumulate", _i32), ("alpha", _f32),
                 ("workspace", _vp), ("workspace_bytes", _i64), ("gather", _i32), ("geo", ConvGeometry), ("colstats", _i32),
-                ("unpack_dw", _i32)]
+                ("unpack_dw", _i32), ("split_k", _i32)]
 
 
 class AdamChunk(C.Structure):

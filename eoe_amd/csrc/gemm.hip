@@ -21,6 +21,8 @@
 // loads/stores are 8-B (16-bit) or 16-B (fp32) vectors along the contiguous dimension.
 #include "gemm_common.h"
 #include <stdlib.h>
+#include <map>
+#include <mutex>
 #include <type_traits>
 
 unsigned long long* g_stamp_buf = nullptr;
@@ -316,7 +318,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmP p) {
     const int total_tiles = tiles_n * ((p.M + BM - 1) / BM);
     const int r = xcd_remap((int)blockIdx.x, total_tiles);
     const int m0 = (r / tiles_n) * BM, n0 = (r % tiles_n) * 128;
-    const int nk = p.K / BK;
+    // split k (launch_nt128_splitk: small M, long K): gridDim.y equal k-ranges, workgroup y writes its fp32 partial tile to slice y of C
+    const int nk = (p.K / BK) / (int)gridDim.y;
+    const unsigned kbase = (unsigned)blockIdx.y * (unsigned)nk * (BK * 2u);
 
     __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.bytesA);
     __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.bytesB);
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmP p) {
     do {                                                                                                                    \
         char* sa_ = smem + (slot) * STAGE128_BYTES;                                                                         \
         char* sb_ = sa_ + A128_BYTES;                                                                                       \
-        const unsigned k0_ = (unsigned)(kt) * (BK * 2u);                                                                    \
+        const unsigned k0_ = kbase + (unsigned)(kt) * (BK * 2u);                                                            \
         if (GATHER == 1) {                                                                                                  \
             /* k-tiles are staged in order 0, 1, 2, ...: the tap cursor advances with them */                                 \
             const unsigned delta_ = (unsigned)(((g_ky * p.gW + g_kx) * p.gC + g_c0) * 2);                                   \
@@ -458,6 +462,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmP p) {
     if (stp && tid == 0) stp[2] = __builtin_amdgcn_s_memtime();
     GemmP ep;
     load_epilogue_args(ep, p);
+    if (gridDim.y > 1) ep.C = (char*)ep.C + (size_t)blockIdx.y * (size_t)ep.M * ep.ldc * sizeof(float);      // split k: slice y
     // scratch: this wave's own 4 KiB of slot 0 (all reads of the ring are behind the final barrier)
     epilogue<T, EPI, NI, MI>(ep, acc, m0 + wm0, n0 + wn0, lane, smem + wave * 4096);
     if (stp && tid == 0) {
@@ -820,6 +825,69 @@ int launch_nt128_auto(const GemmP& p, int epi, hipStream_t s) {
     return five ? launch_nt128<T, 5>(p, epi, s) : launch_nt128<T, 4>(p, epi, s);
 }
 
+// ---- split k for small M behind a long K, on request (eoe_gemm_args.split_k; round 3: the last ViT block on its class-token rows: 256 x 768 x
+// 3072 is 12 tiles of 48 k-tiles each -- 50 us of one latency chain per CU on 12 CUs).  Not chosen by shape alone: a block's result must not
+// depend on the batch size (test_full_batch_properties), and the split depends on K only.  S equal k-ranges per tile (grid.y), fp32 partial tiles in a library-owned buffer, then one
+// elementwise kernel that adds the S partials IN ORDER (reproducible) and applies alpha / bias / residual / the output type.
+template <typename T>
+__global__ __launch_bounds__(256) void nt_splitk_finish_kernel(const float* __restrict__ part, int S, int M, int N, float alpha,
+                                                               const float* __restrict__ bias, const float* __restrict__ res, int ldres,
+                                                               void* __restrict__ C, int ldc, int out_f32) {
+    const int nq = N / 4;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * nq) return;
+    const int m = i / nq, n = (i - m * nq) * 4;
+    f32x4 v = *(const f32x4*)(part + (size_t)m * N + n);
+    for (int s2 = 1; s2 < S; ++s2) v += *(const f32x4*)(part + ((size_t)s2 * M + m) * N + n);
+    v *= alpha;
+    if (bias) v += *(const f32x4*)(bias + n);
+    if (res) v += *(const f32x4*)(res + (size_t)m * ldres + n);
+    if (out_f32) *(f32x4*)((float*)C + (size_t)m * ldc + n) = v;
+    else *(u32x2*)((T*)C + (size_t)m * ldc + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+}
+
+// the partial-tile buffer: one per (device, stream), grown on demand outside stream capture (inside a capture: the plain launch)
+static float* splitk_buffer(hipStream_t s, size_t floats) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, std::pair<float*, size_t>> table;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    auto& e = table[{dev, s}];
+    if (e.second >= floats) return e.first;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
+    if (e.first) { if (hipStreamSynchronize(s) != hipSuccess) return nullptr; (void)hipFree(e.first); e = {nullptr, 0}; }
+    float* buf = nullptr;
+    if (hipMalloc(&buf, floats * sizeof(float)) != hipSuccess) return nullptr;
+    e = {buf, floats};
+    return buf;
+}
+
+// returns -1 when the split form does not apply (the caller then takes the plain launch)
+template <typename T>
+int launch_nt128_splitk(const GemmP& p, int epi, hipStream_t s) {
+    const int nk = p.K / BK;
+    if ((g_nt_flags & 8192) || !p.split_k || p.M > 1024 || nk < 24 || (epi != EOE_EPI_NONE && epi != EOE_EPI_RESIDUAL) || p.colsum || p.colsum_sq || p.accumulate ||
+        (p.N & 15) || (p.ldc & 3) || (epi == EOE_EPI_RESIDUAL && (p.ldaux & 3)))
+        return -1;
+    int S = 8;
+    while (S > 1 && (nk % S) != 0) S >>= 1;
+    if (S < 2 || nk / S < 3) return -1;
+    float* part = splitk_buffer(s, (size_t)S * p.M * p.N);
+    if (!part) return -1;
+    GemmP q = p;
+    q.C = part; q.ldc = p.N; q.out_f32 = 1; q.bias = nullptr; q.aux = nullptr; q.alpha = 1.0f;
+    const int tiles = cdiv(p.M, 128) * cdiv(p.N, 128);
+    { static bool once = (hipFuncSetAttribute((const void*)gemm_nt128_kernel<T, EOE_EPI_NONE, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem128_bytes(4)), true); (void)once; }
+    hipLaunchKernelGGL((gemm_nt128_kernel<T, EOE_EPI_NONE, 4>), dim3(tiles, S), dim3(256), smem128_bytes(4), s, q);
+    EOE_CHECK_LAUNCH("gemm_nt128 (split k)");
+    hipLaunchKernelGGL((nt_splitk_finish_kernel<T>), dim3(cdiv(p.M * (p.N / 4), 256)), dim3(256), 0, s, (const float*)part, S, p.M, p.N, p.alpha,
+                       p.bias, epi == EOE_EPI_RESIDUAL ? (const float*)p.aux : nullptr, p.ldaux, p.C, p.ldc, p.out_f32);
+    EOE_CHECK_LAUNCH("nt_splitk_finish");
+    return 0;
+}
+
 // (round 2) Delaying the workgroup in the odd wave slot of each SIMD (HW_REG_HW_ID[3:0]) by half a k-tile at kernel entry, so that the
 // two workgroups of a CU would issue their LDS-DMA / fragment reads next to each other's MFMA clusters: null (layer total 592 / 601 us
 // against 605 us in the same process, within run-to-run spread).
@@ -940,6 +1008,10 @@ int launch_nt(const GemmP& p, int epi, int gather, hipStream_t s) {
     // layers): the one-wave kernel wins where the epilogue is the GELU pair of outputs behind a short K loop -- c_fc forward 1.167 against
     // 1.260 --, ties on the K >= 2304 shapes (-0.001 ... -0.010) and loses on QKV (+0.135), GELU' x dY (+0.057) and the two K = 768 -> 768
     // shapes (+0.056, +0.020).  So: c_fc forward only (nt_flags bit 10 = 1024 turns the rule off).
+    if (gather == 0 && p.split_k) {          // asked for: small M behind a long K (nt_flags bit 13 = 8192 switches it off)
+        const int rc = launch_nt128_splitk<T>(p, epi, s);
+        if (rc >= 0) return rc;
+    }
     // the 160x256x32 two-workgroup kernel on the wide-N shapes (c_fc forward, GELU' x dY: 10.64 -> 10.54 ms per step, three interleaved
     // pairs, same bits; nt_flags bit 12 = 4096 switches it off)
     if (!(g_nt_flags & (4096 | 4 | 8 | 512)) && gather == 0 && !p.colsum_sq && (p.N % 256) == 0 && p.N >= 2048 && (p.K % 32) == 0 && p.M >= 2048) {
@@ -985,7 +1057,7 @@ int fill_params(const eoe_gemm_args* a, GemmP& p) {
     p.A = a->A; p.B = a->B; p.C = a->C; p.bias = a->bias; p.aux = a->aux; p.aux_out = a->aux_out; p.colsum = a->colsum;
     p.colsum_part = nullptr; p.colsum_sq = 0; p.colsum_blocked = 0;
     p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ldaux = a->ldaux;
-    p.out_f32 = a->out_f32; p.accumulate = a->accumulate; p.alpha = a->alpha;
+    p.out_f32 = a->out_f32; p.accumulate = a->accumulate; p.alpha = a->alpha; p.split_k = a->split_k;
     EOE_CHECK_ARG((a->K % BK) == 0, "gemm_nt: K=%d must be a multiple of %d", a->K, BK);
     EOE_CHECK_ARG(a->ldb >= a->K, "gemm_nt: leading dims smaller than K");
     size_t ba = ((size_t)(a->M - 1) * a->lda + a->K) * 2;

@@ -19,6 +19,7 @@ struct GemmP {
     int colsum_blocked;            // layout of the partial rows: N % 64 == 0 -> blocked (BatchNorm statistics: always plain [R][2][N])
     int colsum_sq;                 // partial rows are [.][2][N]: sums and sums of squares (BatchNorm statistics); no finish kernel
     int M, N, K, lda, ldb, ldc, ldaux, out_f32, accumulate;
+    int split_k;                   // eoe_gemm_args.split_k (a hint: launch_nt128_splitk)
     float alpha;
     unsigned bytesA, bytesB;
     unsigned long long* stamp;     // diagnostics (EOE_GEMM_STAMP=1): per-workgroup s_memtime stamps, else NULL

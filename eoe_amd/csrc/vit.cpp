@@ -93,6 +93,7 @@ extern "C" int eoe_vit_block_fwd(const eoe_vit_block_fwd_args* a, void* stream) 
     TRY(eoe_gemm_nt(&g, stream));
     g = gemm(a->hact, a->w_proj, a->x_out, a->b_proj, Mo, D, H, H, H, D, dt);
     g.epilogue = EOE_EPI_RESIDUAL; g.aux = a->x_mid; g.ldaux = D; g.out_f32 = 1;
+    g.split_k = a->cls_only ? 1 : 0;          // n x D x 4D: twelve tiles behind 48 k-tiles each (eoe_hip.h, eoe_gemm_args.split_k)
     TRY(eoe_gemm_nt(&g, stream));
     return 0;
 }
@@ -160,6 +161,7 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
         TRY(eoe_colsum(b->dh, H, b->g_b_fc, Mo, H, dt, 1, stream));
     }
     g = gemm(b->dh, a->w_fc_t, b->d16_b, nullptr, Mo, D, H, H, H, D, dt);                   // d xn2
+    g.split_k = cls ? 1 : 0;
     TRY(eoe_gemm_nt(&g, stream));
     // (cls_only: dx_mid of the class-token rows goes to a dense [n, D] piece behind the dY copy in d16_a -- L >= 4 leaves the room --
     //  and is scattered into the zeroed full dx_mid LayerNorm-1 backward reads; d att likewise through the GEMM's row stride)

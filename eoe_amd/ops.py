@@ -89,7 +89,7 @@ def _chk(*ts):
 
 # ------------------------------------------------------------------------------------------------ raw ops
 def gemm_nt(a, b, out, bias=None, epilogue=EPI_NONE, aux=None, aux_out=None, accumulate=False, alpha=1.0,
-            colsum_out=None, colsum_atomic=False, colstats_ws=None):
+            colsum_out=None, colsum_atomic=False, colstats_ws=None, split_k=False):
     """out[M,N] = a[M,K] @ b[N,K]^T  (+ epilogue); a, b 16-bit row-major (row stride may exceed K).
     colstats_ws: fp32 [ceil(M/64), 2, N] -> receives the per-64-row column sums / sums of squares of the fp32 result"""
     _chk(a, b, out, bias, aux, aux_out, colsum_out)
@@ -108,6 +108,7 @@ def gemm_nt(a, b, out, bias=None, epilogue=EPI_NONE, aux=None, aux_out=None, acc
         g.workspace, g.workspace_bytes = _p(scratch("nt_colsum_ws", (nbytes,), torch.uint8, a.device)), nbytes
     if colstats_ws is not None:
         g.workspace, g.workspace_bytes, g.colstats = _p(colstats_ws), colstats_ws.numel() * 4, 1
+    g.split_k = 1 if split_k else 0          # hint (eoe_hip.h): small M behind a long K as k-ranges + an in-order sum
     check(lib.eoe_gemm_nt(C.byref(g), _stream()), "eoe_gemm_nt")
     return out
 

@@ -96,6 +96,11 @@ typedef struct {
                          * [cout][cin][kh][kw] (not the [kh*kw*cin][cout] matrix): the launch goes through the workspace's partial
                          * tiles and the reduce kernel writes that order directly -- no eoe_conv_unpack_wgrad pass.  Needs the
                          * workspace (>= splits * M * N * 4 bytes, EOE_TN_WORKSPACE_BYTES always suffices for the shapes here) */
+    int32_t split_k;    /* NT only, a hint: != 0 asks for the split form of a small-M problem behind a long K (M <= 1024, K >= 1536, plain or
+                         * fp32-residual epilogue, no column sums): up to 8 equal k-ranges per output tile in one launch, fp32 partial tiles in a
+                         * library-owned buffer, summed in a fixed order by a second kernel.  The split depends on K only, so a row's result
+                         * does not depend on M (eoe_vit_block_fwd / _bwd ask for it on the class-token-only block's n x 768 x 3072 products:
+                         * 12 tiles of 48 k-tiles are one 50-us latency chain on 12 CUs).  Ignored where it does not apply. */
 } eoe_gemm_args;
 #define EOE_NT_COLSUM_WORKSPACE_BYTES(M, N) ((size_t)(((M) + 63) / 64) * (size_t)(N) * 4)
 

@@ -386,6 +386,10 @@ def test_vit_last_block_on_class_token_rows_only_equals_the_full_block():
     m = ClipViTB32Custom(layers=3).cuda().train()
     y = torch.cat([torch.zeros(12, dtype=torch.long), torch.ones(12, dtype=torch.long)]).cuda()
     old = ops.VIT_CLS_ONLY_LAST
+    # (the class-token-only block's n x 768 x 3072 GEMMs would otherwise run split over k -- another fp32 summation order, which the fp16
+    #  rounding of the head's input turns into 1e-4 of the embedding: that form has its own test; here the two block forms run the same kernels)
+    from eoe_amd import _lib
+    _lib.check(_lib.lib.eoe_set_option(b"nt_flags", 8192), "eoe_set_option")
     try:
         for nimg in (24, 256):
             x = torch.randn(nimg, 3, 224, 224, device="cuda")
@@ -417,6 +421,7 @@ def test_vit_last_block_on_class_token_rows_only_equals_the_full_block():
         assert (a - b).abs().max().item() <= 1e-6 * a.abs().max().item()
     finally:
         ops.VIT_CLS_ONLY_LAST = old
+        _lib.check(_lib.lib.eoe_set_option(b"nt_flags", 0), "eoe_set_option")
 
 
 def test_vit_async_weight_gradients_keep_their_bits():
@@ -543,5 +548,46 @@ def test_wide_two_workgroup_nt_kernel_keeps_the_bits(dtype):
             assert d < 1e-5, (m, n, k, d)          # the column sums go through partial rows per 80 output rows either way
             ref = (a.float() @ w.float().t() + bias)
             assert (res[0][0].float() - ref).abs().max().item() < 0.05 * ref.abs().max().item()
+    finally:
+        flags(0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_split_k_for_small_m_matches_the_plain_launch(dtype):
+    """asked for with eoe_gemm_args.split_k, a small-M product behind K >= 1536 (the last ViT block on its class-token rows: 256 x 768 x 3072)
+    runs as up to 8 k-ranges per tile + an in-order sum of the fp32 partial tiles: the plain launch's result to fp32 summation order,
+    reproducible, independent of M row by row, with bias / fp32 residual / 16-bit output"""
+    from eoe_amd import ops, _lib
+
+    def flags(v):
+        _lib.check(_lib.lib.eoe_set_option(b"nt_flags", v), "eoe_set_option")
+
+    g = torch.Generator(device="cuda").manual_seed(11)
+    try:
+        for m, n, k in ((256, 768, 3072), (250, 768, 3072), (512, 256, 1536), (64, 3072, 2048)):
+            a = torch.randn(m, k, device="cuda", generator=g).to(dtype)
+            w = (torch.randn(n, k, device="cuda", generator=g) * 0.05).to(dtype)
+            bias = torch.randn(n, device="cuda", generator=g)
+            res = torch.randn(m, n, device="cuda", generator=g)
+            out = {}
+            for f in (8192, 0, 0):
+                flags(f)
+                o16 = torch.empty(m, n, device="cuda", dtype=dtype)
+                ops.gemm_nt(a, w, o16, bias=bias, split_k=True)
+                o32 = torch.empty(m, n, device="cuda", dtype=torch.float32)
+                ops.gemm_nt(a, w, o32, bias=bias, epilogue=ops.EPI_RESIDUAL, aux=res, split_k=True)
+                torch.cuda.synchronize()
+                out.setdefault(f, []).append((o16, o32))
+            (p16, p32), (s16, s32), (t16, t32) = out[8192][0], out[0][0], out[0][1]
+            assert torch.equal(s16, t16) and torch.equal(s32, t32)                                   # reproducible
+            if m > 8:                                                                                # a row's result does not depend on M
+                h32 = torch.empty(8, n, device="cuda", dtype=torch.float32)
+                ops.gemm_nt(a[:8].contiguous(), w, h32, bias=bias, epilogue=ops.EPI_RESIDUAL, aux=res[:8].contiguous(), split_k=True)
+                assert torch.equal(h32, s32[:8]), (m, n, k)
+            ref = a.float() @ w.float().t() + bias + res
+            scale = ref.abs().max().item()
+            assert (s32 - p32).abs().max().item() < 2e-6 * scale, (m, n, k)
+            assert (s32 - ref).abs().max().item() < 1e-4 * scale, (m, n, k)
+            assert (s16.float() - p16.float()).abs().max().item() <= 2.0 ** (-7 if dtype == torch.bfloat16 else -10) * scale
     finally:
         flags(0)

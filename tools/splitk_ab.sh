@@ -1,0 +1,9 @@
+set -e
+mkdir -p gpurun_out/splitk
+timeout -k 10 600 python -m pytest tests/test_gpu_round3.py tests/test_gpu_ops.py tests/test_gpu_parity_big.py tests/test_gpu_model.py -q -m gpu -k "split_k or gemm or vit or block or wide_two" 2>&1 | tail -4
+for r in 1 2 3; do for v in 8192 0; do
+  timeout -k 10 200 python bench.py --steps 200 --warmup 20 --nt-flags $v --no-roofline --no-cpu-baseline --no-torch-baseline > gpurun_out/splitk/b_${v}_${r}.json 2> gpurun_out/splitk/b_${v}_${r}.err
+  python -c "
+import json
+d=json.loads(open('gpurun_out/splitk/b_${v}_${r}.json').read().strip().splitlines()[-1]); print('nt_flags=$v run $r: %.3f ms %.0f img/s loss %s' % (d['ms_per_step'], d['value'], d['final_loss']), flush=True)"
+done; done
