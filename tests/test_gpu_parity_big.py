@@ -250,6 +250,9 @@ def check(what, dtype, g, losses, scores, first, labels, feat_tol, k_noise=None,
           f"sum|d|/sum {agg_dev:.2e}; max AUC dev {max(aucs):.1e}")
     print(f"   loss dev  {_fmt(dl)}\n   ref noise {_fmt(nl)}")
     print(f"   score dev {_fmt(ds)}\n   ref noise {_fmt(ns)}")
+    # how much of the single-batch AUC the measured score deviation leaves undecided (parity_util.auc_flip_share): context for the AUC bars
+    flips = np.array([parity_util.auc_flip_share(labels, g["scores"][k], max(float(ds[k]), 1e-12)) for k in range(len(losses))])
+    print(f"   AUC dev   {_fmt(np.array(aucs))}\n   pairs within 2 x the step's score deviation (share of all pairs = the AUC they could move) {_fmt(flips)}")
     if REPORT_ONLY:
         return
     assert rf < feat_tol, rf
