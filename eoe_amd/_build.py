@@ -20,8 +20,10 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libeoe_hip.so")
 OBJDIR = os.path.join(HERE, "build")
 SOURCES = ["api.cpp", "gemm.hip", "gemm_tn.hip", "elementwise.hip", "attention.hip", "conv.hip", "cbam.hip", "augment.hip",
-           "vit.cpp", "parity.hip", "gemm256.hip", "comm.cpp", "gemm_tn256.hip"]
+           "vit.cpp", "parity.hip", "gemm256.hip", "comm.cpp", "gemm_tn256.hip", "gemm_ntp.hip"]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+# gemm_ntp.hip names its 256 accumulator registers literally: the compiler must not park spilled VGPRs in AGPRs there (the file's header)
+EXTRA_CFLAGS = {"gemm_ntp.hip": ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]}
 LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--no-undefined"]
 
 
@@ -51,13 +53,13 @@ def _headers_digest() -> str:
     return _sha(*[_read(h) for h in hs])
 
 
-def _flags():
-    return CFLAGS + (["-DEOE_AB"] if os.environ.get("EOE_AB") else [])
+def _flags(src: str = ""):
+    return CFLAGS + EXTRA_CFLAGS.get(src, []) + (["-DEOE_AB"] if os.environ.get("EOE_AB") else [])
 
 
 def source_digest(src: str, headers: str = None) -> str:
     """what the object file of `src` depends on"""
-    return _sha(_read(os.path.join(CSRC, src)), headers or _headers_digest(), " ".join(_flags()))
+    return _sha(_read(os.path.join(CSRC, src)), headers or _headers_digest(), " ".join(_flags(src)))
 
 
 def library_digest() -> str:
@@ -108,7 +110,7 @@ def _build_locked(hipcc: str, force: bool, verbose: bool) -> str:
         digest = source_digest(src, headers)
         if not force and os.path.exists(obj) and _stamp(obj) == digest:
             continue
-        cmd = [hipcc] + _flags() + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + _flags(src) + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, obj, digest, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
