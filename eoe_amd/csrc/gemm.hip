@@ -32,8 +32,8 @@ extern int g_attn_flags;        // attention.hip
 extern int g_tn256_launches;    // gemm_tn256.hip
 extern int g_parity_flags;      // parity.hip
 int eoe_launch_nt256(const void* gemm_p, int dtype, int epi, int mi, hipStream_t s);   // gemm256.hip
-bool eoe_ntp_applies(const void* gemm_p, int epi);                                      // gemm_ntp.hip
-int eoe_launch_ntp(const void* gemm_p, int dtype, int epi, hipStream_t s);
+bool eoe_w8_applies(const void* gemm_p, int epi);                                       // gemm_w8.hip
+int eoe_launch_w8(const void* gemm_p, int dtype, int epi, hipStream_t s);
 
 namespace {
 extern int g_nt_flags;
@@ -1014,9 +1014,14 @@ int launch_nt(const GemmP& p, int epi, int gather, hipStream_t s) {
         const int rc = launch_nt128_splitk<T>(p, epi, s);
         if (rc >= 0) return rc;
     }
-    // the drained-under-the-next-tile kernel (gemm_ntp.hip; round 4): nt_flags bit 14 = 16384 opts in
-    if ((g_nt_flags & 16384) && gather == 0 && p.M >= 2048 && eoe_ntp_applies(&p, epi))
-        return eoe_launch_ntp(&p, std::is_same<T, f16_t>::value ? EOE_F16 : EOE_BF16, epi, s);
+    // the eight-wave 256 x 256 kernel (gemm_w8.hip; round 4) for the plain / GELU 16-bit shapes whose 256 x 256 tiles fill the CUs to >= 85 %
+    // in every round (M = 12 800: N = 2304 -> 450 tiles = 2 rounds at 88 %: the in-projection, 55 against 65 us, same bits; N = 3072 -> 600
+    // = 3 rounds at 78 %: stays on the 160 x 256 x 32 kernel below).  nt_flags bit 17 = 131072 switches it off, bit 18 = 262144 forces it
+    if (!(g_nt_flags & (131072 | 4 | 8 | 512)) && gather == 0 && p.M >= 2048 && eoe_w8_applies(&p, epi)) {
+        const long tiles = (long)cdiv(p.M, 256) * (p.N / 256);
+        if ((g_nt_flags & 262144) || tiles * 100 >= ((tiles + ncu - 1) / ncu) * ncu * 85) 
+            return eoe_launch_w8(&p, std::is_same<T, f16_t>::value ? EOE_F16 : EOE_BF16, epi, s);
+    }
     // the 160x256x32 two-workgroup kernel on the wide-N shapes (c_fc forward, GELU' x dY: 10.64 -> 10.54 ms per step, three interleaved
     // pairs, same bits; nt_flags bit 12 = 4096 switches it off)
     if (!(g_nt_flags & (4096 | 4 | 8 | 512)) && gather == 0 && !p.colsum_sq && (p.N % 256) == 0 && p.N >= 2048 && (p.K % 32) == 0 && p.M >= 2048) {

@@ -26,28 +26,36 @@
 
 namespace {
 
-constexpr int NTP_MI = 4;                                                              // 16-row MFMA tiles per wave along M: 128-row tiles
-constexpr int NTP_A_BYTES = 32 * NTP_MI * BK * 2;                                      // 16 KiB
-constexpr int NTP_STAGE_BYTES = NTP_A_BYTES + 256 * BK * 2;                            // 48 KiB
+// MI = 16-row MFMA tiles per wave along M: (32 MI) x 256 tiles.  MI = 4: acc + hold = all 256 AGPRs.  MI = 5 (160 x 256: 98 flop per byte staged
+// against 85 -- a CU takes in ~70 GB/s from L2, i.e. ~71 flop per byte are needed to feed its matrix pipes): 32 of the 40 accumulator quads
+// in AGPRs as for MI = 4, the last 8 (acc and hold: C and D of an MFMA share one register file) in VGPRs as ordinary tied operands
+constexpr int ntp_a_bytes(int MI) { return 32 * MI * BK * 2; }                         // 16 / 20 KiB
+constexpr int ntp_stage_bytes(int MI) { return ntp_a_bytes(MI) + 256 * BK * 2; }       // 48 / 52 KiB
 constexpr int NTP_NST = 3;
-constexpr int NTP_BIAS_OFF = NTP_NST * NTP_STAGE_BYTES;                                // behind the ring: one KiB per wave (512 B used)
-constexpr int NTP_SMEM_BYTES = NTP_BIAS_OFF + 4096;
-static_assert(NTP_SMEM_BYTES <= 160 * 1024, "LDS");
+constexpr int ntp_bias_off(int MI) { return NTP_NST * ntp_stage_bytes(MI); }           // behind the ring: one KiB per wave (512 B used)
+constexpr int ntp_smem_bytes(int MI) { return ntp_bias_off(MI) + 4096; }
+static_assert(ntp_smem_bytes(5) <= 160 * 1024, "LDS");
+constexpr int NTP_QA = 32;                                                             // accumulator quads (acc + hold) that live in AGPRs
 
 // The three MFMA forms on accumulator quad E (and held quad H): in place; first k-step of a tile (C = 0); last k-step (C = the acc quad,
 // D = the hold quad: the finished tile moves aside).  E, H: constants after unrolling ("i" operands spliced into the register text)
-#define EOE_NTP_MFMA_INPLACE(MNEM, E, A, B) asm volatile(MNEM " a[%c0:%c1], %2, %3, a[%c0:%c1]" :: "i"(4 * (E)), "i"(4 * (E) + 3), "v"(A), "v"(B))
-#define EOE_NTP_MFMA_FIRST(MNEM, E, A, B) asm volatile(MNEM " a[%c0:%c1], %2, %3, 0" :: "i"(4 * (E)), "i"(4 * (E) + 3), "v"(A), "v"(B))
+#define EOE_NTP_MFMA_INPLACE(MNEM, E, A, B) asm volatile(MNEM " a[%c0:%c1], %2, %3, a[%c0:%c1]" :: "i"(4 * (E)), "i"(4 * (E) + 3), "v"(A), "v"(B) : NTP_AGPRS)
+#define EOE_NTP_MFMA_FIRST(MNEM, E, A, B) asm volatile(MNEM " a[%c0:%c1], %2, %3, 0" :: "i"(4 * (E)), "i"(4 * (E) + 3), "v"(A), "v"(B) : NTP_AGPRS)
 #define EOE_NTP_MFMA_LAST(MNEM, E, H, A, B) \
-    asm volatile(MNEM " a[%c0:%c1], %4, %5, a[%c2:%c3]" :: "i"(4 * (H)), "i"(4 * (H) + 3), "i"(4 * (E)), "i"(4 * (E) + 3), "v"(A), "v"(B))
+    asm volatile(MNEM " a[%c0:%c1], %4, %5, a[%c2:%c3]" :: "i"(4 * (H)), "i"(4 * (H) + 3), "i"(4 * (E)), "i"(4 * (E) + 3), "v"(A), "v"(B) : NTP_AGPRS)
+// the same on a VGPR-resident quad (tied operands: one value updated in place; `first` does not read it, `last` writes the held quad)
+#define EOE_NTP_MFMA_INPLACE_V(MNEM, C, A, B) asm volatile(MNEM " %0, %1, %2, %0" : "+v"(C) : "v"(A), "v"(B))
+#define EOE_NTP_MFMA_FIRST_V(MNEM, C, A, B) asm volatile(MNEM " %0, %1, %2, 0" : "+v"(C) : "v"(A), "v"(B))
+#define EOE_NTP_MFMA_LAST_V(MNEM, C, H, A, B) asm volatile(MNEM " %0, %2, %3, %1" : "+v"(H) : "v"(C), "v"(A), "v"(B))
 
-__device__ __forceinline__ void ntp_reserve_agprs() {
-#define A10(n) "a" #n "0", "a" #n "1", "a" #n "2", "a" #n "3", "a" #n "4", "a" #n "5", "a" #n "6", "a" #n "7", "a" #n "8", "a" #n "9"
-    asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", A10(1), A10(2), A10(3), A10(4), A10(5), A10(6), A10(7), A10(8),
-                 A10(9), A10(10), A10(11), A10(12), A10(13), A10(14), A10(15), A10(16), A10(17), A10(18), A10(19), A10(20), A10(21), A10(22),
-                 A10(23), A10(24), "a250", "a251", "a252", "a253", "a254", "a255");
-#undef A10
-}
+// every accumulator register, as a clobber list: on ntp_reserve_agprs() (the kernel descriptor then allocates all 256) and on EVERY MFMA
+// statement -- under VGPR pressure the compiler parks values in AGPRs it believes free (seen: a0..a3, with -amdgpu-spill-vgpr-to-agpr=0),
+// and a register it must assume overwritten by each of the 64-80 MFMAs of an iteration is of no use to it
+#define NTP_A10(n) "a" #n "0", "a" #n "1", "a" #n "2", "a" #n "3", "a" #n "4", "a" #n "5", "a" #n "6", "a" #n "7", "a" #n "8", "a" #n "9"
+#define NTP_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", NTP_A10(1), NTP_A10(2), NTP_A10(3), NTP_A10(4), NTP_A10(5), NTP_A10(6), \
+    NTP_A10(7), NTP_A10(8), NTP_A10(9), NTP_A10(10), NTP_A10(11), NTP_A10(12), NTP_A10(13), NTP_A10(14), NTP_A10(15), NTP_A10(16), NTP_A10(17),        \
+    NTP_A10(18), NTP_A10(19), NTP_A10(20), NTP_A10(21), NTP_A10(22), NTP_A10(23), NTP_A10(24), "a250", "a251", "a252", "a253", "a254", "a255"
+__device__ __forceinline__ void ntp_reserve_agprs() { asm volatile("" ::: NTP_AGPRS); }
 
 template <int N> __device__ __forceinline__ void ntp_wait_vm() {
     static_assert(N >= 0, "vmcnt");
@@ -55,16 +63,18 @@ template <int N> __device__ __forceinline__ void ntp_wait_vm() {
 }
 
 // EPI: EOE_EPI_NONE (16-bit C = alpha acc + bias) or EOE_EPI_GELU (pre -> aux_out, C = QuickGELU of the rounded pre)
-template <typename T, int EPI>
+template <typename T, int EPI, int MI>
 __global__ __launch_bounds__(256, 1) void gemm_ntp_kernel(GemmP p) {
     static_assert(EPI == EOE_EPI_NONE || EPI == EOE_EPI_GELU, "epilogues with a second input are not built yet");
-    constexpr int MI = NTP_MI, BMT = 32 * MI, A_B = NTP_A_BYTES, STAGE = NTP_STAGE_BYTES, NST = NTP_NST, PER = MI + 8;
+    static_assert(MI == 4 || MI == 5, "MI");
+    constexpr int BMT = 32 * MI, A_B = ntp_a_bytes(MI), STAGE = ntp_stage_bytes(MI), NST = NTP_NST, PER = MI + 8;
     constexpr int P1 = (PER + 1) / 2;                  // pieces of a k-tile issued in a second half; the rest in the next first half
     constexpr int NMF = MI * 8;                        // MFMAs per cluster (one 32-deep k-step of the wave's tile) = accumulator quads
     constexpr int NB = 2 * MI;                         // bands of a wave's tile: b = h * MI + mi (h: 64-column half, mi: 16-row tile)
     constexpr int ES = (EPI == EOE_EPI_GELU) ? 2 : 1;  // stores per half band = per cluster in the iterations that carry the drain
     constexpr int L = (EPI == EOE_EPI_GELU) ? 66 : 13; // micro-operations per half band (epi_op below)
-    static_assert(2 * NMF * 4 == 256, "acc + hold fill the AGPR file");
+    constexpr int QA = NTP_QA, QV = NMF - QA;         // quads in AGPRs: acc a[4e : 4e+3], hold a[128 + 4e : ...]; quads e >= QA in VGPRs
+    static_assert(QA == 32 && QV >= 0 && QV <= 8, "quads");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     ntp_reserve_agprs();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -83,8 +93,24 @@ __global__ __launch_bounds__(256, 1) void gemm_ntp_kernel(GemmP p) {
     __amdgpu_buffer_rsrc_t rpre = make_rsrc(p.aux_out ? p.aux_out : p.C, p.aux_out ? c_bytes : 0u);
     __amdgpu_buffer_rsrc_t rbias = make_rsrc(p.bias ? (const void*)p.bias : p.C, p.bias ? (unsigned)p.N * 4u : 0u);
 
-    unsigned offA[MI], offB[8];
+    const unsigned lds0 = (unsigned)(uintptr_t)((lds_void_t*)smem);
+    const unsigned wave_u = (unsigned)__builtin_amdgcn_readfirstlane(wave);
+    // staging addresses: a piece is 8 rows x 128 B; lane -> (row lane >> 3, 16-byte slot lane & 7 holding chunk slot ^ ((row >> 1) & 7)).  The
+    // swizzle term of piece j depends on j's parity only, so two per-lane offsets per operand (VGPRs) + a uniform offset per piece (the
+    // instruction's soffset) address everything: 5 registers instead of the MI + 8 per-piece offsets.  B rows are permuted inside each
+    // 64-row group (eoe_direct_row, 16-bit C) so that a lane's accumulator values are runs of 8 consecutive output columns and the four
+    // lanes of a row write adjacent 16-byte pieces: row (wave, j, lane) -> 64 wave + fj(j) + gl(lane)
+    const int l8 = lane >> 3;
+    unsigned voffA[2], voffB[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        const int c = (lane & 7) ^ ((par * 4 + (lane >> 4)) & 7);
+        voffA[par] = (unsigned)((l8 * p.lda + c * 8) * 2);
+        voffB[par] = (unsigned)((((lane >> 5) * 8 + (l8 & 3)) * p.ldb + c * 8) * 2);
+    }
     int st_tile = 0, st_kt = 0, st_slot = 0;
+    unsigned sA_base = 0, sB_base = 0;                 // byte offsets of the staging tile's first row of this wave (uniform)
+    int rows_left = 0;                                 // rows of A below M from this wave's first staged row on
     auto tile_origin = [&](int seq, int& m0, int& n0) {
         const int r = xcd_remap((int)blockIdx.x + seq * G, total_tiles);
         m0 = (r / tiles_n) * BMT;
@@ -93,39 +119,32 @@ __global__ __launch_bounds__(256, 1) void gemm_ntp_kernel(GemmP p) {
     auto set_offsets = [&](int t) {
         int m0, n0;
         tile_origin(t, m0, n0);
-#pragma unroll
-        for (int j = 0; j < MI; ++j) {
-            const int row = (wave * MI + j) * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ ((row >> 1) & 7);
-            offA[j] = (m0 + row < p.M) ? (unsigned)(((size_t)(m0 + row) * p.lda + c * 8) * 2) : EOE_OOB;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            // rows of each 64-row group permuted (eoe_direct_row, 16-bit C) so that a lane's accumulator values are runs of 8 consecutive
-            // output columns and the four lanes of a row write adjacent 16-byte pieces
-            const int row = (wave * 8 + j) * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ ((row >> 1) & 7);
-            const int grow = (row & ~63) + eoe_direct_row(row & 63, 0);
-            offB[j] = (n0 + grow < p.N) ? (unsigned)(((size_t)(n0 + grow) * p.ldb + c * 8) * 2) : EOE_OOB;
-        }
+        const int ra0 = m0 + (int)wave_u * MI * 8;
+        sA_base = (unsigned)ra0 * (unsigned)p.lda * 2u;
+        rows_left = p.M - ra0;
+        sB_base = (unsigned)(n0 + (int)wave_u * 64) * (unsigned)p.ldb * 2u;
     };
-    const unsigned lds0 = (unsigned)(uintptr_t)((lds_void_t*)smem);
-    const unsigned wave_u = (unsigned)__builtin_amdgcn_readfirstlane(wave);
-#define EOE_DMA16(rsrc, lds_addr, voff)                                                                               \
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"                            \
-                 :: "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory")
+#define EOE_DMA16(rsrc, lds_addr, voff, soff)                                                                         \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"                           \
+                 :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory")
     // piece j of the staging cursor's k-tile (j < MI: the A image, else the B image).  A piece with nothing to fetch (`live` false: past
-    // the workgroup's last k-tile) keeps its place in the instruction stream and in the vmcnt count; it lands (zeros, or a few bytes of
-    // A / B) in the slot of the third-last k-tile, which nothing reads any more
+    // the workgroup's last k-tile) keeps its place in the instruction stream and in the vmcnt count; it lands (zeros) in the slot of the
+    // third-last k-tile, which nothing reads any more.  Rows of A at or past M: out-of-range offset (zero fill)
     auto stage_piece = [&](int j, bool live) {
         const unsigned sa = lds0 + (unsigned)st_slot * STAGE;
-        const unsigned k0 = live ? (unsigned)st_kt * (BK * 2u) : EOE_OOB;
+        const unsigned k0 = (unsigned)st_kt * (BK * 2u);
         if (j < MI) {
-            const unsigned la = sa + (wave_u * MI + j) * 1024u, vo = offA[j < MI ? j : 0] + k0;
-            EOE_DMA16(ra, la, vo);
+            const int pj = ((int)wave_u * MI + j) & 1;
+            const unsigned la = sa + (wave_u * MI + j) * 1024u;
+            const unsigned vo = (live && l8 + j * 8 < rows_left) ? (pj ? voffA[1] : voffA[0]) : EOE_OOB;
+            const unsigned so = sA_base + (unsigned)(j * 8) * (unsigned)p.lda * 2u + k0;
+            EOE_DMA16(ra, la, vo, so);
         } else {
-            const unsigned lb = sa + A_B + (wave_u * 8 + (j - MI)) * 1024u, vo = offB[j >= MI ? j - MI : 0] + k0;
-            EOE_DMA16(rb, lb, vo);
+            const int jb = j - MI;
+            const unsigned lb = sa + A_B + (wave_u * 8 + jb) * 1024u;
+            const unsigned vo = live ? voffB[jb & 1] : EOE_OOB;
+            const unsigned so = sB_base + (unsigned)((jb >> 2) * 32 + (jb & 1) * 16 + ((jb >> 1) & 1) * 4) * (unsigned)p.ldb * 2u + k0;
+            EOE_DMA16(rb, lb, vo, so);
         }
     };
     auto stage_advance = [&]() {
@@ -146,11 +165,10 @@ __global__ __launch_bounds__(256, 1) void gemm_ntp_kernel(GemmP p) {
 
 #define EOE_NTP_LANDED(XA, WB)                                                                                   \
     do {                                                                                                         \
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(XA[0]), "+v"(XA[1]), "+v"(XA[2]), "+v"(XA[3]),               \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(XA[0]), "+v"(XA[1]), "+v"(XA[2]), "+v"(XA[3]), "+v"(XA[MI - 1]),        \
                      "+v"(WB[0]), "+v"(WB[1]), "+v"(WB[2]), "+v"(WB[3]), "+v"(WB[4]), "+v"(WB[5]), "+v"(WB[6]), "+v"(WB[7]) :: "memory"); \
         __builtin_amdgcn_sched_barrier(0);                                                                       \
     } while (0)
-    static_assert(MI == 4, "EOE_NTP_LANDED names four A fragments");
 
     // ------------------------------------------------------------------------------------------------ the drain of the held tile
     // accumulator quad e = (h * MI + mi) * 4 + ni4 (h: 64-column half, mi: 16-row tile, ni4: 16-column tile of the half): a[4e : 4e+3];
@@ -168,7 +186,10 @@ __global__ __launch_bounds__(256, 1) void gemm_ntp_kernel(GemmP p) {
     for (int c = 0; c < 16; ++c) bias16[c] = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) cv[c] = 0.f;
-    const unsigned bias_lds = (unsigned)NTP_BIAS_OFF + wave_u * 1024u;
+    const unsigned bias_lds = (unsigned)ntp_bias_off(MI) + wave_u * 1024u;
+    f32x4 vacc[QV > 0 ? QV : 1], vhold[QV > 0 ? QV : 1];   // the VGPR-resident quads (MI = 5)
+#pragma unroll
+    for (int i = 0; i < (QV > 0 ? QV : 1); ++i) { vacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; vhold[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     // the held values of half band q (16-column tiles 2q, 2q + 1) of band `band` -> cv[0..7]: a uniform branch per band
     auto load_cv = [&](const int q) {
 #pragma unroll
@@ -177,8 +198,11 @@ __global__ __launch_bounds__(256, 1) void gemm_ntp_kernel(GemmP p) {
 #pragma unroll
                 for (int e = 0; e < 2; ++e)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(cv[4 * e + r]) : "i"(4 * (NMF + b * 4 + 2 * q + e) + r));
+                    for (int r = 0; r < 4; ++r) {
+                        const int hq = b * 4 + 2 * q + e;
+                        if (hq < QA) asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(cv[4 * e + r]) : "i"(4 * (QA + hq) + r));
+                        else asm volatile("v_mov_b32 %0, %1" : "=v"(cv[4 * e + r]) : "v"(vhold[hq >= QA ? hq - QA : 0][r]));
+                    }
             }
         }
     };
@@ -204,7 +228,11 @@ __global__ __launch_bounds__(256, 1) void gemm_ntp_kernel(GemmP p) {
     // micro-operation k of half band q (constants after unrolling).  Phases of 8 independent operations: a dependent operation is 8 apart.
     constexpr float C1702 = -1.702f * 1.4426950408889634f;
     auto epi_op = [&](const int q, const int k) {
-        if (k < 8) { xv[k] = cv[k] * alpha + bias16[8 * q + k]; return; }
+        if (k < 8) {
+            xv[k] = cv[k] * alpha + bias16[8 * q + k];
+            asm volatile("" : "+v"(xv[k]));           // round to fp32 HERE, then to 16 bits, as the other kernels' epilogues do: fused into
+            return;                                    // v_fma_mixlo_f16 (one rounding from the exact sum) 1 in 2e5 results differs by an ulp
+        }
         if (k < 12) { const int j = k - 8; hv[2 * j] = (T)xv[2 * j]; hv[2 * j + 1] = (T)xv[2 * j + 1]; return; }
         if (k == 12) {
             if (EPI == EOE_EPI_GELU) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv), rpre, (int)e_voff, e_soff + q * 64, 0);
@@ -229,9 +257,15 @@ __global__ __launch_bounds__(256, 1) void gemm_ntp_kernel(GemmP p) {
     constexpr int RSTEP = NMF / (MI + 8);
 #define EOE_NTP_MFMA(MNEM, MODE, E, A, B)                                                                        \
     do {                                                                                                         \
-        if ((MODE) == 0) EOE_NTP_MFMA_INPLACE(MNEM, E, A, B);                                                    \
-        else if ((MODE) == 1) EOE_NTP_MFMA_FIRST(MNEM, E, A, B);                                                 \
-        else EOE_NTP_MFMA_LAST(MNEM, E, NMF + (E), A, B);                                                        \
+        if ((E) < QA) {                                                                                          \
+            if ((MODE) == 0) EOE_NTP_MFMA_INPLACE(MNEM, E, A, B);                                                \
+            else if ((MODE) == 1) EOE_NTP_MFMA_FIRST(MNEM, E, A, B);                                             \
+            else EOE_NTP_MFMA_LAST(MNEM, E, QA + (E), A, B);                                                     \
+        } else {                                                                                                 \
+            if ((MODE) == 0) EOE_NTP_MFMA_INPLACE_V(MNEM, vacc[(E) >= QA ? (E) - QA : 0], A, B);                 \
+            else if ((MODE) == 1) EOE_NTP_MFMA_FIRST_V(MNEM, vacc[(E) >= QA ? (E) - QA : 0], A, B);              \
+            else EOE_NTP_MFMA_LAST_V(MNEM, vacc[(E) >= QA ? (E) - QA : 0], vhold[(E) >= QA ? (E) - QA : 0], A, B); \
+        }                                                                                                        \
     } while (0)
 #define EOE_NTP_CLUSTER(MODE, ACT, Q, XA, WB, RA, RB, rbase, rks, PLO, PHI, LIVE)                                \
     do {                                                                                                         \
@@ -261,6 +295,11 @@ __global__ __launch_bounds__(256, 1) void gemm_ntp_kernel(GemmP p) {
 
     V8 xa0[MI], wb0[8], xa1[MI], wb1[8];
     int cur = 0, it = 0;
+    // diagnostics (EOE_GEMM_STAMP=1): wave 0's cycles per workgroup -- [0] prologue, [1] sum of first halves, [2] DMA wait + fragment wait,
+    // [3] at the barrier, [4] second halves, [5] drain in the open, [6] whole kernel, [7] tiles
+    unsigned long long* stp = (p.stamp && wave == 0) ? p.stamp + (size_t)blockIdx.x * 16 : nullptr;
+    unsigned long long t_0 = 0, t_a = 0, t_b = 0, t_c = 0, t_d = 0, c_a = 0, c_w = 0, c_bar = 0, c_b = 0;
+    if (stp) t_0 = __builtin_amdgcn_s_memtime();
     bool part = false;                                 // the staging cursor's k-tile has its first P1 pieces issued, the rest are due
     // one k-tile iteration.  FIRST / LAST: of its tile;  ACT: carries the drain's micro-operations and ES stores per cluster (band = kt < NB;
     // in a workgroup's first tile they run on nothing and store out of range: no second set of bodies);  PREV: the previous iteration was
@@ -272,17 +311,22 @@ __global__ __launch_bounds__(256, 1) void gemm_ntp_kernel(GemmP p) {
         const int nxt = (cur == NST - 1) ? 0 : cur + 1;                                                          \
         const char* sc = smem + cur * STAGE;                                                                     \
         const char* sn = smem + nxt * STAGE;                                                                     \
+        if (stp) t_a = __builtin_amdgcn_s_memtime();                                                             \
         EOE_NTP_CLUSTER((FIRST) ? 1 : 0, ACT, 0, xa0, wb0, xa1, wb1, sc, 1, P1, PER, part);                      \
         if (part) { stage_advance(); part = false; }                                                             \
+        if (stp) t_b = __builtin_amdgcn_s_memtime();                                                             \
         if (wx) ntp_wait_vm<PER + ES + 1>(); else ntp_wait_vm<PER + ((PREV) ? ES : 0) + ((ACT) ? ES : 0)>();     \
         EOE_NTP_LANDED(xa1, wb1);                                                                                \
+        if (stp) t_c = __builtin_amdgcn_s_memtime();                                                             \
         __builtin_amdgcn_s_barrier();                                                                            \
+        if (stp) t_d = __builtin_amdgcn_s_memtime();                                                             \
         if (wave_u & 1) asm volatile("s_nop 15" ::: "memory");                                                   \
         if (wave_u & 2) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                                       \
         const bool dma_ = it + NST < iters;                                                                      \
         EOE_NTP_CLUSTER((LAST) ? 2 : 0, ACT, 1, xa1, wb1, xa0, wb0, sn, 0, 0, P1, dma_);                         \
         part = dma_;                                                                                             \
         EOE_NTP_LANDED(xa0, wb0);                                                                                \
+        if (stp) { c_a += t_b - t_a; c_w += t_c - t_b; c_bar += t_d - t_c; c_b += __builtin_amdgcn_s_memtime() - t_d; } \
         cur = nxt;                                                                                               \
         ++it;                                                                                                    \
     } while (0)
@@ -309,6 +353,7 @@ __global__ __launch_bounds__(256, 1) void gemm_ntp_kernel(GemmP p) {
         for (int i = 0; i < 8; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wb0[i]) : "v"(b_), "i"(i * 2048));
     }
     EOE_NTP_LANDED(xa0, wb0);
+    if (stp && lane == 0) stp[0] = __builtin_amdgcn_s_memtime() - t_0;
 
     // ------------------------------------------------------------------------------------------------ tiles
     for (int c_tile = 0; c_tile < my_tiles; ++c_tile) {
@@ -331,7 +376,7 @@ __global__ __launch_bounds__(256, 1) void gemm_ntp_kernel(GemmP p) {
             if (kt == NB) {
                 const unsigned vo = lane < 32 ? (unsigned)((n0 + wn0 + lane * 4) * 4) : EOE_OOB;
                 const unsigned la = lds0 + bias_lds;
-                EOE_DMA16(rbias, la, vo);
+                EOE_DMA16(rbias, la, vo, 0);
             }
             EOE_NTP_ITER(false, false, false, false, kt == NB);
         }
@@ -342,6 +387,7 @@ __global__ __launch_bounds__(256, 1) void gemm_ntp_kernel(GemmP p) {
         have_held = true;
     }
     // ------------------------------------------------------------------------------------------------ the last tile: drained in the open
+    if (stp) t_a = __builtin_amdgcn_s_memtime();
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");            // the last MFMAs' results have landed in `hold`
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // incl. this wave's bias piece
     __builtin_amdgcn_sched_barrier(0);
@@ -356,6 +402,11 @@ __global__ __launch_bounds__(256, 1) void gemm_ntp_kernel(GemmP p) {
 #pragma unroll
         for (int k = 0; k < L; ++k) epi_op(1, k);
     }
+    if (stp && lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_e = __builtin_amdgcn_s_memtime();
+        stp[1] = c_a; stp[2] = c_w; stp[3] = c_bar; stp[4] = c_b; stp[5] = t_e - t_a; stp[6] = t_e - t_0; stp[7] = (unsigned long long)my_tiles;
+    }
 #undef EOE_NTP_ITER
 #undef EOE_NTP_CLUSTER
 #undef EOE_NTP_MFMA
@@ -363,15 +414,15 @@ __global__ __launch_bounds__(256, 1) void gemm_ntp_kernel(GemmP p) {
 #undef EOE_DMA16
 }
 
-template <typename T>
+template <typename T, int MI>
 int launch_ntp(const GemmP& p, int epi, hipStream_t s) {
-    const int tiles = cdiv(p.M, 32 * NTP_MI) * (p.N / 256);
+    const int tiles = cdiv(p.M, 32 * MI) * (p.N / 256);
     const int ncu = num_cus();
     const int grid = tiles < ncu ? tiles : ncu;
 #define EOE_NTP_CASE(E)                                                                     \
     case E:                                                                                 \
-        { static bool once = (hipFuncSetAttribute((const void*)gemm_ntp_kernel<T, E>, hipFuncAttributeMaxDynamicSharedMemorySize, NTP_SMEM_BYTES), true); (void)once; } \
-        hipLaunchKernelGGL((gemm_ntp_kernel<T, E>), dim3(grid), dim3(256), NTP_SMEM_BYTES, s, p); \
+        { static bool once = (hipFuncSetAttribute((const void*)gemm_ntp_kernel<T, E, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, ntp_smem_bytes(MI)), true); (void)once; } \
+        hipLaunchKernelGGL((gemm_ntp_kernel<T, E, MI>), dim3(grid), dim3(256), ntp_smem_bytes(MI), s, p); \
         break;
     switch (epi) {
         EOE_NTP_CASE(EOE_EPI_NONE)
@@ -386,21 +437,22 @@ int launch_ntp(const GemmP& p, int epi, hipStream_t s) {
 }  // namespace
 
 // what the kernel is built for (the launcher in gemm.hip sends everything else to the other kernels)
-bool eoe_ntp_applies(const void* gemm_p, int epi) {
+bool eoe_ntp_applies(const void* gemm_p, int epi, int mi) {
     const GemmP& p = *(const GemmP*)gemm_p;
     if (epi != EOE_EPI_NONE && epi != EOE_EPI_GELU) return false;
     if (p.out_f32 || p.accumulate || p.colsum || p.colsum_part || p.colsum_sq || p.split_k) return false;
-    if ((p.N & 255) || (p.K % BK) || p.K / BK < 2 * NTP_MI + 2 || p.M < 32 * NTP_MI) return false;
+    if ((p.N & 255) || (p.K % BK) || p.K / BK < 2 * mi + 2 || p.M < 32 * mi) return false;
     if (!epilogue_fast_ok(p)) return false;
-    const size_t c_bytes = (((size_t)p.M - 1) * p.ldc + p.N) * 2 + (size_t)32 * NTP_MI * p.ldc * 2;   // + one tile of rows: soffset of a ragged last tile
+    const size_t c_bytes = (((size_t)p.M - 1) * p.ldc + p.N) * 2 + (size_t)32 * mi * p.ldc * 2;   // + one tile of rows: soffset of a ragged last tile
     return c_bytes < 0x7fffffffull;
 }
 
-int eoe_launch_ntp(const void* gemm_p, int dtype, int epi, hipStream_t s) {
+int eoe_launch_ntp(const void* gemm_p, int dtype, int epi, int mi, hipStream_t s) {
     const GemmP& p = *(const GemmP*)gemm_p;
 #ifdef EOE_NTP_DEV         // development builds: one instantiation family only (compile time)
-    return launch_ntp<f16_t>(p, epi, s);
+    return mi == 4 ? launch_ntp<f16_t, 4>(p, epi, s) : launch_ntp<f16_t, 5>(p, epi, s);
 #else
-    return dtype == EOE_F16 ? launch_ntp<f16_t>(p, epi, s) : launch_ntp<bf16_t>(p, epi, s);
+    if (dtype == EOE_F16) return mi == 4 ? launch_ntp<f16_t, 4>(p, epi, s) : launch_ntp<f16_t, 5>(p, epi, s);
+    return mi == 4 ? launch_ntp<bf16_t, 4>(p, epi, s) : launch_ntp<bf16_t, 5>(p, epi, s);
 #endif
 }

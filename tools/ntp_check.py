@@ -61,7 +61,7 @@ if "--time-only" not in sys.argv:
     print("BITWISE", "PASS" if ok else "FAIL")
 
 # ---- timing: interleaved, operands rotated through NSET buffer sets
-NSET = 6
+NSET = int(os.environ.get("NSET", "6"))
 M = 12800
 for name, n, k, kind in (("in_proj fwd", 2304, 768, "none"), ("c_fc fwd (GELU pair)", 3072, 768, "gelu")):
     sets = []
