@@ -31,17 +31,19 @@ int g_tn256_launches = 0;      // diagnostics: eoe_get_option("tn256_launches")
 namespace {
 
 constexpr int BK = 64;
-constexpr int IMG_BYTES = BK * 256 * 2;           // 32 KiB: [64 t][256 cols] 16-bit
-constexpr int STAGE = 2 * IMG_BYTES;              // 64 KiB
-constexpr int NST = 2;
-constexpr int SMEM = NST * STAGE;                 // 128 KiB: one 4-wave workgroup per CU
-// NW = waves per workgroup.  4: one wave per SIMD, 128 x 128 of the tile each (256 accumulator registers).  8 (round 4, the default): two
-// waves per SIMD, 128 x 64 each (128 accumulators + 128 other registers) -- a wave issues one instruction at a time, and the fragment reads,
-// LDS-DMA pieces and scalar work of a k-step need about as many issue cycles as its MFMAs leave free (stamps: 3196 cycles per k-tile for
-// 2048 of matrix work); instructions of DIFFERENT waves of a SIMD issue side by side (gemm_w8.hip's header).  Same products in the same k
-// order per accumulator, same slice meeting: same bits.  Block wgrad 206 -> 201 us stand-alone (tools/gemm_tn_ab.py 0 8).
-// (round 4, measured and dropped -- tools/attic/gemm_tn256_ring4.hip: a ring of FOUR 32-deep stages, three in flight instead of one of two:
-//  215 us.  The k-loop is not bound by the bytes in flight: twice the barriers cost more than the longer lead gains.)
+// (round 4) The ring holds FOUR stages of one 32-deep k-step each instead of two 64-deep k-tiles.  Same 128 KiB, but three stages (96 KiB)
+// are in flight while the fourth is read, against one of two (64 KiB): the k-loop is bound by the LATENCY of the staged operands -- a CU
+// receives (bytes in flight) / (~2 us under load), measured 2.0 us per 64-deep k-tile against 1.37 us of MFMA work -- not by their bandwidth.
+constexpr int KS = 32;                            // rows of t per stage
+constexpr int IMG_BYTES = KS * 256 * 2;           // 16 KiB: [32 t][256 cols] 16-bit
+constexpr int STAGE = 2 * IMG_BYTES;              // 32 KiB
+constexpr int NST = 4;
+constexpr int SMEM = NST * STAGE;                 // 128 KiB: one workgroup per CU
+// NW = waves per workgroup.  4: one wave per SIMD, 128 x 128 of the tile each (256 accumulator registers).  8 (round 4): two waves per SIMD,
+// 128 x 64 each (128 accumulators + 128 other registers) -- a wave issues one instruction at a time and the fragment reads, LDS-DMA pieces
+// and scalar work of a k-step need about as many issue cycles as its MFMAs leave free (stamps: 3196 cycles per k-tile for 2048 of matrix
+// work); instructions of DIFFERENT waves of a SIMD issue side by side (gemm_w8.hip's header).  Same products in the same k order per
+// accumulator, same slice meeting: same bits.
 constexpr int ROWB = 512;                         // bytes per image row
 
 struct P256 {
@@ -85,7 +87,8 @@ template <typename T, int NW>
 __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_tn256_kernel(G256 g) {
     static_assert(NW == 4 || NW == 8, "waves");
     constexpr int NI = NW == 8 ? 4 : 8;                    // 16-column groups of the B image per wave: 128 x (16 NI) of the tile
-    constexpr int PIW = 32 / NW;                           // wave-loads (2 rows) per wave and image
+    constexpr int PIW = 16 / NW;                           // wave-loads (2 rows) per wave, image and stage
+    constexpr int NMF = 8 * NI;                            // MFMAs per cluster
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int items = g.total_tiles * g.splits;
@@ -102,14 +105,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_tn256_kernel(G256 g) {
     const int lt = gt - P.tile_start;
     const int m0 = (lt / P.tiles_n) * 256, n0 = (lt % P.tiles_n) * 256;
     const int kt0 = (int)(((long long)g.nk_tile * slice) / g.splits), kt1 = (int)(((long long)g.nk_tile * (slice + 1)) / g.splits);
-    const int nk = kt1 - kt0;
-    const int t_begin = kt0 * BK, t_end = min(g.T, kt1 * BK);
+    const int nk = 2 * (kt1 - kt0);                        // 32-deep k-steps of this slice
+    const int t_begin = kt0 * BK;
 
     __amdgpu_buffer_rsrc_t ra = make_rsrc(P.A, P.bytesA);
     __amdgpu_buffer_rsrc_t rb = make_rsrc(P.B, P.bytesB);
     const int lda = P.lda, ldb = P.ldb;
 
-    // staging: an image is 64 rows x 512 B = 32 wave-loads of 2 rows, PIW per wave; lane -> (row, 16-B slot holding granule-swizzled chunk)
+    // staging: a stage's image is 32 rows x 512 B = 16 wave-loads of 2 rows, PIW per wave; lane -> (row, 16-B slot holding granule-swizzled chunk)
     unsigned baseA[PIW], baseB[PIW];
     const int row_in = lane >> 5, s = lane & 31;
 #pragma unroll
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_tn256_kernel(G256 g) {
     // out-of-range base, and a cursor past the slice's last k-tile (`st_off_*` = out of range) fills a dead slot with zeros
     unsigned st_off_a = 0, st_off_b = 0;                   // byte offset of the cursor's k-tile in A / B (wave-uniform)
     auto stage_cursor = [&]() {
-        const int t0 = t_begin + st_kt * BK;
+        const int t0 = t_begin + st_kt * KS;
         const bool live = st_kt < nk;
         st_off_a = live ? (unsigned)((size_t)t0 * lda * 2) : EOE_OOB;
         st_off_b = live ? (unsigned)((size_t)t0 * ldb * 2) : EOE_OOB;
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_tn256_kernel(G256 g) {
 #pragma unroll
         for (int j = 0; j < 2 * PIW; ++j) stage_piece(j);
     };
-    auto stage_advance = [&]() { st_slot ^= 1; ++st_kt; };
+    auto stage_advance = [&]() { st_slot = (st_slot + 1) & (NST - 1); ++st_kt; };
 
     // fragments: lane 4q+p of a 16-lane group addresses row q of the group's 4-row block, columns 4p..4p+3 (transposed read)
     const int wm0 = NW == 8 ? (wave >> 2) * 128 : (wave >> 1) * 128, wn0 = NW == 8 ? (wave & 3) * 64 : (wave & 1) * 128;
@@ -188,9 +191,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_tn256_kernel(G256 g) {
     // the 64 MFMAs of one 32-deep k-step on fragment set X, with woven between them (a) the 32 half-reads of the OTHER set R from
     // ring slot `rbase`, k-step `rks` -- one behind every second MFMA --, and (b) (DMA) this wave's 16 LDS-DMA pieces of the next
     // k-tile behind the (wave + 1)-th quarter of the cluster (the four SIMDs share one LDS-DMA path: staggered, not a burst)
-#define EOE_CLUSTER(XLA, XHA, XLB, XHB, RLA, RHA, RLB, RHB, rbase, rks, DMA, PH)                                                 \
+#define EOE_CLUSTER(XLA, XHA, XLB, XHB, RLA, RHA, RLB, RHB, rbase, DMA, PH)                                                      \
     do {                                                                                                                     \
-        const unsigned rb_ = (unsigned)(rbase) + (unsigned)(rks) * 32u * ROWB;                                               \
+        const unsigned rb_ = (unsigned)(rbase);                                                                              \
         _Pragma("unroll") for (int mi = 0; mi < 8; ++mi) {                                                                   \
             const V8 xa_ = join<T>(XLA[mi], XHA[mi]);                                                                        \
             _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                                              \
@@ -207,31 +210,19 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_tn256_kernel(G256 g) {
                         else EOE_TRREAD(RLB[fr >= 8 ? fr - 8 : 0], rb_ + offB[fr >= 8 ? fr - 8 : 0], 0);                     \
                     }                                                                                                        \
                 }                                                                                                            \
-                {                                                                                                            \
-                    if (DMA_SPREAD) {                                                                                        \
-                        /* one piece behind every 4th MFMA, the four waves one MFMA (16 cycles = one piece on the CU's shared  \
-                           LDS-DMA path) apart: the path sees a steady piece per 16 cycles instead of four bursts of 16 */     \
-                        if ((DMA) && DMA_EVERY == 4 && (idx & 3) == (PH)) stage_piece(idx >> 2);                              \
-                        if ((DMA) && DMA_EVERY == 3 && (idx % 3) == 2 && idx / 3 < 2 * PIW) stage_piece(idx / 3);             \
-                    } else {                                                                                                 \
-                        if ((DMA) && (idx & 15) == 15 && (int)(wave_u & 3) == (idx >> 4)) stage_issue();                     \
-                    }                                                                                                        \
-                }                                                                                                            \
+                /* this wave's 2 PIW pieces of the k-step four ahead, one behind every 8th MFMA (spread: the SIMDs share one LDS-DMA path) */ \
+                if ((DMA) && (idx & 7) == (PH) && (idx >> 3) < 2 * PIW) stage_piece(idx >> 3);                               \
             }                                                                                                                \
         }                                                                                                                    \
     } while (0)
 
-    constexpr bool DMA_SPREAD = true;
-#ifndef EOE_TN256_DMA_EVERY
-#define EOE_TN256_DMA_EVERY 4
-#endif
-    constexpr int DMA_EVERY = EOE_TN256_DMA_EVERY;         // a piece behind every 3rd (front-loaded: the last piece has a longer lead) or 4th MFMA
-    const int dma_phase = (int)(wave_u & 3);               // 0..3
     i16x4v la0[8], ha0[8], lb0[NI], hb0[NI], la1[8], ha1[8], lb1[NI], hb1[NI];
-    if (nk > 0) {
-        const int pre = nk < NST ? nk : NST;
-        for (int i = 0; i < pre; ++i) { stage_issue(); stage_advance(); }
-        if (pre > 1) { if (NW == 8) { EOE_WAIT_VM(8); } else { EOE_WAIT_VM(16); } } else { EOE_WAIT_VM(0); }       // k-tile 0 landed; k-tile 1 may stay in flight
+    // counted wait: everything but the pieces of the two youngest stages has landed (2 PIW pieces per wave and stage)
+#define EOE_WAIT_2STAGES() do { if (PIW == 2) { EOE_WAIT_VM(8); } else { EOE_WAIT_VM(16); } } while (0)
+    if (nk > 0) {                                          // nk is even and >= 48 (eoe_tn256_splits: >= 24 k-tiles per slice)
+#pragma unroll 1
+        for (int i = 0; i < NST; ++i) { stage_issue(); stage_advance(); }
+        if (PIW == 2) { EOE_WAIT_VM(12); } else { EOE_WAIT_VM(24); }       // k-step 0 landed; k-steps 1..3 may stay in flight
         __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -243,41 +234,46 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_tn256_kernel(G256 g) {
             EOE_TRREAD(lb0[i], offB[i], 0);
             EOE_TRREAD(hb0[i], offB[i], 4 * ROWB);
         }
-        EOE_LANDED(la0, ha0, lb0, hb0);
-        int cur = 0;
-        // diagnostics: wave 0's cycles in [first half + DMA wait], [at the barrier], [second half incl. the LDS-DMA issue]; stamped only
-        // where every LDS read has just been waited for (s_memtime returns through lgkmcnt)
+        int cur = 0;                                       // ring stage of the k-step being multiplied
+        // diagnostics: wave 0's cycles [waiting for the staged k-step and its fragments], [at the barrier], [in the clusters]
         unsigned long long* stp = g.stamp ? g.stamp + (size_t)blockIdx.x * 8 : nullptr;
         unsigned long long t_a = 0, t_b = 0, t_c = 0, c_first = 0, c_bar = 0, c_second = 0, t_loop0 = 0;
         if (stp) { t_c = __builtin_amdgcn_s_memtime(); t_loop0 = t_c; }
-        for (int kt = 0; kt < nk; ++kt) {
-            const unsigned sc = (unsigned)cur * STAGE, sn = (unsigned)(cur ^ 1) * STAGE;
-            // first half: MFMA(F0) with the reads of F1 (k-step 1 of this k-tile) woven in
-            EOE_CLUSTER(la0, ha0, lb0, hb0, la1, ha1, lb1, hb1, sc, 1, false, 0);
-            EOE_WAIT_VM(0);                                // k-tile kt+1 (issued one iteration ago) has landed
-            EOE_LANDED(la1, ha1, lb1, hb1);                // this wave's reads of slot `cur` are complete
-            if (stp) { t_a = __builtin_amdgcn_s_memtime(); c_first += t_a - t_c; }
-            __builtin_amdgcn_s_barrier();
-            if (stp) { t_b = __builtin_amdgcn_s_memtime(); c_bar += t_b - t_a; }
-            // second half: MFMA(F1) with the reads of the next k-tile's F0 and this wave's share of the LDS-DMA of k-tile kt+2 (into
-            // the slot just consumed) woven in.  Past the last k-tile the reads fetch a stale slot and are discarded.
-            // (past the slice's last k-tile the pieces carry the out-of-range offset: nothing is fetched, a dead slot is zero-filled --
-            //  cheaper than a branch around every piece)
-            stage_cursor();
-            // the four waves one MFMA (16 cycles = one piece on the CU's shared LDS-DMA path) apart for the rest of this half
-            if (dma_phase & 1) asm volatile("s_nop 15" ::: "memory");
-            if (dma_phase & 2) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-            EOE_CLUSTER(la1, ha1, lb1, hb1, la0, ha0, lb0, hb0, sn, 0, true, 3);
-            stage_advance();
-            EOE_LANDED(la0, ha0, lb0, hb0);                // before the back edge: no fragment register is in flight across it
-            if (stp) { t_c = __builtin_amdgcn_s_memtime(); c_second += t_c - t_b; }
-            cur ^= 1;
+        // k-step s (fragments in set s & 1, read from stage s % 4 during the previous cluster):
+        //   wait: stage s + 1 has landed (the pieces of s + 2, s + 3 stay in flight) and this wave's reads of stage s are complete;
+        //   barrier: ... for every wave -- stage s + 1 may be read, stage s may be refilled;
+        //   cluster: the MFMAs of k-step s + the reads of k-step s + 1 + the pieces of k-step s + 4 into stage s.
+        // Past the slice's last k-step the pieces carry the out-of-range offset (nothing fetched, a dead stage zero-filled) and the reads
+        // fetch a stale stage and are discarded: the counts stay constant.
+#define EOE_KSTEP(XLA, XHA, XLB, XHB, RLA, RHA, RLB, RHB)                                                                    \
+        do {                                                                                                                 \
+            EOE_WAIT_2STAGES();                                                                                              \
+            EOE_LANDED(XLA, XHA, XLB, XHB);                                                                                  \
+            if (stp) { t_a = __builtin_amdgcn_s_memtime(); c_first += t_a - t_c; }                                           \
+            __builtin_amdgcn_s_barrier();                                                                                    \
+            if (stp) { t_b = __builtin_amdgcn_s_memtime(); c_bar += t_b - t_a; }                                             \
+            stage_cursor();                                                                                                  \
+            if (dma_phase & 1) asm volatile("s_nop 15" ::: "memory");                                                        \
+            if (dma_phase & 2) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                                            \
+            EOE_CLUSTER(XLA, XHA, XLB, XHB, RLA, RHA, RLB, RHB, (unsigned)((cur + 1) & (NST - 1)) * STAGE, true, 7);         \
+            stage_advance();                                                                                                 \
+            if (stp) { t_c = __builtin_amdgcn_s_memtime(); c_second += t_c - t_b; }                                          \
+            cur = (cur + 1) & (NST - 1);                                                                                     \
+        } while (0)
+        const int dma_phase = (int)(wave_u & 3);           // the waves of a SIMD pair / of the CU a little apart behind the barrier
+#pragma unroll 1
+        for (int ks = 0; ks < nk; ks += 2) {
+            EOE_KSTEP(la0, ha0, lb0, hb0, la1, ha1, lb1, hb1);
+            EOE_KSTEP(la1, ha1, lb1, hb1, la0, ha0, lb0, hb0);
         }
+        EOE_LANDED(la0, ha0, lb0, hb0);                    // the discarded reads of the last cluster
+#undef EOE_KSTEP
         if (stp && lane == 0) {
-            unsigned long long* o = stp + (wave & 1) * 4;          // waves 0 and 1 report (wave 1 issues its LDS-DMA in the 2nd quarter)
+            unsigned long long* o = stp + (wave & 1) * 4;
             if (wave < 2) { o[0] = c_first; o[1] = c_bar; o[2] = c_second; o[3] = t_c - t_loop0; }
         }
     }
+#undef EOE_WAIT_2STAGES
     EOE_WAIT_VM(0);                                        // the (dead) LDS-DMA pieces of the last iterations have landed: the ring is reused below
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the last MFMAs' results have landed before the accumulators are read
 #undef EOE_CLUSTER
