@@ -31,6 +31,13 @@ static_assert(W8_SMEM_BYTES <= 160 * 1024, "LDS");
 #define W8_MFMA_INPLACE(MNEM, E, A, B) asm volatile(MNEM " a[%c0:%c1], %2, %3, a[%c0:%c1]" :: "i"(4 * (E)), "i"(4 * (E) + 3), "v"(A), "v"(B) : W8_AGPRS)
 #define W8_MFMA_FIRST(MNEM, E, A, B) asm volatile(MNEM " a[%c0:%c1], %2, %3, 0" :: "i"(4 * (E)), "i"(4 * (E) + 3), "v"(A), "v"(B) : W8_AGPRS)
 
+// cache policy of the output stores: 2 = nt (non-temporal).  The outputs (59 - 157 MB per launch) stream through the 4 MB L2 of each XCD and
+// evict the operand panels the other workgroups are about to re-read; PMC (profiles/r4/gemm_pmc_*.txt): 70 % L2 hit rate on the
+// in-projection, the L1 stalled on its outstanding-request limit half of the kernel's time -- a CU's intake is (requests in flight) x 128 B
+// / (L1 -> L2 latency), and every miss that goes to the fabric makes that latency longer
+#ifndef W8_ST_AUX
+#define W8_ST_AUX 2
+#endif
 template <int N> __device__ __forceinline__ void w8_wait_vm() {
     static_assert(N >= 0 && N <= 63, "vmcnt");
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
@@ -271,8 +278,8 @@ __global__ __launch_bounds__(512, 2) void gemm_w8_kernel(GemmP p) {
             }
             if (k < 12) { const int j = k - 8; hv[2 * j] = (T)xv[2 * j]; hv[2 * j + 1] = (T)xv[2 * j + 1]; return; }
             if (k == 12) {
-                if (EPI == EOE_EPI_GELU) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv), rpre, (int)e_voff, e_soff + q * 64, 0);
-                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv), rc, (int)e_voff, e_soff + q * 64, 0);
+                if (EPI == EOE_EPI_GELU) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv), rpre, (int)e_voff, e_soff + q * 64, W8_ST_AUX);
+                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv), rc, (int)e_voff, e_soff + q * 64, W8_ST_AUX);
                 return;
             }
             if (EPI != EOE_EPI_GELU) return;
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8_kernel(GemmP p) {
             if (k < 53) { const int j = k - 45; wv[j] = __builtin_amdgcn_rcpf(wv[j]); return; }
             if (k < 61) { const int j = k - 53; wv[j] = xv[j] * wv[j]; return; }
             if (k < 65) { const int j = k - 61; av[2 * j] = (T)wv[2 * j]; av[2 * j + 1] = (T)wv[2 * j + 1]; return; }
-            if (k == 65) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, av), rc, (int)e_voff, e_soff + q * 64, 0);
+            if (k == 65) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, av), rc, (int)e_voff, e_soff + q * 64, W8_ST_AUX);
         };
 
         load_bias16((unsigned)W8_BIAS_OFF + (unsigned)(c_tile & 1) * 1024u);
