@@ -287,6 +287,7 @@ class ADTrainer(ABC):
         arena = comm = None
         nominal = getattr(ds, "nominal_label", 0)
         self.last_losses = []
+        self.last_scores = []                               # per epoch: (labels, scores) of every step batch, in order, on the device
         self.scale_events = []                              # (global step, new scale) whenever the fp16 gradient scale moved
         graphed = None                                      # (batch shape, GraphedStep) of the full-size step batch
         # process-wide state this loop changes (gradient scale, wgrad launch form, BatchNorm hook) is restored on every way out
@@ -368,6 +369,7 @@ class ADTrainer(ABC):
                     la, sc = parallel.all_gather_1d(la), parallel.all_gather_1d(sc)
                     torch.distributed.all_reduce(ls)          # local losses are already divided by the global batch
                 self.last_losses.extend(ls.cpu().tolist())
+                self.last_scores.append((la, sc))
                 if bool(torch.isnan(sc).any()):
                     raise NanGradientsError()                                                           # :448-449
                 if bool((la == 1).any()):

@@ -39,6 +39,47 @@ def test_train_cls_matches_golden_trajectory(golden):
     assert not next(model.parameters()).is_cuda and not model.training      # returned on the CPU in eval mode (:471)
 
 
+@pytest.mark.parametrize("obj,fixture,clf", [("hsc", "g3_vit_l12_hsc_big", False), ("bce", "g3_vit_l12_bce_big", True)])
+def test_train_cls_at_the_benchmark_batch_matches_the_reference_trajectory(golden, obj, fixture, clf):
+    """the TRAINER (not a loop written in the test) on the benchmark's model at the benchmark's batch: `ADTrainer.train_cls` with its
+    defaults -- fp16 gradient-scale policy, backward hand-over buffers, asynchronous weight gradients, the last block on its class-token
+    rows, eager launches -- over the K = 10 reference-made step batches of the 12-layer ViT-B/32 (128 + 128 images, a new batch every
+    step; ad_trainer.py:406-455).  Loss, scores and the per-batch AUC within the stated 1e-3 of the reference's trajectory on every
+    step; next to each AUC deviation the share of pairs the step's own score deviation leaves undecided (parity_util.auc_flip_share)"""
+    import eoe_amd
+    import parity_util
+    from eoe_amd import ops
+    from eoe_amd.data import ListSource
+    from eoe_amd.models import ClipViTB32Custom
+    from eoe_amd.training import TRAINER
+    eoe_amd.set_compute_dtype("fp16")
+    g = golden(fixture)
+    K = len(g["losses"])
+    m = omodels.deterministic_init(ClipViTB32Custom(layers=12, clf=clf), tag="vit", layers=12)
+    batches = [otrainer.synthetic_batch(f"g3big/b{i}", 128, 128, 224) for i in range(K)]
+    tr = TRAINER[obj](m, dataset=ListSource(batches), epochs=1, lr=1e-4, wdk=1e-3, milestones=[], batch_size=128)
+    assert ops.VIT_ASYNC_WGRAD and ops.VIT_HANDOVER and ops.VIT_CLS_ONLY_LAST and not tr.graph_steps     # the defaults are what is pinned
+    model, roc = tr.train_cls(m, tr.ds, 0, "0", 0)
+    labels, scores = tr.last_scores[0]
+    labels, scores = labels.cpu().numpy().reshape(K, 256), scores.float().cpu().numpy().reshape(K, 256)
+    assert (labels == batches[0][1].numpy()[None, :]).all()
+    dl, ds = parity_util.trajectory_deviation(tr.last_losses, list(scores), g)
+    aucs = np.array([abs(parity_util.auc_of(labels[k], scores[k]) - parity_util.auc_of(labels[k], g["scores"][k])) for k in range(K)])
+    flips = np.array([parity_util.auc_flip_share(labels[k], g["scores"][k], max(float(ds[k]), 1e-12)) for k in range(K)])
+    fmt = lambda a: "[" + " ".join(f"{v:.1e}" for v in a) + "]"          # noqa: E731
+    print(f"\n[train_cls {obj}, 12 layers, 128 + 128] loss dev {fmt(dl)}\n   score dev {fmt(ds)}\n   AUC dev   {fmt(aucs)}\n"
+          f"   pairs within 2 x the step's score deviation (the AUC they could move) {fmt(flips)}; gradient-scale events {tr.scale_events}")
+    # (BCE, config 5: the loss spike 0.73 -> 9.7 -> 6.0 at the start carries the forward's logit error; test_gpu_parity_big.py holds the
+    #  same run to 2e-3 on the loss there and to 1e-3 on the first three steps: VIT_BCE_BARS)
+    loss_bar = 1e-3 if obj == "hsc" else 2e-3
+    assert dl.max() <= loss_bar and dl[:3].max() <= 1e-3 and ds.max() <= 1e-3, (fmt(dl), fmt(ds))
+    assert aucs.max() <= 1e-3, (fmt(aucs), fmt(flips))
+    # the epoch AUC the trainer returns = the oracle's metric on the reference's scores of all K batches
+    from oracle import metrics as ometrics
+    want = ometrics.roc_auc(labels.reshape(-1), g["scores"].reshape(-1))
+    assert abs(roc.auc - want) < 1e-3, (roc.auc, want)
+
+
 def test_run_loop_and_eval_determinism(tmp_path):
     import eoe_amd
     from eoe_amd.data import SyntheticAD
