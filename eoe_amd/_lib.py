@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must precede the CDLL below)
 
 from . import _build
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 EOE_F16, EOE_BF16, EOE_F32 = 1, 2, 3
 EOE_RESIZE_BILINEAR, EOE_RESIZE_BICUBIC = 2, 3
 EOE_COMM_I64, EOE_COMM_ID_BYTES, EOE_COMM_ALGO_RING, EOE_COMM_ALGO_RS_AG = 8, 128, 0, 1
@@ -200,7 +200,7 @@ SIGNATURES = {
     "eoe_comm_allreduce_sum_async": [_vp, _vp, _i64, C.c_int, C.c_int, _vp],
     "eoe_comm_allgather_async": [_vp, _vp, _vp, _i64, C.c_int, _vp],
     "eoe_comm_join": [_vp, _vp],
-    "eoe_comm_sync_bn": [_vp, C.c_int],
+    "eoe_comm_sync_bn": [_vp, C.c_int, _vp],
     "eoe_set_bn_sync": [_vp, _vp],
     "eoe_prof_enable": [C.c_int],
     "eoe_set_option": [C.c_char_p, C.c_int],

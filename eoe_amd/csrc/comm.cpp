@@ -193,36 +193,27 @@ extern "C" int eoe_comm_join(eoe_comm_t c, void* stream) {
 static int comm_bn_hook(void* user, void* buf, int64_t count, int is_f64, void* stream) {
     eoe_comm_t c = (eoe_comm_t)user;
     Rccl* r = rccl();
-    if (!c || !r || !c->bn_comm) return 1;
-    return r->AllReduce(buf, buf, (size_t)count, is_f64 ? ncclFloat64 : ncclFloat32, ncclSum, c->bn_comm, (hipStream_t)stream) == ncclSuccess ? 0 : 1;
-}
-
-// the second communicator: rank 0 draws a fresh id and hands it to the others through the first one (side stream, then a host wait)
-static int make_bn_comm(eoe_comm_t c) {
-    Rccl* r;
-    EOE_TRY(need_rccl(r));
-    ncclUniqueId uid;
-    memset(&uid, 0, sizeof(uid));
-    if (c->rank == 0) EOE_NCCL(r, r->GetUniqueId(&uid), "ncclGetUniqueId");
-    if (c->world > 1) {
-        void* dbuf = nullptr;
-        EOE_HIP(hipMalloc(&dbuf, sizeof(uid)), "hipMalloc");
-        hipError_t e = hipMemcpy(dbuf, &uid, sizeof(uid), hipMemcpyHostToDevice);
-        ncclResult_t rc = ncclSuccess;
-        if (e == hipSuccess) rc = r->Broadcast(dbuf, dbuf, sizeof(uid), ncclChar, 0, c->comm, c->side);
-        if (e == hipSuccess && rc == ncclSuccess) e = hipStreamSynchronize(c->side);
-        if (e == hipSuccess && rc == ncclSuccess) e = hipMemcpy(&uid, dbuf, sizeof(uid), hipMemcpyDeviceToHost);
-        (void)hipFree(dbuf);
-        if (rc != ncclSuccess) return eoe_set_error(EOE_ERR_LAUNCH, "eoe_comm_sync_bn: ncclBroadcast: %s", r->GetErrorString(rc));
-        if (e != hipSuccess) return eoe_set_error(EOE_ERR_LAUNCH, "eoe_comm_sync_bn: %s", hipGetErrorString(e));
-    }
-    EOE_NCCL(r, r->CommInitRank(&c->bn_comm, c->world, uid, c->rank), "ncclCommInitRank (BatchNorm communicator)");
+    if (!c || !r || !c->bn_comm)
+        return eoe_set_error(EOE_ERR_LAUNCH, "synchronised BatchNorm: the registered communicator is gone (or RCCL is not loaded)");
+    const ncclResult_t rc = r->AllReduce(buf, buf, (size_t)count, is_f64 ? ncclFloat64 : ncclFloat32, ncclSum, c->bn_comm, (hipStream_t)stream);
+    if (rc != ncclSuccess) return eoe_set_error(EOE_ERR_LAUNCH, "synchronised BatchNorm: ncclAllReduce of %lld values: %s", (long long)count, r->GetErrorString(rc));
     return 0;
 }
 
-extern "C" int eoe_comm_sync_bn(eoe_comm_t c, int enable) {
+// The BatchNorm sums travel on a SECOND communicator (they are issued on the compute stream while bucket all-reduces of the first one are in
+// flight on the side stream).  Its id comes from the caller like the first one's (eoe_comm_unique_id on rank 0, handed to every rank by
+// whatever launched the job): the library allocates no device memory and synchronises nothing for it (ownership)
+extern "C" int eoe_comm_sync_bn(eoe_comm_t c, int enable, const void* bn_id) {
     EOE_CHECK_ARG(c != nullptr || !enable, "eoe_comm_sync_bn: null communicator");
-    if (enable && !c->bn_comm) EOE_TRY(make_bn_comm(c));
+    if (enable && !c->bn_comm) {
+        EOE_CHECK_ARG(bn_id != nullptr, "eoe_comm_sync_bn: the second communicator needs its own id (eoe_comm_unique_id on rank 0, the same %d bytes on every rank)", EOE_COMM_ID_BYTES);
+        Rccl* r;
+        EOE_TRY(need_rccl(r));
+        EOE_HIP(hipSetDevice(c->device), "hipSetDevice");
+        ncclUniqueId uid;
+        memcpy(&uid, bn_id, sizeof(uid));
+        EOE_NCCL(r, r->CommInitRank(&c->bn_comm, c->world, uid, c->rank), "ncclCommInitRank (BatchNorm communicator)");
+    }
     if (!enable) {
         // clears the hook only if it is this communicator's (or none was given): another live communicator keeps its registration
         if (c && eoe_bn_sync_user() != (void*)c) return 0;

@@ -61,20 +61,24 @@ class NativeComm:
         self.rank, self.world = rank, world
         self.device = torch.cuda.current_device() if device is None else device
         self.algo = _lib.EOE_COMM_ALGO_RING if algo is None else algo
+        handle = C.c_void_p()
+        _lib.check(_lib.lib.eoe_comm_init(self.fresh_id(), rank, world, self.device, C.byref(handle)), "eoe_comm_init")
+        self.handle = handle
+
+    def fresh_id(self) -> bytes:
+        """a new RCCL id: drawn on rank 0 (`eoe_comm_unique_id`), the same bytes on every rank (broadcast over the launcher's process group)"""
+        _lib, C = self._lib, self._C
         ident = torch.zeros(_lib.EOE_COMM_ID_BYTES, dtype=torch.uint8)
-        if rank == 0:
+        if self.rank == 0:
             buf = (C.c_char * _lib.EOE_COMM_ID_BYTES)()
             _lib.check(_lib.lib.eoe_comm_unique_id(buf), "eoe_comm_unique_id")
             ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
-        if world > 1:
+        if self.world > 1:
             dev = torch.device("cuda", self.device) if dist.get_backend() == "nccl" else torch.device("cpu")
             ident = ident.to(dev)
             dist.broadcast(ident, src=0)
             ident = ident.cpu()
-        handle = C.c_void_p()
-        raw = bytes(ident.numpy().tobytes())
-        _lib.check(_lib.lib.eoe_comm_init(raw, rank, world, self.device, C.byref(handle)), "eoe_comm_init")
-        self.handle = handle
+        return bytes(ident.numpy().tobytes())
 
     @staticmethod
     def _code(t: torch.Tensor) -> int:
@@ -307,7 +311,8 @@ def enable_sync_bn(process_group=None, comm: "NativeComm" = None) -> bool:
     global _bn_sync_cb
     from . import _lib
     if comm is not None:
-        _lib.check(_lib.lib.eoe_comm_sync_bn(comm.handle, 1), "eoe_comm_sync_bn")
+        # the BatchNorm sums get a second RCCL communicator; its id travels like the first one's (made on rank 0, broadcast by torch)
+        _lib.check(_lib.lib.eoe_comm_sync_bn(comm.handle, 1, comm.fresh_id()), "eoe_comm_sync_bn")
         _bn_sync_cb = comm                    # keeps the communicator alive while registered
         return True
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:

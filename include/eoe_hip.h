@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define EOE_ABI_VERSION 2
+#define EOE_ABI_VERSION 3
 
 enum { EOE_OK = 0, EOE_ERR_ARG = 1, EOE_ERR_LAUNCH = 2, EOE_ERR_UNSUPPORTED = 3 };
 enum { EOE_F16 = 1, EOE_BF16 = 2, EOE_F32 = 3 /* only where an entry point says so */ };
@@ -485,8 +485,11 @@ int eoe_comm_allgather_async(eoe_comm_t comm, const void* send, void* recv, int6
 int eoe_comm_join(eoe_comm_t comm, void* stream);
 /* synchronised BatchNorm over this communicator without leaving the library: registers (enable != 0) or clears an eoe_set_bn_sync
  * hook that sums the BatchNorm reduction buffers with ncclAllReduce IN the stream the BatchNorm kernels run on (no side stream: the
- * very next kernel consumes the sums).  The communicator must outlive the registration. */
-int eoe_comm_sync_bn(eoe_comm_t comm, int enable);
+ * very next kernel consumes the sums).  The sums use a SECOND RCCL communicator over the same ranks (bucket all-reduces of the first one
+ * may be in flight on the side stream); `bn_id` is its id -- EOE_COMM_ID_BYTES bytes from eoe_comm_unique_id() on rank 0, identical on
+ * every rank, handed over like the first one's (NULL once the communicator has it, and with enable == 0).  The library allocates no
+ * device memory and synchronises nothing here.  The communicator must outlive the registration. */
+int eoe_comm_sync_bn(eoe_comm_t comm, int enable, const void* bn_id);
 
 /* ------------------------------------------------------------------------------------------------------
  * Parity mode (SURVEY.md section 7 "Hard parts", section 8d "Parity run"): the convolutions / linear layers of the BatchNorm

@@ -191,3 +191,41 @@ def test_task_definition_matches_oracle_and_golden(golden):
             normal = g[f"subset/{name}/{mode}/normal_classes"].tolist()
             assert data.normal_subset(labels, normal).tolist() == g[f"subset/{name}/{mode}/indices"].tolist()
             assert data.ad_targets(labels, normal).tolist() == batching.ad_targets(labels, normal).tolist()
+
+
+def test_w8_kernel_keeps_out_of_the_accumulators(tmp_path):
+    """gemm_w8.hip names its 128 accumulator registers literally (a[0:127] inside inline asm).  That is only sound while the compiler keeps
+    out of the accumulator file: rebuild the file to assembly with the product's flags and require, per kernel, no AGPR reference and no
+    v_accvgpr_* outside the asm statements, no scratch (a spilled fragment register would be stored before its LDS read has landed), and
+    a kernel descriptor that allocates the 128 AGPRs."""
+    import os
+    import re
+    import subprocess
+    from eoe_amd import _build
+    hipcc = _build.hipcc_path()
+    if hipcc is None:
+        pytest.skip("hipcc not available")
+    src = os.path.join(_build.CSRC, "gemm_w8.hip")
+    out = str(tmp_path / "w8.s")
+    r = subprocess.run([hipcc] + _build._flags("gemm_w8.hip") + ["--cuda-device-only", "-S", "-x", "hip", src, "-o", out],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    text = open(out).read()
+    kernels = re.findall(r"^(_ZN\S*gemm_w8_kernel\S*):[^\n]*\n(.*?)s_endpgm", text, flags=re.S | re.M)
+    assert len(kernels) == 4, [k for k, _ in kernels]            # {fp16, bf16} x {plain, GELU}
+    for name, body in kernels:
+        inside, bad = False, []
+        for line in body.split("\n"):
+            if ";;#ASMSTART" in line:
+                inside = True
+            elif ";;#ASMEND" in line:
+                inside = False
+            elif not inside:
+                code = line.split(";")[0]
+                if re.search(r"\ba\[?\d+", code) or "accvgpr" in code or "scratch_" in code:
+                    bad.append(line.strip())
+        assert not bad, (name, bad[:5])
+        assert body.count("v_mfma_f32_16x16x32") == 6 * 32, name          # three iteration bodies of two 32-MFMA clusters
+    for name, _ in kernels:
+        assert re.search(r"\.set %s\.num_agpr, 128\b" % re.escape(name), text), name
+        assert re.search(r"\.set %s\.private_seg_size, 0\b" % re.escape(name), text), name
