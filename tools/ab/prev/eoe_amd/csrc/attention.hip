@@ -45,18 +45,6 @@ __device__ __forceinline__ V8<T> gfrag(const T* src, int ld, int L, int t, int k
     if (row >= L) return zero8<T>();
     return __builtin_bit_cast(V8<T>, *(const u32x4*)(src + (size_t)row * ld + (ks * 4 + (lane >> 4)) * 8));
 }
-// The loads above sit behind `row < L` branches, and hipcc turns every one of them into load -> s_waitcnt vmcnt(0) -> use: a wave's
-// operand fetch became a chain of 8-11 dependent HBM round trips (round 4: attn_fwd's ISA showed eight load/wait/ds_write groups for V alone).
-// The forms below read through a buffer resource that covers the (image, head) slab; a row >= L gets an out-of-range offset, which reads
-// zeros, so the loads are unconditional and a whole batch is in flight before the first wait.
-__device__ __forceinline__ u32x4 bload16(__amdgpu_buffer_rsrc_t r, int row, int L, unsigned pitchb, unsigned cb) {
-    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)(row < L ? (unsigned)row * pitchb + cb : EOE_OOB), 0, 0));
-}
-// gfrag through the resource: cb0 = byte offset of the operand's head slice inside a row
-template <typename T>
-__device__ __forceinline__ V8<T> bfrag(__amdgpu_buffer_rsrc_t r, unsigned pitchb, unsigned cb0, int L, int t, int ks, int lane) {
-    return __builtin_bit_cast(V8<T>, bload16(r, t * 16 + (lane & 15), L, pitchb, cb0 + (unsigned)(ks * 4 + (lane >> 4)) * 16u));
-}
 // the same fragment from an LDS image
 template <typename T>
 __device__ __forceinline__ V8<T> lfrag(const char* lds, int t, int ks, int lane) {
@@ -149,7 +137,7 @@ __device__ __forceinline__ void softmax_T(f32x4 (&s)[4][4], int L, float scale, 
 
 // ------------------------------------------------------------------------------------------------ forward
 template <typename T>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L,
+__global__ __launch_bounds__(64) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L,
                                                       int heads, float scale) {
     __shared__ __attribute__((aligned(16))) char vs[TILEB];
     const int lane = threadIdx.x;
@@ -159,26 +147,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     const T* kp = qp + D;
     const T* vp = qp + 2 * D;
 
-    // one resource over this (image, head)'s Q | K | V slices: rows of 3 D elements, the last one ending behind V's 64 columns
-    const unsigned pitchb = (unsigned)ld * 2u, kcb = (unsigned)D * 2u, vcb = (unsigned)D * 4u;
-    const __amdgpu_buffer_rsrc_t rq = make_rsrc(qp, ((unsigned)(L - 1) * (unsigned)ld + 2u * D + 64u) * 2u);
-    (void)kp; (void)vp;
-    // all 24 loads of the wave back to back: V (for the LDS image), then the K / Q fragments of both k-steps
-    u32x4 vv[8];
-#pragma unroll
-    for (int it = 0; it < 8; ++it) vv[it] = bload16(rq, it * 8 + (lane >> 3), L, pitchb, vcb + (unsigned)(lane & 7) * 16u);
-    V8<T> kf[2][4], qf[2][4];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            kf[ks][t] = bfrag<T>(rq, pitchb, kcb, L, t, ks, lane);
-            qf[ks][t] = bfrag<T>(rq, pitchb, 0u, L, t, ks, lane);
-        }
-    __builtin_amdgcn_sched_barrier(0);          // (left alone the scheduler weaves the first MFMAs, and their waits, in among the loads)
-#pragma unroll
-    for (int it = 0; it < 8; ++it) *(u32x4*)(vs + (it * 8 + (lane >> 3)) * ROWB + (lane & 7) * 16) = vv[it];
-    __builtin_amdgcn_sched_barrier(0);
+    stage_tile<T>(vs, vp, ld, L, lane);
 
     f32x4 s[4][4];
 #pragma unroll
@@ -186,22 +155,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 #pragma unroll
         for (int j = 0; j < 4; ++j) s[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < 2; ++ks) {
+        V8<T> kf[4], qf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            kf[t] = gfrag<T>(kp, ld, L, t, ks, lane);
+            qf[t] = gfrag<T>(qp, ld, L, t, ks, lane);
+        }
 #pragma unroll
         for (int tk = 0; tk < 4; ++tk)
 #pragma unroll
-            for (int tq = 0; tq < 4; ++tq) s[tk][tq] = T16<T>::mfma16(kf[ks][tk], qf[ks][tq], s[tk][tq]);
+            for (int tq = 0; tq < 4; ++tq) s[tk][tq] = T16<T>::mfma16(kf[tk], qf[tq], s[tk][tq]);
+    }
     float mx[4], sm[4];
     softmax_T<T>(s, L, scale, lane, mx, sm);
 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    // O^T tile td, register r of lane (lr, lg) = d 16 lg + 4 td + r (tfrag_il): over the four tiles a lane holds 16 consecutive d of its
-    // query's row -- two 16-byte stores, and the four lanes of a query write its whole 128-byte head slice (round 4; before: sixteen 8-byte
-    // pieces per lane).  Same products in the same order.
     const int lr = lane & 15, lg = lane >> 4;
-    u32x2 pk[4][4];
 #pragma unroll
     for (int td = 0; td < 4; ++td) {
         f32x4 o[4];
@@ -209,21 +181,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         for (int tq = 0; tq < 4; ++tq) o[tq] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-            const V8<T> vf = tfrag_il<T>(vs, td, st, lane);
+            const V8<T> vf = tfrag<T>(vs, td, st, lane);
 #pragma unroll
             for (int tq = 0; tq < 4; ++tq)
                 o[tq] = T16<T>::mfma16(vf, acc_as_operand<T>(s[2 * st][tq], s[2 * st + 1][tq]), o[tq]);
         }
 #pragma unroll
-        for (int tq = 0; tq < 4; ++tq) pk[tq][td] = pack4<T>(o[tq][0], o[tq][1], o[tq][2], o[tq][3]);
-    }
-#pragma unroll
-    for (int tq = 0; tq < 4; ++tq) {
-        const int query = 16 * tq + lr;
-        if (query < L) {
-            T* d = out + ((size_t)img * L + query) * D + h * 64 + 16 * lg;
-            *(u32x4*)d = (u32x4){pk[tq][0][0], pk[tq][0][1], pk[tq][1][0], pk[tq][1][1]};
-            *(u32x4*)(d + 8) = (u32x4){pk[tq][2][0], pk[tq][2][1], pk[tq][3][0], pk[tq][3][1]};
+        for (int tq = 0; tq < 4; ++tq) {
+            const int query = 16 * tq + lr;
+            if (query < L)
+                *(u32x2*)(out + ((size_t)img * L + query) * D + h * 64 + 16 * td + 4 * lg) =
+                    pack4<T>(o[tq][0], o[tq][1], o[tq][2], o[tq][3]);
         }
     }
 }
@@ -462,6 +430,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // so 4 workgroups = 16 waves fit a CU and one workgroup's load / store latency is another's issue time.  Same arithmetic per element
 // as the one-wave kernel (same products, same k order); only the bias column sums associate differently (per-wave partials summed in
 // wave order).
+template <typename T>
+__device__ __forceinline__ void stage_slab(char* lds, const T* src, int ld, int L, int lane, int w) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int row = 16 * w + it * 8 + (lane >> 3), ch = lane & 7;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row < L) v = *(const u32x4*)(src + (size_t)row * ld + ch * 8);
+        *(u32x4*)(lds + row * ROWB + ch * 16) = v;
+    }
+}
 // column sums over the 16 tokens of one accumulator tile (token = lane & 15): the DPP row reduction of token_sum
 __device__ __forceinline__ f32x4 slab_sum(const f32x4& o, bool valid) {
     f32x4 t = valid ? o : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -504,34 +482,16 @@ __global__ __launch_bounds__(256) void attn_bwd4_kernel(const T* __restrict__ qk
     float* myred = red + w * 192;
 
     // V only ever is a row-major MFMA operand: fragments straight from global memory (phase A: all keys; phase B: this wave's keys)
-    // (all 16 loads of the wave unconditional and back to back -- see bload16; the slabs for the LDS images first: the barrier waits for them)
-    const unsigned pitchb = (unsigned)ld * 2u, kcb = (unsigned)D * 2u, vcb = (unsigned)D * 4u;
-    const __amdgpu_buffer_rsrc_t rq = make_rsrc(qp, ((unsigned)(L - 1) * (unsigned)ld + 2u * D + 64u) * 2u);
-    const __amdgpu_buffer_rsrc_t rdo = make_rsrc(dop, ((unsigned)(L - 1) * (unsigned)D + 64u) * 2u);
-    (void)kp; (void)vp;
-    u32x4 sq[2], sk[2], sd[2];
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int row = 16 * w + it * 8 + (lane >> 3);
-        const unsigned cb = (unsigned)(lane & 7) * 16u;
-        sq[it] = bload16(rq, row, L, pitchb, cb);
-        sk[it] = bload16(rq, row, L, pitchb, kcb + cb);
-        sd[it] = bload16(rdo, row, L, (unsigned)D * 2u, cb);
-    }
     V8<T> vfr[2][4], vfw[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) vfr[ks][t] = bfrag<T>(rq, pitchb, vcb, L, t, ks, lane);
-        vfw[ks] = bfrag<T>(rq, pitchb, vcb, L, w, ks, lane);
+        for (int t = 0; t < 4; ++t) vfr[ks][t] = gfrag<T>(vp, ld, L, t, ks, lane);
+        vfw[ks] = gfrag<T>(vp, ld, L, w, ks, lane);
     }
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int o = (16 * w + it * 8 + (lane >> 3)) * ROWB + (lane & 7) * 16;
-        *(u32x4*)(qs + o) = sq[it];
-        *(u32x4*)(ks_ + o) = sk[it];
-        *(u32x4*)(dos + o) = sd[it];
-    }
+    stage_slab<T>(qs, qp, ld, L, lane, w);
+    stage_slab<T>(ks_, kp, ld, L, lane, w);
+    stage_slab<T>(dos, dop, D, L, lane, w);
     __syncthreads();
 
     // ---- phase A: lane = query of this wave's slab.  S^T = K Q^T, dP^T = V dO^T
@@ -606,9 +566,6 @@ __global__ __launch_bounds__(256) void attn_bwd4_kernel(const T* __restrict__ qk
                 if (lr == 0) *(f32x4*)(myred + 16 * lg + 4 * td) = cs;
             }
         }
-        // phase B's V fragments have long landed; without this use the wait for them sits BEHIND the stores below, and vmcnt cannot tell a
-        // load from a store that was issued later: phase B would start with s_waitcnt vmcnt(0), i.e. after the dQ stores have drained
-        asm volatile("" : "+v"(vfw[0]), "+v"(vfw[1]));
         if (mine < L) {
             T* d = dqp + (size_t)mine * ld + 16 * lg;
             *(u32x4*)d = (u32x4){pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
@@ -689,9 +646,8 @@ extern "C" int eoe_attn_fwd(const void* qkv, void* out, int n, int L, int heads,
     EOE_CHECK_ARG(L >= 1 && L <= 64, "attn: sequence length %d not in [1, 64]", L);
     const float scale = 0.125f;   // 1/sqrt(64)
     ProfScope ps("attn_fwd", 4.0 * n * heads * (double)L * L * 64, 2.0 * (double)n * L * heads * 64 * 4, stream);
-    static const int padf = getenv("EOE_ATTN_PAD_FWD") ? atoi(getenv("EOE_ATTN_PAD_FWD")) : 0;
     if (dtype == EOE_F16)
-        hipLaunchKernelGGL((attn_fwd_kernel<f16_t>), dim3(n * heads), dim3(64), padf, (hipStream_t)stream,
+        hipLaunchKernelGGL((attn_fwd_kernel<f16_t>), dim3(n * heads), dim3(64), 0, (hipStream_t)stream,
                            (const f16_t*)qkv, (f16_t*)out, L, heads, scale);
     else if (dtype == EOE_BF16)
         hipLaunchKernelGGL((attn_fwd_kernel<bf16_t>), dim3(n * heads), dim3(64), 0, (hipStream_t)stream,
@@ -710,7 +666,6 @@ extern "C" int eoe_attn_bwd(const void* qkv, const void* dout, void* dqkv, float
     const float scale = 0.125f;
     ProfScope ps("attn_bwd", 14.0 * n * heads * (double)L * L * 64, 2.0 * (double)n * L * heads * 64 * 7, stream);
     const bool one_wave = g_attn_flags & 1;     // A/B switch: the round-1 kernel
-    static const int padb = getenv("EOE_ATTN_PAD_BWD") ? atoi(getenv("EOE_ATTN_PAD_BWD")) : 0;
     if (dtype == EOE_F16 && one_wave)
         hipLaunchKernelGGL((attn_bwd_kernel<f16_t>), dim3(n * heads), dim3(64), 0, (hipStream_t)stream,
                            (const f16_t*)qkv, (const f16_t*)dout, (f16_t*)dqkv, bias_scratch, L, heads, scale);
@@ -718,7 +673,7 @@ extern "C" int eoe_attn_bwd(const void* qkv, const void* dout, void* dqkv, float
         hipLaunchKernelGGL((attn_bwd_kernel<bf16_t>), dim3(n * heads), dim3(64), 0, (hipStream_t)stream,
                            (const bf16_t*)qkv, (const bf16_t*)dout, (bf16_t*)dqkv, bias_scratch, L, heads, scale);
     else if (dtype == EOE_F16)
-        hipLaunchKernelGGL((attn_bwd4_kernel<f16_t>), dim3(n * heads), dim3(256), padb, (hipStream_t)stream,
+        hipLaunchKernelGGL((attn_bwd4_kernel<f16_t>), dim3(n * heads), dim3(256), 0, (hipStream_t)stream,
                            (const f16_t*)qkv, (const f16_t*)dout, (f16_t*)dqkv, bias_scratch, L, heads, scale);
     else if (dtype == EOE_BF16)
         hipLaunchKernelGGL((attn_bwd4_kernel<bf16_t>), dim3(n * heads), dim3(256), 0, (hipStream_t)stream,

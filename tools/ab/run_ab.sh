@@ -27,8 +27,7 @@ for v in ("old", "new"):
         d = json.loads(open(f"gpurun_out/sh/ab_{v}_{r}.json").read())
         steps.setdefault(v, []).append(d["ms_per_step"])
         for n, x in (d.get("roofline") or {}).get("kernels_ms_per_step", {}).items():
-            if n.startswith("nt_128"):
-                res.setdefault(n, {}).setdefault(v, []).append(x)
+            res.setdefault(n, {}).setdefault(v, []).append(x)
 print("step ms:", steps)
 for n in sorted(res, key=lambda n: -sum(res[n]["old"])):
     a, b = res[n]["old"], res[n]["new"]
