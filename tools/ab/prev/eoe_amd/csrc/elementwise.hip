@@ -54,21 +54,14 @@ __global__ __launch_bounds__(256) void cast_transpose_vec_kernel(const float* __
     __shared__ T tile[64][68];
     const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
     const int sub = threadIdx.x >> 4, q4 = (threadIdx.x & 15) * 4;
-    // the four loads of a thread first, unconditionally (an out-of-range piece re-reads the matrix's first 16 bytes and is zeroed): behind
-    // `if (in range)` each load was issued only after the previous piece's store had drained (s_waitcnt vmcnt(0) between them)
-    f32x4 v4[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int gr = r0 + p * 16 + sub, gc = c0 + q4;
-        const bool ok = gr < rows && gc < cols;
-        v4[p] = *(const f32x4*)(src + (ok ? (size_t)gr * cols + gc : (size_t)0));
-        if (!ok) v4[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int r = p * 16 + sub, gr = r0 + r, gc = c0 + q4;
-        const f32x4 v = v4[p];
-        if (dst && gr < rows && gc < cols) *(u32x2*)(dst + (size_t)gr * cols + gc) = pack4<T>(v[0], v[1], v[2], v[3]);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gr < rows && gc < cols) {
+            v = *(const f32x4*)(src + (size_t)gr * cols + gc);
+            if (dst) *(u32x2*)(dst + (size_t)gr * cols + gc) = pack4<T>(v[0], v[1], v[2], v[3]);
+        }
         tile[r][q4 + 0] = (T)v[0]; tile[r][q4 + 1] = (T)v[1]; tile[r][q4 + 2] = (T)v[2]; tile[r][q4 + 3] = (T)v[3];
     }
     __syncthreads();
@@ -108,21 +101,14 @@ __global__ __launch_bounds__(256) void cast_transpose_multi_kernel(CtBatch b) {
     T* __restrict__ dst_t = (T*)b.dst_t[j];
     const int c0 = (t % tc) * 64, r0 = (t / tc) * 64;
     const int sub = threadIdx.x >> 4, q4 = (threadIdx.x & 15) * 4;
-    // the four loads of a thread first, unconditionally (an out-of-range piece re-reads the matrix's first 16 bytes and is zeroed): behind
-    // `if (in range)` each load was issued only after the previous piece's store had drained (s_waitcnt vmcnt(0) between them)
-    f32x4 v4[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int gr = r0 + p * 16 + sub, gc = c0 + q4;
-        const bool ok = gr < rows && gc < cols;
-        v4[p] = *(const f32x4*)(src + (ok ? (size_t)gr * cols + gc : (size_t)0));
-        if (!ok) v4[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int r = p * 16 + sub, gr = r0 + r, gc = c0 + q4;
-        const f32x4 v = v4[p];
-        if (dst && gr < rows && gc < cols) *(u32x2*)(dst + (size_t)gr * cols + gc) = pack4<T>(v[0], v[1], v[2], v[3]);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gr < rows && gc < cols) {
+            v = *(const f32x4*)(src + (size_t)gr * cols + gc);
+            if (dst) *(u32x2*)(dst + (size_t)gr * cols + gc) = pack4<T>(v[0], v[1], v[2], v[3]);
+        }
         tile[r][q4 + 0] = (T)v[0]; tile[r][q4 + 1] = (T)v[1]; tile[r][q4 + 2] = (T)v[2]; tile[r][q4 + 3] = (T)v[3];
     }
     __syncthreads();
@@ -243,17 +229,11 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
     constexpr int nv = NV;    // float4 groups per lane (D = 256 * NV)
-    f32x4 v[NV], gv[NV], bv[NV];
+    f32x4 v[NV];
     const float* xr = x + (size_t)row * ldx;
-    // gamma / beta with the row (round 4): loaded where they are used, each pair sat behind s_waitcnt vmcnt(0) -- which also waits for the
-    // previous piece's store -- i.e. NV dependent round trips after the reduction
 #pragma unroll
     for (int i = 0; i < NV; ++i)
-        if (i < nv) {
-            v[i] = *(const f32x4*)(xr + i * 256 + lane * 4);
-            gv[i] = *(const f32x4*)(gamma + i * 256 + lane * 4);
-            bv[i] = *(const f32x4*)(beta + i * 256 + lane * 4);
-        }
+        if (i < nv) v[i] = *(const f32x4*)(xr + i * 256 + lane * 4);
     const RowStats st = row_stats<NV>(v, D, lane, eps);
     if (stats && lane == 0) {
         stats[row * 2] = st.mean;
@@ -263,7 +243,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     for (int i = 0; i < NV; ++i)
         if (i < nv) {
             const int c = i * 256 + lane * 4;
-            const f32x4 g = gv[i], b = bv[i];
+            const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
             float o[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = (v[i][r] - st.mean) * st.rstd * g[r] + b[r];
@@ -276,11 +256,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 
 // backward: rows are strided over the grid; each wave accumulates dgamma/dbeta partials in registers,
 // the block combines its 4 waves through LDS and issues one fp32 atomic per column.
-// (round 4: `dy_f32` and `dres` are template parameters.  As run-time branches around the loads they made hipcc emit every conditional load as
-//  load -> s_waitcnt vmcnt(0) -> use -- and vmcnt(0) also waits for the row's earlier STORES: a row was ~7 dependent HBM round trips.  Now the
-//  row's 3 NV + 1 loads are issued back to back ahead of the first use.)
-template <typename T, int NV, bool DYF32, bool DRES>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NV <= 3 ? 4 : 2, NV <= 3 ? 4 : 2))) void layernorm_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x, int ldx,
+template <typename T, int NV>
+__global__ __launch_bounds__(512) void layernorm_bwd_kernel(const void* __restrict__ dy, int dy_f32, const float* __restrict__ x, int ldx,
                                      const float* __restrict__ stats, const float* __restrict__ gamma,
                                      const float* __restrict__ dres, float* __restrict__ dx_out, int ld_out,
                                      T* __restrict__ dx16, float* __restrict__ dgamma, float* __restrict__ dbeta,
@@ -289,8 +266,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NV <= 3 ? 4
     constexpr int NW = 8;
     extern __shared__ float red_raw[];               // [3][NW][256*NV]
     float (*red)[NW][256 * NV] = (float (*)[NW][256 * NV])red_raw;
-    // the wave index as a scalar: the row, and with it every row pointer, lives in SGPRs and a lane's address is one 32-bit offset
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int nv = NV;
     f32x4 ag[NV], ab[NV], ax[NV], gm[NV];
 #pragma unroll
@@ -298,63 +274,54 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NV <= 3 ? 4
         ag[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         ab[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         ax[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        gm[i] = *(const f32x4*)(gamma + i * 256 + lane * 4);
+        if (i < nv) gm[i] = *(const f32x4*)(gamma + i * 256 + lane * 4);
     }
     for (int row = blockIdx.x * NW + wave; row < rows; row += gridDim.x * NW) {
-        f32x4 df[NV], xv[NV], rv[NV];
-        u32x2 dh[NV];
-        const f32x2 st = *(const f32x2*)(stats + row * 2);
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = i * 256 + lane * 4;
-            if (DYF32) df[i] = *(const f32x4*)((const float*)dy + (size_t)row * D + c);
-            else dh[i] = *(const u32x2*)((const T*)dy + (size_t)row * D + c);
-            xv[i] = *(const f32x4*)(x + (size_t)row * ldx + c);
-            if (DRES) rv[i] = *(const f32x4*)(dres + (size_t)row * ld_out + c);
-        }
-        const float mean = st[0], rstd = st[1];
-        // two passes over the row's registers (d and x stay, g = d * gamma and xhat are formed twice: 24 registers less than keeping them, which
-        // is what holds the kernel at 128 = two workgroups per CU)
-        auto dval = [&](int i) -> f32x4 {
-            if (DYF32) return df[i];
-            float t[4];
-            unpack4<T>(dh[i], t);
-            return (f32x4){t[0], t[1], t[2], t[3]};
-        };
+        const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+        f32x4 g[NV], xh[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const f32x4 d = dval(i);
+        for (int i = 0; i < NV; ++i)
+            if (i < nv) {
+                const int c = i * 256 + lane * 4;
+                f32x4 d;
+                if (dy_f32) {
+                    d = *(const f32x4*)((const float*)dy + (size_t)row * D + c);
+                } else {
+                    float t[4];
+                    unpack4<T>(*(const u32x2*)((const T*)dy + (size_t)row * D + c), t);
+                    d = (f32x4){t[0], t[1], t[2], t[3]};
+                }
+                const f32x4 xv = *(const f32x4*)(x + (size_t)row * ldx + c);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float xh = (xv[i][r] - mean) * rstd, g = d[r] * gm[i][r];
-                ab[i][r] += d[r];
-                ag[i][r] += d[r] * xh;
-                s1 += g;
-                s2 += g * xh;
+                for (int r = 0; r < 4; ++r) {
+                    xh[i][r] = (xv[r] - mean) * rstd;
+                    ab[i][r] += d[r];
+                    ag[i][r] += d[r] * xh[i][r];
+                    g[i][r] = d[r] * gm[i][r];
+                    s1 += g[i][r];
+                    s2 += g[i][r] * xh[i][r];
+                }
             }
-        }
         s1 = wave_sum(s1) / D;
         s2 = wave_sum(s2) / D;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = i * 256 + lane * 4;
-            const f32x4 d = dval(i);
-            float o[4];
+        for (int i = 0; i < NV; ++i)
+            if (i < nv) {
+                const int c = i * 256 + lane * 4;
+                float o[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float xh = (xv[i][r] - mean) * rstd, g = d[r] * gm[i][r];
-                o[r] = rstd * (g - s1 - xh * s2);
+                for (int r = 0; r < 4; ++r) o[r] = rstd * (g[i][r] - s1 - xh[i][r] * s2);
+                if (dres) {
+                    const f32x4 rv = *(const f32x4*)(dres + (size_t)row * ld_out + c);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] += rv[r];
+                }
+                *(f32x4*)(dx_out + (size_t)row * ld_out + c) = (f32x4){o[0], o[1], o[2], o[3]};
+                if (dx16) *(u32x2*)(dx16 + (size_t)row * D + c) = pack4<T>(o[0], o[1], o[2], o[3]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ax[i][r] += o[r];
             }
-            if (DRES) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] += rv[i][r];
-            }
-            *(f32x4*)(dx_out + (size_t)row * ld_out + c) = (f32x4){o[0], o[1], o[2], o[3]};
-            if (dx16) *(u32x2*)(dx16 + (size_t)row * D + c) = pack4<T>(o[0], o[1], o[2], o[3]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ax[i][r] += o[r];
-        }
     }
     if (!dgamma && !dxsum) return;
 #pragma unroll
@@ -1127,15 +1094,7 @@ __global__ __launch_bounds__(256) void grads_nonfinite_kernel(const float* __res
     auto test = [&](float x) { bad |= ((__float_as_uint(x) & 0x7f800000u) == 0x7f800000u) ? 1u : 0u; };
     if ((ck.g_off & 3) == 0) {
         const int n4 = ck.n >> 2;
-        int i = threadIdx.x;
-        for (; i + 3 * (int)blockDim.x < n4; i += 4 * blockDim.x) {          // four independent loads per thread in flight
-            f32x4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)(gg + (size_t)(i + u * (int)blockDim.x) * 4);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { test(v[u][0]); test(v[u][1]); test(v[u][2]); test(v[u][3]); }
-        }
-        for (; i < n4; i += blockDim.x) {
+        for (int i = threadIdx.x; i < n4; i += blockDim.x) {
             const f32x4 v = *(const f32x4*)(gg + i * 4);
             test(v[0]); test(v[1]); test(v[2]); test(v[3]);
         }
@@ -1256,15 +1215,10 @@ extern "C" int eoe_layernorm_bwd(const void* dy, int dy_f32, const float* x, int
     if (grid > EOE_LN_PARTIALS) grid = EOE_LN_PARTIALS;
     float* part = (dgamma || dxsum) ? red_scratch : nullptr;
     // (the attribute once per instantiation, not per launch)
-#define EOE_LNB_LAUNCH(F, R)                                                                                                           \
-    { static bool once = (hipFuncSetAttribute((const void*)layernorm_bwd_kernel<T, NV, F, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 8 * 256 * NV * 4), true); (void)once; } \
-    hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV, F, R>), dim3(grid), dim3(512), 3 * 8 * 256 * NV * 4, (hipStream_t)stream, dy, x, ldx, stats, gamma, \
-                       dres, dx_out, ld_out, (T*)dx16, dgamma, dbeta, dxsum, part, rows, D)
-    DISPATCH_T(dtype, DISPATCH_NV(D, {
-        if (dy_f32) { if (dres) { EOE_LNB_LAUNCH(true, true); } else { EOE_LNB_LAUNCH(true, false); } }
-        else { if (dres) { EOE_LNB_LAUNCH(false, true); } else { EOE_LNB_LAUNCH(false, false); } }
-    }));
-#undef EOE_LNB_LAUNCH
+    DISPATCH_T(dtype, DISPATCH_NV(D, { static bool once = (hipFuncSetAttribute((const void*)layernorm_bwd_kernel<T, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 8 * 256 * NV * 4), true); (void)once; }
+                                  hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV>), dim3(grid), dim3(512), 3 * 8 * 256 * NV * 4, (hipStream_t)stream, dy,
+                                         dy_f32, x, ldx, stats, gamma, dres, dx_out, ld_out, (T*)dx16, dgamma, dbeta,
+                                         dxsum, part, rows, D)));
     EOE_CHECK_LAUNCH("layernorm_bwd");
     if (part) EOE_TRY(eoe_finish_reduce(part, grid, 3 * D, D, dgamma, dbeta, dxsum, 1, stream));
     return 0;
