@@ -379,15 +379,24 @@ __global__ __launch_bounds__(256) void sgate_conv_fwd_kernel(const float* __rest
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
         const int x = (int)(p % W), y = (int)((p / W) % H);
         const size_t base = p - (size_t)y * W - x;
+        // (round 4: every tap's load unconditional -- a tap outside the map re-reads the pixel itself and is dropped; behind `continue` each of
+        //  the 49 loads was waited for where it was issued.  Same taps added in the same order.)
         float acc = 0.f;
+#pragma unroll
         for (int ky = 0; ky < 7; ++ky) {
             const int yy = y + ky - 3;
-            if (yy < 0 || yy >= H) continue;
+            const bool oky = yy >= 0 && yy < H;
+            f32x2 v[7];
+#pragma unroll
             for (int kx = 0; kx < 7; ++kx) {
                 const int xx = x + kx - 3;
-                if (xx < 0 || xx >= W) continue;
-                const f32x2 v = *(const f32x2*)(comp + (base + (size_t)yy * W + xx) * 2);
-                acc += v[0] * lw[ky * 7 + kx] + v[1] * lw[49 + ky * 7 + kx];
+                const bool ok = oky && xx >= 0 && xx < W;
+                v[kx] = *(const f32x2*)(comp + (ok ? base + (size_t)yy * W + xx : p) * 2);
+            }
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) {
+                const int xx = x + kx - 3;
+                if (oky && xx >= 0 && xx < W) acc += v[kx][0] * lw[ky * 7 + kx] + v[kx][1] * lw[49 + ky * 7 + kx];
             }
         }
         z[p] = acc;
@@ -481,15 +490,23 @@ __global__ __launch_bounds__(256) void sgate_conv_bwd_data_kernel(const float* _
         const int x = (int)(p % W), y = (int)((p / W) % H);
         const size_t base = p - (size_t)y * W - x;
         float a0 = 0.f, a1 = 0.f;
-        for (int ky = 0; ky < 7; ++ky) {
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) {                   // (loads unconditional, as in sgate_conv_fwd_kernel)
             const int yy = y - ky + 3;
-            if (yy < 0 || yy >= H) continue;
+            const bool oky = yy >= 0 && yy < H;
+            float d[7];
+#pragma unroll
             for (int kx = 0; kx < 7; ++kx) {
                 const int xx = x - kx + 3;
-                if (xx < 0 || xx >= W) continue;
-                const float d = dz[base + (size_t)yy * W + xx];
-                a0 += d * lw[ky * 7 + kx];
-                a1 += d * lw[49 + ky * 7 + kx];
+                d[kx] = dz[(oky && xx >= 0 && xx < W) ? base + (size_t)yy * W + xx : p];
+            }
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) {
+                const int xx = x - kx + 3;
+                if (oky && xx >= 0 && xx < W) {
+                    a0 += d[kx] * lw[ky * 7 + kx];
+                    a1 += d[kx] * lw[49 + ky * 7 + kx];
+                }
             }
         }
         if (pack) *(f32x4*)(dcomp + p * 4) = (f32x4){sp[p], a0, a1, __int_as_float(am[p])};

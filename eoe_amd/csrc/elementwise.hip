@@ -192,18 +192,39 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
     const int per_c = p * res;                        // floats per channel in this patch row
     const int total = 3 * per_c;
     const int kdim = 3 * p * p;
-    for (int i = threadIdx.x * 4; i < total; i += blockDim.x * 4) {
-        const int c = i / per_c, rem = i % per_c;
-        const int ky = rem / res, xx = rem % res;     // xx multiple of 4, p multiple of 4
-        const int px = xx / p, kx = xx % p;
-        f32x4 v = *(const f32x4*)(x + (((size_t)n * 3 + c) * res + (py * p + ky)) * res + xx);
-        if (mean) {
-            const float m = mean[c], s = 1.0f / stdv[c];
+    float mu[3] = {0.f, 0.f, 0.f}, is[3] = {1.f, 1.f, 1.f};
+    if (mean) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (v[r] - m) * s;
+        for (int c = 0; c < 3; ++c) { mu[c] = mean[c]; is[c] = 1.0f / stdv[c]; }
+    }
+    // four pieces per thread and pass, their loads first (one load -> wait -> store per pass left a single 16-byte request per thread in flight)
+    constexpr int U = 4;
+    for (int i0 = threadIdx.x * 4; i0 < total; i0 += blockDim.x * 4 * U) {
+        f32x4 v[U];
+        int c_[U], o_[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * (int)blockDim.x * 4;
+            const bool ok = i < total;
+            const int ii = ok ? i : 0;
+            const int c = ii / per_c, rem = ii % per_c;
+            const int ky = rem / res, xx = rem % res;     // xx multiple of 4, p multiple of 4
+            const int px = xx / p, kx = xx % p;
+            v[u] = *(const f32x4*)(x + (((size_t)n * 3 + c) * res + (py * p + ky)) * res + xx);
+            c_[u] = c;
+            o_[u] = ok ? px * kdim + c * p * p + ky * p + kx : -1;
         }
-        T* o = out + ((size_t)(n * g + py) * g + px) * kdim + c * p * p + ky * p + kx;
-        *(u32x2*)o = pack4<T>(v[0], v[1], v[2], v[3]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (o_[u] < 0) continue;
+            const float m = c_[u] == 0 ? mu[0] : (c_[u] == 1 ? mu[1] : mu[2]), s = c_[u] == 0 ? is[0] : (c_[u] == 1 ? is[1] : is[2]);
+            f32x4 w = v[u];
+            if (mean) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w[r] = (w[r] - m) * s;
+            }
+            *(u32x2*)(out + (size_t)(n * g + py) * g * kdim + o_[u]) = pack4<T>(w[0], w[1], w[2], w[3]);
+        }
     }
 }
 
@@ -343,8 +364,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NV <= 3 ? 4
             float o[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float xh = (xv[i][r] - mean) * rstd, g = d[r] * gm[i][r];
-                o[r] = rstd * (g - s1 - xh * s2);
+                // the two contractions spelled out (g - s1 as ONE fma of d * gamma, then -s2 * xhat into it): which of these hipcc fuses on its
+                // own changed with the surrounding code (the round-3 kernel fused both here and 2 of the 12 sums of the first pass), and dx
+                // moves by an ulp in a sixth of its elements with it -- enough to move the single-batch AUC of tests/test_gpu_parity_big.py
+                // by a few of its 16 384 pairs (6.7e-4 / 1.04e-3 / 7e-4 for three such builds)
+                const float xh = (xv[i][r] - mean) * rstd;
+                o[r] = rstd * __builtin_fmaf(-s2, xh, __builtin_fmaf(d[r], gm[i][r], -s1));
             }
             if (DRES) {
 #pragma unroll

@@ -147,6 +147,12 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const float* __restrict__
 // valid taps come in the same (ky, kx, channel) order as before: bitwise the same sums.
 // Split k (forward / dgrad with few output tiles and a long reduction: the small maps of the 32 x 32 WideResNet, the FC layers): nslab > 1
 // slabs of the reduction write partial outputs [slab][rows][N] (`out` = the workspace), summed in slab order by slab_sum_out_kernel.
+// 16 bytes at p[idx] if `ok`, else zeros -- as an UNCONDITIONAL load (from a 16-byte block of zeros when !ok; p may then be anything), so that
+// a batch of them is issued back to back instead of one load -> wait -> use group per `if`
+__device__ __forceinline__ f32x4 load4_if(const float* __restrict__ p, size_t idx, bool ok) {
+    static __device__ const float zero4[4] = {0.f, 0.f, 0.f, 0.f};
+    return *(const f32x4*)(ok ? p + idx : zero4);
+}
 template <int MODE, int BN, int WV = 0, bool S2 = false, bool WK = false>      // WK: forward / dgrad weights from the k-major packed copy `wk` (eoe_conv_f32_pack_weights); WV (wgrad variants): 0 = both sides float4, 1 = the x side element-wise (OIHW order), 2 = roles exchanged, 3 = both
 __global__ __launch_bounds__(256, (WK && BN == 128) ? 4 : 1) void conv_f32_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ dy, const float* __restrict__ bias,
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(256, (WK && BN == 128) ? 4 : 1) void conv_f32_mfma_
             for (int i = 0; i < AV; ++i) {
                 const int kk = a_r[i], q4 = a_kq[i] * 4, k = k0 + kk;
                 f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
-                if (k < k_hi) {
+                if (k < k_hi) {                             // (measured: the unconditional form of these -- load4_if -- is 5 % slower here)
                     if (!swap) {
                         if (m0 + q4 < M) va = *(const f32x4*)(dy + (size_t)k * g.cout + m0 + q4);
                         if (q4 < BN) vb = gather_x(k, i);
@@ -294,29 +300,24 @@ __global__ __launch_bounds__(256, (WK && BN == 128) ? 4 : 1) void conv_f32_mfma_
         const bool c4 = MODE == P_FWD && g.C == 4;
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (a_ok[i]) {
-                if (MODE == P_FWD && c4) {
-                    const int tp = (k0 >> 2) + a_kq[i];
-                    if (tp < taps) {
-                        const int ty = tp / g.kw, iy = a_y[i] + ty, ix = a_x[i] + (tp - ty * g.kw);
-                        if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
-                            v = *(const f32x4*)(x + (((size_t)a_img[i] * g.H + iy) * g.W + ix) * 4);
-                    }
-                } else if (MODE == P_FWD) {
-                    const int iy = a_y[i] + ky, ix = a_x[i] + kx;
-                    if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
-                        v = *(const f32x4*)(x + (((size_t)a_img[i] * g.H + iy) * g.W + ix) * g.C + c0 + a_kq[i] * 4);
-                } else {
-                    const int ny = a_y[i] - ky, nx = a_x[i] - kx;                       // (iy + pad - ky, ix + pad - kx)
-                    if (ny >= 0 && nx >= 0) {
-                        int oy = ny, ox = nx;
-                        bool okd = true;
-                        if (g.stride != 1) { oy = ny / g.stride; ox = nx / g.stride; okd = (oy * g.stride == ny) && (ox * g.stride == nx); }
-                        if (okd && oy < g.Ho && ox < g.Wo)
-                            v = *(const f32x4*)(dy + (((size_t)a_img[i] * g.Ho + oy) * g.Wo + ox) * g.cout + c0 + a_kq[i] * 4);
-                    }
-                }
+            // (every fetch unconditional -- load4_if: a pixel outside the map reads the tensor's first 16 bytes and is zeroed.  Behind `if (inside)`
+            //  hipcc waits for each load where it is issued, and the k-tile's loads no longer fly under the MFMAs)
+            f32x4 v;
+            if (MODE == P_FWD && c4) {
+                const int tp = (k0 >> 2) + a_kq[i];
+                const int ty = tp / g.kw, iy = a_y[i] + ty, ix = a_x[i] + (tp - ty * g.kw);
+                v = load4_if(x, (((size_t)a_img[i] * g.H + iy) * g.W + ix) * 4,
+                             a_ok[i] && tp < taps && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W);
+            } else if (MODE == P_FWD) {
+                const int iy = a_y[i] + ky, ix = a_x[i] + kx;
+                v = load4_if(x, (((size_t)a_img[i] * g.H + iy) * g.W + ix) * g.C + c0 + a_kq[i] * 4,
+                             a_ok[i] && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W);
+            } else {
+                const int ny = a_y[i] - ky, nx = a_x[i] - kx;                       // (iy + pad - ky, ix + pad - kx)
+                int oy = ny, ox = nx;
+                bool okd = a_ok[i] && ny >= 0 && nx >= 0;
+                if (g.stride != 1) { oy = ny / g.stride; ox = nx / g.stride; okd = okd && (oy * g.stride == ny) && (ox * g.stride == nx); }
+                v = load4_if(dy, (((size_t)a_img[i] * g.Ho + oy) * g.Wo + ox) * g.cout + c0 + a_kq[i] * 4, okd && oy < g.Ho && ox < g.Wo);
             }
             ra[i] = v;
         }
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(256, (WK && BN == 128) ? 4 : 1) void conv_f32_mfma_
             for (int i = 0; i < NBV / 4; ++i) {
                 const int e = t + 256 * i, kk = e / (BN / 4), nq = (e - kk * (BN / 4)) * 4, nn = n0 + nq;
                 const int krow = (MODE == P_DGRAD && S2) ? (ky * g.kw + kx) * g.cout + c0 + kk : k0 + kk;
-                rbq[i] = (nn < N && krow < wk_rows) ? *(const f32x4*)(wk + (size_t)krow * N + nn) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                rbq[i] = load4_if(wk, (size_t)krow * N + nn, nn < N && krow < wk_rows);
             }
             return;
         }
@@ -336,14 +337,18 @@ __global__ __launch_bounds__(256, (WK && BN == 128) ? 4 : 1) void conv_f32_mfma_
 #pragma unroll
         for (int i = 0; i < NBV; ++i) {
             const int e = t + 256 * i, kk = e & 15, r = e >> 4, nn = n0 + r;
-            float b = 0.f;
+            size_t wi;
+            bool wok = nn < N;
             if (MODE == P_FWD && c4) {
-                const int tp = (k0 >> 2) + (kk >> 2);
-                if (nn < N && tp < taps) { const int ty = tp / g.kw; b = w[(((size_t)nn * 4 + (kk & 3)) * g.kh + ty) * g.kw + (tp - ty * g.kw)]; }
-            } else if (nn < N)
-                b = MODE == P_FWD ? w[(((size_t)nn * g.C + c0 + kk) * g.kh + ky) * g.kw + kx]
-                                  : w[(((size_t)(c0 + kk) * g.C + nn) * g.kh + ky) * g.kw + kx];
-            rb[i] = b;
+                const int tp = (k0 >> 2) + (kk >> 2), ty = tp / g.kw;
+                wok = wok && tp < taps;
+                wi = (((size_t)nn * 4 + (kk & 3)) * g.kh + ty) * g.kw + (tp - ty * g.kw);
+            } else {
+                wi = MODE == P_FWD ? (((size_t)nn * g.C + c0 + kk) * g.kh + ky) * g.kw + kx
+                                   : (((size_t)(c0 + kk) * g.C + nn) * g.kh + ky) * g.kw + kx;
+            }
+            const float b = w[wok ? wi : (size_t)0];
+            rb[i] = wok ? b : 0.f;
         }
     };
     auto store_tile = [&](int buf) {
@@ -403,6 +408,15 @@ __global__ __launch_bounds__(256, (WK && BN == 128) ? 4 : 1) void conv_f32_mfma_
     const size_t rows_all = S2 ? (size_t)g.n * g.H * g.W : (size_t)M;
     float* dst = out + (MODE == P_WGRAD ? (size_t)blockIdx.z * M * N : (nslab > 1 ? (size_t)slab * rows_all * N : 0));
     const bool vec = (N & 3) == 0, plain = nslab > 1;
+    // the bias once per column group, ahead of the stores (a load between two stores waits for the first store to drain: the tile's 4 x NI
+    // stores went out one at a time)
+    f32x4 bv[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int nn = n0 + wn0 + j * 16 + lg * 4;
+        bv[j] = load4_if(bias, (size_t)nn, MODE == P_FWD && bias != nullptr && !plain && vec && nn < N);
+    }
+    const bool acc_dst = MODE == P_DGRAD && accumulate && !plain;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm0 + i * 16 + lr;
@@ -420,8 +434,8 @@ __global__ __launch_bounds__(256, (WK && BN == 128) ? 4 : 1) void conv_f32_mfma_
             f32x4 v = acc[i][j];
             float* d = dst + row * N + nn;
             if (vec) {
-                if (MODE == P_FWD && bias && !plain) v += *(const f32x4*)(bias + nn);
-                if (MODE == P_DGRAD && accumulate && !plain) v += *(const f32x4*)d;
+                v += bv[j];
+                if (acc_dst) v += *(const f32x4*)d;
                 *(f32x4*)d = v;
             } else {
 #pragma unroll
