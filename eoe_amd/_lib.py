@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must precede the CDLL below)
 
 from . import _build
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 EOE_F16, EOE_BF16, EOE_F32 = 1, 2, 3
 EOE_RESIZE_BILINEAR, EOE_RESIZE_BICUBIC = 2, 3
 EOE_COMM_I64, EOE_COMM_ID_BYTES, EOE_COMM_ALGO_RING, EOE_COMM_ALGO_RS_AG = 8, 128, 0, 1
@@ -40,6 +40,11 @@ class GemmArgs(C.Structure):
 
 class AdamChunk(C.Structure):
     _fields_ = [("p_off", _i64), ("g_off", _i64), ("m_off", _i64), ("v_off", _i64), ("n", _i32), ("group", _i32)]
+
+
+class AdamTile(C.Structure):
+    _fields_ = [("p_off", _i64), ("g_off", _i64), ("m_off", _i64), ("v_off", _i64), ("d16", _vp), ("d16_t", _vp), ("rows", _i32),
+                ("cols", _i32), ("tile", _i32), ("group", _i32)]
 
 
 class AdamScalars(C.Structure):
@@ -139,6 +144,7 @@ SIGNATURES = {
     "eoe_hsc_score": [_vp, _vp, C.c_int, C.c_int, _vp],
     "eoe_bce_fwd": [_vp, _vp, _i64, _vp, _vp, _vp, C.c_int, _f32, _vp],
     "eoe_bce_bwd": [_vp, _vp, _vp, _vp, C.c_int, _f32, _vp],
+    "eoe_adam_tiles": [_vp, _vp, _vp, _vp, _vp, C.c_int, C.POINTER(AdamScalars), _f32, _f32, _f32, _f32, C.c_int, _vp, _vp],
     "eoe_adam_multi": [_vp, _vp, _vp, _vp, _vp, C.c_int, C.POINTER(AdamScalars), _f32, _f32, _f32, _f32, _vp, C.c_int,
                        _vp, _vp],
     "eoe_grads_nonfinite": [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp],
@@ -221,7 +227,7 @@ def header_symbols():
 
 # the argument structs mirrored above, by their eoe_struct_size index (include/eoe_hip.h)
 _STRUCTS = {0: GemmArgs, 1: ConvGeometry, 2: AdamChunk, 3: AdamScalars, 4: VitBlockFwdArgs, 5: VitBlockBwdArgs, 6: CGateArgs,
-            7: CGateBwdArgs, 8: SGateArgs, 9: SGateBwdArgs}
+            7: CGateBwdArgs, 8: SGateArgs, 9: SGateBwdArgs, 10: AdamTile}
 
 
 def _load():

@@ -33,6 +33,7 @@ extern "C" int eoe_struct_size(int which) {
         case 7: return (int)sizeof(eoe_cgate_bwd_args);
         case 8: return (int)sizeof(eoe_sgate_args);
         case 9: return (int)sizeof(eoe_sgate_bwd_args);
+        case 10: return (int)sizeof(eoe_adam_tile);
         default: return -1;
     }
 }

@@ -532,6 +532,31 @@ __global__ __launch_bounds__(256) void attn_bwd4_kernel(const T* __restrict__ qk
         *(u32x4*)(ks_ + o) = sk[it];
         *(u32x4*)(dos + o) = sd[it];
     }
+    if (bpart) {
+        // The K and V thirds of the in-projection bias gradient need no sums over dK / dV (round 4; they were 2 x 64 DPP operations per wave):
+        //   sum_key dV[key][d] = sum_q (sum_key P[q][key]) dO[q][d] = sum_q dO[q][d]      -- a softmax row sums to one,
+        //   sum_key dK[key][d] = sum_q (sum_key dS[q][key]) Q[q][d] = 0                   -- a softmax-backward row sums to zero
+        // (a key bias does not reach the output at all; the reference's fp32 autograd leaves rounding noise there).  The dO column sums
+        // come from the slab this wave has just staged: lane (row lane >> 3, 8 columns from 8 * (lane & 7)), rows >= L read as zeros.
+        float cv[8];
+        {
+            float a0[8], a1[8];
+            unpack8<T>(sd[0], a0);
+            unpack8<T>(sd[1], a1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = a0[j] + a1[j];
+                v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+                cv[j] = v;
+            }
+        }
+        if (lane < 8) {
+            *(f32x4*)(myred + 128 + 8 * lane) = (f32x4){cv[0], cv[1], cv[2], cv[3]};
+            *(f32x4*)(myred + 128 + 8 * lane + 4) = (f32x4){cv[4], cv[5], cv[6], cv[7]};
+        } else if (lane < 24) {
+            *(f32x4*)(myred + 64 + 4 * (lane - 8)) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
     __syncthreads();
 
     // ---- phase A: lane = query of this wave's slab.  S^T = K Q^T, dP^T = V dO^T
@@ -658,13 +683,6 @@ __global__ __launch_bounds__(256) void attn_bwd4_kernel(const T* __restrict__ qk
             }
             pv[td] = pack4<T>(ov[0], ov[1], ov[2], ov[3]);
             pk[td] = pack4<T>(ok[0], ok[1], ok[2], ok[3]);
-            if (bpart) {
-                const f32x4 cv = slab_sum(ov, mine < L), ck = slab_sum(ok, mine < L);
-                if (lr == 0) {
-                    *(f32x4*)(myred + 128 + 16 * lg + 4 * td) = cv;
-                    *(f32x4*)(myred + 64 + 16 * lg + 4 * td) = ck;
-                }
-            }
         }
         if (mine < L) {
             T* dv = dqp + (size_t)mine * ld + 2 * D + 16 * lg;
@@ -689,9 +707,8 @@ extern "C" int eoe_attn_fwd(const void* qkv, void* out, int n, int L, int heads,
     EOE_CHECK_ARG(L >= 1 && L <= 64, "attn: sequence length %d not in [1, 64]", L);
     const float scale = 0.125f;   // 1/sqrt(64)
     ProfScope ps("attn_fwd", 4.0 * n * heads * (double)L * L * 64, 2.0 * (double)n * L * heads * 64 * 4, stream);
-    static const int padf = getenv("EOE_ATTN_PAD_FWD") ? atoi(getenv("EOE_ATTN_PAD_FWD")) : 0;
     if (dtype == EOE_F16)
-        hipLaunchKernelGGL((attn_fwd_kernel<f16_t>), dim3(n * heads), dim3(64), padf, (hipStream_t)stream,
+        hipLaunchKernelGGL((attn_fwd_kernel<f16_t>), dim3(n * heads), dim3(64), 0, (hipStream_t)stream,
                            (const f16_t*)qkv, (f16_t*)out, L, heads, scale);
     else if (dtype == EOE_BF16)
         hipLaunchKernelGGL((attn_fwd_kernel<bf16_t>), dim3(n * heads), dim3(64), 0, (hipStream_t)stream,
@@ -710,7 +727,6 @@ extern "C" int eoe_attn_bwd(const void* qkv, const void* dout, void* dqkv, float
     const float scale = 0.125f;
     ProfScope ps("attn_bwd", 14.0 * n * heads * (double)L * L * 64, 2.0 * (double)n * L * heads * 64 * 7, stream);
     const bool one_wave = g_attn_flags & 1;     // A/B switch: the round-1 kernel
-    static const int padb = getenv("EOE_ATTN_PAD_BWD") ? atoi(getenv("EOE_ATTN_PAD_BWD")) : 0;
     if (dtype == EOE_F16 && one_wave)
         hipLaunchKernelGGL((attn_bwd_kernel<f16_t>), dim3(n * heads), dim3(64), 0, (hipStream_t)stream,
                            (const f16_t*)qkv, (const f16_t*)dout, (f16_t*)dqkv, bias_scratch, L, heads, scale);
@@ -718,7 +734,7 @@ extern "C" int eoe_attn_bwd(const void* qkv, const void* dout, void* dqkv, float
         hipLaunchKernelGGL((attn_bwd_kernel<bf16_t>), dim3(n * heads), dim3(64), 0, (hipStream_t)stream,
                            (const bf16_t*)qkv, (const bf16_t*)dout, (bf16_t*)dqkv, bias_scratch, L, heads, scale);
     else if (dtype == EOE_F16)
-        hipLaunchKernelGGL((attn_bwd4_kernel<f16_t>), dim3(n * heads), dim3(256), padb, (hipStream_t)stream,
+        hipLaunchKernelGGL((attn_bwd4_kernel<f16_t>), dim3(n * heads), dim3(256), 0, (hipStream_t)stream,
                            (const f16_t*)qkv, (const f16_t*)dout, (f16_t*)dqkv, bias_scratch, L, heads, scale);
     else if (dtype == EOE_BF16)
         hipLaunchKernelGGL((attn_bwd4_kernel<bf16_t>), dim3(n * heads), dim3(256), 0, (hipStream_t)stream,

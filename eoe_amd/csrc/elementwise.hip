@@ -1074,6 +1074,82 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(float* __restrict__ p, c
     }
 }
 
+// one element of torch.optim.Adam's update (shared by the chunk and the tile kernel: the same expression, the same contractions)
+struct AdamK { float step_size, bc2_sqrt, ginv, beta1, beta2, eps, wd; };
+__device__ __forceinline__ float adam_upd(const AdamK& k, float pv, float gv, float& mv, float& vvv) {
+    gv *= k.ginv;
+    if (k.wd != 0.f) gv = gv + k.wd * pv;
+    mv = mv + (gv - mv) * (1.0f - k.beta1);
+    vvv = vvv * k.beta2 + (1.0f - k.beta2) * gv * gv;
+    const float denom = sqrtf(vvv) / k.bc2_sqrt + k.eps;
+    return pv - k.step_size * (mv / denom);
+}
+
+// eoe_adam_tiles: one workgroup per 64 x 64 tile of a 2-D weight.  Thread (sub = t >> 4, q4 = 4 (t & 15)) owns the four 16-byte pieces
+// (row 16 i + sub, columns q4 .. q4 + 3): 16 loads in flight (p, g, m, v), the update, p / m / v and the [rows, cols] 16-bit piece stored
+// from the registers, the transposed copy through a padded LDS tile (as cast_transpose_multi_kernel).
+template <typename T>
+__global__ __launch_bounds__(256) void adam_tiles_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                         float* __restrict__ v, const eoe_adam_tile* __restrict__ tiles, eoe_adam_scalars sc,
+                                                         float beta1, float beta2, float eps, float wd, const int* __restrict__ skip) {
+    if (skip && *skip) return;                      // (the copies then stay those of the unchanged weight)
+    __shared__ T tile[64][68];
+    const eoe_adam_tile tl = tiles[blockIdx.x];
+    const AdamK k = {sc.step_size[tl.group & (EOE_ADAM_GROUPS - 1)], sc.bc2_sqrt[tl.group & (EOE_ADAM_GROUPS - 1)], sc.grad_scale_inv,
+                     beta1, beta2, eps, wd};
+    float* pp = p + tl.p_off;
+    const float* gg = g + tl.g_off;
+    float* mm = m + tl.m_off;
+    float* vv = v + tl.v_off;
+    T* dst = (T*)tl.d16;
+    T* dst_t = (T*)tl.d16_t;
+    const int rows = tl.rows, cols = tl.cols, tc = (cols + 63) >> 6;
+    const int c0 = (tl.tile % tc) * 64, r0 = (tl.tile / tc) * 64;
+    const int sub = threadIdx.x >> 4, q4 = (threadIdx.x & 15) * 4;
+    f32x4 pv[4], gv[4], mv[4], vx[4];
+    size_t at[4];
+    bool ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                   // (a piece outside the matrix re-reads the matrix's first 16 bytes and is dropped)
+        const int gr = r0 + i * 16 + sub, gc = c0 + q4;
+        ok[i] = gr < rows && gc < cols;
+        at[i] = ok[i] ? (size_t)gr * cols + gc : (size_t)0;
+        pv[i] = *(const f32x4*)(pp + at[i]);
+        gv[i] = *(const f32x4*)(gg + at[i]);
+        mv[i] = *(const f32x4*)(mm + at[i]);
+        vx[i] = *(const f32x4*)(vv + at[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float a = mv[i][r], b = vx[i][r];
+            pv[i][r] = adam_upd(k, pv[i][r], gv[i][r], a, b);
+            mv[i][r] = a;
+            vx[i][r] = b;
+        }
+        const int rr = i * 16 + sub;
+        if (ok[i]) {
+            *(f32x4*)(pp + at[i]) = pv[i];
+            *(f32x4*)(mm + at[i]) = mv[i];
+            *(f32x4*)(vv + at[i]) = vx[i];
+            if (dst) *(u32x2*)(dst + at[i]) = pack4<T>(pv[i][0], pv[i][1], pv[i][2], pv[i][3]);
+        }
+        tile[rr][q4 + 0] = (T)pv[i][0]; tile[rr][q4 + 1] = (T)pv[i][1]; tile[rr][q4 + 2] = (T)pv[i][2]; tile[rr][q4 + 3] = (T)pv[i][3];
+    }
+    if (!dst_t) return;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = i * 16 + sub, gc = c0 + c, gr = r0 + q4;
+        if (gc < cols && gr < rows) {
+            typename T16<T>::v4 o;
+            o[0] = tile[q4 + 0][c]; o[1] = tile[q4 + 1][c]; o[2] = tile[q4 + 2][c]; o[3] = tile[q4 + 3][c];
+            *(u32x2*)(dst_t + (size_t)gc * rows + gr) = __builtin_bit_cast(u32x2, o);
+        }
+    }
+}
+
 // one block per chunk of <= EOE_ADAM_CHUNK elements; float4 accesses (chunk offsets are multiples of 4 for
 // 16-B aligned parameter starts; scalar path otherwise).
 template <typename T>
@@ -1091,15 +1167,9 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(float* __restrict__ p, 
     float* vv = v + ck.v_off;
     T* sh = shadow ? shadow + ck.p_off : nullptr;
     const bool aligned = (((ck.p_off | ck.g_off | ck.m_off | ck.v_off) & 3) == 0);
-    const float ginv = sc.grad_scale_inv;          // gradients arrive multiplied by the loss scale (a power of two: exact)
-    auto upd = [&](float pv, float gv, float& mv, float& vvv) -> float {
-        gv *= ginv;
-        if (wd != 0.f) gv = gv + wd * pv;
-        mv = mv + (gv - mv) * (1.0f - beta1);
-        vvv = vvv * beta2 + (1.0f - beta2) * gv * gv;
-        const float denom = sqrtf(vvv) / bc2_sqrt + eps;
-        return pv - step_size * (mv / denom);
-    };
+    // (gradients arrive multiplied by the loss scale, a power of two: the division back is exact)
+    const AdamK k = {step_size, bc2_sqrt, sc.grad_scale_inv, beta1, beta2, eps, wd};
+    auto upd = [&](float pv, float gv, float& mv, float& vvv) -> float { return adam_upd(k, pv, gv, mv, vvv); };
     if (aligned) {
         const int n4 = ck.n >> 2;
         for (int i = threadIdx.x; i < n4; i += blockDim.x) {
@@ -1646,6 +1716,20 @@ extern "C" int eoe_sgd_multi(float* p, const float* g, float* buf, const eoe_ada
     hipLaunchKernelGGL(sgd_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, p, g, buf, chunks, lr, momentum, weight_decay,
                        nesterov, grad_scale_inv > 0.f ? grad_scale_inv : 1.0f, (const int*)skip_flag);
     EOE_CHECK_LAUNCH("sgd_multi");
+    return 0;
+}
+
+extern "C" int eoe_adam_tiles(float* p, const float* g, float* m, float* v, const eoe_adam_tile* tiles, int n_tiles,
+                              const eoe_adam_scalars* scalars, float beta1, float beta2, float eps, float weight_decay, int dtype,
+                              const int32_t* skip_flag, void* stream) {
+    EOE_CHECK_ARG(p && g && m && v && tiles && scalars && n_tiles > 0, "adam_tiles: bad args");
+    // per tile: p, g, m, v read (16 B), p, m, v written (12 B), the two 16-bit copies written (4 B)
+    ProfScope ps("adam_tiles", 0, 32.0 * n_tiles * 4096, stream);
+    eoe_adam_scalars sc = *scalars;
+    if (!(sc.grad_scale_inv > 0.f)) sc.grad_scale_inv = 1.0f;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((adam_tiles_kernel<T>), dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, p, g, m, v, tiles, sc,
+                                         beta1, beta2, eps, weight_decay, (const int*)skip_flag));
+    EOE_CHECK_LAUNCH("adam_tiles");
     return 0;
 }
 

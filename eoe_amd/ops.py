@@ -253,6 +253,20 @@ class _Shadow:
         return d, dt
 
 
+    def entry(self, p):
+        """(copy, transposed copy) of a 2-D parameter if both exist and are current, else None: the pair `eoe_adam_tiles` may rewrite in place"""
+        hit = self.cache.get(id(p))
+        if hit is None or hit[0]() is not p or hit[2] is None or hit[3] is None:
+            return None
+        if hit[1] != (p._version, p.data_ptr(), _compute_dtype, True, True) or p.dim() != 2 or hit[2].shape != p.shape:
+            return None
+        return hit[2], hit[3]
+
+    def mark(self, p, d, dt):
+        """the optimiser has just written `d` / `dt` from the updated parameter (and bumped its version): they are current"""
+        key = id(p)
+        self.cache[key] = (weakref.ref(p, lambda _r, k=key, c=self.cache: c.pop(k, None)), (p._version, p.data_ptr(), _compute_dtype, True, True), d, dt)
+
     def refresh(self, params):
         """bring the [out,in] + transposed copies of all (2-D, contiguous) `params` up to date with ONE batched launch
         (`eoe_cast_transpose_multi`); the per-use `get` calls of the step then hit the cache.  No-op under graph capture."""

@@ -8,6 +8,7 @@ and the same arithmetic: L2-in-gradient weight decay, bias correction, eps 1e-8;
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -18,6 +19,12 @@ from ._lib import lib, check
 _CHUNK_DT = np.dtype([("p_off", "<i8"), ("g_off", "<i8"), ("m_off", "<i8"), ("v_off", "<i8"), ("n", "<i4"),
                       ("group", "<i4")])
 assert _CHUNK_DT.itemsize == C.sizeof(_lib.AdamChunk)
+_TILE_DT = np.dtype([("p_off", "<i8"), ("g_off", "<i8"), ("m_off", "<i8"), ("v_off", "<i8"), ("d16", "<u8"), ("d16_t", "<u8"),
+                     ("rows", "<i4"), ("cols", "<i4"), ("tile", "<i4"), ("group", "<i4")])
+assert _TILE_DT.itemsize == C.sizeof(_lib.AdamTile)
+# 2-D weights whose 16-bit operand copies exist are updated by 64 x 64 tiles and get the copies rewritten in the same pass
+# (eoe_adam_tiles, include/eoe_hip.h); EOE_ADAM_TILES=0: every parameter through the chunk kernel, the copies by the cast pass (A/B, tests)
+ADAM_TILES = os.environ.get("EOE_ADAM_TILES", "1") != "0"
 
 
 _warned_unscaled = False
@@ -135,13 +142,43 @@ class FusedAdam(_NonFiniteGuard, torch.optim.Optimizer):
         self._tables[gi] = (sig, tab, len(rows), (pb, gb, mb, vb))
         return (tab, len(rows), (pb, gb, mb, vb)), distinct
 
+    def _split(self, gi, active, steps, distinct, bases, pairs):
+        """the group's table in two parts: 64 x 64 tile rows for the parameters in `pairs` (id -> (copy, transposed copy)), chunk rows for
+        the rest; same bases as the full table (which the non-finite check keeps walking).  Cached on the full table's identity and the
+        copies' addresses."""
+        full = self._tables[gi]
+        sig = (id(full[1]), tuple((k, d.data_ptr(), dt.data_ptr()) for k, (d, dt) in pairs.items()))
+        hit = self._tables.get(("split", gi))
+        if hit is not None and hit[0] == sig:
+            return hit[1:]
+        pb, gb, mb, vb = bases
+        rows, tiles = [], []
+        for p, s in zip(active, steps):
+            st = self.state[p]
+            po, go = (p.data_ptr() - pb) // 4, (p.grad.data_ptr() - gb) // 4
+            mo, vo = (st["exp_avg"].data_ptr() - mb) // 4, (st["exp_avg_sq"].data_ptr() - vb) // 4
+            pr = pairs.get(id(p))
+            if pr is None:
+                n = p.numel()
+                for c0 in range(0, n, _lib.ADAM_CHUNK):
+                    rows.append((po + c0, go + c0, mo + c0, vo + c0, min(_lib.ADAM_CHUNK, n - c0), distinct.index(s)))
+            else:
+                R, Cc = p.shape
+                for t in range(((R + 63) // 64) * ((Cc + 63) // 64)):
+                    tiles.append((po, go, mo, vo, pr[0].data_ptr(), pr[1].data_ptr(), R, Cc, t, distinct.index(s)))
+        dev = active[0].device
+        ctab = torch.from_numpy(np.array(rows, dtype=_CHUNK_DT).view(np.uint8).copy()).to(dev) if rows else None
+        ttab = torch.from_numpy(np.array(tiles, dtype=_TILE_DT).view(np.uint8).copy()).to(dev)
+        self._tables[("split", gi)] = (sig, ctab, len(rows), ttab, len(tiles))
+        return ctab, len(rows), ttab, len(tiles)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        work = []
+        work, work_index = [], {}
         for gi, group in enumerate(self.param_groups):
             active = [p for p in group["params"] if p.grad is not None]
             if not active:
@@ -162,6 +199,7 @@ class FusedAdam(_NonFiniteGuard, torch.optim.Optimizer):
             if len(distinct) > _lib.ADAM_GROUPS:
                 raise RuntimeError("FusedAdam: more than %d distinct step counts in one group" % _lib.ADAM_GROUPS)
             work.append((group, active, tab, n_chunks, bases, distinct))
+            work_index[id(group)] = (gi, steps)
         if not work:
             return loss
         stream = torch.cuda.current_stream().cuda_stream
@@ -185,10 +223,31 @@ class FusedAdam(_NonFiniteGuard, torch.optim.Optimizer):
                 bc2 = 1.0 - beta2 ** s
                 sc.step_size[i] = lr / bc1
                 sc.bc2_sqrt[i] = math.sqrt(bc2)
-            check(lib.eoe_adam_multi(bases[0], bases[1], bases[2], bases[3], tab.data_ptr(), n_chunks, C.byref(sc),
-                                     float(beta1), float(beta2), float(group["eps"]), float(group["weight_decay"]),
-                                     None, _lib.EOE_BF16, skip, stream), "eoe_adam_multi")
-            torch._C._increment_version(active)     # the kernel wrote in place: invalidate 16-bit weight copies
+            # 2-D weights with live 16-bit operand copies: by tiles, the copies rewritten from the update's registers
+            pairs = {}
+            if ADAM_TILES and not torch.cuda.is_current_stream_capturing():
+                for p in active:
+                    if p.dim() == 2 and p.shape[0] % 4 == 0 and p.shape[1] % 4 == 0:
+                        pr = ops.shadow.entry(p)
+                        if pr is not None:
+                            pairs[id(p)] = pr
+            hyper = (float(beta1), float(beta2), float(group["eps"]), float(group["weight_decay"]))
+            if pairs:
+                gi, steps = work_index[id(group)]
+                ctab, n_c, ttab, n_t = self._split(gi, active, steps, distinct, bases, pairs)
+                if n_c:
+                    check(lib.eoe_adam_multi(bases[0], bases[1], bases[2], bases[3], ctab.data_ptr(), n_c, C.byref(sc), *hyper,
+                                             None, _lib.EOE_BF16, skip, stream), "eoe_adam_multi")
+                check(lib.eoe_adam_tiles(bases[0], bases[1], bases[2], bases[3], ttab.data_ptr(), n_t, C.byref(sc), *hyper,
+                                         ops.dtype_code(ops._compute_dtype), skip, stream), "eoe_adam_tiles")
+            else:
+                check(lib.eoe_adam_multi(bases[0], bases[1], bases[2], bases[3], tab.data_ptr(), n_chunks, C.byref(sc), *hyper,
+                                         None, _lib.EOE_BF16, skip, stream), "eoe_adam_multi")
+            torch._C._increment_version(active)     # the kernel wrote in place: invalidate 16-bit weight copies ...
+            for p in active:                        # ... except the ones it has just rewritten
+                pr = pairs.get(id(p))
+                if pr is not None:
+                    ops.shadow.mark(p, pr[0], pr[1])
         return loss
 
 

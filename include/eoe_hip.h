@@ -22,14 +22,14 @@
 extern "C" {
 #endif
 
-#define EOE_ABI_VERSION 3
+#define EOE_ABI_VERSION 4
 
 enum { EOE_OK = 0, EOE_ERR_ARG = 1, EOE_ERR_LAUNCH = 2, EOE_ERR_UNSUPPORTED = 3 };
 enum { EOE_F16 = 1, EOE_BF16 = 2, EOE_F32 = 3 /* only where an entry point says so */ };
 
 int eoe_abi_version(void);
 /* sizeof of an argument struct as compiled into the library: 0 eoe_gemm_args, 1 eoe_conv_geometry, 2 eoe_adam_chunk,
- * 3 eoe_adam_scalars, 4/5 eoe_vit_block_fwd/bwd_args, 6/7 eoe_cgate(_bwd)_args, 8/9 eoe_sgate(_bwd)_args; -1 otherwise */
+ * 3 eoe_adam_scalars, 4/5 eoe_vit_block_fwd/bwd_args, 6/7 eoe_cgate(_bwd)_args, 8/9 eoe_sgate(_bwd)_args, 10 eoe_adam_tile; -1 otherwise */
 int eoe_struct_size(int which);
 const char* eoe_last_error(void);
 
@@ -266,6 +266,23 @@ int eoe_sgd_multi(float* p, const float* g, float* buf, const eoe_adam_chunk* ch
 int eoe_adam_multi(float* p, const float* g, float* m, float* v, const eoe_adam_chunk* chunks /*device*/,
                    int n_chunks, const eoe_adam_scalars* scalars /*host*/, float beta1, float beta2, float eps,
                    float weight_decay, void* shadow16, int dtype, const int32_t* skip_flag /* device, may be NULL */, void* stream);
+/* The same update for 2-D weights, walked by 64 x 64 tiles, which ALSO writes the two 16-bit MFMA operand copies of the new weight --
+ * [rows, cols] and its transpose [cols, rows] -- that the next forward / backward multiply with (round 4).  Until then the copies were
+ * made by a pass of their own before the next forward (eoe_cast_transpose_multi: the 85 M weights of the 12 blocks read again as fp32,
+ * 0.14 ms per step); here they leave from the registers the update is in, through an LDS transposition.  p, m, v get exactly what
+ * eoe_adam_multi writes (the same update function).  One table row per tile; rows, cols multiples of 4.  New relative to the
+ * reference (torch.optim.Adam has no such copies: autocast re-casts the weights in every forward). */
+typedef struct {
+    int64_t p_off, g_off, m_off, v_off; /* element offsets of the MATRIX (not of the tile) from the four base pointers */
+    void* d16;                          /* [rows, cols] 16-bit copy (may be NULL) */
+    void* d16_t;                        /* [cols, rows] 16-bit transposed copy (may be NULL) */
+    int32_t rows, cols;
+    int32_t tile;                       /* this row's tile: (tile / ceil(cols / 64), tile % ceil(cols / 64)) */
+    int32_t group;                      /* as in eoe_adam_chunk */
+} eoe_adam_tile;
+int eoe_adam_tiles(float* p, const float* g, float* m, float* v, const eoe_adam_tile* tiles /*device*/, int n_tiles,
+                   const eoe_adam_scalars* scalars /*host*/, float beta1, float beta2, float eps, float weight_decay, int dtype,
+                   const int32_t* skip_flag /* device, may be NULL */, void* stream);
 /* Non-finite guard for the scaled fp16 step.  The reference's numerical-failure policy is the per-epoch NaN check with retry
  * (ad_trainer.py:257-280, 448-449); the loss-gradient scale this build adds for fp16 can overflow the 16-bit backward chain, so the
  * optimisers can be told to drop such a step whole.  One streaming pass over the gradients of the chunk table the optimiser is about to

@@ -591,3 +591,51 @@ def test_split_k_for_small_m_matches_the_plain_launch(dtype):
             assert (s16.float() - p16.float()).abs().max().item() <= 2.0 ** (-7 if dtype == torch.bfloat16 else -10) * scale
     finally:
         flags(0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_adam_by_tiles_writes_the_operand_copies(dtype):
+    """round 4 (`eoe_adam_tiles`): 2-D weights whose 16-bit operand copies exist are updated by 64 x 64 tiles and the copies rewritten in the
+    same pass.  p / m / v are bit for bit the chunk kernel's, the copies bit for bit a fresh `cast_transpose` of the new weight, a skipped
+    (non-finite) step leaves all of them alone, and the next `shadow.get` is a cache hit on the rewritten tensors."""
+    import eoe_amd
+    from eoe_amd import ops, optim
+    eoe_amd.set_compute_dtype(dtype)
+    shapes = ((768, 3072), (2304, 768), (100, 68), (64, 64), (33,), (4, 3, 2))          # ragged tiles, a vector, a 3-D tensor
+    gen = torch.Generator(device="cuda").manual_seed(3)
+
+    def make():
+        return [torch.nn.Parameter(torch.randn(s, device="cuda", generator=torch.Generator(device="cuda").manual_seed(10 + i)) * 0.3)
+                for i, s in enumerate(shapes)]
+    a, b = make(), make()
+    oa = eoe_amd.FusedAdam(a, lr=1e-2, weight_decay=1e-3, guard=True)
+    ob = eoe_amd.FusedAdam(b, lr=1e-2, weight_decay=1e-3, guard=True)
+    pairs = [ops.shadow.get(p, True, True) for p in a if p.dim() == 2]                     # the copies exist (as after a forward)
+    ptrs = [(d.data_ptr(), t.data_ptr()) for d, t in pairs]
+    for step in range(3):
+        gs = [torch.randn(p.shape, device="cuda", generator=gen) * 0.1 for p in a]
+        if step == 1:
+            gs[0].view(-1)[12345] = float("inf")                                          # dropped whole by both paths
+        for p, q, g in zip(a, b, gs):
+            p.grad, q.grad = g.clone(), g.clone()
+        assert optim.ADAM_TILES
+        oa.step()
+        optim.ADAM_TILES = False
+        try:
+            ob.step()
+        finally:
+            optim.ADAM_TILES = True
+        torch.cuda.synchronize()
+        for p, q in zip(a, b):
+            assert torch.equal(p.detach(), q.detach())
+            assert torch.equal(oa.state[p]["exp_avg"], ob.state[q]["exp_avg"]) and torch.equal(oa.state[p]["exp_avg_sq"], ob.state[q]["exp_avg_sq"])
+        k = 0
+        for p in a:
+            if p.dim() != 2:
+                continue
+            d, t = ops.shadow.get(p, True, True)
+            assert (d.data_ptr(), t.data_ptr()) == ptrs[k], "the rewritten copies are the cached ones"
+            d2, t2 = ops.cast_transpose(p.detach(), dtype, True, True)
+            assert torch.equal(d, d2) and torch.equal(t, t2)
+            k += 1
+    assert oa.skipped_steps() == 1 and ob.skipped_steps() == 1
