@@ -161,7 +161,8 @@ def pmc_traffic(kernel):
     with open(paths[-1]) as f:
         for line in f:
             parts = line.strip().split(",")
-            if len(parts) != 4 or parts[0] not in tot or kernel not in parts[1]:
+            # (the library's scope names are prefixes of the kernel names; "cast" alone would also collect cast_transpose / cast_colsum)
+            if len(parts) != 4 or parts[0] not in tot or (kernel + "_kernel" if kernel == "cast" else kernel) not in parts[1]:
                 continue
             tot[parts[0]][0] += float(parts[3]) * 1024.0 * int(parts[2])
             tot[parts[0]][1] += int(parts[2])
