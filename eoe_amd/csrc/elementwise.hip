@@ -189,41 +189,50 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
                                 const float* __restrict__ stdv, T* __restrict__ out, int res, int p) {
     const int g = res / p;
     const int n = blockIdx.x / g, py = blockIdx.x % g;
-    const int per_c = p * res;                        // floats per channel in this patch row
-    const int total = 3 * per_c;
     const int kdim = 3 * p * p;
     float mu[3] = {0.f, 0.f, 0.f}, is[3] = {1.f, 1.f, 1.f};
     if (mean) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) { mu[c] = mean[c]; is[c] = 1.0f / stdv[c]; }
     }
-    // four pieces per thread and pass, their loads first (one load -> wait -> store per pass left a single 16-byte request per thread in flight)
+    // a thread's pieces are 16-byte quads i = t, t + 256, ... of the (channel, kernel row, x) order; (c, ky, xq) of the first one by division,
+    // of the following ones by stepping (256 quads = sq rows + rq quads): no division inside the loop.  Four pieces per pass, their loads
+    // first (one load -> wait -> store per pass left a single request per thread in flight).
+    const int rq_row = res >> 2;                        // quads per image row
+    const int nq = 3 * p * rq_row;                      // quads of this patch row
+    const int sq = 256 / rq_row, rq = 256 - sq * rq_row;
+    int i = threadIdx.x;
+    int c = i / (p * rq_row), rem = i - c * (p * rq_row);
+    int ky = rem / rq_row, xq = rem - ky * rq_row;
+    const float* img = x + (size_t)n * 3 * res * res + (size_t)py * p * res;
+    T* orow = out + (size_t)(n * g + py) * g * kdim;
     constexpr int U = 4;
-    for (int i0 = threadIdx.x * 4; i0 < total; i0 += blockDim.x * 4 * U) {
+    while (i < nq) {
         f32x4 v[U];
-        int c_[U], o_[U];
+        int cc[U], oo[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int i = i0 + u * (int)blockDim.x * 4;
-            const bool ok = i < total;
-            const int ii = ok ? i : 0;
-            const int c = ii / per_c, rem = ii % per_c;
-            const int ky = rem / res, xx = rem % res;     // xx multiple of 4, p multiple of 4
-            const int px = xx / p, kx = xx % p;
-            v[u] = *(const f32x4*)(x + (((size_t)n * 3 + c) * res + (py * p + ky)) * res + xx);
-            c_[u] = c;
-            o_[u] = ok ? px * kdim + c * p * p + ky * p + kx : -1;
+            const bool ok = i < nq;
+            const int xx = xq * 4;
+            v[u] = *(const f32x4*)(img + (ok ? ((size_t)c * res + ky) * res + xx : (size_t)0));
+            const int px = xx / p, kx = xx - px * p;
+            cc[u] = c;
+            oo[u] = ok ? px * kdim + c * p * p + ky * p + kx : -1;
+            i += 256;
+            ky += sq; xq += rq;
+            if (xq >= rq_row) { xq -= rq_row; ++ky; }
+            while (ky >= p) { ky -= p; ++c; }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (o_[u] < 0) continue;
-            const float m = c_[u] == 0 ? mu[0] : (c_[u] == 1 ? mu[1] : mu[2]), s = c_[u] == 0 ? is[0] : (c_[u] == 1 ? is[1] : is[2]);
+            if (oo[u] < 0) continue;
+            const float m = cc[u] == 0 ? mu[0] : (cc[u] == 1 ? mu[1] : mu[2]), sc = cc[u] == 0 ? is[0] : (cc[u] == 1 ? is[1] : is[2]);
             f32x4 w = v[u];
             if (mean) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) w[r] = (w[r] - m) * s;
+                for (int r = 0; r < 4; ++r) w[r] = (w[r] - m) * sc;
             }
-            *(u32x2*)(out + (size_t)(n * g + py) * g * kdim + o_[u]) = pack4<T>(w[0], w[1], w[2], w[3]);
+            *(u32x2*)(orow + oo[u]) = pack4<T>(w[0], w[1], w[2], w[3]);
         }
     }
 }
@@ -423,22 +432,24 @@ __global__ __launch_bounds__(1024) void multi_reduce_kernel(EoeRedJobs jobs) {
     const int cq = threadIdx.x & 15, lane = threadIdx.x >> 4;
     const int i = (blockIdx.x - jobs.tile_start[j]) * 64 + cq * 4, n = jb.N, P = jb.R;
     // row p of this thread's column quad: blocked layout = contiguous R x 256 B per 64-column block
+    // (round 4) the job's pointer comes out of a by-value struct array: hipcc treats it as a generic pointer (flat loads), and the ragged tail's
+    // `row < P ? load : 0` compiled to one load -> wait per row -- R = 160 (the GEMM's column sums) and R = 256 (attention) ran 3 and 4 dependent
+    // round trips.  Global address space spelled out; a row past P re-reads the thread's first row and is zeroed: ONE batch of eight loads
+    typedef const __attribute__((address_space(1))) f32x4 gf32x4;
     const float* base = jb.blocked ? part + (size_t)(i >> 6) * P * 64 + (i & 63) : part + i;
     const size_t pitch = jb.blocked ? 64 : (size_t)n;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (i < n) {
-        int p = lane;
-        for (; p + 448 < P; p += 512) {
+        for (int p = lane; p < P; p += 512) {
             f32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(base + (size_t)(p + 64 * u) * pitch);
-            s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-        }
-        if (p < P) {                               // ragged tail: still one batch (rows beyond P are not read)
-            f32x4 v[8];
+            for (int u = 0; u < 8; ++u) {
+                const int q = p + 64 * u;
+                v[u] = *(gf32x4*)(base + (size_t)(q < P ? q : p) * pitch);
+            }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                v[u] = (p + 64 * u < P) ? *(const f32x4*)(base + (size_t)(p + 64 * u) * pitch) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int u = 1; u < 8; ++u)
+                if (p + 64 * u >= P) v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
             s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
         }
     }
@@ -1390,6 +1401,9 @@ int eoe_finish_reduce(const float* part, int R, int N, int seg, float* o0, float
 
 int eoe_flush_reduce(EoeRedJobs* jobs, void* stream) {
     if (!jobs || jobs->count == 0) return 0;
+    double bytes = 0;
+    for (int j = 0; j < jobs->count; ++j) bytes += 4.0 * jobs->job[j].R * jobs->job[j].N;
+    ProfScope ps("finish_reduce", 0, bytes, stream);
     hipLaunchKernelGGL(multi_reduce_kernel, dim3(jobs->tile_start[jobs->count]), dim3(1024), 0, (hipStream_t)stream, *jobs);
     EOE_CHECK_LAUNCH("multi_reduce");
     jobs->count = 0;
