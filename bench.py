@@ -24,6 +24,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# Kernel arguments in device memory (a HIP runtime setting, read when libamdhip64 is loaded, i.e. at `import torch`): by default the runtime
+# keeps kernarg blocks in host memory and every workgroup's first scalar loads of its arguments cross PCIe -- a few microseconds per launch,
+# 0.40 ms of a 10.46 ms ViT step with its ~250 launches (measured, round 4: 10.46 -> 10.06 ms, interleaved).  A default only: an explicit
+# setting in the environment wins.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 MFMA_PEAK_TFLOPS = 2500.0    # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
 F32_MFMA_PEAK_TFLOPS = 157.3 # fp32-input MFMA (v_mfma_f32_16x16x4_f32) = the fp32 vector rate (same guide)
 HBM_PEAK_GBS = 8000.0

@@ -1,6 +1,8 @@
 import os
 import sys
 
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")      # kernel arguments in device memory (see bench.py); before anything imports torch
+
 import numpy as np
 import pytest
 
