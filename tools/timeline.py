@@ -13,7 +13,7 @@ def main():
     cols = [r[1] for r in con.execute("pragma table_info(kernels)")]
     print("columns:", cols)
     rows = list(con.execute("select name, start, end from kernels order by start"))
-    steps_marker = "adam_multi"
+    steps_marker = "adam_tiles" if any("adam_tiles" in r[0] for r in rows) else "adam_multi"
     idx = [i for i, r in enumerate(rows) if steps_marker in r[0]]
     if len(idx) < 4:
         print("fewer than 4 optimiser launches in the trace")
