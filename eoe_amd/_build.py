@@ -54,7 +54,8 @@ def _headers_digest() -> str:
 
 
 def _flags(src: str = ""):
-    return CFLAGS + EXTRA_CFLAGS.get(src, []) + (["-DEOE_AB"] if os.environ.get("EOE_AB") else [])
+    # EOE_CFLAGS: extra compiler flags for an experiment (part of the content stamp, so a library built with them is rebuilt without them)
+    return CFLAGS + EXTRA_CFLAGS.get(src, []) + (["-DEOE_AB"] if os.environ.get("EOE_AB") else []) + os.environ.get("EOE_CFLAGS", "").split()
 
 
 def source_digest(src: str, headers: str = None) -> str:
