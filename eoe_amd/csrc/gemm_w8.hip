@@ -31,12 +31,13 @@ static_assert(W8_SMEM_BYTES <= 160 * 1024, "LDS");
 #define W8_MFMA_INPLACE(MNEM, E, A, B) asm volatile(MNEM " a[%c0:%c1], %2, %3, a[%c0:%c1]" :: "i"(4 * (E)), "i"(4 * (E) + 3), "v"(A), "v"(B) : W8_AGPRS)
 #define W8_MFMA_FIRST(MNEM, E, A, B) asm volatile(MNEM " a[%c0:%c1], %2, %3, 0" :: "i"(4 * (E)), "i"(4 * (E) + 3), "v"(A), "v"(B) : W8_AGPRS)
 
-// cache policy of the output stores: 2 = nt (non-temporal).  The outputs (59 - 157 MB per launch) stream through the 4 MB L2 of each XCD and
-// evict the operand panels the other workgroups are about to re-read; PMC (profiles/r4/gemm_pmc_*.txt): 70 % L2 hit rate on the
-// in-projection, the L1 stalled on its outstanding-request limit half of the kernel's time -- a CU's intake is (requests in flight) x 128 B
-// / (L1 -> L2 latency), and every miss that goes to the fabric makes that latency longer
+// cache policy of the output stores: 0 = default, 2 = nt (non-temporal).  Stand-alone the streaming hint is worth 2 us of 55 (the outputs, 59 -
+// 157 MB per launch, then do not evict the operand panels the other workgroups are about to re-read: PMC, profiles/r4/gemm_pmc_*.txt).  In
+// the training step it LOSES: the in-projection's output is what the attention kernel reads next, and with the hint that kernel finds nothing in
+// L2 / the Infinity Cache -- attn_fwd 0.299 -> 0.236 ms per step without it against +0.03 for the GEMMs (tools/cflags_ab.sh -DW8_ST_AUX=2,
+// three interleaved pairs: 10.116 / 10.085 ms per step).  Default 0 since the end of round 4.
 #ifndef W8_ST_AUX
-#define W8_ST_AUX 2
+#define W8_ST_AUX 0
 #endif
 template <int N> __device__ __forceinline__ void w8_wait_vm() {
     static_assert(N >= 0 && N <= 63, "vmcnt");
