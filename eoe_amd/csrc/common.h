@@ -201,4 +201,19 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
+// (tile row, tile column) of logical tile r = xcd_remap(...) (round 4).  With the plain row-major order an XCD's chunk is a band of whole tile rows
+// and the ~64 workgroups it has resident touch EVERY tile column at once, i.e. the whole weight matrix -- 4.7 MB for the ViT's MLP against 4 MB of
+// L2 per XCD: PMC showed the weights fetched 2.4 times per XCD (c_fc forward: 111 MB from the fabric for 24 MB of operands).  Where the chunk is
+// whole rows and the column count is even, the chunk's LEFT half of the columns goes first for all its rows, then the right half: a resident round
+// works on half the weights.  c_fc forward 0.937 -> 0.906 ms per step, step -0.04 ms (tools/nt_shapes_ab.sh 524288 0); quarters measured worse.
+__device__ __forceinline__ void xcd_halves(int r, int total, int tiles_n, bool on, int& mt, int& nt) {
+    mt = r / tiles_n;
+    nt = r - mt * tiles_n;
+    if (!on || (total & 7) || (tiles_n & 1) || ((total >> 3) % tiles_n)) return;
+    const int q = total >> 3, x = r / q, l = r - x * q, rows = q / tiles_n, hn = tiles_n >> 1, per = rows * hn;
+    const int half = l / per, ll = l - half * per;
+    mt = x * rows + ll / hn;
+    nt = half * hn + ll % hn;
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
