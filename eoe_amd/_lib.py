@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must precede the CDLL below)
 
 from . import _build
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 EOE_F16, EOE_BF16, EOE_F32 = 1, 2, 3
 EOE_RESIZE_BILINEAR, EOE_RESIZE_BICUBIC = 2, 3
 EOE_COMM_I64, EOE_COMM_ID_BYTES, EOE_COMM_ALGO_RING, EOE_COMM_ALGO_RS_AG = 8, 128, 0, 1
@@ -35,7 +35,7 @@ class GemmArgs(C.Structure):
                 ("lda", _i32), ("ldb", _i32), ("ldc", _i32), ("ldaux", _i32),
                 ("dtype", _i32), ("epilogue", _i32), ("out_f32", _i32), ("accumulate", _i32), ("alpha", _f32),
                 ("workspace", _vp), ("workspace_bytes", _i64), ("gather", _i32), ("geo", ConvGeometry), ("colstats", _i32),
-                ("unpack_dw", _i32), ("split_k", _i32)]
+                ("unpack_dw", _i32), ("split_k", _i32), ("sk_workspace", _vp), ("sk_workspace_bytes", _i64)]
 
 
 class AdamChunk(C.Structure):
@@ -95,7 +95,7 @@ class VitBlockFwdArgs(C.Structure):
                 ("w_in_t", _vp), ("w_out_t", _vp), ("w_fc_t", _vp), ("w_proj_t", _vp),
                 ("x_in", _vp), ("x_mid", _vp), ("x_out", _vp),
                 ("xn1", _vp), ("qkv", _vp), ("att", _vp), ("xn2", _vp), ("hpre", _vp), ("hact", _vp),
-                ("stats1", _vp), ("stats2", _vp), ("cls_only", _i32)]
+                ("stats1", _vp), ("stats2", _vp), ("cls_only", _i32), ("nt_sk_workspace", _vp), ("nt_sk_workspace_bytes", _i64)]
 
 
 class VitBlockBwdArgs(C.Structure):

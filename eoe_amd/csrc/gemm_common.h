@@ -20,6 +20,9 @@ struct GemmP {
     int colsum_sq;                 // partial rows are [.][2][N]: sums and sums of squares (BatchNorm statistics); no finish kernel
     int M, N, K, lda, ldb, ldc, ldaux, out_f32, accumulate;
     int split_k;                   // eoe_gemm_args.split_k (a hint: launch_nt128_splitk)
+    // stream-K form of the eight-wave 256 x 256 kernel (gemm_w8.hip): partial accumulator slots and ticket / flag words in the CALLER's
+    // workspace (eoe_gemm_args.sk_workspace), sk_rounds data-parallel rounds in front of the stream-K part, sk_flags bit 0 = stream-K first
+    float* sk_part; int* sk_sync; int sk_rounds, sk_flags;
     float alpha;
     unsigned bytesA, bytesB;
     unsigned long long* stamp;     // diagnostics (EOE_GEMM_STAMP=1): per-workgroup s_memtime stamps, else NULL

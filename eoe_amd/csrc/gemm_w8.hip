@@ -16,13 +16,16 @@
 #include "gemm_common.h"
 #include <type_traits>
 
+int eoe_nt_flags();             // gemm.hip: the nt_flags option
+
 namespace {
 
 constexpr int W8_A_BYTES = 256 * BK * 2;                                               // 32 KiB
 constexpr int W8_STAGE_BYTES = 2 * W8_A_BYTES;                                         // 64 KiB
 constexpr int W8_NST = 2;
 constexpr int W8_BIAS_OFF = W8_NST * W8_STAGE_BYTES;                                   // behind the ring: 2 slots x 1 KiB
-constexpr int W8_SMEM_BYTES = W8_BIAS_OFF + 2 * 1024;
+constexpr int W8_SYNC_OFF = W8_BIAS_OFF + 2 * 1024;                                   // stream-K: ticket / wait words (64 B)
+constexpr int W8_SMEM_BYTES = W8_SYNC_OFF + 64;
 static_assert(W8_SMEM_BYTES <= 160 * 1024, "LDS");
 
 #define W8_A10(n) "a" #n "0", "a" #n "1", "a" #n "2", "a" #n "3", "a" #n "4", "a" #n "5", "a" #n "6", "a" #n "7", "a" #n "8", "a" #n "9"
@@ -45,7 +48,7 @@ template <int N> __device__ __forceinline__ void w8_wait_vm() {
 }
 
 // EPI: EOE_EPI_NONE (16-bit C = alpha acc + bias) or EOE_EPI_GELU (pre -> aux_out, C = QuickGELU of the rounded pre)
-template <typename T, int EPI>
+template <typename T, int EPI, bool SK>
 __global__ __launch_bounds__(512, 2) void gemm_w8_kernel(GemmP p) {
     static_assert(EPI == EOE_EPI_NONE || EPI == EOE_EPI_GELU, "epilogues with a second input are not built yet");
     constexpr int A_B = W8_A_BYTES, STAGE = W8_STAGE_BYTES, NST = W8_NST;
@@ -61,13 +64,55 @@ __global__ __launch_bounds__(512, 2) void gemm_w8_kernel(GemmP p) {
     const int tiles_n = p.N >> 8;                      // N % 256 == 0 (host)
     const int total_tiles = tiles_n * ((p.M + 255) >> 8);
     const int G = gridDim.x;
-    const int my_tiles = (total_tiles - (int)blockIdx.x + G - 1) / G;
-    const int nk = p.K / BK;                           // >= 2 (host)
-    const int iters = my_tiles * nk;
+    const int nk = p.K / BK;                           // >= 2 (host; stream-K: >= 4)
+    // ---- the workgroup's segments.  Data-parallel form (SK false): tiles b, b + G, ... each over the whole of K.  Stream-K form (the file's
+    // header): sk_rounds full rounds of such tiles, then this workgroup's range [sk_lo, sk_hi) of its XCD's (tile, k-tile) space
+    const int xcd = (int)blockIdx.x & 7, wq = (int)blockIdx.x >> 3, Wn = G >> 3;
+    const int sk_R = SK ? p.sk_rounds : 0;
+    const int sk_Ix = SK ? ((total_tiles - sk_R * G - xcd + 7) >> 3) * nk : 0;      // this XCD's stream-K tiles x k-tiles
+    auto sk_bound = [&](int i) -> int {                // first (tile, k-tile) index of workgroup i of the XCD: never 1 k-tile from a tile edge
+        int v = (int)(((long long)i * sk_Ix) / Wn);
+        const int m = v % nk;
+        if (m == 1) v -= 1;
+        else if (m == nk - 1) v += 1;
+        return v;
+    };
+    auto sk_wg_of = [&](int v) -> int {                // the workgroup (of this XCD) whose range holds index v
+        int g = (int)(((long long)v * Wn) / (sk_Ix > 0 ? sk_Ix : 1));
+        if (g > Wn - 1) g = Wn - 1;
+        while (g + 1 < Wn && sk_bound(g + 1) <= v) ++g;
+        while (g > 0 && sk_bound(g) > v) --g;
+        return g;
+    };
+    const int sk_lo = SK ? sk_bound(wq) : 0, sk_hi = SK ? sk_bound(wq + 1) : 0;
+    const int sk_t0 = sk_lo / nk;
+    const int n_sk = sk_hi > sk_lo ? (sk_hi - 1) / nk - sk_t0 + 1 : 0;
+    const int my_tiles = SK ? sk_R + n_sk : (total_tiles - (int)blockIdx.x + G - 1) / G;      // segments
+    const int iters = SK ? sk_R * nk + (sk_hi - sk_lo) : my_tiles * nk;
     if (iters <= 0) return;
+    const bool sk_first = SK && (p.sk_flags & 1);      // the stream-K segments before the data-parallel tiles
     const unsigned lds0 = (unsigned)(uintptr_t)((lds_void_t*)smem);
-    auto tile_origin = [&](int seq, int& m0, int& n0) {
-        const int r = xcd_remap((int)blockIdx.x + seq * G, total_tiles);
+    // segment j: virtual block id (-> tile), k-tiles [kb, ke); js = its index among the stream-K segments or -1
+    auto seg_get = [&](int j, int& vb, int& kb, int& ke, int& js) {
+        js = -1;
+        if (SK) {
+            const bool is_sk = sk_first ? (j < n_sk) : (j >= sk_R);
+            if (is_sk) {
+                js = sk_first ? j : j - sk_R;
+                const int t = sk_t0 + js;
+                kb = js == 0 ? sk_lo - sk_t0 * nk : 0;
+                ke = sk_hi - t * nk < nk ? sk_hi - t * nk : nk;
+                vb = sk_R * G + t * 8 + xcd;
+                return;
+            }
+            if (sk_first) j -= n_sk;
+        }
+        vb = (int)blockIdx.x + j * G;
+        kb = 0;
+        ke = nk;
+    };
+    auto tile_of = [&](int vb, int& m0, int& n0) {
+        const int r = xcd_remap(vb, total_tiles);
         m0 = (r / tiles_n) * 256;
         n0 = (r % tiles_n) * 256;
     };
@@ -88,12 +133,14 @@ __global__ __launch_bounds__(512, 2) void gemm_w8_kernel(GemmP p) {
         voffA[par] = (unsigned)((l8 * p.lda + c * 8) * 2);
         voffB[par] = (unsigned)((((lane >> 5) * 8 + (l8 & 3)) * p.ldb + c * 8) * 2);
     }
-    int st_tile = 0, st_kt = 0, st_slot = 0;
+    int st_tile = 0, st_kt = 0, st_kb = 0, st_kend = nk, st_slot = 0;
     unsigned sA_base = 0, sB_base = 0, bias_vo = EOE_OOB;
     int rows_left = 0;
     auto set_offsets = [&](int t) {
-        int m0, n0;
-        tile_origin(t, m0, n0);
+        int m0, n0, vb, js;
+        seg_get(t, vb, st_kb, st_kend, js);
+        st_kt = st_kb;
+        tile_of(vb, m0, n0);
         if (p.dbg & 4) m0 = 0;                         // diagnostics (EOE_GEMM_DEBUG=4 / 8): every tile stages the first A / B panel
         if (p.dbg & 8) n0 = 0;
         const int ra0 = m0 + (int)wave_u * 32;
@@ -126,15 +173,14 @@ __global__ __launch_bounds__(512, 2) void gemm_w8_kernel(GemmP p) {
     };
     // before the first piece of a tile's first k-tile: the tile's bias row (wave 0; into the slot of the tile's parity)
     auto stage_bias = [&](bool live) {
-        if (live && wave_u == 0 && st_kt == 0) {
+        if (live && wave_u == 0 && st_kt == st_kb) {
             const unsigned la = lds0 + (unsigned)W8_BIAS_OFF + (unsigned)(st_tile & 1) * 1024u;
             W8_DMA16(rbias, la, bias_vo, 0);
         }
     };
     auto stage_advance = [&]() {
         st_slot ^= 1;
-        if (++st_kt == nk) {
-            st_kt = 0;
+        if (++st_kt == st_kend) {
             st_tile += 1;
             if (st_tile < my_tiles) set_offsets(st_tile);
         }
@@ -226,17 +272,116 @@ __global__ __launch_bounds__(512, 2) void gemm_w8_kernel(GemmP p) {
         _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wb0[i]) : "v"(b_), "i"(i * 2048)); \
         _Pragma("unroll") for (int i = 0; i < 8; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xa[i]) : "v"(a_), "i"(i * 2048)); \
     } while (0)
+    // ---- stream-K: the partial-accumulator slots (fragment order: quad e of wave w = 1 KiB at (32 w + e) KiB / 1024; 256 KiB per slot; two
+    // slots per workgroup: its first stream-K segment and its last) and the routines that move a wave's 32 quads
+    __amdgpu_buffer_rsrc_t rpart = make_rsrc(SK ? (const void*)p.sk_part : p.C, SK ? (unsigned)(2 * G) * 262144u : 0u);
+    const unsigned part_voff = (unsigned)lane * 16u;
+    auto part_store = [&](int slot) {                  // straight from the accumulation registers
+        const int so = slot * 262144 + (int)wave_u * 32768;
+#pragma unroll
+        for (int e = 0; e < 32; ++e)
+            asm volatile("buffer_store_dwordx4 a[%c0:%c1], %2, %3, %4 offen sc1" :: "i"(4 * e), "i"(4 * e + 3), "v"(part_voff), "s"(rpart), "s"(so + e * 1024) : "memory");
+    };
+    auto part_load = [&](int slot) {                   // accumulators = the slot
+        const int so = slot * 262144 + (int)wave_u * 32768;
+#pragma unroll
+        for (int e = 0; e < 32; ++e)
+            asm volatile("buffer_load_dwordx4 a[%c0:%c1], %2, %3, %4 offen sc1" :: "i"(4 * e), "i"(4 * e + 3), "v"(part_voff), "s"(rpart), "s"(so + e * 1024) : "memory", W8_AGPRS);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory", W8_AGPRS);
+    };
+    auto part_add = [&](int slot) {                    // accumulators += the slot: 8 quads in flight (the compiler counts these loads itself:
+        const int so = slot * 262144 + (int)wave_u * 32768;       // every memory operation it cannot see is older)
+        constexpr int DEPTH = 8;
+        f32x4 ld[DEPTH];
+#pragma unroll
+        for (int e = 0; e < DEPTH; ++e) ld[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rpart, (int)part_voff, so + e * 1024, 16));
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            const f32x4 v = ld[e % DEPTH];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a;
+                asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(a) : "i"(4 * e + r));
+                a += v[r];
+                asm volatile("v_accvgpr_write_b32 a[%c0], %1" :: "i"(4 * e + r), "v"(a) : W8_AGPRS);
+            }
+            if (e + DEPTH < 32) ld[e % DEPTH] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rpart, (int)part_voff, so + (e + DEPTH) * 1024, 16));
+        }
+    };
     for (int c_tile = 0; c_tile < my_tiles; ++c_tile) {
+        int c_vb, c_kb, c_ke, c_js;
+        seg_get(c_tile, c_vb, c_kb, c_ke, c_js);
         // behind an epilogue its NB * 2 * ES stores are younger than the pieces of this k-tile + 1: they stay in flight
         W8_FIRST_FRAGS();
         W8_ITER(true, false);
-        _Pragma("unroll 1") for (int kt = 1; kt < nk - 1; ++kt) W8_ITER(false, false);
+        _Pragma("unroll 1") for (int kt = c_kb + 1; kt < c_ke - 1; ++kt) W8_ITER(false, false);
         W8_ITER(false, true);
         // ---- epilogue (the next tile's first k-step is already in xa0 / wb0, its first two k-tiles staged or in flight)
         int m0, n0;
-        tile_origin(c_tile, m0, n0);
+        tile_of(c_vb, m0, n0);
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");        // the last MFMAs' results have landed
         __builtin_amdgcn_sched_barrier(0);
+        if (SK && c_ke - c_kb < nk) {
+            // ---- a split tile: its S segments (consecutive workgroups of this XCD) meet.  Whoever arrives LAST owns the tile (gemm_tn256.hip's
+            // rule: the owner only ever waits for workgroups that have arrived, i.e. are resident and a few microseconds from done -- no
+            // co-residency assumption); the others leave their accumulators in their slot and raise its flag.  The owner adds the segments in
+            // SEGMENT order whoever it is (me <= 1: own + p0 == p0 + own, then the rest; me >= 2: its own accumulators go through its slot as
+            // well): bitwise reproducible.  The owner leaves the ticket counter and the flags zeroed for the next launch.
+            const int t = sk_t0 + c_js;
+            const int w_first = sk_wg_of(t * nk), w_last = sk_wg_of(t * nk + nk - 1);
+            const int S = w_last - w_first + 1, me = wq - w_first;
+            int* arrive = p.sk_sync + (t * 8 + xcd);
+            int* flags = p.sk_sync + 1024;
+            const int my_slot = (int)blockIdx.x * 2 + (c_js == 0 ? 0 : 1);
+            auto slot_of = [&](int sgm) -> int {       // segment sgm of this tile: workgroup w_first + sgm of the XCD; its first segment iff its range starts here
+                const int wc = w_first + sgm;
+                return (wc * 8 + xcd) * 2 + ((sgm > 0 || sk_bound(wc) >= t * nk) ? 0 : 1);
+            };
+            volatile int* sw = (volatile int*)(smem + W8_SYNC_OFF);
+            if (tid == 0) sw[0] = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const bool owner = __builtin_amdgcn_readfirstlane(sw[0]) == S - 1;
+            if (!owner) {
+                part_store(my_slot);
+                // publish (cdna_hip_programming.md, Guideline 16, R1 with write-through payload): the slot's stores carry sc1, every storing
+                // wave drains, the workgroup meets, ONE lane raises the flag with an agent-scope (sc1) store.  No release fence: it would write
+                // back the XCD's whole L2 -- megabytes of freshly written output tiles (measured: in-projection 56 -> 72 us with it)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(flags + my_slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                continue;
+            }
+            if (me >= 2) {
+                part_store(my_slot);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (tid == 0) {
+                __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int bad = 0;
+                for (int sgm = 0; sgm < S; ++sgm) {
+                    if (sgm == me) continue;
+                    int* f = flags + slot_of(sgm);
+                    int spins = 0;
+                    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(4);
+                    if (spins >= (1 << 22)) bad = 1;
+                    __hip_atomic_store(f, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                sw[1] = bad;                           // (no acquire fence: EVERY load of a slot below is an sc1 load -- the guide's table, row 1)
+            }
+            __syncthreads();
+            const bool poisoned = __builtin_amdgcn_readfirstlane(sw[1]) != 0;
+            if (me >= 2) part_load(slot_of(0));
+            for (int sgm = me >= 2 ? 1 : 0; sgm < S; ++sgm) {
+                if (me < 2 && sgm == me) continue;
+                part_add(sgm == me ? my_slot : slot_of(sgm));
+            }
+            if (poisoned) {                             // loud, not silent
+                const float qnan = __builtin_nanf("");
+#pragma unroll
+                for (int e = 0; e < 128; ++e) asm volatile("v_accvgpr_write_b32 a[%c0], %1" :: "i"(e), "v"(qnan) : W8_AGPRS);
+            }
+            asm volatile("s_nop 7" ::: "memory");
+        }
         // (everything below lives inside the epilogue: declared at kernel scope the half-written vectors and the branch-assigned cv[] were
         //  carried around the k-loop -- 16 registers too many for the 128 a wave has beside its accumulators)
         float bias16[16];                                  // bias of the lane's 16 columns of the wave's 64
@@ -313,15 +458,42 @@ __global__ __launch_bounds__(512, 2) void gemm_w8_kernel(GemmP p) {
 #undef W8_DMA16
 }
 
+// The stream-K plan of a launch, or rounds = -1 for the data-parallel form.  OPT-IN (nt_flags bit 20 = 1048576): measured, it loses on every ViT
+// shape -- a split costs its 256 KiB fp32 partial tile twice over the fabric, ~0.1 us of the whole chip's memory time per split, 256 splits per
+// launch (profiles/r5/streamk_nt.txt).  Full rounds of tiles stay data-parallel; the fractional last round
+// (with nt_flags bit 21: the last full round too -- "two-tile" stream-K) is cut along k over all workgroups, XCD by XCD.  Preconditions: the
+// caller's workspace, one workgroup per CU on a multiple of 8 CUs, >= 4 k-tiles per tile, and every XCD's share >= 4 k-tiles per workgroup
+// (segments are then >= 2 k-tiles long, which the kernel's pipeline needs)
+int w8_sk_rounds(const GemmP& p, int tiles, int ncu) {
+    const int g_nt_flags = eoe_nt_flags();
+    if (!(g_nt_flags & 1048576) || !p.sk_part || !p.sk_sync || (ncu & 7) || ncu > 256 || tiles <= 0) return -1;
+    const int nk = p.K / BK;
+    if (nk < 4 || tiles % ncu == 0) return -1;
+    int R = tiles / ncu;
+    if ((g_nt_flags & 2097152) && R >= 1) R -= 1;
+    const int tsk = tiles - R * ncu;
+    if (tsk < 8 || (long)(tsk / 8) * nk < 4L * (ncu / 8)) return -1;
+    return R;
+}
+
 template <typename T>
-int launch_w8(const GemmP& p, int epi, hipStream_t s) {
+int launch_w8(const GemmP& p0, int epi, hipStream_t s) {
+    GemmP p = p0;
     const int tiles = cdiv(p.M, 256) * (p.N / 256);
     const int ncu = num_cus();
-    const int grid = tiles < ncu ? tiles : ncu;
+    const int R = w8_sk_rounds(p, tiles, ncu);
+    const bool sk = R >= 0;
+    const int grid = sk ? ncu : (tiles < ncu ? tiles : ncu);
+    p.sk_rounds = sk ? R : 0;
+    p.sk_flags = (eoe_nt_flags() & 4194304) ? 1 : 0;
+#define EOE_W8_LAUNCH(E, SK_)                                                               \
+    do {                                                                                    \
+        static bool once = (hipFuncSetAttribute((const void*)gemm_w8_kernel<T, E, SK_>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_SMEM_BYTES), true); (void)once; \
+        hipLaunchKernelGGL((gemm_w8_kernel<T, E, SK_>), dim3(grid), dim3(512), W8_SMEM_BYTES, s, p); \
+    } while (0)
 #define EOE_W8_CASE(E)                                                                      \
     case E:                                                                                 \
-        { static bool once = (hipFuncSetAttribute((const void*)gemm_w8_kernel<T, E>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_SMEM_BYTES), true); (void)once; } \
-        hipLaunchKernelGGL((gemm_w8_kernel<T, E>), dim3(grid), dim3(512), W8_SMEM_BYTES, s, p); \
+        if (sk) EOE_W8_LAUNCH(E, true); else EOE_W8_LAUNCH(E, false);                       \
         break;
     switch (epi) {
         EOE_W8_CASE(EOE_EPI_NONE)
@@ -329,6 +501,7 @@ int launch_w8(const GemmP& p, int epi, hipStream_t s) {
         default: return eoe_set_error(EOE_ERR_ARG, "gemm_w8: epilogue %d is not built", epi);
     }
 #undef EOE_W8_CASE
+#undef EOE_W8_LAUNCH
     EOE_CHECK_LAUNCH("gemm_w8");
     return 0;
 }
@@ -345,6 +518,12 @@ bool eoe_w8_applies(const void* gemm_p, int epi) {
     const size_t c_bytes = (((size_t)p.M - 1) * p.ldc + p.N) * 2 + (size_t)256 * p.ldc * 2;           // + one tile of rows: soffset of a ragged last tile
     const size_t a_reach = ((size_t)p.M + 256) * p.lda * 2 + (size_t)p.K * 2;                          // soffset + voffset of a staged row past M
     return c_bytes < 0x7fffffffull && a_reach < 0x7fffffffull;
+}
+
+// would the launch run in the stream-K form (the dispatcher's rule in gemm.hip asks)
+bool eoe_w8_streamk(const void* gemm_p) {
+    const GemmP& p = *(const GemmP*)gemm_p;
+    return w8_sk_rounds(p, cdiv(p.M, 256) * (p.N / 256), num_cus()) >= 0;
 }
 
 int eoe_launch_w8(const void* gemm_p, int dtype, int epi, hipStream_t s) {

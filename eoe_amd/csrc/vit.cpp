@@ -57,6 +57,13 @@ eoe_gemm_args gemm(const void* A, const void* B, void* C, const float* bias, int
     g.dtype = dtype; g.epilogue = EOE_EPI_NONE; g.out_f32 = 0; g.accumulate = 0; g.alpha = 1.0f;
     return g;
 }
+// the same with the block's stream-K workspace attached
+eoe_gemm_args gemm(const eoe_vit_block_fwd_args* a, const void* A, const void* B, void* C, const float* bias, int M, int N, int K, int lda,
+                   int ldb, int ldc, int dtype) {
+    eoe_gemm_args g = gemm(A, B, C, bias, M, N, K, lda, ldb, ldc, dtype);
+    g.sk_workspace = a->nt_sk_workspace; g.sk_workspace_bytes = a->nt_sk_workspace ? a->nt_sk_workspace_bytes : 0;
+    return g;
+}
 
 int check_fwd(const eoe_vit_block_fwd_args* a) {
     if (!a) return eoe_set_error(EOE_ERR_ARG, "vit_block: null args");
@@ -77,21 +84,21 @@ extern "C" int eoe_vit_block_fwd(const eoe_vit_block_fwd_args* a, void* stream) 
     const int M = a->n * a->L, D = a->D, H = 4 * a->D, dt = a->dtype;
     // x_mid = x_in + out_proj(attn(ln_1(x_in)))
     TRY(eoe_layernorm_fwd(a->x_in, D, a->ln1_g, a->ln1_b, a->xn1, a->stats1, M, D, a->eps, dt, 0, stream));
-    eoe_gemm_args g = gemm(a->xn1, a->w_in, a->qkv, a->b_in, M, 3 * D, D, D, D, 3 * D, dt);
+    eoe_gemm_args g = gemm(a, a->xn1, a->w_in, a->qkv, a->b_in, M, 3 * D, D, D, D, 3 * D, dt);
     TRY(eoe_gemm_nt(&g, stream));
     TRY(eoe_attn_fwd(a->qkv, a->att, a->n, a->L, a->heads, dt, stream));
     // (cls_only: from here on only the class-token rows -- row i*L of image i, gathered by the row strides of the GEMM's A operand
     //  and of its residual input; everything downstream is a dense [n, ...] matrix)
     const int Mo = a->cls_only ? a->n : M, ldrow = a->cls_only ? a->L * D : D;
-    g = gemm(a->att, a->w_out, a->x_mid, a->b_out, Mo, D, D, ldrow, D, D, dt);
+    g = gemm(a, a->att, a->w_out, a->x_mid, a->b_out, Mo, D, D, ldrow, D, D, dt);
     g.epilogue = EOE_EPI_RESIDUAL; g.aux = a->x_in; g.ldaux = ldrow; g.out_f32 = 1;
     TRY(eoe_gemm_nt(&g, stream));
     // x_out = x_mid + c_proj(quick_gelu(c_fc(ln_2(x_mid))))
     TRY(eoe_layernorm_fwd(a->x_mid, D, a->ln2_g, a->ln2_b, a->xn2, a->stats2, Mo, D, a->eps, dt, 0, stream));
-    g = gemm(a->xn2, a->w_fc, a->hact, a->b_fc, Mo, H, D, D, D, H, dt);
+    g = gemm(a, a->xn2, a->w_fc, a->hact, a->b_fc, Mo, H, D, D, D, H, dt);
     g.epilogue = EOE_EPI_GELU; g.aux_out = a->hpre;
     TRY(eoe_gemm_nt(&g, stream));
-    g = gemm(a->hact, a->w_proj, a->x_out, a->b_proj, Mo, D, H, H, H, D, dt);
+    g = gemm(a, a->hact, a->w_proj, a->x_out, a->b_proj, Mo, D, H, H, H, D, dt);
     g.epilogue = EOE_EPI_RESIDUAL; g.aux = a->x_mid; g.ldaux = D; g.out_f32 = 1;
     g.split_k = a->cls_only ? 1 : 0;          // n x D x 4D: twelve tiles behind 48 k-tiles each (eoe_hip.h, eoe_gemm_args.split_k)
     TRY(eoe_gemm_nt(&g, stream));
@@ -149,7 +156,7 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
     } else {
         TRY(eoe_cast_colsum(b->dx_out, b->d16_a, b->g_b_proj, red_cast, Mo, D, dt, 1, stream));
     }
-    g = gemm(dy_proj, a->w_proj_t, b->dh, nullptr, Mo, H, D, D, D, H, dt);                 // d hact, then * gelu'(hpre)
+    g = gemm(a, dy_proj, a->w_proj_t, b->dh, nullptr, Mo, H, D, D, D, H, dt);                 // d hact, then * gelu'(hpre)
     g.epilogue = EOE_EPI_GELU_BWD; g.aux = a->hpre; g.ldaux = H;
     if (b->red_scratch) {
         // db_fc = column sums of dh, from the GEMM's epilogue through per-wave partial rows in the scratch (with fp32 atomics
@@ -160,7 +167,7 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
         TRY(eoe_gemm_nt(&g, stream));
         TRY(eoe_colsum(b->dh, H, b->g_b_fc, Mo, H, dt, 1, stream));
     }
-    g = gemm(b->dh, a->w_fc_t, b->d16_b, nullptr, Mo, D, H, H, H, D, dt);                   // d xn2
+    g = gemm(a, b->dh, a->w_fc_t, b->d16_b, nullptr, Mo, D, H, H, H, D, dt);                   // d xn2
     g.split_k = cls ? 1 : 0;
     TRY(eoe_gemm_nt(&g, stream));
     // (cls_only: dx_mid of the class-token rows goes to a dense [n, D] piece behind the dY copy in d16_a -- L >= 4 leaves the room --
@@ -176,11 +183,11 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
             return eoe_set_error(EOE_ERR_LAUNCH, "vit_block_bwd: zero-fill / scatter of the class-token rows failed");
     }
     // ---- attention branch:  x_mid = x_in + out_proj(attn(ln_1(x_in)))
-    g = gemm(b->d16_c, a->w_out_t, b->d16_b, nullptr, Mo, D, D, D, D, ldrow, dt);           // d att
+    g = gemm(a, b->d16_c, a->w_out_t, b->d16_b, nullptr, Mo, D, D, D, D, ldrow, dt);           // d att
     TRY(eoe_gemm_nt(&g, stream));
     // + db_in = column sums of dqkv, from the attention kernel's accumulators when the scratch is there
     TRY(eoe_attn_bwd(a->qkv, b->d16_b, b->dqkv, red_attn ? b->g_b_in : nullptr, red_attn, a->n, a->L, a->heads, dt, stream));
-    g = gemm(b->dqkv, a->w_in_t, b->d16_b, nullptr, M, D, 3 * D, 3 * D, 3 * D, D, dt);      // d xn1
+    g = gemm(a, b->dqkv, a->w_in_t, b->d16_b, nullptr, M, D, 3 * D, 3 * D, 3 * D, D, dt);      // d xn1
     TRY(eoe_gemm_nt(&g, stream));
     if (!b->red_scratch) TRY(eoe_colsum(b->dqkv, 3 * D, b->g_b_in, M, 3 * D, dt, 1, stream));
     // ---- the four weight gradients of the block in one grouped launch (every dY and X is still live)

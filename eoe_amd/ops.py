@@ -109,6 +109,9 @@ def gemm_nt(a, b, out, bias=None, epilogue=EPI_NONE, aux=None, aux_out=None, acc
     if colstats_ws is not None:
         g.workspace, g.workspace_bytes, g.colstats = _p(colstats_ws), colstats_ws.numel() * 4, 1
     g.split_k = 1 if split_k else 0          # hint (eoe_hip.h): small M behind a long K as k-ranges + an in-order sum
+    if M >= 2048 and N % 256 == 0:           # the shapes the eight-wave kernel's stream-K form takes (eoe_hip.h, eoe_gemm_args.sk_workspace)
+        ws = nt_sk_workspace(a.device)
+        g.sk_workspace, g.sk_workspace_bytes = _p(ws), ws.numel()
     check(lib.eoe_gemm_nt(C.byref(g), _stream()), "eoe_gemm_nt")
     return out
 
@@ -308,6 +311,19 @@ def scratch(name, shape, dtype, device):
     if t is None:
         t = torch.empty(shape, dtype=dtype, device=device)
         if not torch.cuda.is_current_stream_capturing():     # a buffer from a graph's private pool dies with the graph
+            _scratch[key] = t
+    return t
+
+
+def nt_sk_workspace(device):
+    """the stream-K workspace of the NT GEMMs (EOE_NT_STREAMK_WORKSPACE_BYTES of include/eoe_hip.h): one per (device, stream), zeroed once --
+    every launch leaves its ticket / flag words zeroed again"""
+    key = ("nt_sk_ws", device, _stream())
+    t = _scratch.get(key)
+    if t is None:
+        cus = torch.cuda.get_device_properties(device).multi_processor_count
+        t = torch.zeros(8192 + cus * 2 * 256 * 256 * 4, dtype=torch.uint8, device=device)
+        if not torch.cuda.is_current_stream_capturing():
             _scratch[key] = t
     return t
 
@@ -526,6 +542,8 @@ class VitBlockFunction(torch.autograd.Function):
         a.xn1, a.qkv, a.att, a.xn2, a.hpre, a.hact = (ptr[k] for k in ("xn1", "qkv", "att", "xn2", "hpre", "hact"))
         a.stats1, a.stats2 = ptr["stats1"], ptr["stats2"]
         a.cls_only = 1 if cls_only else 0
+        sk_ws = nt_sk_workspace(x.device)
+        a.nt_sk_workspace, a.nt_sk_workspace_bytes = _p(sk_ws), sk_ws.numel()
         keep = any(ctx.needs_input_grad)            # (grad mode itself is always off inside a Function's forward)
         if not keep:
             a.hpre = None          # forward only (frozen encoder, scoring): the MLP's pre-activation is not kept (79 MB per block)

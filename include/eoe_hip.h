@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define EOE_ABI_VERSION 4
+#define EOE_ABI_VERSION 5
 
 enum { EOE_OK = 0, EOE_ERR_ARG = 1, EOE_ERR_LAUNCH = 2, EOE_ERR_UNSUPPORTED = 3 };
 enum { EOE_F16 = 1, EOE_BF16 = 2, EOE_F32 = 3 /* only where an entry point says so */ };
@@ -101,7 +101,17 @@ typedef struct {
                          * library-owned buffer, summed in a fixed order by a second kernel.  The split depends on K only, so a row's result
                          * does not depend on M (eoe_vit_block_fwd / _bwd ask for it on the class-token-only block's n x 768 x 3072 products:
                          * 12 tiles of 48 k-tiles are one 50-us latency chain on 12 CUs).  Ignored where it does not apply. */
+    void* sk_workspace; /* NT only, optional: >= EOE_NT_STREAMK_WORKSPACE_BYTES(#CUs) bytes, 16-byte aligned, ZEROED ONCE by the caller before its
+                         * first use (every launch leaves the ticket / flag words at its head zeroed again), used by one stream at a time.
+                         * With it the eight-wave 256 x 256 kernel runs in its stream-K form where the tiles do not fill the CUs a whole
+                         * number of times: full rounds of tiles data-parallel, the fractional last round cut along k over all CUs, fp32
+                         * partial accumulators through this workspace, added in segment order by the tile's last-arriving workgroup
+                         * (bitwise reproducible; no atomics on data).  A row's bits then depend on M (where the cut falls) at the level of
+                         * fp32 summation order.  NULL: data-parallel tiles only. */
+    int64_t sk_workspace_bytes;
 } eoe_gemm_args;
+/* head: 8 KiB of ticket / flag words; then two 256 x 256 fp32 partial tiles per CU */
+#define EOE_NT_STREAMK_WORKSPACE_BYTES(cus) ((size_t)8192 + (size_t)(cus) * 2 * (256 * 256 * 4))
 #define EOE_NT_COLSUM_WORKSPACE_BYTES(M, N) ((size_t)(((M) + 63) / 64) * (size_t)(N) * 4)
 
 int eoe_gemm_nt(const eoe_gemm_args* args, void* stream);
@@ -318,6 +328,10 @@ typedef struct {
      * fp32 [n, D]; dx_in and every parameter gradient are what the full computation gives with zero dx_out on the other rows (the
      * weight gradients to fp32 summation order: the zero rows are left out of the sums). */
     int32_t cls_only;
+    /* optional: the stream-K workspace of the block's NT GEMMs (eoe_gemm_args.sk_workspace: zeroed once by the caller, one stream at a time;
+     * forward and backward use the same one).  NULL: data-parallel tiles only. */
+    void* nt_sk_workspace;
+    int64_t nt_sk_workspace_bytes;
 } eoe_vit_block_fwd_args;
 
 typedef struct {
