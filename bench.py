@@ -82,6 +82,7 @@ def parse():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --batch normal (+ as many OE) images per GPU; strong: that many per JOB, split over the ranks")
     ap.add_argument("--no-torch-baseline", action="store_true")
+    ap.add_argument("--no-box-probe", action="store_true", help="skip the three calibration probes in front of the timed region")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=5)
     return ap.parse_args()
@@ -153,6 +154,51 @@ def torch_rocm_baseline(args, dev):
             out[name] = None
             out[name + "_error"] = repr(e)[:200]
     return out
+
+
+def box_probe(dev):
+    """Three fixed probes of THIS box, run before the timed region (MI355X boxes of the pool differ by +-4 % on identical code): a bare
+    fp16 MFMA loop (no memory traffic), a 1 GB 16-byte-per-lane copy, and this library's own 4096^3 NT GEMM.  The step time normalised
+    to a reference box is ms_per_step * gemm_4096_tf / (the reference box's gemm_4096_tf) -- DESIGN.md section 5."""
+    import ctypes as C
+    import torch
+    from eoe_amd import _lib, ops
+    s = torch.cuda.current_stream().cuda_stream
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) / reps
+            best = t if best is None else min(best, t)
+        return best * 1e-3
+
+    iters, blocks = 20000, cus * 8                      # 8 workgroups of 4 waves per CU = 8 waves per SIMD
+    t = timed(lambda: _lib.check(_lib.lib.eoe_probe_mfma_f16(None, iters, blocks, s), "eoe_probe_mfma_f16"), 2)
+    mfma_tf = 2.0 * 16 * 16 * 32 * 8 * iters * 4 * blocks / t / 1e12
+    nbytes = 1 << 30
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev).fill_(1)
+    dst = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    t = timed(lambda: _lib.check(_lib.lib.eoe_probe_copy(dst.data_ptr(), src.data_ptr(), nbytes, s), "eoe_probe_copy"), 3)
+    copy_gbs = 2.0 * nbytes / t / 1e9                   # bytes read + bytes written
+    del src, dst
+    a = torch.randn(4096, 4096, device=dev).half()
+    b = (torch.randn(4096, 4096, device=dev) * 0.05).half()
+    c = torch.empty(4096, 4096, device=dev, dtype=torch.float16)
+    t = timed(lambda: ops.gemm_nt(a, b, c), 10)
+    gemm_tf = 2.0 * 4096 ** 3 / t / 1e12
+    del a, b, c
+    torch.cuda.empty_cache()
+    return {"mfma_f16_loop_tf": round(mfma_tf, 1), "hbm_copy_gbs": round(copy_gbs, 1), "gemm_4096_tf": round(gemm_tf, 1),
+            "note": "bare v_mfma_f32_16x16x32_f16 loop (8 waves per SIMD); 1 GiB copy, read + written bytes; eoe_gemm_nt 4096^3 fp16"}
 
 
 def pmc_traffic(kernel):
@@ -301,13 +347,17 @@ def main():
             score_buf[i % score_buf.shape[0]] = scores
             return loss
 
+    box = box_probe(dev) if (rank == 0 and not args.no_box_probe) else None
     for i in range(args.warmup):
         loss = step(i)
     sync()
     wait_events.clear()
+    host_s = 0.0                                           # host time inside step() (enqueue; no device synchronisation in there)
     t0 = time.perf_counter()
     for i in range(args.steps):
+        h0 = time.perf_counter()
         loss = step(args.warmup + i)
+        host_s += time.perf_counter() - h0
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -430,7 +480,10 @@ def main():
             "model_tflops": round(value * flop_per_img / 1e3, 1),
             "mfma_roofline_frac_end_to_end": round(value * flop_per_img / 1e3 / (MFMA_PEAK_TFLOPS * world), 4),
             "final_loss": round(final_loss, 5) if training else None, "auc_last_step": round(auc, 4),
+            "host_enqueue_ms": round(host_s / args.steps * 1e3, 3),
         }
+        if box is not None:
+            out["box"] = box
         if world > 1 and training:
             # what the first hardware scaling run needs to be read: how much was sent, in how many collectives, and how long the
             # compute stream stood waiting for them at the end of backward (hipEvents around the join; everything else overlapped)

@@ -20,7 +20,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libeoe_hip.so")
 OBJDIR = os.path.join(HERE, "build")
 SOURCES = ["api.cpp", "gemm.hip", "gemm_tn.hip", "elementwise.hip", "attention.hip", "conv.hip", "cbam.hip", "augment.hip",
-           "vit.cpp", "parity.hip", "gemm256.hip", "comm.cpp", "gemm_tn256.hip", "gemm_w8.hip"]
+           "vit.cpp", "parity.hip", "gemm256.hip", "comm.cpp", "gemm_tn256.hip", "gemm_w8.hip", "probe.hip"]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 # gemm_w8.hip names its 128 accumulator registers literally: the compiler must not park spilled VGPRs in AGPRs there (the file's header)
 EXTRA_CFLAGS = {"gemm_w8.hip": ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]}

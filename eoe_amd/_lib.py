@@ -208,6 +208,8 @@ SIGNATURES = {
     "eoe_comm_join": [_vp, _vp],
     "eoe_comm_sync_bn": [_vp, C.c_int, _vp],
     "eoe_set_bn_sync": [_vp, _vp],
+    "eoe_probe_mfma_f16": [_vp, C.c_int, C.c_int, _vp],
+    "eoe_probe_copy": [_vp, _vp, _i64, _vp],
     "eoe_prof_enable": [C.c_int],
     "eoe_set_option": [C.c_char_p, C.c_int],
     "eoe_get_option": [C.c_char_p, C.POINTER(C.c_int)],

@@ -715,6 +715,13 @@ typedef struct {
     double bytes;      /* sum of algorithmic HBM bytes (inputs read once + outputs written once) */
 } eoe_prof_entry;
 int eoe_prof_enable(int on);
+
+/* Box calibration probes (bench.py prints them in its line so that numbers from different boxes can be compared; not on the product path):
+ * a bare v_mfma_f32_16x16x32_f16 loop -- `blocks` workgroups of 4 waves, 8 independent accumulators each, `iters` rounds of 8 MFMAs per wave
+ * (2 * 16*16*32 * 8 * iters * 4 * blocks FLOP), out: blocks * 256 floats or NULL -- and a 16-byte-per-lane streaming copy. */
+int eoe_probe_mfma_f16(float* out, int iters, int blocks, void* stream);
+int eoe_probe_copy(void* dst, const void* src, int64_t bytes, void* stream);
+
 /* tuning switches for A/B measurements inside one process ("nt_flags": see gemm.hip) */
 int eoe_set_option(const char* name, int value);
 int eoe_get_option(const char* name, int* value);    /* the current value (callers that change a switch restore what they found) */

@@ -212,7 +212,7 @@ def test_w8_kernel_keeps_out_of_the_accumulators(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:]
     text = open(out).read()
     kernels = re.findall(r"^(_ZN\S*gemm_w8_kernel\S*):[^\n]*\n(.*?)s_endpgm", text, flags=re.S | re.M)
-    assert len(kernels) == 4, [k for k, _ in kernels]            # {fp16, bf16} x {plain, GELU}
+    assert len(kernels) == 8, [k for k, _ in kernels]            # {fp16, bf16} x {plain, GELU} x {data-parallel, stream-K}
     for name, body in kernels:
         inside, bad = False, []
         for line in body.split("\n"):

@@ -23,8 +23,11 @@ def ops():
 # the 256x64 two-workgroup kernel for N <= 64), the persistent 256-row kernel (also for N <= 64: bit 6), and the two-workgroup
 # kernel with 128- and with 160-row tiles, and the one-wave-per-SIMD kernel (gemm256.hip) with 160x256 and 256x256 tiles -- every
 # test below must hold for each
+# (round 5) "eight_wave": gemm_w8.hip forced wherever it applies (bit 18), "eight_wave_stream_k": the same in its stream-K form (bit 20), "halves_off":
+# the 160x256 kernel's tile order without the column halves (bit 19), "nt128w_old_image": its round-3 LDS swizzle (bit 23)
 NT_VARIANTS = {"auto": 1, "persistent256": 1 | 4 | 64, "two_wg_128": 1 | 8 | 16, "two_wg_160": 1 | 8 | 32,
-               "one_wave_160x256": 1 | 128, "one_wave_256x256": 1 | 256, "one_wave_cost_model": 1 | 512}
+               "one_wave_160x256": 1 | 128, "one_wave_256x256": 1 | 256, "one_wave_cost_model": 1 | 512,
+               "eight_wave": 1 | 262144, "eight_wave_stream_k": 1 | 262144 | 1048576, "halves_off": 1 | 524288, "nt128w_old_image": 1 | 8388608}
 
 
 @pytest.fixture(params=list(NT_VARIANTS))
@@ -254,6 +257,14 @@ def test_gemm_tn_wide_tiles(ops, dtype, case):
             o.fill_(-1.0)
         _lib.check(_lib.lib.eoe_gemm_tn_grouped(args, n, st), "grouped wide again")
         assert all(torch.equal(o, f) for o, f in zip(outs, first)), "the wide-tile wgrad is not bitwise repeatable"
+    old = _lib.set_option("tn_flags", 8)             # the one-wave-per-SIMD form of the same kernel: same products, same slice meeting -> same bits
+    try:
+        for o in outs:
+            o.fill_(-1.0)
+        _lib.check(_lib.lib.eoe_gemm_tn_grouped(args, n, st), "grouped wide, four waves")
+        assert all(torch.equal(o, f) for o, f in zip(outs, first)), "four-wave and eight-wave wide-tile wgrad differ"
+    finally:
+        _lib.set_option("tn_flags", old)
     old = _lib.set_option("tn_flags", 4)             # the 256x128 kernel on the same problems
     try:
         _lib.check(_lib.lib.eoe_gemm_tn_grouped(args, n, st), "grouped 256x128")
@@ -269,6 +280,110 @@ def test_gemm_tn_wide_tiles(ops, dtype, case):
     _lib.check(_lib.lib.eoe_gemm_tn_grouped(args, n, st), "grouped wide acc")
     for out, ref in zip(outs, refs):
         assert_close(out, 1.5 * ref, 4e-6, 6e-5 * math.sqrt(T), f"gemm_tn wide accumulate {case}")
+
+
+W8_SHAPES = [(12800, 2304, 768), (12750, 2304, 768), (12763, 3072, 768), (2049, 3072, 768), (2048, 768, 3072), (6400, 2048, 1024)]
+
+
+def _nt_kinds(ops, kind, a, w, bias, out, pre):
+    if kind == "bias":
+        ops.gemm_nt(a, w, out, bias=bias)
+    elif kind == "nobias":
+        ops.gemm_nt(a, w, out)
+    elif kind == "gelu":
+        ops.gemm_nt(a, w, out, bias=bias, epilogue=ops.EPI_GELU, aux_out=pre)
+    elif kind == "gelu_nopre":
+        ops.gemm_nt(a, w, out, bias=bias, epilogue=ops.EPI_GELU)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", W8_SHAPES)
+def test_gemm_nt_eight_wave(ops, dtype, M, N, K):
+    """the eight-wave 256 x 256 kernel (gemm_w8.hip) at the shapes it serves and at ragged M (rows of A past M staged from an out-of-range
+    offset, rows of C past M not stored), every epilogue it has (bias / none / GELU pair / GELU without the saved pre-activation): forced
+    (nt_flags bit 18) against an fp64 product on sampled rows -- the first and the last rows among them -- and BITWISE against the
+    160 x 128 kernel (same products in the same k order, same epilogue arithmetic); the launcher's own choice (auto) equal to both.
+    Stream-K form (bit 20): within an ulp of the 16-bit result (fp32 partial sums re-associated), bitwise repeatable, and the workspace's
+    ticket / flag words zero again after every launch"""
+    from eoe_amd import _lib
+    a, ar = t16(f"w8/a{M}x{K}", (M, K), 1.0, dtype)
+    w, wr = t16(f"w8/w{N}x{K}", (N, K), 0.05, dtype)
+    bias, biasr = f32(f"w8/bias{N}", (N,), 1.0)
+    rows = torch.cat([torch.arange(0, 8), torch.arange(M - 8, M), torch.from_numpy(np.random.RandomState(M + N).randint(0, M, 240))])
+    acc = ar[rows].double() @ wr.double().t()
+    ws_head = ops.nt_sk_workspace(a.device)[:8192].view(torch.int32)
+    for kind in ("bias", "nobias", "gelu", "gelu_nopre"):
+        res = {}
+        for name, f in (("two_wg_160", 1 | 8 | 32), ("eight_wave", 1 | 262144), ("auto", 1), ("stream_k", 1 | 262144 | 1048576), ("stream_k_again", 1 | 262144 | 1048576),
+                        ("stream_k_two_tile", 1 | 262144 | 1048576 | 2097152), ("stream_k_first", 1 | 262144 | 1048576 | 4194304)):
+            old = _lib.set_option("nt_flags", f)
+            try:
+                out = torch.full((M, N), float("nan"), dtype=dtype, device="cuda")
+                pre = torch.full((M, N), float("nan"), dtype=dtype, device="cuda")
+                _nt_kinds(ops, kind, a, w, bias, out, pre)
+                torch.cuda.synchronize()
+            finally:
+                _lib.set_option("nt_flags", old)
+            assert int(ws_head.abs().sum()) == 0, f"{name}: ticket / flag words not zero after the launch"
+            res[name] = (out, pre)
+        out8, pre8 = res["eight_wave"]
+        want = acc + (biasr.double() if kind != "nobias" else 0.0)
+        if kind in ("bias", "nobias"):
+            assert_close(out8[rows.cuda()], want, 2 * EPS16[dtype], 1e-4 * math.sqrt(K), f"eight-wave {kind} {M}x{N}x{K}")
+        elif kind == "gelu":
+            assert_close(pre8[rows.cuda()], want, 2 * EPS16[dtype], 1e-4 * math.sqrt(K), f"eight-wave GELU pre-activation {M}x{N}x{K}")
+            assert torch.equal(pre8, res["two_wg_160"][1])
+            # the activation of the ROUNDED pre-activation
+            assert_close(out8[rows.cuda()], _qgelu(pre8[rows.cuda()].float().cpu().double()), 2 * EPS16[dtype], 1e-4, "eight-wave GELU activation")
+            gelu_out = out8
+        else:
+            assert torch.equal(out8, gelu_out), "GELU without the saved pre-activation: a different activation"
+        assert torch.equal(out8, res["two_wg_160"][0]), f"eight-wave {kind}: not bitwise the 160x128 kernel's result"
+        assert torch.equal(res["auto"][0], out8), f"auto {kind}: differs from the forced kernels"
+        # stream-K forms: the same products, partial sums of the split tiles added in segment order
+        ulps = 4.5 if kind.startswith("gelu") else 2.5       # (the activation of a pre-activation one ulp away: up to two ulps)
+        for name in ("stream_k", "stream_k_two_tile", "stream_k_first"):
+            o = res[name][0].float()
+            assert torch.isfinite(o).all()
+            d = ((o - out8.float()).abs() / out8.float().abs().clamp_min(1.0)).max().item()
+            assert d <= ulps * EPS16[dtype], (name, kind, d)
+        assert torch.equal(res["stream_k"][0], res["stream_k_again"][0]), "stream-K: not bitwise repeatable"
+        if kind == "gelu":
+            assert torch.equal(res["stream_k"][1], res["stream_k_again"][1])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_nt_wide_kernel_tile_order_and_image(ops, dtype):
+    """the 160 x 256 x 32 two-workgroup kernel at the shape it serves (M = 12 800, N = 3072, K = 768; GELU pair and GELU' x dY with fused
+    column sums): the column-halves tile order (nt_flags bit 19 switches it off) and the LDS image swizzled for the ds_read_b128 lane
+    groups (bit 23: the round-3 image) change where and when, not what: bitwise the same results, which equal the 160 x 128 kernel's"""
+    from eoe_amd import _lib
+    M, N, K = 12800, 3072, 768
+    a, ar = t16("wk/a", (M, K), 1.0, dtype)
+    w, wr = t16("wk/w", (N, K), 0.05, dtype)
+    bias, _ = f32("wk/bias", (N,), 1.0)
+    res = {}
+    for name, f in (("default", 1), ("halves_off", 1 | 524288), ("old_image", 1 | 8388608), ("two_wg_160", 1 | 8 | 32)):
+        old = _lib.set_option("nt_flags", f)
+        try:
+            act = torch.empty((M, N), dtype=dtype, device="cuda")
+            pre = torch.empty((M, N), dtype=dtype, device="cuda")
+            ops.gemm_nt(a, w, act, bias=bias, epilogue=ops.EPI_GELU, aux_out=pre)
+            dz = torch.empty((M, N), dtype=dtype, device="cuda")
+            cs = torch.zeros(N, dtype=torch.float32, device="cuda")
+            ops.gemm_nt(a, w, dz, epilogue=ops.EPI_GELU_BWD, aux=pre, colsum_out=cs)
+            torch.cuda.synchronize()
+        finally:
+            _lib.set_option("nt_flags", old)
+        res[name] = (act, pre, dz, cs)
+    rows = torch.arange(0, M, 97)
+    acc = ar[rows].double() @ wr.double().t()
+    assert_close(res["default"][1][rows.cuda()], acc + bias.cpu().double(), 2 * EPS16[dtype], 1e-4 * math.sqrt(K), "wide kernel: pre-activation")
+    for name in ("halves_off", "old_image", "two_wg_160"):
+        for i, what in enumerate(("activation", "pre-activation", "GELU' x dY")):
+            assert torch.equal(res[name][i], res["default"][i]), f"{name}: {what} differs"
+    for name in ("halves_off", "old_image"):
+        assert torch.equal(res[name][3], res["default"][3]), f"{name}: column sums differ"
 
 
 def test_gemm_rejects_bad_shapes(ops):
