@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--comm-algo", choices=["rs_ag", "ring"], default="rs_ag",
                     help="native transport: reduce-scatter + all-gather per bucket (every xGMI link busy in both phases) or one all-reduce")
     ap.add_argument("--dtype", choices=["fp16", "bf16"], default="fp16")
+    ap.add_argument("--bucket-dtype", choices=["fp32", "bf16"], default="fp32",
+                    help="N > 1: the type the gradient buckets cross the ranks in (fp32 = the reference arithmetic; bf16 halves the xGMI bytes)")
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--model", choices=["vit", "cnn32", "wrn"], default="vit",
                     help="vit = the BASELINE.json metric config; cnn32 = secondary (config 1/2 backbone, 32x32); "
@@ -284,7 +286,7 @@ def main():
     # and all-gathered on a side HIP stream from inside backward, BatchNorm sums added inside the library (no Python in that path).
     comm, comm_kind = parallel.make_comm(args.comm, args.comm_algo) if world > 1 else (None, "none")
     training = args.mode != "eval"
-    arena = parallel.GradArena(model, comm=comm) if training else None
+    arena = parallel.GradArena(model, comm=comm, bucket_dtype=torch.bfloat16 if args.bucket_dtype == "bf16" else None) if training else None
     if world > 1 and training:
         arena.install_hooks()
         if any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in model.modules()):
@@ -488,8 +490,9 @@ def main():
             # what the first hardware scaling run needs to be read: how much was sent, in how many collectives, and how long the
             # compute stream stood waiting for them at the end of backward (hipEvents around the join; everything else overlapped)
             sent = [hi - lo for _, lo, hi in arena.block_buckets] + [hi - lo for _, lo, hi in arena.run_buckets]
-            out["comm"] = {"transport": comm_kind, "buckets": len(sent), "allreduce_bytes_per_step": int(4 * sum(sent)),
-                           "largest_bucket_bytes": int(4 * max(sent)), "comm_exposed_ms": round(comm_exposed_ms, 3),
+            esz = 2 if args.bucket_dtype == "bf16" else 4
+            out["comm"] = {"transport": comm_kind, "buckets": len(sent), "bucket_dtype": args.bucket_dtype, "allreduce_bytes_per_step": int(esz * sum(sent)),
+                           "largest_bucket_bytes": int(esz * max(sent)), "comm_exposed_ms": round(comm_exposed_ms, 3),
                            "sync_bn": bool(parallel._bn_sync_cb is not None)}
         if roof is not None:
             out["roofline"] = roof

@@ -98,6 +98,17 @@ class VitBlockFwdArgs(C.Structure):
                 ("stats1", _vp), ("stats2", _vp), ("cls_only", _i32), ("nt_sk_workspace", _vp), ("nt_sk_workspace_bytes", _i64)]
 
 
+class RedJob(C.Structure):
+    _fields_ = [("part", _vp), ("R", _i32), ("N", _i32), ("seg", _i32), ("blocked", _i32), ("out", _vp * 3)]
+
+
+RED_TABLE_MAX = 128
+
+
+class RedTable(C.Structure):
+    _fields_ = [("job", RedJob * RED_TABLE_MAX), ("count", _i32), ("overwrite", _i32)]
+
+
 class VitBlockBwdArgs(C.Structure):
     _fields_ = [("f", VitBlockFwdArgs), ("dx_out", _vp), ("dx_in", _vp),
                 ("g_ln1_g", _vp), ("g_ln1_b", _vp), ("g_ln2_g", _vp), ("g_ln2_b", _vp),
@@ -106,7 +117,7 @@ class VitBlockBwdArgs(C.Structure):
                 ("accumulate", _i32),
                 ("d16_a", _vp), ("d16_b", _vp), ("d16_c", _vp), ("dh", _vp), ("dqkv", _vp), ("dx_mid", _vp), ("red_scratch", _vp),
                 ("tn_workspace", _vp), ("tn_workspace_bytes", _i64),
-                ("next_d16", _vp), ("in_d16", _vp), ("in_red_scratch", _vp), ("async_wgrad", _i32)]
+                ("next_d16", _vp), ("in_d16", _vp), ("in_red_scratch", _vp), ("async_wgrad", _i32), ("red_table", C.POINTER(RedTable))]
 
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); must match include/eoe_hip.h
@@ -118,6 +129,7 @@ SIGNATURES = {
     "eoe_struct_size": [C.c_int],
     "eoe_last_error": [],
     "eoe_vit_side_join": [_vp],
+    "eoe_red_table_flush": [C.POINTER(RedTable), _vp],
     "eoe_gemm_nt": [C.POINTER(GemmArgs), _vp],
     "eoe_gemm_tn": [C.POINTER(GemmArgs), _vp],
     "eoe_gemm_tn_grouped": [C.POINTER(GemmArgs), C.c_int, _vp],
@@ -229,7 +241,7 @@ def header_symbols():
 
 # the argument structs mirrored above, by their eoe_struct_size index (include/eoe_hip.h)
 _STRUCTS = {0: GemmArgs, 1: ConvGeometry, 2: AdamChunk, 3: AdamScalars, 4: VitBlockFwdArgs, 5: VitBlockBwdArgs, 6: CGateArgs,
-            7: CGateBwdArgs, 8: SGateArgs, 9: SGateBwdArgs, 10: AdamTile}
+            7: CGateBwdArgs, 8: SGateArgs, 9: SGateBwdArgs, 10: AdamTile, 11: RedTable}
 
 
 def _load():

@@ -34,6 +34,7 @@ extern "C" int eoe_struct_size(int which) {
         case 8: return (int)sizeof(eoe_sgate_args);
         case 9: return (int)sizeof(eoe_sgate_bwd_args);
         case 10: return (int)sizeof(eoe_adam_tile);
+        case 11: return (int)sizeof(eoe_red_table);
         default: return -1;
     }
 }

@@ -57,6 +57,13 @@ struct EoeRedJobs {
     int count;
     int overwrite;            // 1: out = sum (no zero-initialised accumulators needed), 0: out += sum
 };
+// the same for a whole tower's jobs, 64 per launch (eoe_red_table_flush; 3.4 KB of kernel arguments)
+struct EoeRedJobsBig {
+    EoeRedJob job[64];
+    int tile_start[65];
+    int count;
+    int overwrite;
+};
 extern thread_local EoeRedJobs* eoe_tls_defer;
 // appends to the deferred list if one is active (returns true), else returns false and the caller launches its own finish
 bool eoe_defer_reduce(const float* part, int R, int N, int seg, float* o0, float* o1, float* o2, int blocked);

@@ -423,10 +423,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NV <= 3 ? 4
 // = 16 thread-columns of one float4 x 64 row lanes, so that a thread's <= 8 rows (R <= 512) are ONE batch of independent 16-B loads:
 // the partial rows were written hundreds of microseconds earlier and come back from HBM, and with four dependent batches per
 // thread this kernel took 23 us (as long as the five launches it replaces).  Fixed summation order; N and seg multiples of 4.
-__global__ __launch_bounds__(1024) void multi_reduce_kernel(EoeRedJobs jobs) {
+template <typename JOBS>
+__global__ __launch_bounds__(1024) void multi_reduce_kernel(JOBS jobs) {
     __shared__ f32x4 l[64][17];
     int j = 0;
-    while (j + 1 < jobs.count && (int)blockIdx.x >= jobs.tile_start[j + 1]) ++j;
+    if (sizeof(JOBS) > sizeof(EoeRedJobs)) {          // a tower's table: binary search over the prefix sums
+        int lo = 0, hi = jobs.count - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if ((int)blockIdx.x >= jobs.tile_start[mid]) lo = mid; else hi = mid - 1;
+        }
+        j = lo;
+    } else {
+        while (j + 1 < jobs.count && (int)blockIdx.x >= jobs.tile_start[j + 1]) ++j;
+    }
     const EoeRedJob jb = jobs.job[j];
     const float* __restrict__ part = jb.part;
     const int cq = threadIdx.x & 15, lane = threadIdx.x >> 4;
@@ -1404,9 +1414,52 @@ int eoe_flush_reduce(EoeRedJobs* jobs, void* stream) {
     double bytes = 0;
     for (int j = 0; j < jobs->count; ++j) bytes += 4.0 * jobs->job[j].R * jobs->job[j].N;
     ProfScope ps("finish_reduce", 0, bytes, stream);
-    hipLaunchKernelGGL(multi_reduce_kernel, dim3(jobs->tile_start[jobs->count]), dim3(1024), 0, (hipStream_t)stream, *jobs);
+    hipLaunchKernelGGL(multi_reduce_kernel<EoeRedJobs>, dim3(jobs->tile_start[jobs->count]), dim3(1024), 0, (hipStream_t)stream, *jobs);
     EOE_CHECK_LAUNCH("multi_reduce");
     jobs->count = 0;
+    return 0;
+}
+
+// a block's jobs go to the caller's table instead of a launch of their own (eoe_vit_block_bwd_args.red_table); a full table is flushed first
+int eoe_red_table_append(eoe_red_table* t, EoeRedJobs* jobs, void* stream) {
+    if (!jobs || jobs->count == 0) return 0;
+    if (t->count < 0 || t->count > EOE_RED_TABLE_MAX) return eoe_set_error(EOE_ERR_ARG, "red_table: bad count %d", t->count);
+    if (t->count + jobs->count > EOE_RED_TABLE_MAX) EOE_TRY(eoe_red_table_flush(t, stream));
+    if (t->count == 0) t->overwrite = jobs->overwrite;
+    else if (t->overwrite != jobs->overwrite) {        // mixed accumulate modes: keep them in separate launches
+        EOE_TRY(eoe_red_table_flush(t, stream));
+        t->overwrite = jobs->overwrite;
+    }
+    for (int j = 0; j < jobs->count; ++j) {
+        const EoeRedJob& s = jobs->job[j];
+        eoe_red_job& d = t->job[t->count++];
+        d.part = s.part; d.R = s.R; d.N = s.N; d.seg = s.seg; d.blocked = s.blocked; d.out[0] = s.out[0]; d.out[1] = s.out[1]; d.out[2] = s.out[2];
+    }
+    jobs->count = 0;
+    return 0;
+}
+
+extern "C" int eoe_red_table_flush(eoe_red_table* t, void* stream) {
+    EOE_CHECK_ARG(t != nullptr && t->count >= 0 && t->count <= EOE_RED_TABLE_MAX, "eoe_red_table_flush: bad table");
+    for (int first = 0; first < t->count; first += 64) {
+        EoeRedJobsBig big;
+        big.count = t->count - first < 64 ? t->count - first : 64;
+        big.overwrite = t->overwrite;
+        big.tile_start[0] = 0;
+        double bytes = 0;
+        for (int j = 0; j < big.count; ++j) {
+            const eoe_red_job& s = t->job[first + j];
+            EOE_CHECK_ARG(s.part && s.R > 0 && s.N > 0 && (s.N & 3) == 0 && s.seg > 0 && (s.seg & 3) == 0, "eoe_red_table_flush: bad job %d", first + j);
+            EoeRedJob& d = big.job[j];
+            d.part = s.part; d.R = s.R; d.N = s.N; d.seg = s.seg; d.blocked = s.blocked; d.out[0] = s.out[0]; d.out[1] = s.out[1]; d.out[2] = s.out[2];
+            big.tile_start[j + 1] = big.tile_start[j] + (s.N + 63) / 64;
+            bytes += 4.0 * s.R * s.N;
+        }
+        ProfScope ps("finish_reduce", 0, bytes, stream);
+        hipLaunchKernelGGL(multi_reduce_kernel<EoeRedJobsBig>, dim3(big.tile_start[big.count]), dim3(1024), 0, (hipStream_t)stream, big);
+        EOE_CHECK_LAUNCH("multi_reduce (table)");
+    }
+    t->count = 0;
     return 0;
 }
 

@@ -841,7 +841,7 @@ int launch_nt128_auto(const GemmP& p, int epi, hipStream_t s) {
 
 // ---- split k for small M behind a long K, on request (eoe_gemm_args.split_k; round 3: the last ViT block on its class-token rows: 256 x 768 x
 // 3072 is 12 tiles of 48 k-tiles each -- 50 us of one latency chain per CU on 12 CUs).  Not chosen by shape alone: a block's result must not
-// depend on the batch size (test_full_batch_properties), and the split depends on K only.  S equal k-ranges per tile (grid.y), fp32 partial tiles in a library-owned buffer, then one
+// depend on the batch size (test_full_batch_properties), and the split depends on K only.  S equal k-ranges per tile (grid.y), fp32 partial tiles in the caller's workspace, then one
 // elementwise kernel that adds the S partials IN ORDER (reproducible) and applies alpha / bias / residual / the output type.
 template <typename T>
 __global__ __launch_bounds__(256) void nt_splitk_finish_kernel(const float* __restrict__ part, int S, int M, int N, float alpha,
@@ -860,24 +860,8 @@ __global__ __launch_bounds__(256) void nt_splitk_finish_kernel(const float* __re
     else *(u32x2*)((T*)C + (size_t)m * ldc + n) = pack4<T>(v[0], v[1], v[2], v[3]);
 }
 
-// the partial-tile buffer: one per (device, stream), grown on demand outside stream capture (inside a capture: the plain launch)
-static float* splitk_buffer(hipStream_t s, size_t floats) {
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, std::pair<float*, size_t>> table;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lk(mu);
-    auto& e = table[{dev, s}];
-    if (e.second >= floats) return e.first;
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
-    if (e.first) { if (hipStreamSynchronize(s) != hipSuccess) return nullptr; (void)hipFree(e.first); e = {nullptr, 0}; }
-    float* buf = nullptr;
-    if (hipMalloc(&buf, floats * sizeof(float)) != hipSuccess) return nullptr;
-    e = {buf, floats};
-    return buf;
-}
-
+// (round 5) the partial tiles live in the CALLER's workspace -- the slot area of eoe_gemm_args.sk_workspace -- and no longer in a library-owned
+// buffer grown with hipMalloc / hipStreamSynchronize / hipFree: nothing the caller's allocator, a graph capture or a second process cannot see
 // returns -1 when the split form does not apply (the caller then takes the plain launch)
 template <typename T>
 int launch_nt128_splitk(const GemmP& p, int epi, hipStream_t s) {
@@ -888,8 +872,8 @@ int launch_nt128_splitk(const GemmP& p, int epi, hipStream_t s) {
     int S = 8;
     while (S > 1 && (nk % S) != 0) S >>= 1;
     if (S < 2 || nk / S < 3) return -1;
-    float* part = splitk_buffer(s, (size_t)S * p.M * p.N);
-    if (!part) return -1;
+    float* part = p.sk_part;                          // 2 x #CUs slots of 256 x 256 floats
+    if (!part || (size_t)S * p.M * p.N > (size_t)2 * num_cus() * 65536) return -1;
     GemmP q = p;
     q.C = part; q.ldc = p.N; q.out_f32 = 1; q.bias = nullptr; q.aux = nullptr; q.alpha = 1.0f;
     const int tiles = cdiv(p.M, 128) * cdiv(p.N, 128);

@@ -12,6 +12,7 @@
 
 extern int g_tn_flags;          // gemm_tn.hip
 bool eoe_tn_streamk_would_run(const eoe_gemm_args* args, int count, void* stream);   // gemm_tn.hip: the stream-K precondition
+int eoe_red_table_append(eoe_red_table* t, EoeRedJobs* jobs, void* stream);          // elementwise.hip
 int g_vit_side_stream = 1;      // eoe_set_option("vit_side_stream", 0|1)
 
 namespace {
@@ -228,7 +229,7 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
         ss->wgrad_pending = true;
         TRY(eoe_layernorm_bwd(b->d16_b, 0, a->x_in, D, a->stats1, a->ln1_g, b->dx_mid, b->dx_in, D, b->next_d16, b->g_ln1_g,
                               b->g_ln1_b, nullptr, red_ln1, M, D, dt, stream));
-        TRY(eoe_flush_reduce(b->red_scratch ? &jobs : nullptr, stream));
+        TRY(b->red_table && b->red_scratch ? eoe_red_table_append(b->red_table, &jobs, stream) : eoe_flush_reduce(b->red_scratch ? &jobs : nullptr, stream));
         return 0;
     }
     if (ss) {
@@ -245,7 +246,7 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
         TRY(eoe_layernorm_bwd(b->d16_b, 0, a->x_in, D, a->stats1, a->ln1_g, b->dx_mid, b->dx_in, D, b->next_d16, b->g_ln1_g,
                               b->g_ln1_b, nullptr, red_ln1, M, D, dt, stream));
     }
-    TRY(eoe_flush_reduce(b->red_scratch ? &jobs : nullptr, stream));
+    TRY(b->red_table && b->red_scratch ? eoe_red_table_append(b->red_table, &jobs, stream) : eoe_flush_reduce(b->red_scratch ? &jobs : nullptr, stream));
     return 0;
 }
 

@@ -109,7 +109,7 @@ def gemm_nt(a, b, out, bias=None, epilogue=EPI_NONE, aux=None, aux_out=None, acc
     if colstats_ws is not None:
         g.workspace, g.workspace_bytes, g.colstats = _p(colstats_ws), colstats_ws.numel() * 4, 1
     g.split_k = 1 if split_k else 0          # hint (eoe_hip.h): small M behind a long K as k-ranges + an in-order sum
-    if M >= 2048 and N % 256 == 0:           # the shapes the eight-wave kernel's stream-K form takes (eoe_hip.h, eoe_gemm_args.sk_workspace)
+    if split_k or (M >= 2048 and N % 256 == 0):      # split-k partial tiles / the eight-wave kernel's stream-K form (eoe_hip.h, eoe_gemm_args.sk_workspace)
         ws = nt_sk_workspace(a.device)
         g.sk_workspace, g.sk_workspace_bytes = _p(ws), ws.numel()
     check(lib.eoe_gemm_nt(C.byref(g), _stream()), "eoe_gemm_nt")
@@ -492,16 +492,33 @@ def _block_ws(M, D, device, dtype):
 
 VIT_HANDOVER = os.environ.get("EOE_VIT_HANDOVER", "1") != "0"     # block-to-block hand-over of dY(c_proj) in the backward sweep (0: A/B)
 VIT_ASYNC_WGRAD = os.environ.get("EOE_VIT_ASYNC_WGRAD", "1") != "0"      # a block's weight gradients on the side stream, under the next block (0: A/B)
+# (round 5) the blocks' finish reductions (bias and LayerNorm-parameter gradients out of their partial rows) collected in ONE table and launched
+# once at the end of the backward sweep instead of one 17-us kernel per block (0: per block, A/B).  Not with a data-parallel bucket hook on the
+# block: its all-reduce reads those gradients right behind the block
+VIT_DEFER_FINISH = os.environ.get("EOE_VIT_DEFER_FINISH", "1") != "0"
+_vit_red_table = _lib.RedTable()
+_vit_red_seq = 0
+VIT_RED_POOL = 16
 _vit_handoff = None
 _vit_parity = 0
 _vit_pending = None
 _vit_deferred_hook = None
 
 
+def vit_flush_finish():
+    """launches the finish reductions the blocks of this backward sweep left in the table (VIT_DEFER_FINISH); called by the autograd engine
+    at the end of the pass, harmless at any other time"""
+    global _vit_red_seq
+    _vit_red_seq = 0
+    if _vit_red_table.count:
+        check(lib.eoe_red_table_flush(C.byref(_vit_red_table), _stream()), "eoe_red_table_flush")
+
+
 def vit_side_join():
     """orders the current stream behind the last asynchronous weight-gradient launch and releases what it was reading; called by the
     autograd engine at the end of a backward pass that used the asynchronous path (and harmless at any other time)"""
     global _vit_pending, _vit_deferred_hook
+    vit_flush_finish()
     check(lib.eoe_vit_side_join(_stream()), "eoe_vit_side_join")
     _vit_pending = None
     if _vit_deferred_hook is not None:                     # the last block of the sweep: its bucket goes out behind the join
@@ -542,6 +559,8 @@ class VitBlockFunction(torch.autograd.Function):
         a.xn1, a.qkv, a.att, a.xn2, a.hpre, a.hact = (ptr[k] for k in ("xn1", "qkv", "att", "xn2", "hpre", "hact"))
         a.stats1, a.stats2 = ptr["stats1"], ptr["stats2"]
         a.cls_only = 1 if cls_only else 0
+        if _vit_red_table.count:                 # jobs of a backward pass that died before its end-of-pass flush: their scratch is about to be reused
+            _vit_red_table.count = 0
         sk_ws = nt_sk_workspace(x.device)
         a.nt_sk_workspace, a.nt_sk_workspace_bytes = _p(sk_ws), sk_ws.numel()
         keep = any(ctx.needs_input_grad)            # (grad mode itself is always off inside a Function's forward)
@@ -600,7 +619,17 @@ class VitBlockFunction(torch.autograd.Function):
         b.dqkv = _p(scratch(f"dqkv{par}", (M, 3 * D), dt, dev))
         b.dx_mid = _p(scratch("dx_mid", (M, D), torch.float32, dev))
         nred = (M + 63) // 64 * 4 * D + 2 * LN_SCRATCH_ROWS * 3 * D + ctx.args.n * 3 * D + 256 * D          # EOE_VIT_RED_SCRATCH(n, L, D)
-        red = scratch(f"vit_red{par}", (nred,), torch.float32, dev)
+        # deferred finish: every block of the sweep keeps its own partial rows until the one flush at the end of the pass
+        global _vit_red_seq
+        defer = VIT_DEFER_FINISH and not has_hook and not torch.cuda.is_current_stream_capturing()
+        if defer:
+            red = scratch(f"vit_red_seq{_vit_red_seq % VIT_RED_POOL}", (nred,), torch.float32, dev)
+            _vit_red_seq += 1
+            if _vit_red_seq >= VIT_RED_POOL:               # a deeper tower than the pool: launch what is queued before a scratch comes round again
+                vit_flush_finish()
+            b.red_table = C.pointer(_vit_red_table)
+        else:
+            red = scratch(f"vit_red{par}", (nred,), torch.float32, dev)
         b.red_scratch = _p(red)
         sk_bytes = torch.cuda.get_device_properties(dev).multi_processor_count * (256 * 256 * 4)      # EOE_TN_STREAMK_WORKSPACE_BYTES
         b.tn_workspace, b.tn_workspace_bytes = _p(scratch("tn_streamk", (sk_bytes,), torch.uint8, dev)), sk_bytes
@@ -616,6 +645,8 @@ class VitBlockFunction(torch.autograd.Function):
             # runs when this backward pass is complete; queued by every block (idempotent): a flag "already queued" would survive a pass
             # that died with an exception and leave the next pass without its join
             torch.autograd.Variable._execution_engine.queue_callback(vit_side_join)
+        elif defer:
+            torch.autograd.Variable._execution_engine.queue_callback(vit_flush_finish)
         if has_hook:      # (weakref to the parameter, callable): the bucket's all-reduce reads this block's weight gradients
             if use_async:
                 _vit_deferred_hook = hook[1]

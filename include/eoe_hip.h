@@ -29,7 +29,8 @@ enum { EOE_F16 = 1, EOE_BF16 = 2, EOE_F32 = 3 /* only where an entry point says 
 
 int eoe_abi_version(void);
 /* sizeof of an argument struct as compiled into the library: 0 eoe_gemm_args, 1 eoe_conv_geometry, 2 eoe_adam_chunk,
- * 3 eoe_adam_scalars, 4/5 eoe_vit_block_fwd/bwd_args, 6/7 eoe_cgate(_bwd)_args, 8/9 eoe_sgate(_bwd)_args, 10 eoe_adam_tile; -1 otherwise */
+ * 3 eoe_adam_scalars, 4/5 eoe_vit_block_fwd/bwd_args, 6/7 eoe_cgate(_bwd)_args, 8/9 eoe_sgate(_bwd)_args, 10 eoe_adam_tile, 11 eoe_red_table;
+ * -1 otherwise */
 int eoe_struct_size(int which);
 const char* eoe_last_error(void);
 
@@ -97,8 +98,8 @@ typedef struct {
                          * tiles and the reduce kernel writes that order directly -- no eoe_conv_unpack_wgrad pass.  Needs the
                          * workspace (>= splits * M * N * 4 bytes, EOE_TN_WORKSPACE_BYTES always suffices for the shapes here) */
     int32_t split_k;    /* NT only, a hint: != 0 asks for the split form of a small-M problem behind a long K (M <= 1024, K >= 1536, plain or
-                         * fp32-residual epilogue, no column sums): up to 8 equal k-ranges per output tile in one launch, fp32 partial tiles in a
-                         * library-owned buffer, summed in a fixed order by a second kernel.  The split depends on K only, so a row's result
+                         * fp32-residual epilogue, no column sums): up to 8 equal k-ranges per output tile in one launch, fp32 partial tiles in the
+                         * slot area of `sk_workspace` (needed: without it the hint is ignored), summed in a fixed order by a second kernel.  The split depends on K only, so a row's result
                          * does not depend on M (eoe_vit_block_fwd / _bwd ask for it on the class-token-only block's n x 768 x 3072 products:
                          * 12 tiles of 48 k-tiles are one 50-us latency chain on 12 CUs).  Ignored where it does not apply. */
     void* sk_workspace; /* NT only, optional: >= EOE_NT_STREAMK_WORKSPACE_BYTES(#CUs) bytes, 16-byte aligned, ZEROED ONCE by the caller before its
@@ -334,6 +335,21 @@ typedef struct {
     int64_t nt_sk_workspace_bytes;
 } eoe_vit_block_fwd_args;
 
+/* deferred finish reductions: out[c / seg][c % seg] (+)= sum over r < R of part[r][c], c < N (blocked: eoe's [N/64][R][64] partial-row layout) */
+typedef struct {
+    const float* part;
+    int32_t R, N, seg, blocked;
+    float* out[3];
+} eoe_red_job;
+#define EOE_RED_TABLE_MAX 128
+typedef struct eoe_red_table {
+    eoe_red_job job[EOE_RED_TABLE_MAX];
+    int32_t count;
+    int32_t overwrite;          /* 1: out = sum, 0: out += sum (set by the first appender; all jobs of a table agree) */
+} eoe_red_table;
+/* launches the table's jobs (64 per launch) on `stream` and empties it */
+int eoe_red_table_flush(eoe_red_table* table, void* stream);
+
 typedef struct {
     eoe_vit_block_fwd_args f;   /* same parameters and saved activations as the forward */
     const float* dx_out;        /* fp32 [M,D] gradient wrt x_out ([n,D] with f.cls_only) */
@@ -372,6 +388,12 @@ typedef struct {
      * behind the previous launch at its own fork point) or eoe_vit_side_join(stream) was called; the weight gradients themselves may only
      * be read after eoe_vit_side_join.  Ignored (synchronous launch) while the stream is being captured or without red_scratch. */
     int32_t async_wgrad;
+    /* optional (round 5): a HOST table the block appends its finish reductions to (the five or six partial-row column sums behind its
+     * bias and LayerNorm-parameter gradients) instead of launching its own finish kernel: the caller flushes the table once, after the
+     * last block of the backward sweep (eoe_red_table_flush), in one or two launches for the whole tower instead of one 17-us launch per
+     * block.  The caller then keeps every block's red_scratch untouched until the flush (one scratch per block, not two alternating), and
+     * reads the bias / LayerNorm gradients only behind it.  NULL: the block finishes its own, as before. */
+    struct eoe_red_table* red_table;
 } eoe_vit_block_bwd_args;
 
 /* floats: partial rows of the fc dgrad GEMM's fused column sums [ceil(n*L/64)][4D] + of the two LayerNorm backwards + the attention

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     # struct layouts the Python side mirrors
     assert C.sizeof(_lib.AdamChunk) == 40 and C.sizeof(_lib.AdamScalars) == 36 and C.sizeof(_lib.AdamTile) == 64
     mirrors = [_lib.GemmArgs, _lib.ConvGeometry, _lib.AdamChunk, _lib.AdamScalars, _lib.VitBlockFwdArgs, _lib.VitBlockBwdArgs,
-               _lib.CGateArgs, _lib.CGateBwdArgs, _lib.SGateArgs, _lib.SGateBwdArgs, _lib.AdamTile]
+               _lib.CGateArgs, _lib.CGateBwdArgs, _lib.SGateArgs, _lib.SGateBwdArgs, _lib.AdamTile, _lib.RedTable]
     for which, cls in enumerate(mirrors):
         assert _lib.lib.eoe_struct_size(which) == C.sizeof(cls), (cls.__name__, _lib.lib.eoe_struct_size(which), C.sizeof(cls))
     assert _lib.lib.eoe_struct_size(len(mirrors)) == -1
