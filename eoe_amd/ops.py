@@ -1109,6 +1109,19 @@ def parity_mode() -> bool:
     return _parity
 
 
+# Measurement switch (round 5; tools/split_operand_noise.sh): EOE_PARITY_EMULATE_BITS=b rounds both operands of every parity-mode FORWARD
+# convolution to b explicit mantissa bits before the exact fp32 product -- the arithmetic of a split-operand 16-bit MFMA product that keeps
+# every cross term (b = 15: bf16 hi + lo; b = 21: fp16 hi + lo), i.e. a LOWER bound on the noise of the three-product form
+# hi.hi + hi.lo + lo.hi.  Not a product mode: it only answers whether such a mode could hold the K_NOISE_PARITY bar.
+PARITY_EMULATE_BITS = int(os.environ.get("EOE_PARITY_EMULATE_BITS", "0"))
+
+
+def _round_mantissa(t: torch.Tensor, bits: int) -> torch.Tensor:
+    drop = 23 - bits
+    i = t.contiguous().view(torch.int32)
+    return ((i + (1 << (drop - 1))) & ~((1 << drop) - 1)).view(torch.float32)
+
+
 def _geo(n, H, W, C, kh, kw, stride, pad, Ho, Wo):
     from ._lib import ConvGeometry
     return ConvGeometry(n, H, W, C, kh, kw, stride, pad, Ho, Wo)
@@ -1159,14 +1172,21 @@ class ConvBnActPoolParityFunction(torch.autograd.Function):
             w4 = scratch("parity_w4", (cout, 4, kh, kw), torch.float32, dev)
             w4.zero_()
             w4[:, :3].copy_(w)
+            xq = x4
+            if PARITY_EMULATE_BITS:
+                xq = _round_mantissa(x4, PARITY_EMULATE_BITS)
+                w4.copy_(_round_mantissa(w4, PARITY_EMULATE_BITS))
             w4f = scratch("parity_w4f", (kh * kw * 4, cout), torch.float32, dev)
             check(lib.eoe_conv_f32_pack_weights(_p(w4), _p(w4f), None, cout, 4, kh, kw, _stream()), "eoe_conv_f32_pack_weights")
-            check(lib.eoe_conv_f32_fwd(_p(x4), 0, None, None, _p(w4), _p(conv_b), _p(y), _geo(n, Hi, Wi, 4, kh, kw, stride, pad, H, W), cout,
+            check(lib.eoe_conv_f32_fwd(_p(xq), 0, None, None, _p(w4), _p(conv_b), _p(y), _geo(n, Hi, Wi, 4, kh, kw, stride, pad, H, W), cout,
                                        _p(ws), PARITY_SPLITK_BYTES, _p(w4f), _stream()), "eoe_conv_f32_fwd")
             x = x4
         else:
             wkf = _parity_packed(conv_w, "f") if (not is_image and cout % 4 == 0) else None
-            check(lib.eoe_conv_f32_fwd(_p(x), 1 if is_image else 0, _p(mean) if is_image else None, _p(std) if is_image else None, _p(w),
+            xq, wq = x, w
+            if PARITY_EMULATE_BITS and not is_image:
+                xq, wq, wkf = _round_mantissa(x, PARITY_EMULATE_BITS), _round_mantissa(w, PARITY_EMULATE_BITS), None      # (the kernel then reads the unpacked weights)
+            check(lib.eoe_conv_f32_fwd(_p(xq), 1 if is_image else 0, _p(mean) if is_image else None, _p(std) if is_image else None, _p(wq),
                                        _p(conv_b), _p(y), geo, cout, _p(ws), PARITY_SPLITK_BYTES, _p(wkf), _stream()), "eoe_conv_f32_fwd")
         stats = torch.empty(2 * cout, dtype=torch.float32, device=dev)
         sums = scratch("bn_sums", (BN_SCRATCH * cout,), torch.float32, dev)
