@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const float* __restrict__
 // 16 bytes at p[idx] if `ok`, else zeros -- as an UNCONDITIONAL load (from a 16-byte block of zeros when !ok; p may then be anything), so that
 // a batch of them is issued back to back instead of one load -> wait -> use group per `if`
 __device__ __forceinline__ f32x4 load4_if(const float* __restrict__ p, size_t idx, bool ok) {
-    static __device__ const float zero4[4] = {0.f, 0.f, 0.f, 0.f};
+    alignas(16) static __device__ const float zero4[4] = {0.f, 0.f, 0.f, 0.f};
     return *(const f32x4*)(ok ? p + idx : zero4);
 }
 template <int MODE, int BN, int WV = 0, bool S2 = false, bool WK = false>      // WK: forward / dgrad weights from the k-major packed copy `wk` (eoe_conv_f32_pack_weights); WV (wgrad variants): 0 = both sides float4, 1 = the x side element-wise (OIHW order), 2 = roles exchanged, 3 = both

@@ -71,7 +71,15 @@ def dtype_code(dt) -> int:
     raise ValueError(f"not a 16-bit compute dtype: {dt}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream() -> int:
+    """the current stream's handle.  torch.cuda.current_stream() builds a Stream object through four Python layers (10 us; the step asked
+    for it 35 times: 0.3 ms of host time per step); the raw getter is one C call"""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -497,6 +505,7 @@ VIT_ASYNC_WGRAD = os.environ.get("EOE_VIT_ASYNC_WGRAD", "1") != "0"      # a blo
 # block: its all-reduce reads those gradients right behind the block
 VIT_DEFER_FINISH = os.environ.get("EOE_VIT_DEFER_FINISH", "1") != "0"
 _vit_red_table = _lib.RedTable()
+_vit_args_cache = {}          # id(w_in) -> (signature, the static part of the block's eoe_vit_block_fwd_args as bytes)
 _vit_red_seq = 0
 VIT_RED_POOL = 16
 _vit_handoff = None
@@ -549,20 +558,33 @@ class VitBlockFunction(torch.autograd.Function):
         x_out = x.new_empty((n, D)) if cls_only else torch.empty_like(x)
         need_t = torch.is_grad_enabled()
         sh = {k: shadow.get(w, True, True) for k, w in (("in", w_in), ("out", w_out), ("fc", w_fc), ("proj", w_proj))}
-        a = _lib.VitBlockFwdArgs()
-        a.n, a.L, a.D, a.heads, a.dtype, a.eps = n, L, D, heads, dtype_code(_compute_dtype), 1e-5
-        a.ln1_g, a.ln1_b, a.ln2_g, a.ln2_b = _p(ln1_g), _p(ln1_b), _p(ln2_g), _p(ln2_b)
-        a.b_in, a.b_out, a.b_fc, a.b_proj = _p(b_in), _p(b_out), _p(b_fc), _p(b_proj)
-        a.w_in, a.w_out, a.w_fc, a.w_proj = (_p(sh[k][0]) for k in ("in", "out", "fc", "proj"))
-        a.w_in_t, a.w_out_t, a.w_fc_t, a.w_proj_t = (_p(sh[k][1]) for k in ("in", "out", "fc", "proj"))
+        # the argument block of a given block changes between steps only in its activation pointers: the parameter / weight-copy / workspace
+        # part is filled once per (block, pointers) and copied (round 5: ~40 ctypes field stores per block and step were 0.4 ms of host time)
+        sk_ws = nt_sk_workspace(x.device)
+        code = dtype_code(_compute_dtype)
+        sig = (n, L, D, heads, code, _p(ln1_g), _p(ln1_b), _p(ln2_g), _p(ln2_b), _p(b_in), _p(b_out), _p(b_fc), _p(b_proj),
+               _p(sh["in"][0]), _p(sh["out"][0]), _p(sh["fc"][0]), _p(sh["proj"][0]), _p(sh["in"][1]), _p(sh["out"][1]), _p(sh["fc"][1]),
+               _p(sh["proj"][1]), _p(sk_ws))
+        hit = _vit_args_cache.get(id(w_in))
+        if hit is not None and hit[0] == sig:
+            a = _lib.VitBlockFwdArgs.from_buffer_copy(hit[1])
+        else:
+            a = _lib.VitBlockFwdArgs()
+            a.n, a.L, a.D, a.heads, a.dtype, a.eps = n, L, D, heads, code, 1e-5
+            a.ln1_g, a.ln1_b, a.ln2_g, a.ln2_b = _p(ln1_g), _p(ln1_b), _p(ln2_g), _p(ln2_b)
+            a.b_in, a.b_out, a.b_fc, a.b_proj = _p(b_in), _p(b_out), _p(b_fc), _p(b_proj)
+            a.w_in, a.w_out, a.w_fc, a.w_proj = (_p(sh[k][0]) for k in ("in", "out", "fc", "proj"))
+            a.w_in_t, a.w_out_t, a.w_fc_t, a.w_proj_t = (_p(sh[k][1]) for k in ("in", "out", "fc", "proj"))
+            a.nt_sk_workspace, a.nt_sk_workspace_bytes = _p(sk_ws), sk_ws.numel()
+            if len(_vit_args_cache) > 256:
+                _vit_args_cache.clear()
+            _vit_args_cache[id(w_in)] = (sig, bytes(a))
         a.x_in, a.x_mid, a.x_out = _p(x), ptr["x_mid"], _p(x_out)
         a.xn1, a.qkv, a.att, a.xn2, a.hpre, a.hact = (ptr[k] for k in ("xn1", "qkv", "att", "xn2", "hpre", "hact"))
         a.stats1, a.stats2 = ptr["stats1"], ptr["stats2"]
         a.cls_only = 1 if cls_only else 0
         if _vit_red_table.count:                 # jobs of a backward pass that died before its end-of-pass flush: their scratch is about to be reused
             _vit_red_table.count = 0
-        sk_ws = nt_sk_workspace(x.device)
-        a.nt_sk_workspace, a.nt_sk_workspace_bytes = _p(sk_ws), sk_ws.numel()
         keep = any(ctx.needs_input_grad)            # (grad mode itself is always off inside a Function's forward)
         if not keep:
             a.hpre = None          # forward only (frozen encoder, scoring): the MLP's pre-activation is not kept (79 MB per block)

@@ -94,7 +94,27 @@ class FusedAdam(_NonFiniteGuard, torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False)
         super().__init__(params, defaults)
         self._tables = {}
+        self._step_flats = []
         self._guard_init(guard)
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._step_flats = []                  # the loaded "step" tensors are their own storage: per-parameter path from here on
+        self._tables = {}
+
+    def _advance_steps(self, active):
+        """step counts of `active` after this step's increment (ints)"""
+        ids = tuple(id(p) for p in active)
+        for flat, owners in self._step_flats:
+            if owners == ids and all(self.state[p]["step"].data_ptr() == flat.data_ptr() + 4 * i for i, p in enumerate(active)):
+                flat += 1
+                return [int(round(v)) for v in flat.tolist()]
+        steps = []
+        for p in active:
+            st = self.state[p]
+            st["step"] += 1
+            steps.append(int(round(st["step"].item())))
+        return steps
 
     def _init_state(self, group):
         """exp_avg / exp_avg_sq of a whole group live in two flat arenas (one allocation each)"""
@@ -106,10 +126,14 @@ class FusedAdam(_NonFiniteGuard, torch.optim.Optimizer):
         m_arena = torch.zeros(tot, dtype=torch.float32, device=dev)
         v_arena = torch.zeros(tot, dtype=torch.float32, device=dev)
         off = 0
-        for p in need:
+        # the step counts of the group live in ONE host tensor, each state's "step" a 0-dim view of it (what torch's state_dict expects per
+        # parameter): the per-step increment and read-back are two tensor operations instead of two per parameter (0.5 ms of host time per step)
+        steps_flat = torch.zeros(len(need), dtype=torch.float32)
+        self._step_flats.append((steps_flat, tuple(id(p) for p in need)))
+        for i, p in enumerate(need):
             n = p.numel()
             st = self.state[p]
-            st["step"] = torch.tensor(0.0, dtype=torch.float32)
+            st["step"] = steps_flat[i]
             st["exp_avg"] = m_arena[off:off + n].view(p.shape)
             st["exp_avg_sq"] = v_arena[off:off + n].view(p.shape)
             off += (n + 3) // 4 * 4
@@ -147,7 +171,8 @@ class FusedAdam(_NonFiniteGuard, torch.optim.Optimizer):
         the rest; same bases as the full table (which the non-finite check keeps walking).  Cached on the full table's identity and the
         copies' addresses."""
         full = self._tables[gi]
-        sig = (id(full[1]), tuple((k, d.data_ptr(), dt.data_ptr()) for k, (d, dt) in pairs.items()))
+        # (keyed on the full table's own signature -- the addresses it was built from -- not on id() of its tensor: CPython reuses ids)
+        sig = (full[0], tuple((k, d.data_ptr(), dt.data_ptr()) for k, (d, dt) in pairs.items()))
         hit = self._tables.get(("split", gi))
         if hit is not None and hit[0] == sig:
             return hit[1:]
@@ -190,11 +215,7 @@ class FusedAdam(_NonFiniteGuard, torch.optim.Optimizer):
                     raise NotImplementedError("fp16-weights mode (eoe_amd.models.convert_weights) is the CLIP objective's: the reference "
                                               "trains such models with SGD (ad_trainer.py:380-381) -- use eoe_amd.FusedSGD")
             self._init_state(group)
-            steps = []
-            for p in active:
-                st = self.state[p]
-                st["step"] += 1
-                steps.append(int(round(st["step"].item())))
+            steps = self._advance_steps(active)
             (tab, n_chunks, bases), distinct = self._table(gi, active, steps)
             if len(distinct) > _lib.ADAM_GROUPS:
                 raise RuntimeError("FusedAdam: more than %d distinct step counts in one group" % _lib.ADAM_GROUPS)
@@ -227,7 +248,11 @@ class FusedAdam(_NonFiniteGuard, torch.optim.Optimizer):
             pairs = {}
             if ADAM_TILES and not torch.cuda.is_current_stream_capturing():
                 for p in active:
-                    if p.dim() == 2 and p.shape[0] % 4 == 0 and p.shape[1] % 4 == 0:
+                    if p.dim() != 2 or p.shape[0] % 4 or p.shape[1] % 4:
+                        continue
+                    st = self.state[p]
+                    # the tile kernel's 16-byte accesses need what the chunk kernel tests per chunk: all four element offsets multiples of 4
+                    if all(((t.data_ptr() - b) // 4) % 4 == 0 for t, b in zip((p, p.grad, st["exp_avg"], st["exp_avg_sq"]), bases)):
                         pr = ops.shadow.entry(p)
                         if pr is not None:
                             pairs[id(p)] = pr

@@ -331,8 +331,11 @@ def enable_sync_bn(process_group=None, comm: "NativeComm" = None) -> bool:
     global _bn_sync_cb
     from . import _lib
     if comm is not None:
-        # the BatchNorm sums get a second RCCL communicator; its id travels like the first one's (made on rank 0, broadcast by torch)
-        _lib.check(_lib.lib.eoe_comm_sync_bn(comm.handle, 1, comm.fresh_id()), "eoe_comm_sync_bn")
+        # the BatchNorm sums get a second RCCL communicator; its id travels like the first one's (made on rank 0, broadcast by torch) -- once:
+        # the library keeps the communicator, so a later enable draws no new id (no bootstrap thread, no broadcast)
+        bn_id = None if getattr(comm, "_bn_ready", False) else comm.fresh_id()
+        _lib.check(_lib.lib.eoe_comm_sync_bn(comm.handle, 1, bn_id), "eoe_comm_sync_bn")
+        comm._bn_ready = True
         _bn_sync_cb = comm                    # keeps the communicator alive while registered
         return True
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:

@@ -3,6 +3,8 @@ import cProfile
 import pstats
 import sys
 
+import os
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")      # as bench.py and the tests: kernel arguments in device memory (read when libamdhip64 loads)
 import torch
 
 sys.path.insert(0, ".")

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
-"""gemm_ntp.hip (the NT kernel that drains a tile under the next one's MFMAs) against the shipped kernels: bitwise equality on full and
-ragged shapes, then interleaved timing with the operands rotated through several buffer sets (so that they come from HBM, as in the
-training step).  nt_flags bit 14 (16384) selects the new kernel.  Usage: python tools/ntp_check.py [fp16|bf16] [--time-only]"""
+"""An NT kernel variant (NTP_FLAGS, default the forced eight-wave 256 x 256 kernel, nt_flags 262144) against another (NTP_OLD_FLAGS, default that
+kernel switched off, 131072): bitwise equality on full and ragged shapes, then interleaved timing with the operands rotated through several
+buffer sets (so that they come from HBM, as in the training step).  The same checks run in the suite: tests/test_gpu_ops.py::test_gemm_nt_eight_wave.
+Usage: python tools/ntp_check.py [fp16|bf16] [--time-only]"""
 import os
 import sys
 import torch
@@ -10,7 +11,9 @@ import eoe_amd.ops as ops
 from eoe_amd import _lib
 
 dt = torch.bfloat16 if "bf16" in sys.argv else torch.float16
-NEW = int(os.environ.get("NTP_FLAGS", "16384"))
+NEW = int(os.environ.get("NTP_FLAGS", "262144"))       # the kernel under test: 262144 = the eight-wave 256 x 256 kernel forced
+OLD = int(os.environ.get("NTP_OLD_FLAGS", "131072"))   # against: 131072 = that kernel off (the 160 x 128 / 160 x 256 kernels)
+assert NEW != OLD, "both flag values select the same kernels: nothing to compare"
 
 
 def flags(v):
@@ -37,19 +40,19 @@ if "--time-only" not in sys.argv:
         bias = torch.randn(n, device="cuda", generator=g)
         for kind in ("none", "gelu", "gelu_nopre", "nobias"):
             res = {}
-            for f in (0, NEW):
+            for f in (OLD, NEW):
                 flags(f)
                 out = torch.full((m, n), float("nan"), device="cuda", dtype=dt)
                 pre = torch.full((m, n), float("nan"), device="cuda", dtype=dt)
                 run(kind, a, w, bias, out, pre)
                 torch.cuda.synchronize()
                 res[f] = (out, pre)
-            same_o = torch.equal(res[0][0], res[NEW][0])
-            same_p = kind != "gelu" or torch.equal(res[0][1], res[NEW][1])
+            same_o = torch.equal(res[OLD][0], res[NEW][0])
+            same_p = kind != "gelu" or torch.equal(res[OLD][1], res[NEW][1])
             nan = torch.isnan(res[NEW][0]).any().item()
             if not (same_o and same_p) or nan:
                 ok = False
-                d = (res[0][0].float() - res[NEW][0].float()).abs()
+                d = (res[OLD][0].float() - res[NEW][0].float()).abs()
                 bad = (d > 0) | torch.isnan(d)
                 rows = bad.any(1).nonzero().flatten()
                 cols = bad.any(0).nonzero().flatten()
@@ -57,7 +60,7 @@ if "--time-only" not in sys.argv:
                       f"rows {rows[:6].tolist()}..{rows[-3:].tolist()} ({len(rows)}), cols {cols[:6].tolist()}..{cols[-3:].tolist()} ({len(cols)}), max {d[~torch.isnan(d)].max().item() if (~torch.isnan(d)).any() else 'nan'}")
             else:
                 print(f"ok {m}x{n}x{k} {kind}")
-    flags(0)
+    flags(1)
     print("BITWISE", "PASS" if ok else "FAIL")
 
 # ---- timing: interleaved, operands rotated through NSET buffer sets
@@ -72,9 +75,9 @@ for name, n, k, kind in (("in_proj fwd", 2304, 768, "none"), ("c_fc fwd (GELU pa
         out = torch.empty(M, n, device="cuda", dtype=dt)
         pre = torch.empty(M, n, device="cuda", dtype=dt)
         sets.append((a, w, bias, out, pre))
-    res = {0: [], NEW: []}
+    res = {OLD: [], NEW: []}
     for rnd in range(5):
-        for f in (0, NEW):
+        for f in (OLD, NEW):
             flags(f)
             for s in sets:
                 run(kind, *s)
@@ -87,9 +90,9 @@ for name, n, k, kind in (("in_proj fwd", 2304, 768, "none"), ("c_fc fwd (GELU pa
             e1.record()
             torch.cuda.synchronize()
             res[f].append(e0.elapsed_time(e1) / (4 * NSET) * 1e3)
-    flags(0)
+    flags(1)
     fl = 2.0 * M * n * k
-    for f in (0, NEW):
+    for f in (OLD, NEW):
         v = sorted(res[f])
         print(f"{name:22s} nt_flags {f:6d}: median {v[len(v) // 2]:7.1f} us  min {v[0]:7.1f}  ({fl / v[len(v) // 2] / 1e6:6.0f} TF)   all {['%.1f' % x for x in res[f]]}")
 sys.exit(0 if ok else 1)
