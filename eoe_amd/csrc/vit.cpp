@@ -22,9 +22,12 @@ namespace {
 // launched on this stream next to it and fills those CUs (measured: 12 of its 31 us hidden, -0.14 ms per step).  Eager launches only.
 struct SideStream {
     hipStream_t s = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr, wgrad_done = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr, wgrad_done[2] = {nullptr, nullptr};
     bool ok = false;
-    bool wgrad_pending = false;      // a weight-gradient launch is on the side stream that no compute stream has been ordered behind yet
+    // asynchronous weight-gradient launches of the current backward sweep: launch number `seq` records wgrad_done[seq & 1]; `recorded[e]`: that
+    // event stands for a launch no compute stream has been ordered behind yet
+    unsigned seq = 0;
+    bool recorded[2] = {false, false};
 };
 // per-device handle table (the only mutable state this file keeps), created once per device under a mutex
 SideStream* side_stream(hipStream_t main) {
@@ -43,7 +46,8 @@ SideStream* side_stream(hipStream_t main) {
         if (hipStreamCreateWithPriority(&ss.s, hipStreamNonBlocking, lo) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ss.wgrad_done, hipEventDisableTiming) != hipSuccess)
+            hipEventCreateWithFlags(&ss.wgrad_done[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ss.wgrad_done[1], hipEventDisableTiming) != hipSuccess)
             return nullptr;
         ss.ok = true;
     }
@@ -220,13 +224,25 @@ extern "C" int eoe_vit_block_bwd(const eoe_vit_block_bwd_args* b, void* stream) 
     // c_proj, the saved activations) stays untouched until a later call on this stream has passed its own fork point -- there the compute
     // stream is ordered behind the previous launch, long finished by then -- or eoe_vit_side_join() was called.
     if (ss && b->async_wgrad) {
-        if (ss->wgrad_pending && hipStreamWaitEvent(s, ss->wgrad_done, 0) != hipSuccess)
-            return eoe_set_error(EOE_ERR_LAUNCH, "vit_block_bwd: stream wait failed");
+        // async_wgrad == 1: this call orders the stream behind the PREVIOUS call's launch (the caller alternates two sets of the buffers a launch
+        // reads).  async_wgrad >= 2 (round 5): behind the launch BEFORE the previous one only (three sets) -- the previous launch (~200 us beside
+        // this call's ~340-us chain) is often still running when this call reaches its fork point, and the wait stalled the compute stream for
+        // ~12 us per block (profiles/r4/timeline.txt); two launches back is long finished.
+        const unsigned e_prev = (ss->seq + 1) & 1, e_old = ss->seq & 1;       // launch seq - 1 / launch seq - 2 (the event this call re-records)
+        if (ss->recorded[e_old]) {
+            if (hipStreamWaitEvent(s, ss->wgrad_done[e_old], 0) != hipSuccess) return eoe_set_error(EOE_ERR_LAUNCH, "vit_block_bwd: stream wait failed");
+            ss->recorded[e_old] = false;
+        }
+        if (b->async_wgrad < 2 && ss->recorded[e_prev]) {
+            if (hipStreamWaitEvent(s, ss->wgrad_done[e_prev], 0) != hipSuccess) return eoe_set_error(EOE_ERR_LAUNCH, "vit_block_bwd: stream wait failed");
+            ss->recorded[e_prev] = false;
+        }
         if (hipEventRecord(ss->fork, s) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess)
             return eoe_set_error(EOE_ERR_LAUNCH, "vit_block_bwd: fork failed");
         TRY(launch_wgrads((void*)ss->s));
-        if (hipEventRecord(ss->wgrad_done, ss->s) != hipSuccess) return eoe_set_error(EOE_ERR_LAUNCH, "vit_block_bwd: event record failed");
-        ss->wgrad_pending = true;
+        if (hipEventRecord(ss->wgrad_done[e_old], ss->s) != hipSuccess) return eoe_set_error(EOE_ERR_LAUNCH, "vit_block_bwd: event record failed");
+        ss->recorded[e_old] = true;
+        ss->seq += 1;
         TRY(eoe_layernorm_bwd(b->d16_b, 0, a->x_in, D, a->stats1, a->ln1_g, b->dx_mid, b->dx_in, D, b->next_d16, b->g_ln1_g,
                               b->g_ln1_b, nullptr, red_ln1, M, D, dt, stream));
         TRY(b->red_table && b->red_scratch ? eoe_red_table_append(b->red_table, &jobs, stream) : eoe_flush_reduce(b->red_scratch ? &jobs : nullptr, stream));
@@ -257,8 +273,11 @@ extern "C" int eoe_vit_side_join(void* stream) {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return 0;      // never used while capturing
     SideStream* ss = side_stream(s);
-    if (!ss || !ss->wgrad_pending) return 0;
-    if (hipStreamWaitEvent(s, ss->wgrad_done, 0) != hipSuccess) return eoe_set_error(EOE_ERR_LAUNCH, "vit_side_join: stream wait failed");
-    ss->wgrad_pending = false;
+    if (!ss) return 0;
+    for (int e = 0; e < 2; ++e) {
+        if (!ss->recorded[e]) continue;
+        if (hipStreamWaitEvent(s, ss->wgrad_done[e], 0) != hipSuccess) return eoe_set_error(EOE_ERR_LAUNCH, "vit_side_join: stream wait failed");
+        ss->recorded[e] = false;
+    }
     return 0;
 }

@@ -504,6 +504,11 @@ VIT_ASYNC_WGRAD = os.environ.get("EOE_VIT_ASYNC_WGRAD", "1") != "0"      # a blo
 # once at the end of the backward sweep instead of one 17-us kernel per block (0: per block, A/B).  Not with a data-parallel bucket hook on the
 # block: its all-reduce reads those gradients right behind the block
 VIT_DEFER_FINISH = os.environ.get("EOE_VIT_DEFER_FINISH", "1") != "0"
+# 1 (default): every block call orders the stream behind the previous block's weight-gradient launch (two sets of scratch); 2: behind the launch
+# before that one (three sets; eoe_hip.h, async_wgrad = 2).  Built in round 5 against the ~12-us stalls the r4 kernel trace shows at the fork
+# points; measured, it moves nothing (10.392 / 10.377 against 10.398 / 10.403 ms per step, two interleaved pairs on one box: the stalls are the
+# profiler's), so the default stays at 1 and the third set of buffers (180 MB) is not taken
+VIT_ASYNC_LAG = int(os.environ.get("EOE_VIT_ASYNC_LAG", "1"))
 _vit_red_table = _lib.RedTable()
 _vit_args_cache = {}          # id(w_in) -> (signature, the static part of the block's eoe_vit_block_fwd_args as bytes)
 _vit_red_seq = 0
@@ -616,7 +621,7 @@ class VitBlockFunction(torch.autograd.Function):
         # also writes the 16-bit copy of dx_in and leaves its column sums in its partial rows -- what the next block to run would compute
         # with a pass of its own (eoe_cast_colsum).  Two alternating sets of (copy, reduction scratch): the previous call's are still read.
         global _vit_handoff, _vit_parity
-        par = _vit_parity = _vit_parity ^ 1
+        par = _vit_parity = (_vit_parity + 1) % (3 if VIT_ASYNC_LAG >= 2 else 2)      # (async_wgrad = 2: a launch's buffers rest until two later calls have returned)
         h = _vit_handoff
         _vit_handoff = None
         d16_next = scratch(f"d16_next{par}", (M, D), dt, dev)
@@ -633,7 +638,9 @@ class VitBlockFunction(torch.autograd.Function):
         # (a data-parallel bucket hook of this block wants its weight gradients: with the asynchronous launch it is fired one block later --
         #  after the next block's call, which orders the stream behind this block's launch -- or by the join at the end of the pass)
         use_async = VIT_ASYNC_WGRAD and not torch.cuda.is_current_stream_capturing()
-        b.async_wgrad = 1 if use_async else 0
+        # 2: this call waits for the launch before the previous one only (eoe_hip.h); a data-parallel bucket hook reads the previous block's weight
+        # gradients right behind this call, so with one installed the call orders the stream behind the previous launch as before (1)
+        b.async_wgrad = (1 if has_hook or VIT_ASYNC_LAG == 1 else 2) if use_async else 0
         b.d16_a = _p(scratch(f"d16_a{par}", (M, D), dt, dev))
         b.d16_b = _p(scratch("d16_b", (M, D), dt, dev))
         b.d16_c = _p(scratch(f"d16_c{par}", (M, D), dt, dev))
@@ -659,7 +666,8 @@ class VitBlockFunction(torch.autograd.Function):
         if VIT_HANDOVER:
             _vit_handoff = dict(dx=dx_in, version=dx_in._version, shape=(M, D, ctx.args.n), dt=dt, stream=_stream(), d16=d16_next, red=red)
         global _vit_pending, _vit_deferred_hook
-        _vit_pending = (x, ws) if use_async else None      # (replaces the previous block's: this call has ordered the stream behind its launch)
+        # what the launches still in flight read: this call's and the previous call's (the call before that has been ordered behind by now)
+        _vit_pending = ((x, ws), _vit_pending[0] if _vit_pending else None) if use_async else None
         if _vit_deferred_hook is not None:                 # the previous block's bucket: its weight gradients are complete in stream order now
             prev, _vit_deferred_hook = _vit_deferred_hook, None
             prev()

@@ -386,7 +386,10 @@ typedef struct {
      * every buffer that launch reads -- dh, dqkv, d16_c, the dY of c_proj (d16_a or in_d16), the saved activations xn1 / xn2 / att / hact --
      * untouched until a later eoe_vit_block_bwd on the same stream has returned (alternate two sets of scratch; that call orders the stream
      * behind the previous launch at its own fork point) or eoe_vit_side_join(stream) was called; the weight gradients themselves may only
-     * be read after eoe_vit_side_join.  Ignored (synchronous launch) while the stream is being captured or without red_scratch. */
+     * be read after eoe_vit_side_join.  Ignored (synchronous launch) while the stream is being captured or without red_scratch.
+     * 2 (round 5): as 1, but a call orders the stream only behind the launch BEFORE the previous call's (the previous one is often still
+     * running at this call's fork point: waiting for it stalled the compute stream ~12 us per block).  The caller then rotates THREE sets of
+     * those buffers and keeps a call's buffers untouched until TWO later calls on the stream have returned (or eoe_vit_side_join). */
     int32_t async_wgrad;
     /* optional (round 5): a HOST table the block appends its finish reductions to (the five or six partial-row column sums behind its
      * bias and LayerNorm-parameter gradients) instead of launching its own finish kernel: the caller flushes the table once, after the
