@@ -11,7 +11,7 @@ if [ "${SKIP_TESTS:-0}" != 1 ]; then timeout -k 10 900 python -m pytest tests -x
 export TMPDIR=/tmp
 db() { find $R/$O/$1 -name "*results.db" | head -1; }
 p() { name=$1; shift; (cd /tmp && timeout -k 10 300 rocprofv3 "$@" > $R/$O/$name.log 2>&1); say "$name rc=$?"; }
-HL="--steps 3 --warmup 2 --no-cpu-baseline --no-torch-baseline --no-roofline --serial-kernels"
+HL="--steps 3 --warmup 2 --no-cpu-baseline --no-torch-baseline --no-roofline --no-box-probe --serial-kernels"      # (no probe launches in a profiled run)
 p pmc_fetch --kernel-trace --pmc FETCH_SIZE -d $R/$O/pmc_fetch -o run -- python $R/bench.py $HL
 p pmc_write --kernel-trace --pmc WRITE_SIZE -d $R/$O/pmc_write -o run -- python $R/bench.py $HL
 p pmc_sq --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $R/$O/pmc_sq -o run -- python $R/bench.py $HL
@@ -34,11 +34,11 @@ b bench_wrn --model wrn --steps 10 --warmup 3 --no-cpu-baseline
 b bench_wrn_parity --model wrn --steps 10 --warmup 3 --no-cpu-baseline --parity-mode
 b bench_wrn32_bf16 --model wrn --res 32 --dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline
 b bench_wrn32_parity --model wrn --res 32 --steps 20 --warmup 5 --no-cpu-baseline --parity-mode
-p stats_default --kernel-trace --stats -d $R/$O/stats_default -o run -- python $R/bench.py --steps 8 --warmup 5 --no-cpu-baseline --no-torch-baseline --no-roofline
-p stats --kernel-trace --stats -d $R/$O/stats -o run -- python $R/bench.py --steps 8 --warmup 5 --no-cpu-baseline --no-torch-baseline --no-roofline --serial-kernels
+p stats_default --kernel-trace --stats -d $R/$O/stats_default -o run -- python $R/bench.py --steps 8 --warmup 5 --no-cpu-baseline --no-torch-baseline --no-roofline --no-box-probe
+p stats --kernel-trace --stats -d $R/$O/stats -o run -- python $R/bench.py --steps 8 --warmup 5 --no-cpu-baseline --no-torch-baseline --no-roofline --no-box-probe --serial-kernels
 for d in stats_default stats; do f=$(db $d); [ -n "$f" ] && python tools/pmc_summary.py stats $f > $O/${d}_kernel_stats.csv; done
 rm -rf $O/stats_default $O/stats
-EOE_PROF_SHAPES=1 timeout -k 10 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-torch-baseline 2>/dev/null > $O/shapes.json
+EOE_PROF_SHAPES=1 timeout -k 10 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-torch-baseline --no-box-probe 2>/dev/null > $O/shapes.json
 python - <<'PY' > gpurun_out/r5m/nt_shapes.txt
 import json
 d = json.loads(open("gpurun_out/r5m/shapes.json").read())
