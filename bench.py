@@ -364,7 +364,8 @@ def main():
             score_buf[i % score_buf.shape[0]] = scores
             return loss
 
-    box = box_probe(dev) if (rank == 0 and not args.no_box_probe) else None
+    # (every rank runs the probes -- rank 0's numbers go into the line --: the ranks reach the first collective of the warm-up together)
+    box = box_probe(dev) if not args.no_box_probe else None
     for i in range(args.warmup):
         loss = step(i)
     sync()

@@ -512,6 +512,7 @@ VIT_ASYNC_LAG = int(os.environ.get("EOE_VIT_ASYNC_LAG", "1"))
 _vit_red_table = _lib.RedTable()
 _vit_args_cache = {}          # id(w_in) -> (signature, the static part of the block's eoe_vit_block_fwd_args as bytes)
 _vit_red_seq = 0
+_vit_red_stream = None        # the stream the current sweep's blocks were enqueued on
 VIT_RED_POOL = 16
 _vit_handoff = None
 _vit_parity = 0
@@ -525,7 +526,10 @@ def vit_flush_finish():
     global _vit_red_seq
     _vit_red_seq = 0
     if _vit_red_table.count:
-        check(lib.eoe_red_table_flush(C.byref(_vit_red_table), _stream()), "eoe_red_table_flush")
+        # on the stream the sweep's kernels ran on (the engine runs this callback in the thread that called backward(), whose current stream may
+        # be another one; the engine orders that stream behind the sweep's only AFTER the callbacks)
+        st = _vit_red_stream if _vit_red_stream is not None else _stream()
+        check(lib.eoe_red_table_flush(C.byref(_vit_red_table), st), "eoe_red_table_flush")
 
 
 def vit_side_join():
@@ -652,6 +656,8 @@ class VitBlockFunction(torch.autograd.Function):
         global _vit_red_seq
         defer = VIT_DEFER_FINISH and not has_hook and not torch.cuda.is_current_stream_capturing()
         if defer:
+            global _vit_red_stream
+            _vit_red_stream = _stream()
             red = scratch(f"vit_red_seq{_vit_red_seq % VIT_RED_POOL}", (nred,), torch.float32, dev)
             _vit_red_seq += 1
             if _vit_red_seq >= VIT_RED_POOL:               # a deeper tower than the pool: launch what is queued before a scratch comes round again
