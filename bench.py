@@ -29,6 +29,9 @@ if ROOT not in sys.path:
 # 0.40 ms of a 10.46 ms ViT step with its ~250 launches (measured, round 4: 10.46 -> 10.06 ms, interleaved).  A default only: an explicit
 # setting in the environment wins.
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL / cross-process tensors fail with "hipIpcGetMemHandle: invalid argument" otherwise);
+# the boxes export it already -- a default only
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 MFMA_PEAK_TFLOPS = 2500.0    # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
 F32_MFMA_PEAK_TFLOPS = 157.3 # fp32-input MFMA (v_mfma_f32_16x16x4_f32) = the fp32 vector rate (same guide)
