@@ -17,6 +17,19 @@ namespace {
 
 constexpr int ROWB = 160;            // LDS row pitch in bytes (64 x 16-bit + pad): conflict-free transposed reads
 constexpr int TILEB = 64 * ROWB;     // one 64 x 64 operand image
+// (round 5) The 16-byte chunks of ODD rows are stored pairwise swapped (in-row byte offset ^ 16).  With the hardware's lane groups (a
+// ds_read_b64_tr_b16 is served in two groups of 32 lanes, banks (a / 4) mod 64) the interleaved transposing read tfrag_il -- dword 40 row + 8 p +
+// 2 tc over rows 0-7 x p 0-3 -- put 32 lanes on 16 banks FOUR ways (8 LDS cycles for an ideal 2; attn_bwd4: SQ_LDS_BANK_CONFLICT 3.56 M cycles
+// per launch); with the swap two ways, the floor for 8-byte pieces of 16-byte-aligned rows (searched by simulation over every GF(2)-linear
+// 3-bit function of the row, pitches 128 / 160 / 192); the ds_read_b128 fragment reads and the plain transposing reads stay conflict-free.
+// attn_bwd 0.480 -> 0.465 ms per step, step 10.256 -> 10.222 (three interleaved pairs, tools/cflags_ab.sh -DEOE_ATTN_NO_RSWZ).  Also measured: an
+// unpadded 128-byte pitch with the 3-bit term ((row >> 1 & 1) * 3 | row & 4) -- the same conflict profile, 28 KB of LDS per attn_bwd4 workgroup --
+// and five workgroups per CU (amdgpu_waves_per_eu(5, 5): 96 registers, 4 spilled): attn_bwd 0.465 -> 0.509 ms per step; not kept.
+#ifdef EOE_ATTN_NO_RSWZ          // A/B builds (tools/cflags_ab.sh): the round-4 image
+__device__ __forceinline__ int rswz(int) { return 0; }
+#else
+__device__ __forceinline__ int rswz(int row) { return (row & 1) << 4; }
+#endif
 
 template <typename T> using V8 = typename T16<T>::v8;
 
@@ -34,7 +47,7 @@ __device__ __forceinline__ void stage_tile(char* lds, const T* src, int ld, int 
         const int row = it * 8 + (lane >> 3), ch = lane & 7;
         u32x4 v = {0u, 0u, 0u, 0u};
         if (row < L) v = *(const u32x4*)(src + (size_t)row * ld + ch * 8);
-        *(u32x4*)(lds + row * ROWB + ch * 16) = v;
+        *(u32x4*)(lds + row * ROWB + ((ch * 16) ^ rswz(row))) = v;
     }
 }
 
@@ -61,13 +74,13 @@ __device__ __forceinline__ V8<T> bfrag(__amdgpu_buffer_rsrc_t r, unsigned pitchb
 template <typename T>
 __device__ __forceinline__ V8<T> lfrag(const char* lds, int t, int ks, int lane) {
     const int row = t * 16 + (lane & 15);
-    return __builtin_bit_cast(V8<T>, *(const u32x4*)(lds + row * ROWB + (ks * 4 + (lane >> 4)) * 16));
+    return __builtin_bit_cast(V8<T>, *(const u32x4*)(lds + row * ROWB + (((ks * 4 + (lane >> 4)) * 16) ^ rswz(row))));
 }
 // transposed fragment: lane <-> column 16*tc + (lane&15); element j <-> row perm(s, lane>>4, j) (see header)
 template <typename T>
 __device__ __forceinline__ V8<T> tfrag(const char* lds, int tc, int s, int lane) {
     const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-    const char* a = lds + (32 * s + 4 * g + q) * ROWB + (16 * tc + 4 * p) * 2;
+    const char* a = lds + (32 * s + 4 * g + q) * ROWB + (((16 * tc + 4 * p) * 2) ^ rswz(4 * g + q));
     i16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4v*)(a));
     i16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4v*)(a + 16 * ROWB));
     i16x8 r;
@@ -83,7 +96,7 @@ __device__ __forceinline__ V8<T> tfrag(const char* lds, int tc, int s, int lane)
 template <typename T>
 __device__ __forceinline__ V8<T> tfrag_il(const char* lds, int tc, int s, int lane) {
     const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-    const char* a = lds + (32 * s + 4 * g + q) * ROWB + (16 * p + 4 * tc) * 2;
+    const char* a = lds + (32 * s + 4 * g + q) * ROWB + (((16 * p + 4 * tc) * 2) ^ rswz(4 * g + q));
     i16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4v*)(a));
     i16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4v*)(a + 16 * ROWB));
     i16x8 r;
@@ -177,7 +190,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         }
     __builtin_amdgcn_sched_barrier(0);          // (left alone the scheduler weaves the first MFMAs, and their waits, in among the loads)
 #pragma unroll
-    for (int it = 0; it < 8; ++it) *(u32x4*)(vs + (it * 8 + (lane >> 3)) * ROWB + (lane & 7) * 16) = vv[it];
+    for (int it = 0; it < 8; ++it) *(u32x4*)(vs + (it * 8 + (lane >> 3)) * ROWB + (((lane & 7) * 16) ^ rswz(it * 8 + (lane >> 3)))) = vv[it];
     __builtin_amdgcn_sched_barrier(0);
 
     f32x4 s[4][4];
@@ -527,7 +540,7 @@ __global__ __launch_bounds__(256) void attn_bwd4_kernel(const T* __restrict__ qk
     }
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-        const int o = (16 * w + it * 8 + (lane >> 3)) * ROWB + (lane & 7) * 16;
+        const int o = (16 * w + it * 8 + (lane >> 3)) * ROWB + (((lane & 7) * 16) ^ rswz(it * 8 + (lane >> 3)));
         *(u32x4*)(qs + o) = sq[it];
         *(u32x4*)(ks_ + o) = sk[it];
         *(u32x4*)(dos + o) = sd[it];
