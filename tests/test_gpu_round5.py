@@ -103,3 +103,48 @@ def test_box_probes_run_and_report_sane_numbers():
     box = bench.box_probe(torch.device("cuda", 0))
     assert 300 < box["mfma_f16_loop_tf"] < 2600 and 1000 < box["hbm_copy_gbs"] < 8200 and 200 < box["gemm_4096_tf"] < 2600
     assert 200 < box["gemm_cfc_tf"] < 2600
+
+
+def test_streamk_and_splitk_fall_back_without_a_usable_workspace():
+    """eoe_gemm_args.sk_workspace is optional: missing, too small or misaligned, the stream-K form and the split-k hint quietly take the plain
+    launches -- same results as with the workspace to within the re-association of fp32 partial sums (split k) / bitwise (data-parallel tiles)"""
+    from eoe_amd import _lib, ops
+    from gpu_util import t16
+    dt = torch.float16
+    a, _ = t16("r5/ska", (4096, 768), 1.0, dt)
+    w, _ = t16("r5/skw", (2304, 768), 0.05, dt)
+    good = ops.nt_sk_workspace(a.device)
+    outs = []
+    old = _lib.set_option("nt_flags", 1 | 262144 | 1048576)          # eight-wave kernel forced, stream-K asked for
+    try:
+        for ws, nbytes in ((good.data_ptr(), good.numel()), (None, 0), (good.data_ptr(), 4096), (good.data_ptr() + 4, good.numel() - 4)):
+            out = torch.full((4096, 2304), float("nan"), dtype=dt, device="cuda")
+            g = _lib.GemmArgs(a.data_ptr(), w.data_ptr(), out.data_ptr(), None, None, None, None, 4096, 2304, 768, 768, 768, 2304, 0,
+                              _lib.EOE_F16, 0, 0, 0, 1.0)
+            g.sk_workspace, g.sk_workspace_bytes = ws, nbytes
+            _lib.check(_lib.lib.eoe_gemm_nt(C.byref(g), torch.cuda.current_stream().cuda_stream), "eoe_gemm_nt")
+            torch.cuda.synchronize()
+            assert torch.isfinite(out).all()
+            outs.append(out)
+    finally:
+        _lib.set_option("nt_flags", old)
+    assert torch.equal(outs[1], outs[2]) and torch.equal(outs[1], outs[3])                 # the three fall-backs: data-parallel tiles
+    d = ((outs[0].float() - outs[1].float()).abs() / outs[1].float().abs().clamp_min(1.0)).max().item()
+    assert d <= 2.5 * 2.0 ** -11, d                                                        # stream-K: within an ulp of them
+    assert int(good[:8192].view(torch.int32).abs().sum()) == 0
+    # the split-k hint (small M behind a long K): with and without the workspace
+    a2, a2r = t16("r5/spa", (256, 3072), 1.0, dt)
+    w2, w2r = t16("r5/spw", (768, 3072), 0.05, dt)
+    ref = a2r.double() @ w2r.double().t()
+    res = []
+    for ws, nbytes in ((good.data_ptr(), good.numel()), (None, 0)):
+        out = torch.empty((256, 768), dtype=torch.float32, device="cuda")
+        g = _lib.GemmArgs(a2.data_ptr(), w2.data_ptr(), out.data_ptr(), None, None, None, None, 256, 768, 3072, 3072, 3072, 768, 0,
+                          _lib.EOE_F16, 0, 1, 0, 1.0)
+        g.split_k = 1
+        g.sk_workspace, g.sk_workspace_bytes = ws, nbytes
+        _lib.check(_lib.lib.eoe_gemm_nt(C.byref(g), torch.cuda.current_stream().cuda_stream), "eoe_gemm_nt")
+        torch.cuda.synchronize()
+        res.append(out.double().cpu())
+    for r in res:
+        assert torch.allclose(r, ref, rtol=2e-6, atol=2e-5 * 3072 ** 0.5)
