@@ -229,3 +229,20 @@ def test_w8_kernel_keeps_out_of_the_accumulators(tmp_path):
     for name, _ in kernels:
         assert re.search(r"\.set %s\.num_agpr, 128\b" % re.escape(name), text), name
         assert re.search(r"\.set %s\.private_seg_size, 0\b" % re.escape(name), text), name
+
+
+def test_round5_entry_points_validate_their_arguments_without_a_gpu():
+    """eoe_red_table_flush / eoe_probe_*: argument errors come back as error codes (no GPU is touched before the checks), an empty table is a no-op"""
+    from eoe_amd import _lib
+    assert _lib.lib.eoe_red_table_flush(None, None) == 1 and b"bad table" in _lib.lib.eoe_last_error()
+    t = _lib.RedTable()
+    t.count = 0
+    assert _lib.lib.eoe_red_table_flush(C.byref(t), None) == 0
+    t.count = _lib.RED_TABLE_MAX + 1
+    assert _lib.lib.eoe_red_table_flush(C.byref(t), None) == 1
+    assert _lib.lib.eoe_probe_mfma_f16(None, 0, 16, None) == 1
+    assert _lib.lib.eoe_probe_copy(None, None, 1024, None) == 1
+    assert C.sizeof(_lib.RedJob) == 48 and C.sizeof(_lib.RedTable) == 48 * _lib.RED_TABLE_MAX + 8
+    # the gemm argument block's new tail (ABI v5): the stream-K / split-k workspace
+    g = _lib.GemmArgs()
+    assert hasattr(g, "sk_workspace") and hasattr(g, "sk_workspace_bytes") and _lib.ABI_VERSION == 5
